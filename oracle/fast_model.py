@@ -1,0 +1,153 @@
+"""TEST INFRASTRUCTURE — python-int model of the *fast* algorithms the HIP kernels use
+(Jacobian Miller loop with sparse lines and no vertical lines, exact split final
+exponentiation, Frobenius constants).  It exists to (i) prove on the CPU that the
+fast algorithm is bit-identical to the faithful oracle (tests/test_fast_model.py)
+and (ii) generate the Frobenius constants for tools/gen_constants.py.
+Tower conventions follow the reference: u^2=-1, v^3=1+u, w^2=v
+(fq2.rs:52-58, fq6.rs:54-62, fq12.rs:135-147)."""
+
+Q = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+X_ABS = 0xD201000000010000  # x = -X_ABS
+
+
+# ---- Fq2 as (c0, c1) = c0 + c1 u -------------------------------------------
+def f2_add(a, b): return ((a[0] + b[0]) % Q, (a[1] + b[1]) % Q)
+def f2_sub(a, b): return ((a[0] - b[0]) % Q, (a[1] - b[1]) % Q)
+def f2_neg(a): return (-a[0] % Q, -a[1] % Q)
+def f2_mul(a, b): return ((a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)
+def f2_sqr(a): return f2_mul(a, a)
+def f2_muls(a, s): return (a[0] * s % Q, a[1] * s % Q)
+def f2_xi(a): return ((a[0] - a[1]) % Q, (a[0] + a[1]) % Q)         # *(1+u)
+def f2_conj(a): return (a[0], -a[1] % Q)
+def f2_inv(a):
+    t = pow(a[0] * a[0] + a[1] * a[1], -1, Q)
+    return (a[0] * t % Q, -a[1] * t % Q)
+F2_0, F2_1 = (0, 0), (1, 0)
+
+
+def f2_pow(a, e):
+    r = F2_1
+    while e:
+        if e & 1: r = f2_mul(r, a)
+        a = f2_sqr(a); e >>= 1
+    return r
+
+
+# ---- Fq6 as (c0,c1,c2) over v ------------------------------------------------
+def f6_add(a, b): return tuple(f2_add(x, y) for x, y in zip(a, b))
+def f6_sub(a, b): return tuple(f2_sub(x, y) for x, y in zip(a, b))
+def f6_neg(a): return tuple(f2_neg(x) for x in a)
+def f6_mulv(a): return (f2_xi(a[2]), a[0], a[1])
+def f6_mul(a, b):
+    a0, a1, a2 = a; b0, b1, b2 = b
+    v0, v1, v2 = f2_mul(a0, b0), f2_mul(a1, b1), f2_mul(a2, b2)
+    c0 = f2_add(v0, f2_xi(f2_sub(f2_sub(f2_mul(f2_add(a1, a2), f2_add(b1, b2)), v1), v2)))
+    c1 = f2_add(f2_sub(f2_sub(f2_mul(f2_add(a0, a1), f2_add(b0, b1)), v0), v1), f2_xi(v2))
+    c2 = f2_add(f2_sub(f2_sub(f2_mul(f2_add(a0, a2), f2_add(b0, b2)), v0), v2), v1)
+    return (c0, c1, c2)
+def f6_inv(a):
+    a0, a1, a2 = a
+    t0 = f2_sub(f2_sqr(a0), f2_xi(f2_mul(a1, a2)))
+    t1 = f2_sub(f2_xi(f2_sqr(a2)), f2_mul(a0, a1))
+    t2 = f2_sub(f2_sqr(a1), f2_mul(a0, a2))
+    f = f2_inv(f2_add(f2_mul(a0, t0), f2_add(f2_xi(f2_mul(a2, t1)), f2_xi(f2_mul(a1, t2)))))
+    return (f2_mul(t0, f), f2_mul(t1, f), f2_mul(t2, f))
+F6_0 = (F2_0, F2_0, F2_0); F6_1 = (F2_1, F2_0, F2_0)
+
+
+# ---- Fq12 as (c0,c1) over w ----------------------------------------------------
+def f12_mul(a, b):
+    v0, v1 = f6_mul(a[0], b[0]), f6_mul(a[1], b[1])
+    return (f6_add(v0, f6_mulv(v1)), f6_sub(f6_sub(f6_mul(f6_add(a[0], a[1]), f6_add(b[0], b[1])), v0), v1))
+def f12_sqr(a): return f12_mul(a, a)
+def f12_conj(a): return (a[0], f6_neg(a[1]))
+def f12_inv(a):
+    t = f6_inv(f6_sub(f6_mul(a[0], a[0]), f6_mulv(f6_mul(a[1], a[1]))))
+    return (f6_mul(a[0], t), f6_neg(f6_mul(a[1], t)))
+F12_1 = (F6_1, F6_0)
+def f12_pow(a, e):
+    r = F12_1
+    while e:
+        if e & 1: r = f12_mul(r, a)
+        a = f12_sqr(a); e >>= 1
+    return r
+
+
+# Frobenius: a = sum a_i w^i over Fq2 with w^6 = xi;  pi^k(a) = sum conj^k(a_i) * xi^(i (q^k-1)/6) w^i
+def frob_consts(k):
+    return [f2_pow((1, 1), i * (Q**k - 1) // 6) for i in range(6)]
+FROB1, FROB2 = frob_consts(1), frob_consts(2)
+def f12_coeffs(a):      # (c0,c1) -> [a_0..a_5] for basis w^i: w^0=1, w^1=w, w^2=v, w^3=vw, w^4=v^2, w^5=v^2 w
+    (x0, x1, x2), (y0, y1, y2) = a
+    return [x0, y0, x1, y1, x2, y2]
+def f12_from_coeffs(c): return ((c[0], c[2], c[4]), (c[1], c[3], c[5]))
+def f12_frob(a, k=1):
+    cs = f12_coeffs(a); g = FROB1 if k == 1 else FROB2
+    return f12_from_coeffs([f2_mul(f2_conj(c) if k % 2 else c, g[i]) for i, c in enumerate(cs)])
+
+
+def to_ref_order(a):
+    """Fq12 -> 12 ints in the reference's to_strs order (fq12.rs:179-195): w1.v2.u1, w1.v2.u0, ..., w0.v0.u0"""
+    out = []
+    for six in (a[1], a[0]):
+        for c in (six[2], six[1], six[0]):
+            out += [c[1], c[0]]
+    return out
+
+
+# ---- fast Tate -------------------------------------------------------------------
+XI_INV = f2_inv((1, 1))
+L_BITS = [int(c) for c in bin(R - 1)[3:]]          # pairing.rs:58-73
+
+
+def miller_fast(P, Qp):
+    """f_{r-1,P}(untwist(Q)) up to Fq6 factors.  P=(x,y) in Fq, Qp=((x0,x1),(y0,y1)) c0/c1 order."""
+    xp, yp = P
+    Xq = f2_mul(Qp[0], XI_INV)     # untwisted x sits at w0.v2  (g12_point.rs:47-68: x * v^-1 = (x/xi) v^2)
+    Yq = f2_mul(Qp[1], XI_INV)     # untwisted y sits at w1.v1  (y * (v w)^-1 = (y/xi) v w)
+    X, Y, Z = xp, yp, 1
+    f = F12_1
+
+    def sparse(a, b, c):           # a + b v^2 + c v w,  a in Fq
+        return (((a, 0), F2_0, b), (F2_0, c, F2_0))
+
+    for bit in L_BITS:
+        # tangent at V, scaled by 2YZ^3:  (3X^3-2Y^2) - 3X^2 Z^2 * X' + Z3 Z^2 * Y'
+        A = X * X % Q; B = Y * Y % Q; C = B * B % Q; ZZ = Z * Z % Q
+        D = 2 * ((X + B) ** 2 - A - C) % Q; E = 3 * A % Q
+        X3 = (E * E - 2 * D) % Q; Y3 = (E * (D - X3) - 8 * C) % Q; Z3 = 2 * Y * Z % Q
+        a = (E * X - 2 * B) % Q
+        f = f12_mul(f12_sqr(f), sparse(a, f2_muls(Xq, -E * ZZ % Q), f2_muls(Yq, Z3 * ZZ % Q)))
+        X, Y, Z = X3, Y3, Z3
+        if bit:
+            # chord through V and P, scaled by Z*H: (R xp - Z3 yp) - R X' + Z3 Y'
+            ZZ = Z * Z % Q; H = (xp * ZZ - X) % Q; Rr = (yp * ZZ * Z - Y) % Q
+            HH = H * H % Q; HHH = H * HH % Q; V = X * HH % Q
+            X3 = (Rr * Rr - HHH - 2 * V) % Q; Y3 = (Rr * (V - X3) - Y * HHH) % Q; Z3 = Z * H % Q
+            a = (Rr * xp - Z3 * yp) % Q
+            f = f12_mul(f, sparse(a, f2_muls(Xq, -Rr % Q), f2_muls(Yq, Z3)))
+            X, Y, Z = X3, Y3, Z3
+    return f
+
+
+def exp_x_neg(a):
+    """a^x for x = -X_ABS, a in the cyclotomic subgroup (inverse = conjugate)."""
+    return f12_conj(f12_pow(a, X_ABS))
+
+
+E1 = (X_ABS + 1) ** 2 // 3      # (x-1)^2/3 with x = -X_ABS
+
+
+def final_exp_fast(f):
+    """f^((q^12-1)/r) = easy then hard = e1*(x+q)*(x^2+q^2-1)+1."""
+    g = f12_mul(f12_conj(f), f12_inv(f))            # f^(q^6-1)
+    g = f12_mul(f12_frob(g, 2), g)                  # ^(q^2+1)
+    a = f12_pow(g, E1)
+    b = f12_mul(exp_x_neg(a), f12_frob(a, 1))       # a^(x+q)
+    c = f12_mul(f12_mul(exp_x_neg(exp_x_neg(b)), f12_frob(b, 2)), f12_conj(b))   # b^(x^2+q^2-1)
+    return f12_mul(c, g)
+
+
+def tate_fast(P, Qp):
+    return final_exp_fast(miller_fast(P, Qp))

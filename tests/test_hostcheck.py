@@ -1,0 +1,126 @@
+"""The exact math headers the HIP kernels are built from (fp.h, tower.h, curve.h,
+pairing.h), compiled for the host, checked against the oracle.  CPU only.
+This validates formulas and constants; the GPU parity tests validate the device build."""
+import ctypes, os, subprocess
+import numpy as np
+import pytest
+from zkt_testlib import *
+from test_oracle_kats import g1_gen, g2_gen, g1_mul, g2_mul, g1_add, g2_add, sp_arr, O
+from test_oracle_pairing import pair
+
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+
+
+def p32(a):
+    return a.ctypes.data_as(_u32p) if a is not None else None
+
+
+@pytest.fixture(scope="module")
+def H():
+    so = os.path.join(ROOT, "zk-toolkit_amd", "libzkt_hostcheck.so")
+    src = os.path.join(ROOT, "zk-toolkit_amd", "csrc")
+    newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src))
+    if not os.path.exists(so) or os.path.getmtime(so) < newest:
+        subprocess.check_call(["hipcc", "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared",
+                               "-o", so, os.path.join(src, "hostcheck.cpp")], timeout=600)
+    return ctypes.CDLL(so)
+
+
+@pytest.mark.parametrize("field,mod,w,pre", [(0, Q, 6, "fq"), (1, R, 4, "fr")])
+def test_field_ops(H, field, mod, w, pre):
+    rng = SplitMix64(31 + field)
+    xs = [rng.below(mod) for _ in range(64)] + [0, 1, mod - 1, mod - 1, 2]
+    ys = [rng.below(mod) for _ in range(64)] + [0, mod - 1, mod - 1, 1, (mod + 1) // 2]
+    a, b = ints_to_arr(xs, w), ints_to_arr(ys, w)
+    for op, f in ((0, lambda x, y: (x + y) % mod), (1, lambda x, y: (x - y) % mod), (2, lambda x, y: x * y % mod),
+                  (3, lambda x, y: x * x % mod), (4, lambda x, y: -x % mod)):
+        o = np.zeros_like(a)
+        assert H.zkt_hostcheck_fp(field, op, p32(a), p32(b), p32(o), len(xs)) == 0
+        assert arr_to_ints(o) == [f(x, y) for x, y in zip(xs, ys)], op
+    nz = ints_to_arr([x for x in xs if x], w); o = np.zeros_like(nz)
+    assert H.zkt_hostcheck_fp(field, 5, p32(nz), None, p32(o), len(nz)) == 0
+    assert arr_to_ints(o) == [pow(x, -1, mod) for x in arr_to_ints(nz)]
+
+
+@pytest.mark.parametrize("field,mod", [(2, SECP_P), (3, SECP_N)])
+def test_field_ops_256bit_moduli(H, field, mod):
+    rng = SplitMix64(41 + field)
+    xs = [rng.below(mod) for _ in range(64)] + [mod - 1, mod - 1, 1]
+    ys = [rng.below(mod) for _ in range(64)] + [mod - 1, 1, mod - 1]
+    a, b = ints_to_arr(xs, 4), ints_to_arr(ys, 4)
+    for op, f in ((0, lambda x, y: (x + y) % mod), (1, lambda x, y: (x - y) % mod), (2, lambda x, y: x * y % mod)):
+        o = np.zeros_like(a)
+        assert H.zkt_hostcheck_fp(field, op, p32(a), p32(b), p32(o), len(xs)) == 0
+        assert arr_to_ints(o) == [f(x, y) for x, y in zip(xs, ys)], op
+
+
+def _rand_tower(rng, w):
+    return ints_to_arr([rng.below(Q) for _ in range(w // 6)], 6).reshape(1, w)
+
+
+@pytest.mark.parametrize("deg,w,fn,ops", [(2, 12, "zkto_fq2_op", (0, 1, 2, 3, 4, 5, 6)), (6, 36, "zkto_fq6_op", (0, 1, 2, 3, 4, 5)),
+                                          (12, 72, "zkto_fq12_op", (0, 1, 2, 3, 4))])
+def test_tower_vs_oracle(H, deg, w, fn, ops):
+    rng = SplitMix64(50 + deg)
+    for _ in range(3):
+        a, b = _rand_tower(rng, w), _rand_tower(rng, w)
+        for op in ops:
+            want = np.zeros((1, w), dtype=np.uint64); got = np.zeros((1, w), dtype=np.uint64)
+            assert getattr(O, fn)(op, ptr(a), ptr(b), ptr(want), 1) == 0
+            assert H.zkt_hostcheck_tower(deg, op, p32(a), p32(b), p32(got)) == 0
+            assert (want == got).all(), (deg, op)
+
+
+def test_fq12_sqr_frobenius_conj(H):
+    rng = SplitMix64(60)
+    a = _rand_tower(rng, 72)
+    want = np.zeros((1, 72), dtype=np.uint64); got = np.zeros((1, 72), dtype=np.uint64)
+    assert O.zkto_fq12_op(2, ptr(a), ptr(a), ptr(want), 1) == 0
+    assert H.zkt_hostcheck_tower(12, 6, p32(a), None, p32(got)) == 0 and (want == got).all()
+    u32 = lambda v: np.array([(v >> (32 * i)) & 0xFFFFFFFF for i in range((v.bit_length() + 31) // 32)], dtype=np.uint32)
+    for op, e in ((7, Q), (8, Q * Q), (9, Q**6)):
+        ev = u32(e)
+        assert O.zkto_fq12_pow(ptr(a), p32(ev), len(ev), ptr(want)) == 0
+        assert H.zkt_hostcheck_tower(12, op, p32(a), None, p32(got)) == 0
+        assert (want == got).all(), op
+
+
+def test_groups_vs_oracle(H):
+    rng = SplitMix64(70)
+    g1, g2 = g1_gen(), g2_gen()
+    secp = np.zeros((1, 9), dtype=np.uint64); O.zkto_secp_generator(ptr(secp))
+    for grp, g, W, omul, oadd in ((0, g1, G1W, O.zkto_g1_mul_batch, O.zkto_g1_add_batch),
+                                  (1, g2, G2W, O.zkto_g2_mul_batch, O.zkto_g2_add_batch),
+                                  (2, secp, 9, O.zkto_secp_mul_batch, O.zkto_secp_add_batch)):
+        order = SECP_N if grp == 2 else R
+        def mul(p, k):
+            s = ints_to_arr([k], 4); o = np.zeros((1, W), dtype=np.uint64)
+            assert omul(ptr(p), ptr(s), 4, ptr(o), 1, 1) == 0; return o
+        ks = [rng.below(order), 1, 2, 0, order, order - 1, order + 5, (1 << 256) - 1]
+        for k in ks:
+            s = ints_to_arr([k], 4); got = np.zeros((1, W), dtype=np.uint64)
+            assert H.zkt_hostcheck_group(grp, 2, p32(g), p32(s), 8, p32(got)) == 0
+            assert (got == mul(g, k)).all(), (grp, k)
+        p, q = mul(g, rng.below(order)), mul(g, rng.below(order))
+        inf = np.zeros((1, W), dtype=np.uint64); inf[0, W - 1] = 1
+        negp = mul(p, order - 1)
+        for a, b in ((p, q), (p, p), (p, negp), (p, inf), (inf, q), (inf, inf)):
+            want = np.zeros((1, W), dtype=np.uint64)
+            assert oadd(ptr(a), ptr(b), ptr(want), 1) == 0
+            for op in (0, 1):
+                got = np.zeros((1, W), dtype=np.uint64)
+                assert H.zkt_hostcheck_group(grp, op, p32(a), p32(b), 0, p32(got)) == 0
+                assert (got == want).all(), (grp, op)
+
+
+def test_tate_vs_oracle(H):
+    rng = SplitMix64(80)
+    ps = np.concatenate([g1_gen(), g1_mul(g1_gen(), rng.below(R))])
+    qs = np.concatenate([g2_gen(), g2_mul(g2_gen(), rng.below(R))])
+    rc, want, _ = pair(3, ps, qs)
+    assert rc == 0
+    for i in range(2):
+        got = np.zeros((1, 72), dtype=np.uint64)
+        assert H.zkt_hostcheck_tate(p32(ps[i:i + 1]), p32(qs[i:i + 1]), p32(got)) == 0
+        assert (got[0] == want[i]).all()
+    assert H.zkt_hostcheck_tate(p32(g1_arr([None])), p32(qs[0:1]), p32(np.zeros((1, 72), dtype=np.uint64))) == 2

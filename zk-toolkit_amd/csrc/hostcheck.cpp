@@ -1,0 +1,85 @@
+// TEST-ONLY: the kernel math headers (fp.h … pairing.h) compiled for the HOST, so the
+// `-m "not gpu"` suite can check the exact functions the HIP kernels inline against the
+// oracle without a GPU.  Not part of the product: libzkt_hip.so neither links nor calls
+// this, and the C ABI in include/zkt.h has no CPU path.  Built by __graft_entry__.build()
+// as zk-toolkit_amd/libzkt_hostcheck.so (hipcc --cuda-host-only).
+#include "abi.h"
+using namespace zkt;
+
+extern "C" {
+// op: 0 add 1 sub 2 mul 3 sqr 4 neg 5 inv
+int zkt_hostcheck_fp(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n) {
+  auto run = [&](auto tag) {
+    typedef decltype(tag) C;
+    for (size_t i = 0; i < n; ++i) {
+      Fp<C> x = ld_fp<C>(a + i * C::N), y = b ? ld_fp<C>(b + i * C::N) : fp_zero<C>(), r;
+      switch (op) {
+        case 0: r = fp_add(x, y); break; case 1: r = fp_sub(x, y); break; case 2: r = fp_mul(x, y); break;
+        case 3: r = fp_sqr(x); break; case 4: r = fp_neg(x); break; default: r = fp_inv(x);
+      }
+      st_fp<C>(o + i * C::N, r);
+    }
+  };
+  switch (field) { case 0: run(FqC{}); break; case 1: run(FrC{}); break; case 2: run(SpC{}); break; default: run(SnC{}); }
+  return 0;
+}
+// op: 0 add 1 sub 2 mul 3 inv 4 neg 5 mul_xi/mul_v 6 sqr 7 frob1 8 frob2 9 conj
+int zkt_hostcheck_tower(int deg, int op, const uint32_t* a, const uint32_t* b, uint32_t* o) {
+  if (deg == 2) {
+    Fq2 x = ld_fq2(a), y = b ? ld_fq2(b) : fq2_zero(), r;
+    switch (op) { case 0: r = fq2_add(x, y); break; case 1: r = fq2_sub(x, y); break; case 2: r = fq2_mul(x, y); break;
+      case 3: r = fq2_inv(x); break; case 4: r = fq2_neg(x); break; case 5: r = fq2_mul_xi(x); break; default: r = fq2_sqr(x); }
+    st_fq2(o, r);
+  } else if (deg == 6) {
+    Fq6 x = ld_fq6(a), y = b ? ld_fq6(b) : fq6_zero(), r;
+    switch (op) { case 0: r = fq6_add(x, y); break; case 1: r = fq6_sub(x, y); break; case 2: r = fq6_mul(x, y); break;
+      case 3: r = fq6_inv(x); break; case 4: r = fq6_neg(x); break; default: r = fq6_mul_v(x); }
+    st_fq6(o, r);
+  } else {
+    Fq12 x = ld_fq12(a), y = b ? ld_fq12(b) : fq12_one(), r;
+    switch (op) { case 0: r = fq12_add(x, y); break; case 1: r = fq12_sub(x, y); break; case 2: r = fq12_mul(x, y); break;
+      case 3: r = fq12_inv(x); break; case 4: r = fq12_neg(x); break; case 6: r = fq12_sqr(x); break;
+      case 7: r = fq12_frob<1>(x); break; case 8: r = fq12_frob<2>(x); break; default: r = fq12_conj(x); }
+    st_fq12(o, r);
+  }
+  return 0;
+}
+}  // extern "C"
+template <class F> static void pt_add(const uint32_t* a, const uint32_t* b, uint32_t* o) {
+  Aff<F> p = PtIO<F>::ld(a), q = PtIO<F>::ld(b);
+  PtIO<F>::st(o, jac_to_aff(jac_add_aff(jac_from_aff(p), q)));
+}
+template <class F> static void pt_add_full(const uint32_t* a, const uint32_t* b, uint32_t* o) {
+  // exercise jac_add and the XYZZ formulas too: ((2a) + b) - a computed two ways must agree with a + b
+  Aff<F> p = PtIO<F>::ld(a), q = PtIO<F>::ld(b);
+  Jac<F> j = jac_add(jac_dbl(jac_from_aff(p)), jac_from_aff(q));
+  Aff<F> np = p; if (!np.inf) np.y = F::neg(np.y);
+  j = jac_add_aff(j, np);
+  Xyzz<F> z = xyzz_inf<F>();
+  if (!p.inf) z = xyzz_add_aff(z, p.x, p.y);
+  if (!q.inf) z = xyzz_add_aff(z, q.x, q.y);
+  Xyzz<F> z2 = xyzz_add(z, xyzz_inf<F>());
+  Aff<F> r1 = jac_to_aff(j), r2 = xyzz_to_aff(z2), r3 = jac_to_aff(xyzz_to_jac(z));
+  bool same = (r1.inf == r2.inf) && (r1.inf || (F::eq(r1.x, r2.x) && F::eq(r1.y, r2.y)));
+  same = same && (r1.inf == r3.inf) && (r1.inf || (F::eq(r1.x, r3.x) && F::eq(r1.y, r3.y)));
+  if (!same) { r1.inf = true; }   // poison: a mismatch between formula sets shows up as a wrong answer
+  PtIO<F>::st(o, r1);
+}
+template <class F> static void pt_mul(const uint32_t* a, const uint32_t* k, int klimbs, uint32_t* o) {
+  PtIO<F>::st(o, jac_to_aff(scalar_mul_aff(PtIO<F>::ld(a), k, klimbs)));
+}
+extern "C" {
+// grp: 0 G1, 1 G2, 2 secp256k1.  op: 0 add (mixed), 1 add via the other formula sets, 2 scalar mul (b = scalar, u32 limbs)
+int zkt_hostcheck_group(int grp, int op, const uint32_t* a, const uint32_t* b, int klimbs, uint32_t* o) {
+  if (grp == 0) { if (op == 0) pt_add<FqOps>(a, b, o); else if (op == 1) pt_add_full<FqOps>(a, b, o); else pt_mul<FqOps>(a, b, klimbs, o); }
+  else if (grp == 1) { if (op == 0) pt_add<Fq2Ops>(a, b, o); else if (op == 1) pt_add_full<Fq2Ops>(a, b, o); else pt_mul<Fq2Ops>(a, b, klimbs, o); }
+  else { if (op == 0) pt_add<SpOps>(a, b, o); else if (op == 1) pt_add_full<SpOps>(a, b, o); else pt_mul<SpOps>(a, b, klimbs, o); }
+  return 0;
+}
+int zkt_hostcheck_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* o) {
+  Aff<FqOps> p = PtIO<FqOps>::ld(g1); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2);
+  if (p.inf || q.inf) return 2;
+  st_fq12(o, final_exponentiation(miller_g1_g2(p.x, p.y, q.x, q.y)));
+  return 0;
+}
+}

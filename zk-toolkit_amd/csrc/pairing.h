@@ -1,0 +1,102 @@
+// Batched Tate pairing for BLS12-381: one pairing per lane.
+//
+// Replaces, value for value,
+//   Pairing::tate     src/building_block/curves/bls12_381/pairing.rs:86-100
+// = calc_g1_g2(P,Q)^((q^12-1)/r)  (textbook Miller loop over the bits of r-1 with
+// explicit untwist, vertical lines and one Fq12 inversion per step, pairing.rs:20-73;
+// then a 4314-bit square-and-multiply, fq12.rs:42-57).
+//
+// What is computed here instead (proved bit-identical on the CPU by
+// tests/test_fast_model.py against the faithful oracle, and on the GPU by
+// tests/test_gpu_parity.py):
+//  * Miller loop over the same bits of r-1, with V in Jacobian coordinates (no
+//    inversion), tangent/chord lines scaled by an Fq factor, vertical lines
+//    dropped.  Every dropped or extra factor lies in Fq6 and is annihilated by
+//    the (q^6-1) part of the final exponent, so tate() is unchanged.
+//  * the untwisted Q has x' = (x/xi) v^2 (slot w0.v2) and y' = (y/xi) v w (slot
+//    w1.v1)  (g12_point.rs:47-68), so a line value is a + b v^2 + c v w with
+//    a in Fq: fq12_mul_line.
+//  * final exponent split exactly: (q^12-1)/r = (q^6-1)(q^2+1) * [e1 (x+q)(x^2+q^2-1) + 1],
+//    e1 = (x-1)^2/3, x = -0xd201000000010000 — the exact exponent, not the usual
+//    3x multiple.
+#pragma once
+#include "curve.h"
+
+namespace zkt {
+
+ZKT_HD Fq2 xi_inv_const() {
+  Fq2 g;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { g.c0.v[i] = xi_inv_limb(0, i); g.c1.v[i] = xi_inv_limb(1, i); }
+  return g;
+}
+
+// f_{r-1,P}(untwist(Q)) up to Fq6 factors.  P, Q affine, Montgomery domain, neither at infinity.
+ZKT_FN Fq12 miller_g1_g2(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq) {
+  const Fq2 xi_inv = xi_inv_const();
+  const Fq2 Xq = fq2_mul(xq, xi_inv), Yq = fq2_mul(yq, xi_inv);
+  Fq X = xp, Y = yp, Z = fp_one<FqC>();
+  Fq12 f = fq12_one();
+  for (int i = 0; i < MILLER_NBITS; ++i) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w = (j == (i >> 5)) ? miller_bits_word(j) : w;
+    const bool bit = (w >> (i & 31)) & 1;          // wave-uniform (compile-time table)
+    {
+      // tangent at V scaled by 2YZ^3: (3X^3 - 2Y^2) - 3X^2 Z^2 * X' + Z3 Z^2 * Y'
+      Fq A = fp_sqr(X), B = fp_sqr(Y), C = fp_sqr(B), ZZ = fp_sqr(Z);
+      Fq t = fp_sqr(fp_add(X, B));
+      Fq D = fp_dbl(fp_sub(fp_sub(t, A), C));
+      Fq E = fp_add(fp_dbl(A), A);
+      Fq X3 = fp_sub(fp_sqr(E), fp_dbl(D));
+      Fq Y3 = fp_sub(fp_mul(E, fp_sub(D, X3)), fp_dbl(fp_dbl(fp_dbl(C))));
+      Fq Z3 = fp_dbl(fp_mul(Y, Z));
+      Fq a = fp_sub(fp_mul(E, X), fp_dbl(B));
+      Fq2 b = fq2_mul_fq(Xq, fp_neg(fp_mul(E, ZZ)));
+      Fq2 c = fq2_mul_fq(Yq, fp_mul(Z3, ZZ));
+      f = fq12_mul_line(fq12_sqr(f), a, b, c);
+      X = X3; Y = Y3; Z = Z3;
+    }
+    if (bit) {
+      // chord through V and P scaled by Z*H: (R xp - Z3 yp) - R X' + Z3 Y'
+      Fq ZZ = fp_sqr(Z), H = fp_sub(fp_mul(xp, ZZ), X), Rr = fp_sub(fp_mul(fp_mul(yp, ZZ), Z), Y);
+      Fq HH = fp_sqr(H), HHH = fp_mul(H, HH), V = fp_mul(X, HH);
+      Fq X3 = fp_sub(fp_sub(fp_sqr(Rr), HHH), fp_dbl(V));
+      Fq Y3 = fp_sub(fp_mul(Rr, fp_sub(V, X3)), fp_mul(Y, HHH));
+      Fq Z3 = fp_mul(Z, H);
+      Fq a = fp_sub(fp_mul(Rr, xp), fp_mul(Z3, yp));
+      Fq2 b = fq2_mul_fq(Xq, fp_neg(Rr));
+      Fq2 c = fq2_mul_fq(Yq, Z3);
+      f = fq12_mul_line(f, a, b, c);
+      X = X3; Y = Y3; Z = Z3;
+    }
+  }
+  return f;
+}
+
+// a^|x| , |x| = 0xd201000000010000 (bits 63,62,60,57,48,16)
+ZKT_FN Fq12 fq12_pow_xabs(const Fq12& a) {
+  Fq12 r = a;
+  for (int i = 62; i >= 0; --i) {
+    r = fq12_sqr(r);
+    if ((BLS_X_ABS >> i) & 1) r = fq12_mul(r, a);
+  }
+  return r;
+}
+// a^x for x = -|x|, a in the cyclotomic subgroup (inverse = conjugate)
+ZKT_HD Fq12 fq12_pow_x(const Fq12& a) { return fq12_conj(fq12_pow_xabs(a)); }
+
+// f^((q^12-1)/r), exact.
+ZKT_FN Fq12 final_exponentiation(const Fq12& f) {
+  Fq12 g = fq12_mul(fq12_conj(f), fq12_inv(f));          // ^(q^6-1)
+  g = fq12_mul(fq12_frob<2>(g), g);                      // ^(q^2+1)
+  uint32_t e1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e1[i] = e1_limb(i);
+  Fq12 a = fq12_pow(g, e1, 4);                           // ^e1
+  Fq12 b = fq12_mul(fq12_pow_x(a), fq12_frob<1>(a));     // ^(x+q)
+  Fq12 c = fq12_mul(fq12_mul(fq12_pow_x(fq12_pow_x(b)), fq12_frob<2>(b)), fq12_conj(b));   // ^(x^2+q^2-1)
+  return fq12_mul(c, g);
+}
+
+}  // namespace zkt

@@ -1,0 +1,148 @@
+// BLS12-381 extension tower Fq2 / Fq6 / Fq12 on top of fp.h.
+//
+// Same fields and the same element *values* as the reference's schoolbook tower
+//   src/building_block/curves/bls12_381/fq2.rs:15-151   u^2 = -1
+//   src/building_block/curves/bls12_381/fq6.rs:15-171   v^3 = 1+u
+//   src/building_block/curves/bls12_381/fq12.rs:17-172  w^2 = v
+// but with the usual fast formulas (Karatsuba 3/6/3, complex squaring, sparse line
+// multiplication, Frobenius by constants).  Coefficients are stored low degree
+// first (c0 + c1*g); the C ABI converts to the reference's struct order
+// {u1,u0} / {v2,v1,v0} / {w1,w0} at the boundary.
+#pragma once
+#include "fp.h"
+
+namespace zkt {
+
+struct Fq2 { Fq c0, c1; };
+struct Fq6 { Fq2 c0, c1, c2; };
+struct Fq12 { Fq6 c0, c1; };
+
+// ---- Fq2 --------------------------------------------------------------------
+ZKT_HD Fq2 fq2_zero() { return Fq2{fp_zero<FqC>(), fp_zero<FqC>()}; }
+ZKT_HD Fq2 fq2_one() { return Fq2{fp_one<FqC>(), fp_zero<FqC>()}; }
+ZKT_HD bool fq2_is_zero(const Fq2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
+ZKT_HD bool fq2_eq(const Fq2& a, const Fq2& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
+ZKT_HD Fq2 fq2_add(const Fq2& a, const Fq2& b) { return Fq2{fp_add(a.c0, b.c0), fp_add(a.c1, b.c1)}; }   // fq2.rs:96-110
+ZKT_HD Fq2 fq2_sub(const Fq2& a, const Fq2& b) { return Fq2{fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; }   // fq2.rs:115-129
+ZKT_HD Fq2 fq2_neg(const Fq2& a) { return Fq2{fp_neg(a.c0), fp_neg(a.c1)}; }                               // fq2.rs:82-94
+ZKT_HD Fq2 fq2_dbl(const Fq2& a) { return Fq2{fp_dbl(a.c0), fp_dbl(a.c1)}; }
+ZKT_HD Fq2 fq2_conj(const Fq2& a) { return Fq2{a.c0, fp_neg(a.c1)}; }
+// fq2.rs:134-146 computes the 4-product schoolbook; Karatsuba gives the same element
+ZKT_FN Fq2 fq2_mul(const Fq2& a, const Fq2& b) {
+  Fq v0 = fp_mul(a.c0, b.c0), v1 = fp_mul(a.c1, b.c1);
+  Fq s = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+  return Fq2{fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
+}
+ZKT_FN Fq2 fq2_sqr(const Fq2& a) {                                      // fq2.rs:34-36
+  Fq t = fp_mul(a.c0, a.c1);
+  return Fq2{fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_dbl(t)};
+}
+ZKT_HD Fq2 fq2_mul_fq(const Fq2& a, const Fq& s) { return Fq2{fp_mul(a.c0, s), fp_mul(a.c1, s)}; }
+ZKT_HD Fq2 fq2_mul_xi(const Fq2& a) { return Fq2{fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1)}; }   // Fq2::reduce, fq2.rs:52-58
+ZKT_FN Fq2 fq2_inv(const Fq2& a) {                                      // fq2.rs:26-32
+  Fq t = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
+  return Fq2{fp_mul(a.c0, t), fp_neg(fp_mul(a.c1, t))};
+}
+ZKT_HD Fq2 fq2_to_mont(const Fq2& a) { return Fq2{fp_to_mont(a.c0), fp_to_mont(a.c1)}; }
+ZKT_HD Fq2 fq2_from_mont(const Fq2& a) { return Fq2{fp_from_mont(a.c0), fp_from_mont(a.c1)}; }
+
+// ---- Fq6 --------------------------------------------------------------------
+ZKT_HD Fq6 fq6_zero() { return Fq6{fq2_zero(), fq2_zero(), fq2_zero()}; }
+ZKT_HD Fq6 fq6_one() { return Fq6{fq2_one(), fq2_zero(), fq2_zero()}; }
+ZKT_HD Fq6 fq6_add(const Fq6& a, const Fq6& b) { return Fq6{fq2_add(a.c0, b.c0), fq2_add(a.c1, b.c1), fq2_add(a.c2, b.c2)}; }
+ZKT_HD Fq6 fq6_sub(const Fq6& a, const Fq6& b) { return Fq6{fq2_sub(a.c0, b.c0), fq2_sub(a.c1, b.c1), fq2_sub(a.c2, b.c2)}; }
+ZKT_HD Fq6 fq6_neg(const Fq6& a) { return Fq6{fq2_neg(a.c0), fq2_neg(a.c1), fq2_neg(a.c2)}; }
+ZKT_HD Fq6 fq6_mul_v(const Fq6& a) { return Fq6{fq2_mul_xi(a.c2), a.c0, a.c1}; }                 // Fq6::reduce, fq6.rs:54-62
+// fq6.rs:148-166 is the 9-product schoolbook; Karatsuba (6 products) gives the same element
+ZKT_FN Fq6 fq6_mul(const Fq6& a, const Fq6& b) {
+  Fq2 v0 = fq2_mul(a.c0, b.c0), v1 = fq2_mul(a.c1, b.c1), v2 = fq2_mul(a.c2, b.c2);
+  Fq2 t0 = fq2_sub(fq2_sub(fq2_mul(fq2_add(a.c1, a.c2), fq2_add(b.c1, b.c2)), v1), v2);
+  Fq2 t1 = fq2_sub(fq2_sub(fq2_mul(fq2_add(a.c0, a.c1), fq2_add(b.c0, b.c1)), v0), v1);
+  Fq2 t2 = fq2_sub(fq2_sub(fq2_mul(fq2_add(a.c0, a.c2), fq2_add(b.c0, b.c2)), v0), v2);
+  return Fq6{fq2_add(v0, fq2_mul_xi(t0)), fq2_add(t1, fq2_mul_xi(v2)), fq2_add(t2, v1)};
+}
+ZKT_FN Fq6 fq6_inv(const Fq6& a) {                                      // fq6.rs:23-37
+  Fq2 t0 = fq2_sub(fq2_sqr(a.c0), fq2_mul_xi(fq2_mul(a.c1, a.c2)));
+  Fq2 t1 = fq2_sub(fq2_mul_xi(fq2_sqr(a.c2)), fq2_mul(a.c0, a.c1));
+  Fq2 t2 = fq2_sub(fq2_sqr(a.c1), fq2_mul(a.c0, a.c2));
+  Fq2 f = fq2_inv(fq2_add(fq2_mul(a.c0, t0), fq2_add(fq2_mul_xi(fq2_mul(a.c2, t1)), fq2_mul_xi(fq2_mul(a.c1, t2)))));
+  return Fq6{fq2_mul(t0, f), fq2_mul(t1, f), fq2_mul(t2, f)};
+}
+
+// ---- Fq12 -------------------------------------------------------------------
+ZKT_HD Fq12 fq12_one() { return Fq12{fq6_one(), fq6_zero()}; }
+ZKT_HD Fq12 fq12_add(const Fq12& a, const Fq12& b) { return Fq12{fq6_add(a.c0, b.c0), fq6_add(a.c1, b.c1)}; }
+ZKT_HD Fq12 fq12_sub(const Fq12& a, const Fq12& b) { return Fq12{fq6_sub(a.c0, b.c0), fq6_sub(a.c1, b.c1)}; }
+ZKT_HD Fq12 fq12_neg(const Fq12& a) { return Fq12{fq6_neg(a.c0), fq6_neg(a.c1)}; }
+ZKT_HD Fq12 fq12_conj(const Fq12& a) { return Fq12{a.c0, fq6_neg(a.c1)}; }
+// fq12.rs:135-147 is 4 Fq6 products; Karatsuba (3) gives the same element
+ZKT_FN Fq12 fq12_mul(const Fq12& a, const Fq12& b) {
+  Fq6 v0 = fq6_mul(a.c0, b.c0), v1 = fq6_mul(a.c1, b.c1);
+  Fq6 s = fq6_mul(fq6_add(a.c0, a.c1), fq6_add(b.c0, b.c1));
+  return Fq12{fq6_add(v0, fq6_mul_v(v1)), fq6_sub(fq6_sub(s, v0), v1)};
+}
+// complex squaring: (a0 + a1 w)^2 = (a0+a1)(a0+v a1) - v0 - v v0 + 2 v0 w,  v0 = a0 a1
+ZKT_FN Fq12 fq12_sqr(const Fq12& a) {
+  Fq6 v0 = fq6_mul(a.c0, a.c1);
+  Fq6 t = fq6_mul(fq6_add(a.c0, a.c1), fq6_add(a.c0, fq6_mul_v(a.c1)));
+  return Fq12{fq6_sub(fq6_sub(t, v0), fq6_mul_v(v0)), fq6_add(v0, v0)};
+}
+ZKT_FN Fq12 fq12_inv(const Fq12& a) {                                    // fq12.rs:31-40
+  Fq6 t = fq6_inv(fq6_sub(fq6_mul(a.c0, a.c0), fq6_mul_v(fq6_mul(a.c1, a.c1))));
+  return Fq12{fq6_mul(a.c0, t), fq6_neg(fq6_mul(a.c1, t))};
+}
+
+// Frobenius pi^K, K in {1,2}: conj^K on every Fq2 coefficient of w^i times gamma_i^(K)
+template <int K> ZKT_HD Fq2 frob_const(int idx) {
+  Fq2 g;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    g.c0.v[i] = K == 1 ? frob1_limb(idx, 0, i) : frob2_limb(idx, 0, i);
+    g.c1.v[i] = K == 1 ? frob1_limb(idx, 1, i) : frob2_limb(idx, 1, i);
+  }
+  return g;
+}
+template <int K> ZKT_HD Fq2 frob_coeff(const Fq2& a, int idx) {
+  Fq2 c = (K & 1) ? fq2_conj(a) : a;
+  if (idx == 0) return c;
+  if (K == 2) return fq2_mul_fq(c, frob_const<2>(idx).c0);   // gamma^(2) lies in Fq
+  return fq2_mul(c, frob_const<1>(idx));
+}
+template <int K> ZKT_FN Fq12 fq12_frob(const Fq12& a) {
+  // basis w^i: 0->c0.c0, 1->c1.c0, 2->c0.c1, 3->c1.c1, 4->c0.c2, 5->c1.c2
+  Fq12 r;
+  r.c0.c0 = frob_coeff<K>(a.c0.c0, 0); r.c1.c0 = frob_coeff<K>(a.c1.c0, 1);
+  r.c0.c1 = frob_coeff<K>(a.c0.c1, 2); r.c1.c1 = frob_coeff<K>(a.c1.c1, 3);
+  r.c0.c2 = frob_coeff<K>(a.c0.c2, 4); r.c1.c2 = frob_coeff<K>(a.c1.c2, 5);
+  return r;
+}
+
+// f * (a + b v^2 + c v w) with a in Fq, b,c in Fq2: the value of a Miller line at
+// an untwisted G2 point has exactly these slots (g12_point.rs:47-68).
+ZKT_FN Fq12 fq12_mul_line(const Fq12& f, const Fq& a, const Fq2& b, const Fq2& c) {
+  const Fq6 &x = f.c0, &y = f.c1;
+  // x*l0, l0 = a + b v^2
+  Fq6 xl0{fq2_add(fq2_mul_fq(x.c0, a), fq2_mul_xi(fq2_mul(x.c1, b))),
+          fq2_add(fq2_mul_fq(x.c1, a), fq2_mul_xi(fq2_mul(x.c2, b))),
+          fq2_add(fq2_mul_fq(x.c2, a), fq2_mul(x.c0, b))};
+  Fq6 yl0{fq2_add(fq2_mul_fq(y.c0, a), fq2_mul_xi(fq2_mul(y.c1, b))),
+          fq2_add(fq2_mul_fq(y.c1, a), fq2_mul_xi(fq2_mul(y.c2, b))),
+          fq2_add(fq2_mul_fq(y.c2, a), fq2_mul(y.c0, b))};
+  // *l1, l1 = c v
+  Fq6 xl1{fq2_mul_xi(fq2_mul(x.c2, c)), fq2_mul(x.c0, c), fq2_mul(x.c1, c)};
+  Fq6 yl1{fq2_mul_xi(fq2_mul(y.c2, c)), fq2_mul(y.c0, c), fq2_mul(y.c1, c)};
+  return Fq12{fq6_add(xl0, fq6_mul_v(yl1)), fq6_add(xl1, yl0)};
+}
+
+// square-and-multiply by a run-time exponent (u32 limbs, little endian), MSB first.
+// Fq12::pow (fq12.rs:42-57) is LSB-first; the power is the same element.
+ZKT_FN Fq12 fq12_pow(const Fq12& a, const uint32_t* e, int nlimbs) {
+  Fq12 r = fq12_one(); bool started = false;
+  for (int i = nlimbs * 32 - 1; i >= 0; --i) {
+    if (started) r = fq12_sqr(r);
+    if ((e[i >> 5] >> (i & 31)) & 1) { r = started ? fq12_mul(r, a) : a; started = true; }
+  }
+  return r;
+}
+
+}  // namespace zkt
