@@ -1,0 +1,150 @@
+/* zkt.h — C ABI of the MI355X-native engine for zk-toolkit's data-parallel hot path.
+ *
+ * The reference (exfinen/zk-toolkit, paths below relative to /root/reference/) has no
+ * FFI of its own: its public surface is value types with operator overloads.  The one
+ * precedent for a native backend is src/building_block/mcl/ (POD handle in a newtype,
+ * free functions with out-params, one global init behind Once: mcl_g1.rs:77-93,
+ * mcl/pairing.rs:11-17, mcl_initializer.rs:4-15).  This header is what a Rust `extern "C"`
+ * block for the zktoolkit_based path binds (INTEGRATION.md shows the stub); every entry
+ * point is batch-first and names the reference symbol it replaces.
+ *
+ * Data layout (all little-endian, plain arrays of uint64_t, caller-owned):
+ *   Fq   6 limbs, canonical residue in [0,q)      (PrimeFieldElem.e, prime_field_elem.rs:263-272)
+ *   Fr   4 limbs, canonical residue in [0,r)
+ *   scalars for point multiplication: `scalar_limbs` limbs each (4 or 6), used as-is,
+ *        NOT reduced mod r (macros.rs:10-21)
+ *   Fq2  {u1,u0} (fq2.rs:16-19) = 12 limbs; Fq6 {v2,v1,v0} (fq6.rs:16-20) = 36 limbs;
+ *   Fq12 {w1,w0} (fq12.rs:18-21) = 72 limbs = the order of the tests' to_strs (fq12.rs:179-195)
+ *   zkt_g1_affine / zkt_g2_affine / zkt_secp_affine: {x, y, is_infinity} mirroring
+ *        enum {Rational{x,y}, AtInfinity} (g1_point.rs:32-36, g2_point.rs:30-34,
+ *        secp256k1/affine_point.rs:23-27); x = y = 0 when is_infinity != 0.
+ * Montgomery form, projective coordinates and 32-bit limbs are internal to the kernels.
+ *
+ * Errors: the reference panics (inverse of zero prime_field_elem.rs:380-382,434-436;
+ * line through / evaluation at infinity rational_function.rs:36,59; index mismatch
+ * polynomial.rs:277-279).  Here every call returns a status and zkt_last_error_index()
+ * gives the first offending element; a Rust shim turns non-OK into panic!.
+ *
+ * Threading: zkt_init once (idempotent); calls are blocking and thread-safe; no host
+ * pointer is retained past return.  There is NO CPU fallback: without a HIP device every
+ * compute entry point returns ZKT_ERR_DEVICE.
+ *
+ * `_dev` variants take DEVICE pointers in the same layouts plus a hipStream_t (as void*)
+ * and are asynchronous on that stream except where they return a host result.
+ */
+#ifndef ZKT_H
+#define ZKT_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKT_OK 0
+#define ZKT_ERR_INV_ZERO 1   /* inverse of zero */
+#define ZKT_ERR_INFINITY 2   /* pairing argument at infinity */
+#define ZKT_ERR_SHAPE 3      /* bad size / null pointer / non-canonical input */
+#define ZKT_ERR_DEVICE 4     /* no HIP device, HIP error, or library not initialised */
+
+typedef struct { uint64_t x[6], y[6]; uint32_t is_infinity, _pad; } zkt_g1_affine;    /* 104 B */
+typedef struct { uint64_t x[12], y[12]; uint32_t is_infinity, _pad; } zkt_g2_affine;  /* 200 B; x = {u1,u0} */
+typedef struct { uint64_t x[4], y[4]; uint32_t is_infinity, _pad; } zkt_secp_affine;  /*  72 B */
+
+/* lifecycle — mcl_initializer.rs:4-15 (init once, panic on failure) */
+int zkt_init(int device);                 /* device = HIP ordinal, -1 = current */
+void zkt_shutdown(void);
+int zkt_version(void);
+const char* zkt_strerror(int status);
+size_t zkt_last_error_index(void);        /* thread-local; valid after a non-OK return */
+
+/* a1–a3: PrimeFieldElem::{plus,minus,times,sq,negate,inv} prime_field_elem.rs:278-457 */
+int zkt_fq_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fq_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fq_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fq_sqr_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_fq_neg_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_fq_inv_batch(const uint64_t* a, uint64_t* out, size_t n);     /* ZKT_ERR_INV_ZERO on a zero */
+int zkt_fr_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fr_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fr_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fr_sqr_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_fr_neg_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_fr_inv_batch(const uint64_t* a, uint64_t* out, size_t n);
+
+/* a4–a6: Fq2 fq2.rs:21-151, Fq6 fq6.rs:22-171, Fq12 fq12.rs:23-172 */
+int zkt_fq2_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fq2_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fq2_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fq2_inv_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_fq2_neg_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_fq2_reduce_batch(const uint64_t* a, uint64_t* out, size_t n);   /* Fq2::reduce = x(1+u), fq2.rs:52-58 */
+int zkt_fq6_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fq6_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fq6_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fq6_inv_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_fq6_neg_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_fq6_reduce_batch(const uint64_t* a, uint64_t* out, size_t n);   /* Fq6::reduce = x v, fq6.rs:54-62 */
+int zkt_fq12_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fq12_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_fq12_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);   /* also GTPoint `*`, gt_point.rs:16-31 */
+int zkt_fq12_inv_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_fq12_neg_batch(const uint64_t* a, uint64_t* out, size_t n);
+/* Fq12::pow fq12.rs:42-57: every element to the same exponent (little-endian u32 limbs) */
+int zkt_fq12_pow_batch(const uint64_t* a, const uint32_t* exp_limbs, size_t exp_nlimbs, uint64_t* out, size_t n);
+
+/* a7, a16: impl_affine_add! macros.rs:34-163; Neg g1_point.rs:177-195 */
+int zkt_g1_add_batch(const zkt_g1_affine* a, const zkt_g1_affine* b, zkt_g1_affine* out, size_t n);
+int zkt_g1_neg_batch(const zkt_g1_affine* a, zkt_g1_affine* out, size_t n);
+int zkt_g2_add_batch(const zkt_g2_affine* a, const zkt_g2_affine* b, zkt_g2_affine* out, size_t n);
+int zkt_g2_neg_batch(const zkt_g2_affine* a, zkt_g2_affine* out, size_t n);
+int zkt_secp_add_batch(const zkt_secp_affine* a, const zkt_secp_affine* b, zkt_secp_affine* out, size_t n);
+/* a8: impl_scalar_mul_point! macros.rs:1-32 — out[i] = scalars[i] * points[i] */
+int zkt_g1_mul_batch(const zkt_g1_affine* points, const uint64_t* scalars, int scalar_limbs, zkt_g1_affine* out, size_t n);
+int zkt_g2_mul_batch(const zkt_g2_affine* points, const uint64_t* scalars, int scalar_limbs, zkt_g2_affine* out, size_t n);
+int zkt_secp_mul_batch(const zkt_secp_affine* points, const uint64_t* scalars, int scalar_limbs, zkt_secp_affine* out, size_t n);
+/* a9: Polynomial::eval_with_g1_hidings polynomial.rs:271-281 — out = sum_i scalars[i]*bases[i];
+ * scalars are 4 limbs (256 bits) each, used as-is */
+int zkt_g1_msm(const zkt_g1_affine* bases, const uint64_t* scalars, size_t n, zkt_g1_affine* out);
+
+/* a10–a13: Pairing::tate pairing.rs:86-100 — out[i] = Fq12 of tate(g1[i], g2[i]) */
+int zkt_tate_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out_fq12, size_t n);
+/* a15: GTPoint == gt_point.rs:33-39 (all 12 coefficients); returns 1/0, or <0 = -status */
+int zkt_gt_eq(const uint64_t* a_fq12, const uint64_t* b_fq12);
+
+/* ---- device-resident entry points (inputs/outputs already in HBM) -------------------- */
+/* Bases kept on the device in kernel layout (Montgomery x,y, 96 B each) — the analogue of
+ * a CRS that is uploaded once (crs.rs:85-135) and reused by every prove call. */
+typedef struct zkt_g1_bases zkt_g1_bases;
+int zkt_g1_bases_upload(const zkt_g1_affine* host_bases, size_t n, zkt_g1_bases** out);
+int zkt_g1_bases_from_device(const zkt_g1_affine* dev_bases, size_t n, void* stream, zkt_g1_bases** out);
+size_t zkt_g1_bases_len(const zkt_g1_bases* b);
+void zkt_g1_bases_free(zkt_g1_bases* b);
+/* MSM over resident bases and DEVICE scalars (4 limbs each).  Writes the affine sum to
+ * host `out` (blocking) — and, if `dev_partial_jac` is non-NULL, the un-normalised
+ * Jacobian partial sum (36 u32 words X,Y,Z Montgomery) to that DEVICE buffer for a
+ * multi-GPU combine (see zkt_g1_jac_sum_dev). */
+int zkt_g1_msm_dev(const zkt_g1_bases* bases, const uint64_t* dev_scalars, size_t n, void* stream,
+                   zkt_g1_affine* out, uint32_t* dev_partial_jac);
+/* combine step of a sharded MSM: sum `count` Jacobian partials (36 u32 words each, device)
+ * and normalise to affine on the host */
+int zkt_g1_jac_sum_dev(const uint32_t* dev_partials, size_t count, void* stream, zkt_g1_affine* out);
+/* bytes of device workspace a zkt_g1_msm_dev of n terms allocates once and keeps */
+size_t zkt_g1_msm_workspace_bytes(size_t n);
+
+int zkt_g1_mul_batch_dev(const zkt_g1_affine* dev_points, const uint64_t* dev_scalars, int scalar_limbs,
+                         zkt_g1_affine* dev_out, size_t n, void* stream);
+int zkt_g2_mul_batch_dev(const zkt_g2_affine* dev_points, const uint64_t* dev_scalars, int scalar_limbs,
+                         zkt_g2_affine* dev_out, size_t n, void* stream);
+int zkt_tate_batch_dev(const zkt_g1_affine* dev_g1, const zkt_g2_affine* dev_g2, uint64_t* dev_out_fq12,
+                       size_t n, void* stream);
+int zkt_fq_mul_batch_dev(const uint64_t* dev_a, const uint64_t* dev_b, uint64_t* dev_out, size_t n, void* stream);
+
+/* timing hook for bench.py: device time (ms, HIP events on `stream`) of the dominant kernel
+ * of the last zkt_g1_msm_dev / zkt_tate_batch_dev call on this thread, and its name */
+float zkt_last_kernel_ms(void);
+const char* zkt_last_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKT_H */

@@ -1,0 +1,42 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every
+symbol include/zkt.h declares, struct sizes match, and compute entry points fail loudly
+(ZKT_ERR_DEVICE) rather than fall back when there is no GPU.  No compute calls here."""
+import ctypes, importlib, os
+import numpy as np
+import pytest
+from zkt_testlib import *
+
+zk = importlib.import_module("zk-toolkit_amd")
+
+
+def test_library_exports_every_declared_symbol():
+    L = zk.lib()
+    names = zk.exported_symbols()
+    assert len(names) >= 55
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_struct_sizes_match_header():
+    # zkt_g1_affine 104 B, zkt_g2_affine 200 B, zkt_secp_affine 72 B (include/zkt.h)
+    assert G1W * 8 == 104 and G2W * 8 == 200 and 9 * 8 == 72 and FQ12 * 8 == 576
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = zk.lib()
+    assert L.zkt_init(-1) == ZKT_ERR_DEVICE
+    a = np.zeros((1, 6), dtype=np.uint64)
+    assert L.zkt_fq_mul_batch(ptr(a), ptr(a), ptr(a), 1) == ZKT_ERR_DEVICE
+    with pytest.raises(zk.ZktError):
+        zk.init()
+
+
+def test_gt_eq_is_plain_memory_equality():
+    L = zk.lib()
+    a = np.arange(72, dtype=np.uint64); b = a.copy()
+    assert L.zkt_gt_eq(ptr(a), ptr(b)) == 1
+    b[5] ^= 1
+    assert L.zkt_gt_eq(ptr(a), ptr(b)) == 0

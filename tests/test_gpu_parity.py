@@ -1,0 +1,252 @@
+"""GPU parity: every entry point of the C ABI (include/zkt.h) against the CPU oracle on the
+same seeded inputs, bit-exact, plus the reference KATs straight through the GPU path and the
+edge cases the reference tests (infinity, P+P, P+(-P), zero scalars, inverse of zero)."""
+import ctypes, importlib
+import numpy as np
+import pytest
+from zkt_testlib import *
+
+pytestmark = pytest.mark.gpu
+zk = importlib.import_module("zk-toolkit_amd")
+O = oracle()
+K = kats()
+
+
+@pytest.fixture(scope="module")
+def L():
+    zk.init()
+    return zk.lib()
+
+
+def _rand_field(seed, n, mod, w):
+    rng = SplitMix64(seed)
+    xs = [rng.below(mod) for _ in range(n - 5)] + [0, 1, mod - 1, 2, mod - 2]
+    return ints_to_arr(xs, w)
+
+
+@pytest.mark.parametrize("pre,mod,w", [("fq", Q, 6), ("fr", R, 4)])
+def test_field_batch_ops(L, pre, mod, w):
+    n = 1000                                      # BASELINE config 1: 1000 Fq multiplications
+    a, b = _rand_field(1, n, mod, w), _rand_field(101, n, mod, w)[::-1].copy()
+    for op in ("add", "sub", "mul"):
+        got, want = np.zeros_like(a), np.zeros_like(a)
+        zk.check(getattr(L, f"zkt_{pre}_{op}_batch")(ptr(a), ptr(b), ptr(got), n))
+        assert getattr(O, f"zkto_{pre}_{op}_batch")(ptr(a), ptr(b), ptr(want), n) == 0
+        assert (got == want).all(), op
+    for op in ("sqr", "neg"):
+        got, want = np.zeros_like(a), np.zeros_like(a)
+        zk.check(getattr(L, f"zkt_{pre}_{op}_batch")(ptr(a), ptr(got), n))
+        assert getattr(O, f"zkto_{pre}_{op}_batch")(ptr(a), ptr(want), n) == 0
+        assert (got == want).all(), op
+    nz = a[(a != 0).any(axis=1)].copy()
+    got, want = np.zeros_like(nz), np.zeros_like(nz)
+    zk.check(getattr(L, f"zkt_{pre}_inv_batch")(ptr(nz), ptr(got), len(nz)))
+    assert getattr(O, f"zkto_{pre}_inv_batch")(ptr(nz), ptr(want), len(nz), None) == 0
+    assert (got == want).all()
+    # inverse of zero: Err("Cannot find inverse of zero") (prime_field_elem.rs:379-382)
+    rc = getattr(L, f"zkt_{pre}_inv_batch")(ptr(a), ptr(np.zeros_like(a)), n)
+    assert rc == ZKT_ERR_INV_ZERO and L.zkt_last_error_index() == n - 5
+    # empty batch
+    zk.check(getattr(L, f"zkt_{pre}_mul_batch")(ptr(a), ptr(b), ptr(got), 0))
+
+
+def test_fq_mul_large_kat(L):                   # prime_field_elem.rs:600-617 is mod secp-n; here the Fq2..12 KAT inputs
+    a1, b1 = Q - 3, Q - 5
+    a = ints_to_arr([a1], 6); b = ints_to_arr([b1], 6); o = np.zeros_like(a)
+    zk.check(L.zkt_fq_mul_batch(ptr(a), ptr(b), ptr(o), 1))
+    assert arr_to_ints(o) == [15]
+
+
+a1, b1, c1, d1 = Q - 3, Q - 5, Q - 7, Q - 9        # fq_test_helper.rs:9-34
+a2, b2, c2, d2 = (a1, b1), (b1, c1), (c1, d1), (d1, a1)
+a6, b6, c6, d6 = a2 + b2 + c2, b2 + c2 + d2, c2 + d2 + a2, d2 + a2 + b2
+
+
+def _tw(L, name, w, x, y=None):
+    a = ints_to_arr(list(x), 6).reshape(1, w); o = np.zeros((1, w), dtype=np.uint64)
+    if y is not None:
+        b = ints_to_arr(list(y), 6).reshape(1, w)
+        zk.check(getattr(L, name)(ptr(a), ptr(b), ptr(o), 1))
+    else:
+        zk.check(getattr(L, name)(ptr(a), ptr(o), 1))
+    return [str(v) for v in arr_to_ints(o.reshape(-1, 6))]
+
+
+def test_tower_reference_kats_on_gpu(L):         # fq2.rs:166-226, fq6.rs:190-275, fq12.rs:198-329
+    k = K["fq2"]; x, y = (a1, b1), (c1, d1)
+    assert _tw(L, "zkt_fq2_add_batch", 12, x, y) == k["add"]
+    assert _tw(L, "zkt_fq2_sub_batch", 12, x, y) == k["sub"]
+    assert _tw(L, "zkt_fq2_mul_batch", 12, x, y) == k["mul"]
+    assert _tw(L, "zkt_fq2_inv_batch", 12, x) == k["inv_a"]
+    assert _tw(L, "zkt_fq2_inv_batch", 12, y) == k["inv_b"]
+    assert _tw(L, "zkt_fq2_reduce_batch", 12, [int(v) for v in k["mul"]]) == k["reduce_mul"]
+    k = K["fq6"]
+    assert _tw(L, "zkt_fq6_add_batch", 36, a6, b6) == k["add"]
+    assert _tw(L, "zkt_fq6_sub_batch", 36, a6, b6) == k["sub"]
+    assert _tw(L, "zkt_fq6_mul_batch", 36, a6, b6) == k["mul"]
+    assert _tw(L, "zkt_fq6_inv_batch", 36, a6) == k["inv_a"]
+    assert _tw(L, "zkt_fq6_inv_batch", 36, b6) == k["inv_b"]
+    assert _tw(L, "zkt_fq6_reduce_batch", 36, [int(v) for v in k["mul"]]) == k["reduce_mul"]
+    k = K["fq12"]; a12, b12 = a6 + b6, c6 + d6
+    assert _tw(L, "zkt_fq12_add_batch", 72, a12, b12) == k["add"]
+    assert _tw(L, "zkt_fq12_sub_batch", 72, a12, b12) == k["sub"]
+    assert _tw(L, "zkt_fq12_mul_batch", 72, a12, b12) == k["mul"]
+    assert _tw(L, "zkt_fq12_inv_batch", 72, a12) == k["inv_a"]
+    assert _tw(L, "zkt_fq12_inv_batch", 72, b12) == k["inv_b"]
+    three = ints_to_arr([0] * 11 + [3], 6).reshape(1, 72); o = np.zeros((1, 72), dtype=np.uint64)
+    e = np.array([4], dtype=np.uint32)
+    zk.check(L.zkt_fq12_pow_batch(ptr(three), e.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 1, ptr(o), 1))
+    assert arr_to_ints(o.reshape(-1, 6)) == [0] * 11 + [81]      # fq12.rs:198-206
+
+
+@pytest.mark.parametrize("deg,w,fn", [(2, 12, "zkto_fq2_op"), (6, 36, "zkto_fq6_op"), (12, 72, "zkto_fq12_op")])
+def test_tower_batch_vs_oracle(L, deg, w, fn):
+    n = 96
+    rng = SplitMix64(200 + deg)
+    a = ints_to_arr([rng.below(Q) for _ in range(n * w // 6)], 6).reshape(n, w)
+    b = ints_to_arr([rng.below(Q) for _ in range(n * w // 6)], 6).reshape(n, w)
+    for op, name in ((0, "add"), (1, "sub"), (2, "mul")):
+        got, want = np.zeros_like(a), np.zeros_like(a)
+        zk.check(getattr(L, f"zkt_fq{deg}_{name}_batch")(ptr(a), ptr(b), ptr(got), n))
+        assert getattr(O, fn)(op, ptr(a), ptr(b), ptr(want), n) == 0
+        assert (got == want).all(), (deg, name)
+    for op, name in ((3, "inv"), (4, "neg")):
+        got, want = np.zeros_like(a), np.zeros_like(a)
+        zk.check(getattr(L, f"zkt_fq{deg}_{name}_batch")(ptr(a), ptr(got), n))
+        assert getattr(O, fn)(op, ptr(a), None, ptr(want), n) == 0
+        assert (got == want).all(), (deg, name)
+    z = np.zeros((2, w), dtype=np.uint64); z[0] = a[0]
+    assert getattr(L, f"zkt_fq{deg}_inv_batch")(ptr(z), ptr(np.zeros_like(z)), 2) == ZKT_ERR_INV_ZERO
+    assert L.zkt_last_error_index() == 1
+
+
+def _gen(grp):
+    g = np.zeros((1, {0: G1W, 1: G2W, 2: 9}[grp]), dtype=np.uint64)
+    [O.zkto_g1_generator, O.zkto_g2_generator, O.zkto_secp_generator][grp](ptr(g))
+    return g
+
+
+GROUPS = [(0, "g1", G1W, R), (1, "g2", G2W, R), (2, "secp", 9, SECP_N)]
+
+
+@pytest.mark.parametrize("grp,name,W,order", GROUPS)
+def test_group_mul_and_add_vs_oracle(L, grp, name, W, order):
+    n = 70 if grp != 1 else 40
+    rng = SplitMix64(300 + grp)
+    g = np.repeat(_gen(grp), n, axis=0)
+    ks = [rng.below(order) for _ in range(n - 8)] + [0, 1, 2, order, order - 1, order + 1, (1 << 256) - 1, 3]
+    sc = ints_to_arr(ks, 4)
+    got, want = np.zeros_like(g), np.zeros_like(g)
+    zk.check(getattr(L, f"zkt_{name}_mul_batch")(ptr(g), ptr(sc), 4, ptr(got), n))
+    assert getattr(O, f"zkto_{name}_mul_batch")(ptr(g), ptr(sc), 4, ptr(want), n, 8) == 0
+    assert (got == want).all()
+    pts = want                                        # k_i * G, includes infinity rows (k = 0, order)
+    # second operand: a rotation, the same points (P+P), negations (P+(-P)), infinities
+    neg = np.zeros_like(pts)
+    if grp < 2:
+        zk.check(getattr(L, f"zkt_{name}_neg_batch")(ptr(pts), ptr(neg), n))
+        wneg = np.zeros_like(pts); assert getattr(O, f"zkto_{name}_neg_batch")(ptr(pts), ptr(wneg), n) == 0
+        assert (neg == wneg).all()
+    else:
+        sc2 = ints_to_arr([(order - k) % order for k in ks], 4)
+        assert O.zkto_secp_mul_batch(ptr(g), ptr(sc2), 4, ptr(neg), n, 8) == 0
+    for other in (np.roll(pts, 1, axis=0), pts, neg):
+        got, want = np.zeros_like(pts), np.zeros_like(pts)
+        zk.check(getattr(L, f"zkt_{name}_add_batch")(ptr(pts), ptr(other.copy()), ptr(got), n))
+        assert getattr(O, f"zkto_{name}_add_batch")(ptr(pts), ptr(other.copy()), ptr(want), n) == 0
+        assert (got == want).all()
+
+
+def test_g1_reference_kats_on_gpu(L):            # g1_point.rs:224-237, 315-345, 352-371, 389-412
+    g = _gen(0)
+    pts = [(int(x), int(y)) for x, y in K["g1_multiples"]["points"]]
+    gs = np.repeat(g, 10, axis=0); sc = ints_to_arr(list(range(1, 11)), 4); got = np.zeros_like(gs)
+    zk.check(L.zkt_g1_mul_batch(ptr(gs), ptr(sc), 4, ptr(got), 10))
+    assert g1_from_arr(got) == pts
+    cases = K["g1_scalar_mul"]["cases"]                # scalar handed over as an Fq element (6 limbs)
+    gs = np.repeat(g, len(cases), axis=0); sc = ints_to_arr([int(c["k"]) for c in cases], 6); got = np.zeros_like(gs)
+    zk.check(L.zkt_g1_mul_batch(ptr(gs), ptr(sc), 6, ptr(got), len(cases)))
+    assert g1_from_arr(got) == [(int(c["x"]), int(c["y"])) for c in cases]
+    tab = K["g1_add_table"]["cases"]
+    a = g1_arr([pts[t[0] - 1] for t in tab]); b = g1_arr([pts[t[1] - 1] for t in tab]); got = np.zeros_like(a)
+    zk.check(L.zkt_g1_add_batch(ptr(a), ptr(b), ptr(got), len(tab)))
+    assert g1_from_arr(got) == [pts[t[2] - 1] for t in tab]
+
+
+def test_g2_and_secp_reference_kats_on_gpu(L):   # g2_point.rs:320-350,357-403; secp256k1/affine_point.rs:292-311,331-380
+    g = _gen(1)
+    pts = [((int(p[0]), int(p[1])), (int(p[2]), int(p[3]))) for p in K["g2_multiples"]["points"]]
+    gs = np.repeat(g, 11, axis=0); c = K["g2_scalar_mul"]["cases"][0]
+    sc = ints_to_arr(list(range(1, 11)) + [int(c["k"])], 4); got = np.zeros_like(gs)
+    zk.check(L.zkt_g2_mul_batch(ptr(gs), ptr(sc), 4, ptr(got), 11))
+    assert g2_from_arr(got) == pts + [((int(c["x1"]), int(c["x0"])), (int(c["y1"]), int(c["y0"])))]
+    g = _gen(2)
+    cases = K["secp_scalar_mul"]["cases"]
+    gs = np.repeat(g, len(cases), axis=0); sc = ints_to_arr([int(c["k"], 16) % SECP_P for c in cases], 4); got = np.zeros_like(gs)
+    zk.check(L.zkt_secp_mul_batch(ptr(gs), ptr(sc), 4, ptr(got), len(cases)))
+    for row, c in zip(got, cases):
+        assert (limbs_to_int(row[:4]), limbs_to_int(row[4:8]), int(row[8])) == (int(c["x"], 16), int(c["y"], 16), 0)
+
+
+def test_tate_batch_vs_oracle_and_bilinearity(L):
+    # BASELINE config 1: 10 Tate pairings, P_i = k_i G1, Q_i = k'_i G2 (g1_point.rs:83-88)
+    n = 10
+    rng = SplitMix64(2)
+    ks = [rng.below(R) for _ in range(n)]; ks[0] = 1
+    kq = [rng.below(R) for _ in range(n)]; kq[0] = 1
+    ps, qs = np.repeat(_gen(0), n, axis=0), np.repeat(_gen(1), n, axis=0)
+    P, Qp = np.zeros_like(ps), np.zeros_like(qs)
+    assert O.zkto_g1_mul_batch(ptr(ps), ptr(ints_to_arr(ks, 4)), 4, ptr(P), n, 8) == 0
+    assert O.zkto_g2_mul_batch(ptr(qs), ptr(ints_to_arr(kq, 4)), 4, ptr(Qp), n, 8) == 0
+    got, want = np.zeros((n, FQ12), dtype=np.uint64), np.zeros((n, FQ12), dtype=np.uint64)
+    zk.check(L.zkt_tate_batch(ptr(P), ptr(Qp), ptr(got), n))
+    assert O.zkto_pairing_batch(3, ptr(P), ptr(Qp), ptr(want), n, 8, None) == 0
+    assert (got == want).all()
+    # bilinearity on the GPU results alone (pairing.rs:107-123): e(P,Q)^(k k') == e(kP, k'Q) via GT mul chain is
+    # too long; check e(P+10P,Q) = e(P,Q) e(10P,Q) as the reference does
+    g1 = _gen(0); p10 = np.zeros_like(g1); p11 = np.zeros_like(g1)
+    assert O.zkto_g1_mul_batch(ptr(g1), ptr(ints_to_arr([10], 4)), 4, ptr(p10), 1, 1) == 0
+    assert O.zkto_g1_add_batch(ptr(g1), ptr(p10), ptr(p11), 1) == 0
+    three = np.concatenate([g1, p10, p11]); q3 = np.repeat(_gen(1), 3, axis=0); e = np.zeros((3, FQ12), dtype=np.uint64)
+    zk.check(L.zkt_tate_batch(ptr(three), ptr(q3), ptr(e), 3))
+    prod = np.zeros((1, FQ12), dtype=np.uint64)
+    zk.check(L.zkt_fq12_mul_batch(ptr(e[0:1].copy()), ptr(e[1:2].copy()), ptr(prod), 1))
+    assert L.zkt_gt_eq(ptr(prod), ptr(e[2:3].copy())) == 1
+    # infinity argument -> error with the index (rational_function.rs:36,59 panic)
+    P[3, :] = 0; P[3, 12] = 1
+    assert L.zkt_tate_batch(ptr(P), ptr(Qp), ptr(got), n) == ZKT_ERR_INFINITY and L.zkt_last_error_index() == 3
+
+
+def _msm_oracle(bases, sc, n):
+    o = np.zeros((1, G1W), dtype=np.uint64)
+    assert O.zkto_g1_msm(ptr(bases), ptr(sc), 4, n, ptr(o)) == 0
+    return o
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 33, 255, 1024])
+def test_g1_msm_vs_oracle(L, n):
+    rng = SplitMix64(400 + n)
+    g = np.repeat(_gen(0), n, axis=0); bases = np.zeros_like(g)
+    zk.check(L.zkt_g1_mul_batch(ptr(g), ptr(ints_to_arr([rng.below(R) for _ in range(n)], 4)), 4, ptr(bases), n))
+    ss = [rng.below(R) for _ in range(n)]
+    if n > 4: ss[1] = 0; ss[2] = 1; ss[3] = R - 1
+    sc = ints_to_arr(ss, 4)
+    got = np.zeros((1, G1W), dtype=np.uint64)
+    zk.check(L.zkt_g1_msm(ptr(bases), ptr(sc), n, ptr(got)))
+    assert (got == _msm_oracle(bases, sc, n)).all()
+
+
+def test_g1_msm_edge_cases(L):
+    # repeated bases (bulletproofs.rs:231-246 uses gg=[g,g]), a base and its negation, infinity bases,
+    # all-zero scalars, scalars >= r used as-is (macros.rs:10-21)
+    g = _gen(0); n = 8
+    neg = np.zeros_like(g); assert O.zkto_g1_neg_batch(ptr(g), ptr(neg), 1) == 0
+    inf = g1_arr([None])
+    bases = np.concatenate([g, g, g, neg, inf, g, neg, inf])
+    for ss in ([1, 1, 1, 1, 5, 0, 0, 7], [5, 5, 3, 13, 1, 2, 2, 0], [0] * 8, [R, R + 1, (1 << 256) - 1, 1, 1, 2**255, 3, 4]):
+        sc = ints_to_arr(ss, 4); got = np.zeros((1, G1W), dtype=np.uint64)
+        zk.check(L.zkt_g1_msm(ptr(bases), ptr(sc), n, ptr(got)))
+        assert (got == _msm_oracle(bases, sc, n)).all(), ss
+    got = np.zeros((1, G1W), dtype=np.uint64)
+    zk.check(L.zkt_g1_msm(ptr(bases), ptr(sc), 0, ptr(got)))
+    assert g1_from_arr(got) == [None]                 # empty sum = G1Point::zero() (polynomial.rs:275)

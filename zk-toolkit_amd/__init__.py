@@ -1,0 +1,64 @@
+"""Host-side loader for the MI355X-native engine (ctypes over the C ABI in include/zkt.h).
+
+Import with  importlib.import_module("zk-toolkit_amd")  (the directory name carries a hyphen).
+The HIP library is the only compute path: if libzkt_hip.so is missing or no GPU is present,
+`lib()` / `init()` raise — there is no CPU fallback."""
+import ctypes, os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkt_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "zkt.h")
+
+ZKT_OK, ZKT_ERR_INV_ZERO, ZKT_ERR_INFINITY, ZKT_ERR_SHAPE, ZKT_ERR_DEVICE = 0, 1, 2, 3, 4
+G1_WORDS64, G2_WORDS64, FQ12_WORDS64 = 13, 25, 72
+
+_lib = None
+
+
+class ZktError(RuntimeError):
+    def __init__(self, status, index=None):
+        self.status, self.index = status, index
+        msg = lib().zkt_strerror(status).decode()
+        super().__init__(f"zkt status {status}: {msg}" + (f" (element {index})" if index is not None else ""))
+
+
+def lib():
+    """ctypes handle on libzkt_hip.so; raises if the extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP library is the only compute path, there is no CPU fallback)")
+        L = ctypes.CDLL(LIB_PATH)
+        L.zkt_strerror.restype = ctypes.c_char_p
+        L.zkt_last_error_index.restype = ctypes.c_size_t
+        L.zkt_last_kernel_ms.restype = ctypes.c_float
+        L.zkt_last_kernel_name.restype = ctypes.c_char_p
+        L.zkt_g1_bases_len.restype = ctypes.c_size_t
+        L.zkt_g1_msm_workspace_bytes.restype = ctypes.c_size_t
+        L.zkt_g1_msm_workspace_bytes.argtypes = [ctypes.c_size_t]
+        _lib = L
+    return _lib
+
+
+def init(device=-1):
+    rc = lib().zkt_init(int(device))
+    if rc != ZKT_OK:
+        raise ZktError(rc)
+
+
+def check(rc):
+    if rc != ZKT_OK:
+        raise ZktError(rc, lib().zkt_last_error_index() if rc in (ZKT_ERR_INV_ZERO, ZKT_ERR_INFINITY) else None)
+
+
+def exported_symbols():
+    """Every zkt_* function declared in include/zkt.h (for the ABI completeness test)."""
+    import re
+    names = []
+    with open(HEADER) as f:
+        txt = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    for m in re.finditer(r"\b(zkt_[a-z0-9_]+)\s*\(", txt):
+        if m.group(1) not in names:
+            names.append(m.group(1))
+    return names

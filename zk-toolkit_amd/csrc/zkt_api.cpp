@@ -1,0 +1,342 @@
+// C ABI (include/zkt.h) over the HIP kernels.  Host-pointer entry points stage through
+// a grow-only device arena; `_dev` entry points launch on the caller's stream.  There is
+// no CPU compute path in this file: without a device every entry point fails.
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include "../../include/zkt.h"
+#include "zkt_internal.h"
+
+using namespace zkt;
+
+namespace zkt {
+hipError_t launch_g1_precompute(uint32_t* table, uint8_t* inf, size_t n, int c, int nwin, hipStream_t s);
+}
+
+namespace {
+
+struct Ctx {
+  bool ready = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  unsigned long long* d_err = nullptr;
+  uint8_t* arena = nullptr; size_t arena_bytes = 0;
+  std::mutex mu;
+};
+Ctx g;
+thread_local size_t t_err_index = 0;
+thread_local float t_kernel_ms = 0.f;
+thread_local const char* t_kernel_name = "";
+
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[zkt] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return ZKT_ERR_DEVICE; } } while (0)
+
+int ensure_ready() { return g.ready ? ZKT_OK : ZKT_ERR_DEVICE; }
+
+// grow-only staging arena (caller holds g.mu)
+int arena_reserve(size_t bytes) {
+  if (bytes <= g.arena_bytes) return ZKT_OK;
+  if (g.arena) { HIPCHK(hipFree(g.arena)); g.arena = nullptr; g.arena_bytes = 0; }
+  size_t want = bytes + (bytes >> 2) + (1 << 20);
+  HIPCHK(hipMalloc((void**)&g.arena, want));
+  g.arena_bytes = want;
+  return ZKT_OK;
+}
+struct Carver {
+  uint8_t* p; size_t off = 0;
+  explicit Carver(uint8_t* base) : p(base) {}
+  template <class T> T* take(size_t bytes) { off = (off + 255) & ~size_t(255); T* r = (T*)(p + off); off += bytes; return r; }
+};
+size_t padded(size_t b) { return (b + 255) & ~size_t(255); }
+
+int reset_err(hipStream_t s) {
+  unsigned long long v = NO_ERR;
+  HIPCHK(hipMemcpyAsync(g.d_err, &v, sizeof(v), hipMemcpyHostToDevice, s));
+  return ZKT_OK;
+}
+int fetch_err(hipStream_t s, int code_if_set) {
+  unsigned long long v = NO_ERR;
+  HIPCHK(hipMemcpyAsync(&v, g.d_err, sizeof(v), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (v != NO_ERR) { t_err_index = (size_t)v; return code_if_set; }
+  return ZKT_OK;
+}
+
+// generic host-staged elementwise op: in_a, in_b (optional) -> out, fixed bytes per element
+template <class Launch>
+int staged(const void* a, size_t a_bytes, const void* b, size_t b_bytes, void* out, size_t out_bytes, size_t n, int err_code, Launch launch) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (n == 0) return ZKT_OK;
+  if (!a || !out || (b_bytes && !b)) return ZKT_ERR_SHAPE;
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCHK(hipSetDevice(g.device));
+  int rc = arena_reserve(padded(a_bytes * n) + padded(b_bytes * n) + padded(out_bytes * n) + 1024);
+  if (rc) return rc;
+  Carver cv(g.arena);
+  uint32_t* da = cv.take<uint32_t>(a_bytes * n);
+  uint32_t* db = b_bytes ? cv.take<uint32_t>(b_bytes * n) : nullptr;
+  uint32_t* dout = cv.take<uint32_t>(out_bytes * n);
+  HIPCHK(hipMemcpyAsync(da, a, a_bytes * n, hipMemcpyHostToDevice, g.stream));
+  if (db) HIPCHK(hipMemcpyAsync(db, b, b_bytes * n, hipMemcpyHostToDevice, g.stream));
+  if ((rc = reset_err(g.stream))) return rc;
+  HIPCHK(launch(da, db, dout, g.stream));
+  HIPCHK(hipMemcpyAsync(out, dout, out_bytes * n, hipMemcpyDeviceToHost, g.stream));
+  return fetch_err(g.stream, err_code);
+}
+
+int fp_batch(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  const size_t w = field == F_FQ ? 48 : 32;
+  const bool binary = op == OP_ADD || op == OP_SUB || op == OP_MUL;
+  return staged(a, w, binary ? b : nullptr, binary ? w : 0, out, w, n, ZKT_ERR_INV_ZERO,
+                [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_fp_op(field, op, da, db, dout, n, g.d_err, s); });
+}
+int tower_batch(int deg, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  const size_t w = (size_t)deg * 48;
+  const bool binary = op == T_ADD || op == T_SUB || op == T_MUL;
+  return staged(a, w, binary ? b : nullptr, binary ? w : 0, out, w, n, ZKT_ERR_INV_ZERO,
+                [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_tower_op(deg, op, da, db, dout, n, g.d_err, s); });
+}
+size_t pt_bytes(int grp) { return grp == G_G1 ? sizeof(zkt_g1_affine) : grp == G_G2 ? sizeof(zkt_g2_affine) : sizeof(zkt_secp_affine); }
+
+}  // namespace
+
+struct zkt_g1_bases {
+  size_t n = 0;
+  MsmPlan plan{};
+  uint32_t* table = nullptr;     // nwin*n x 24 words
+  uint8_t* inf = nullptr;        // nwin*n flags
+  void* workspace = nullptr;
+  uint32_t* d_result_jac = nullptr;   // 36 words
+  uint32_t* d_out_abi = nullptr;      // 26 words
+};
+
+extern "C" {
+
+int zkt_version(void) { return 1; }
+const char* zkt_strerror(int s) {
+  switch (s) {
+    case ZKT_OK: return "ok";
+    case ZKT_ERR_INV_ZERO: return "Cannot find inverse of zero";
+    case ZKT_ERR_INFINITY: return "pairing argument is the point at infinity";
+    case ZKT_ERR_SHAPE: return "bad size, null pointer or non-canonical input";
+    case ZKT_ERR_DEVICE: return "no HIP device / HIP error / zkt_init not called";
+  }
+  return "unknown";
+}
+size_t zkt_last_error_index(void) { return t_err_index; }
+float zkt_last_kernel_ms(void) { return t_kernel_ms; }
+const char* zkt_last_kernel_name(void) { return t_kernel_name; }
+
+int zkt_init(int device) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (g.ready) return ZKT_OK;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { fprintf(stderr, "[zkt] no HIP device: this library has no CPU path\n"); return ZKT_ERR_DEVICE; }
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return ZKT_ERR_DEVICE; }
+  if (device >= count) return ZKT_ERR_DEVICE;
+  HIPCHK(hipSetDevice(device));
+  g.device = device;
+  HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  HIPCHK(hipMalloc((void**)&g.d_err, 64));
+  g.ready = true;
+  return ZKT_OK;
+}
+void zkt_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.ready) return;
+  (void)hipSetDevice(g.device);
+  if (g.arena) (void)hipFree(g.arena);
+  if (g.d_err) (void)hipFree(g.d_err);
+  if (g.stream) (void)hipStreamDestroy(g.stream);
+  g.ready = false; g.device = -1; g.stream = nullptr; g.d_err = nullptr; g.arena = nullptr; g.arena_bytes = 0;
+}
+
+#define FP_BIN(name, field, op) int name(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return fp_batch(field, op, a, b, out, n); }
+#define FP_UN(name, field, op) int name(const uint64_t* a, uint64_t* out, size_t n) { return fp_batch(field, op, a, nullptr, out, n); }
+FP_BIN(zkt_fq_add_batch, F_FQ, OP_ADD) FP_BIN(zkt_fq_sub_batch, F_FQ, OP_SUB) FP_BIN(zkt_fq_mul_batch, F_FQ, OP_MUL)
+FP_UN(zkt_fq_sqr_batch, F_FQ, OP_SQR) FP_UN(zkt_fq_neg_batch, F_FQ, OP_NEG) FP_UN(zkt_fq_inv_batch, F_FQ, OP_INV)
+FP_BIN(zkt_fr_add_batch, F_FR, OP_ADD) FP_BIN(zkt_fr_sub_batch, F_FR, OP_SUB) FP_BIN(zkt_fr_mul_batch, F_FR, OP_MUL)
+FP_UN(zkt_fr_sqr_batch, F_FR, OP_SQR) FP_UN(zkt_fr_neg_batch, F_FR, OP_NEG) FP_UN(zkt_fr_inv_batch, F_FR, OP_INV)
+
+#define TW_BIN(name, deg, op) int name(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return tower_batch(deg, op, a, b, out, n); }
+#define TW_UN(name, deg, op) int name(const uint64_t* a, uint64_t* out, size_t n) { return tower_batch(deg, op, a, nullptr, out, n); }
+TW_BIN(zkt_fq2_add_batch, 2, T_ADD) TW_BIN(zkt_fq2_sub_batch, 2, T_SUB) TW_BIN(zkt_fq2_mul_batch, 2, T_MUL)
+TW_UN(zkt_fq2_inv_batch, 2, T_INV) TW_UN(zkt_fq2_neg_batch, 2, T_NEG) TW_UN(zkt_fq2_reduce_batch, 2, T_REDUCE)
+TW_BIN(zkt_fq6_add_batch, 6, T_ADD) TW_BIN(zkt_fq6_sub_batch, 6, T_SUB) TW_BIN(zkt_fq6_mul_batch, 6, T_MUL)
+TW_UN(zkt_fq6_inv_batch, 6, T_INV) TW_UN(zkt_fq6_neg_batch, 6, T_NEG) TW_UN(zkt_fq6_reduce_batch, 6, T_REDUCE)
+TW_BIN(zkt_fq12_add_batch, 12, T_ADD) TW_BIN(zkt_fq12_sub_batch, 12, T_SUB) TW_BIN(zkt_fq12_mul_batch, 12, T_MUL)
+TW_UN(zkt_fq12_inv_batch, 12, T_INV) TW_UN(zkt_fq12_neg_batch, 12, T_NEG)
+
+int zkt_fq12_pow_batch(const uint64_t* a, const uint32_t* e, size_t nl, uint64_t* out, size_t n) {
+  if (!e || nl == 0 || nl > 4096) return ZKT_ERR_SHAPE;
+  // the exponent rides in front of the `a` staging area as a second input of fixed size
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (n == 0) return ZKT_OK;
+  if (!a || !out) return ZKT_ERR_SHAPE;
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCHK(hipSetDevice(g.device));
+  int rc = arena_reserve(padded(576 * n) * 2 + padded(nl * 4) + 1024);
+  if (rc) return rc;
+  Carver cv(g.arena);
+  uint32_t* da = cv.take<uint32_t>(576 * n); uint32_t* dout = cv.take<uint32_t>(576 * n); uint32_t* de = cv.take<uint32_t>(nl * 4);
+  HIPCHK(hipMemcpyAsync(da, a, 576 * n, hipMemcpyHostToDevice, g.stream));
+  HIPCHK(hipMemcpyAsync(de, e, nl * 4, hipMemcpyHostToDevice, g.stream));
+  HIPCHK(launch_fq12_pow(da, de, (int)nl, dout, n, g.stream));
+  HIPCHK(hipMemcpyAsync(out, dout, 576 * n, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return ZKT_OK;
+}
+
+static int group_add(int grp, const void* a, const void* b, void* out, size_t n) {
+  size_t w = pt_bytes(grp);
+  return staged(a, w, b, w, out, w, n, ZKT_ERR_SHAPE,
+                [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_group_add(grp, da, db, dout, n, s); });
+}
+static int group_neg(int grp, const void* a, void* out, size_t n) {
+  size_t w = pt_bytes(grp);
+  return staged(a, w, nullptr, 0, out, w, n, ZKT_ERR_SHAPE,
+                [&](uint32_t* da, uint32_t*, uint32_t* dout, hipStream_t s) { return launch_group_neg(grp, da, dout, n, s); });
+}
+static int group_mul(int grp, const void* pts, const uint64_t* scalars, int limbs, void* out, size_t n) {
+  if (limbs < 1 || limbs > 6) return ZKT_ERR_SHAPE;
+  size_t w = pt_bytes(grp);
+  return staged(pts, w, scalars, (size_t)limbs * 8, out, w, n, ZKT_ERR_SHAPE,
+                [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_group_mul(grp, da, db, limbs * 2, dout, n, s); });
+}
+int zkt_g1_add_batch(const zkt_g1_affine* a, const zkt_g1_affine* b, zkt_g1_affine* o, size_t n) { return group_add(G_G1, a, b, o, n); }
+int zkt_g2_add_batch(const zkt_g2_affine* a, const zkt_g2_affine* b, zkt_g2_affine* o, size_t n) { return group_add(G_G2, a, b, o, n); }
+int zkt_secp_add_batch(const zkt_secp_affine* a, const zkt_secp_affine* b, zkt_secp_affine* o, size_t n) { return group_add(G_SECP, a, b, o, n); }
+int zkt_g1_neg_batch(const zkt_g1_affine* a, zkt_g1_affine* o, size_t n) { return group_neg(G_G1, a, o, n); }
+int zkt_g2_neg_batch(const zkt_g2_affine* a, zkt_g2_affine* o, size_t n) { return group_neg(G_G2, a, o, n); }
+int zkt_g1_mul_batch(const zkt_g1_affine* p, const uint64_t* k, int l, zkt_g1_affine* o, size_t n) { return group_mul(G_G1, p, k, l, o, n); }
+int zkt_g2_mul_batch(const zkt_g2_affine* p, const uint64_t* k, int l, zkt_g2_affine* o, size_t n) { return group_mul(G_G2, p, k, l, o, n); }
+int zkt_secp_mul_batch(const zkt_secp_affine* p, const uint64_t* k, int l, zkt_secp_affine* o, size_t n) { return group_mul(G_SECP, p, k, l, o, n); }
+
+int zkt_tate_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out, size_t n) {
+  return staged(g1, sizeof(zkt_g1_affine), g2, sizeof(zkt_g2_affine), out, 576, n, ZKT_ERR_INFINITY,
+                [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_tate(da, db, dout, n, g.d_err, s); });
+}
+int zkt_gt_eq(const uint64_t* a, const uint64_t* b) {
+  if (!a || !b) return -ZKT_ERR_SHAPE;
+  return memcmp(a, b, 576) == 0 ? 1 : 0;   // canonical residues: memcmp equality <=> Fq12 equality (fq12.rs:88-93)
+}
+
+// ---- device-resident entry points --------------------------------------------------
+int zkt_fq_mul_batch_dev(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  HIPCHK(launch_fp_op(F_FQ, OP_MUL, (const uint32_t*)a, (const uint32_t*)b, (uint32_t*)out, n, g.d_err, (hipStream_t)stream));
+  return ZKT_OK;
+}
+int zkt_g1_mul_batch_dev(const zkt_g1_affine* p, const uint64_t* k, int limbs, zkt_g1_affine* out, size_t n, void* stream) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (limbs < 1 || limbs > 6) return ZKT_ERR_SHAPE;
+  HIPCHK(launch_group_mul(G_G1, (const uint32_t*)p, (const uint32_t*)k, limbs * 2, (uint32_t*)out, n, (hipStream_t)stream));
+  return ZKT_OK;
+}
+int zkt_g2_mul_batch_dev(const zkt_g2_affine* p, const uint64_t* k, int limbs, zkt_g2_affine* out, size_t n, void* stream) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (limbs < 1 || limbs > 6) return ZKT_ERR_SHAPE;
+  HIPCHK(launch_group_mul(G_G2, (const uint32_t*)p, (const uint32_t*)k, limbs * 2, (uint32_t*)out, n, (hipStream_t)stream));
+  return ZKT_OK;
+}
+int zkt_tate_batch_dev(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out, size_t n, void* stream) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lk(g.mu);
+  int rc = reset_err(s); if (rc) return rc;
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, s));
+  HIPCHK(launch_tate((const uint32_t*)g1, (const uint32_t*)g2, (uint32_t*)out, n, g.d_err, s));
+  HIPCHK(hipEventRecord(e1, s));
+  rc = fetch_err(s, ZKT_ERR_INFINITY);
+  HIPCHK(hipEventElapsedTime(&t_kernel_ms, e0, e1)); t_kernel_name = "k_tate";
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return rc;
+}
+
+static int bases_build(zkt_g1_bases* h, const uint32_t* dev_abi, hipStream_t s) {
+  const size_t n = h->n;
+  h->plan = msm_plan(n);
+  const size_t tot = (size_t)h->plan.nwin * (n ? n : 1);
+  HIPCHK(hipMalloc((void**)&h->table, tot * 96));
+  HIPCHK(hipMalloc((void**)&h->inf, tot));
+  HIPCHK(hipMalloc(&h->workspace, h->plan.ws_bytes));
+  HIPCHK(hipMalloc((void**)&h->d_result_jac, 36 * 4));
+  HIPCHK(hipMalloc((void**)&h->d_out_abi, 26 * 4));
+  HIPCHK(launch_g1_to_kernel_layout(dev_abi, h->table, h->inf, n, s));
+  HIPCHK(launch_g1_precompute(h->table, h->inf, n, h->plan.c, h->plan.nwin, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKT_OK;
+}
+int zkt_g1_bases_from_device(const zkt_g1_affine* dev_bases, size_t n, void* stream, zkt_g1_bases** out) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!out || (n && !dev_bases) || n >= (size_t(1) << 26)) return ZKT_ERR_SHAPE;
+  zkt_g1_bases* h = new zkt_g1_bases(); h->n = n;
+  int rc = bases_build(h, (const uint32_t*)dev_bases, (hipStream_t)stream);
+  if (rc) { zkt_g1_bases_free(h); return rc; }
+  *out = h; return ZKT_OK;
+}
+int zkt_g1_bases_upload(const zkt_g1_affine* host, size_t n, zkt_g1_bases** out) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!out || (n && !host)) return ZKT_ERR_SHAPE;
+  HIPCHK(hipSetDevice(g.device));
+  uint32_t* tmp = nullptr;
+  HIPCHK(hipMalloc((void**)&tmp, (n ? n : 1) * sizeof(zkt_g1_affine)));
+  if (n) HIPCHK(hipMemcpy(tmp, host, n * sizeof(zkt_g1_affine), hipMemcpyHostToDevice));
+  int rc = zkt_g1_bases_from_device((const zkt_g1_affine*)tmp, n, g.stream, out);
+  hipFree(tmp);
+  return rc;
+}
+size_t zkt_g1_bases_len(const zkt_g1_bases* b) { return b ? b->n : 0; }
+void zkt_g1_bases_free(zkt_g1_bases* h) {
+  if (!h) return;
+  if (h->table) hipFree(h->table); if (h->inf) hipFree(h->inf); if (h->workspace) hipFree(h->workspace);
+  if (h->d_result_jac) hipFree(h->d_result_jac); if (h->d_out_abi) hipFree(h->d_out_abi);
+  delete h;
+}
+size_t zkt_g1_msm_workspace_bytes(size_t n) { MsmPlan p = msm_plan(n); return p.ws_bytes + (size_t)p.nwin * n * 97; }
+
+int zkt_g1_msm_dev(const zkt_g1_bases* h, const uint64_t* dev_scalars, size_t n, void* stream, zkt_g1_affine* out, uint32_t* dev_partial_jac) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!h || n != h->n || (n && !dev_scalars) || (!out && !dev_partial_jac)) return ZKT_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  float ms = 0.f;
+  HIPCHK(launch_g1_msm(h->plan, h->table, h->inf, (const uint32_t*)dev_scalars, h->workspace, h->d_result_jac, s, &ms));
+  t_kernel_ms = ms; t_kernel_name = "k_accumulate";
+  if (dev_partial_jac) HIPCHK(hipMemcpyAsync(dev_partial_jac, h->d_result_jac, 36 * 4, hipMemcpyDeviceToDevice, s));
+  if (out) {
+    HIPCHK(launch_g1_jac_sum_to_affine(h->d_result_jac, 1, h->d_out_abi, s));
+    HIPCHK(hipMemcpyAsync(out, h->d_out_abi, sizeof(zkt_g1_affine), hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKT_OK;
+}
+int zkt_g1_jac_sum_dev(const uint32_t* dev_partials, size_t count, void* stream, zkt_g1_affine* out) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!dev_partials || !out || count == 0) return ZKT_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t* d_out = nullptr;
+  HIPCHK(hipMalloc((void**)&d_out, 26 * 4));
+  HIPCHK(launch_g1_jac_sum_to_affine(dev_partials, count, d_out, s));
+  HIPCHK(hipMemcpyAsync(out, d_out, sizeof(zkt_g1_affine), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  hipFree(d_out);
+  return ZKT_OK;
+}
+int zkt_g1_msm(const zkt_g1_affine* bases, const uint64_t* scalars, size_t n, zkt_g1_affine* out) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!out || (n && (!bases || !scalars))) return ZKT_ERR_SHAPE;
+  if (n == 0) { memset(out, 0, sizeof(*out)); out->is_infinity = 1; return ZKT_OK; }
+  zkt_g1_bases* h = nullptr;
+  int rc = zkt_g1_bases_upload(bases, n, &h);
+  if (rc) return rc;
+  uint64_t* d_s = nullptr;
+  if (hipMalloc((void**)&d_s, n * 32) != hipSuccess) { zkt_g1_bases_free(h); return ZKT_ERR_DEVICE; }
+  hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice);
+  rc = zkt_g1_msm_dev(h, d_s, n, g.stream, out, nullptr);
+  hipFree(d_s); zkt_g1_bases_free(h);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+// Batched prime-field and tower kernels: one element per lane.
+// Rows a1–a6 of SURVEY §8: PrimeFieldElem ops (prime_field_elem.rs:278-457), Fq2/Fq6/Fq12
+// ops (fq2.rs, fq6.rs, fq12.rs).  Inputs/outputs are canonical residues (include/zkt.h).
+#include "abi.h"
+#include "zkt_internal.h"
+
+namespace zkt {
+
+static constexpr int TPB = 256;
+static inline unsigned nblocks(size_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
+
+template <class C, int OP>
+__global__ void __launch_bounds__(TPB) k_fp_op(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                               uint32_t* __restrict__ out, size_t n, unsigned long long* err) {
+  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  Fp<C> x = ld_raw<C>(a + i * C::N), r;
+  if (OP == OP_ADD) r = fp_add(x, ld_raw<C>(b + i * C::N));          // canonical in, canonical out
+  else if (OP == OP_SUB) r = fp_sub(x, ld_raw<C>(b + i * C::N));
+  else if (OP == OP_NEG) r = fp_neg(x);
+  else if (OP == OP_MUL) {                                             // (a b R^-1) R^2 R^-1 = a b
+    Fp<C> r2; for (int j = 0; j < C::N; ++j) r2.v[j] = C::r2(j);
+    r = fp_mul(fp_mul(x, ld_raw<C>(b + i * C::N)), r2);
+  } else if (OP == OP_SQR) {
+    Fp<C> r2; for (int j = 0; j < C::N; ++j) r2.v[j] = C::r2(j);
+    r = fp_mul(fp_mul(x, x), r2);
+  } else {                                                             // safe_inv: Err on zero (prime_field_elem.rs:379-382)
+    if (fp_is_zero(x)) { atomicMin(err, (unsigned long long)i); r = x; }
+    else r = fp_from_mont(fp_inv(fp_to_mont(x)));
+  }
+  st_raw<C>(out + i * C::N, r);
+}
+
+template <class C>
+static hipError_t launch_fp_c(int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n, unsigned long long* err, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  dim3 g(nblocks(n)), t(TPB);
+  switch (op) {
+    case OP_ADD: hipLaunchKernelGGL((k_fp_op<C, OP_ADD>), g, t, 0, s, a, b, o, n, err); break;
+    case OP_SUB: hipLaunchKernelGGL((k_fp_op<C, OP_SUB>), g, t, 0, s, a, b, o, n, err); break;
+    case OP_MUL: hipLaunchKernelGGL((k_fp_op<C, OP_MUL>), g, t, 0, s, a, b, o, n, err); break;
+    case OP_SQR: hipLaunchKernelGGL((k_fp_op<C, OP_SQR>), g, t, 0, s, a, b, o, n, err); break;
+    case OP_NEG: hipLaunchKernelGGL((k_fp_op<C, OP_NEG>), g, t, 0, s, a, b, o, n, err); break;
+    case OP_INV: hipLaunchKernelGGL((k_fp_op<C, OP_INV>), g, t, 0, s, a, b, o, n, err); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_fp_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n, unsigned long long* err, hipStream_t s) {
+  switch (field) {
+    case F_FQ: return launch_fp_c<FqC>(op, a, b, o, n, err, s);
+    case F_FR: return launch_fp_c<FrC>(op, a, b, o, n, err, s);
+    case F_SP: return launch_fp_c<SpC>(op, a, b, o, n, err, s);
+    case F_SN: return launch_fp_c<SnC>(op, a, b, o, n, err, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// ---- tower ---------------------------------------------------------------------
+template <int DEG> struct TowerT;
+template <> struct TowerT<2> { typedef Fq2 T; static constexpr int W = 24;
+  __device__ static T ld(const uint32_t* p) { return ld_fq2(p); } __device__ static void st(uint32_t* p, const T& v) { st_fq2(p, v); } };
+template <> struct TowerT<6> { typedef Fq6 T; static constexpr int W = 72;
+  __device__ static T ld(const uint32_t* p) { return ld_fq6(p); } __device__ static void st(uint32_t* p, const T& v) { st_fq6(p, v); } };
+template <> struct TowerT<12> { typedef Fq12 T; static constexpr int W = 144;
+  __device__ static T ld(const uint32_t* p) { return ld_fq12(p); } __device__ static void st(uint32_t* p, const T& v) { st_fq12(p, v); } };
+
+__device__ inline Fq2 t_op(int op, const Fq2& x, const Fq2& y, bool& zero_inv) {
+  switch (op) {
+    case T_ADD: return fq2_add(x, y); case T_SUB: return fq2_sub(x, y); case T_MUL: return fq2_mul(x, y);
+    case T_NEG: return fq2_neg(x); case T_REDUCE: return fq2_mul_xi(x);
+    default: if (fq2_is_zero(x)) { zero_inv = true; return x; } return fq2_inv(x);
+  }
+}
+__device__ inline bool fq6_is_zero(const Fq6& a) { return fq2_is_zero(a.c0) && fq2_is_zero(a.c1) && fq2_is_zero(a.c2); }
+__device__ inline Fq6 t_op(int op, const Fq6& x, const Fq6& y, bool& zero_inv) {
+  switch (op) {
+    case T_ADD: return fq6_add(x, y); case T_SUB: return fq6_sub(x, y); case T_MUL: return fq6_mul(x, y);
+    case T_NEG: return fq6_neg(x); case T_REDUCE: return fq6_mul_v(x);
+    default: if (fq6_is_zero(x)) { zero_inv = true; return x; } return fq6_inv(x);
+  }
+}
+__device__ inline Fq12 t_op(int op, const Fq12& x, const Fq12& y, bool& zero_inv) {
+  switch (op) {
+    case T_ADD: return fq12_add(x, y); case T_SUB: return fq12_sub(x, y); case T_MUL: return fq12_mul(x, y);
+    case T_NEG: return fq12_neg(x);
+    default: if (fq6_is_zero(x.c0) && fq6_is_zero(x.c1)) { zero_inv = true; return x; } return fq12_inv(x);
+  }
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(64) k_tower_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                 uint32_t* __restrict__ out, size_t n, unsigned long long* err) {
+  typedef TowerT<DEG> TT;
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  typename TT::T x = TT::ld(a + i * TT::W), y = x;
+  if (b) y = TT::ld(b + i * TT::W);
+  bool zero_inv = false;
+  typename TT::T r = t_op(op, x, y, zero_inv);
+  if (zero_inv) atomicMin(err, (unsigned long long)i);
+  TT::st(out + i * TT::W, r);
+}
+hipError_t launch_tower_op(int deg, int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n, unsigned long long* err, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  dim3 g(nblocks(n, 64)), t(64);
+  if (deg == 2) hipLaunchKernelGGL(k_tower_op<2>, g, t, 0, s, op, a, b, o, n, err);
+  else if (deg == 6) hipLaunchKernelGGL(k_tower_op<6>, g, t, 0, s, op, a, b, o, n, err);
+  else if (deg == 12) { if (op == T_REDUCE) return hipErrorInvalidValue; hipLaunchKernelGGL(k_tower_op<12>, g, t, 0, s, op, a, b, o, n, err); }
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(64) k_fq12_pow(const uint32_t* __restrict__ a, const uint32_t* __restrict__ e, int nl,
+                                                 uint32_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Fq12 x = ld_fq12(a + i * 144);
+  st_fq12(out + i * 144, fq12_pow(x, e, nl));
+}
+hipError_t launch_fq12_pow(const uint32_t* a, const uint32_t* e, int nl, uint32_t* o, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_fq12_pow, dim3(nblocks(n, 64)), dim3(64), 0, s, a, e, nl, o, n);
+  return hipGetLastError();
+}
+
+}  // namespace zkt

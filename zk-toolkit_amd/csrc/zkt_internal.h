@@ -1,0 +1,44 @@
+// Internal launch interface between the C ABI (zkt_api.cpp) and the HIP kernel files.
+// All pointers are DEVICE pointers in the include/zkt.h layouts, viewed as u32 words.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace zkt {
+
+enum FieldId { F_FQ = 0, F_FR = 1, F_SP = 2, F_SN = 3 };
+enum FpOp { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_SQR = 3, OP_NEG = 4, OP_INV = 5 };
+enum TowerOp { T_ADD = 0, T_SUB = 1, T_MUL = 2, T_INV = 3, T_NEG = 4, T_REDUCE = 5 };
+enum GroupId { G_G1 = 0, G_G2 = 1, G_SECP = 2 };
+
+// error word: index of the first offending element, or ~0ull
+static constexpr unsigned long long NO_ERR = ~0ull;
+
+hipError_t launch_fp_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n,
+                        unsigned long long* err, hipStream_t s);
+hipError_t launch_tower_op(int deg, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n,
+                           unsigned long long* err, hipStream_t s);
+hipError_t launch_fq12_pow(const uint32_t* a, const uint32_t* exp_dev, int exp_nlimbs, uint32_t* out, size_t n, hipStream_t s);
+hipError_t launch_group_add(int grp, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n, hipStream_t s);
+hipError_t launch_group_neg(int grp, const uint32_t* a, uint32_t* out, size_t n, hipStream_t s);
+hipError_t launch_group_mul(int grp, const uint32_t* pts, const uint32_t* scalars, int scalar_words, uint32_t* out, size_t n, hipStream_t s);
+hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s);
+
+// ---- MSM (zkt_msm.hip) ---------------------------------------------------------
+struct MsmPlan {
+  size_t n;            // terms
+  int c;               // window bits
+  int nwin;            // windows
+  size_t nbuckets;     // buckets per window = 2^(c-1)
+  size_t ws_bytes;     // workspace bytes
+};
+MsmPlan msm_plan(size_t n);
+// bases_mont: n x 24 u32 (x,y Montgomery), base_inf: n bytes or nullptr.  scalars: n x 8 u32.
+// result: Jacobian X,Y,Z Montgomery (36 u32) written to dev_result.
+hipError_t launch_g1_msm(const MsmPlan& plan, const uint32_t* bases_mont, const uint8_t* base_inf, const uint32_t* scalars,
+                         void* workspace, uint32_t* dev_result_jac, hipStream_t s, float* accum_kernel_ms);
+hipError_t launch_g1_to_kernel_layout(const uint32_t* abi_pts, uint32_t* bases_mont, uint8_t* base_inf, size_t n, hipStream_t s);
+hipError_t launch_g1_jac_sum_to_affine(const uint32_t* jac_partials, size_t count, uint32_t* out_abi_pt, hipStream_t s);
+
+}  // namespace zkt

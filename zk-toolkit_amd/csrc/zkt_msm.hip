@@ -1,0 +1,292 @@
+// G1 multi-scalar multiplication  sum_i s_i * P_i  for gfx950 (row a9 of SURVEY §8).
+//   Polynomial::eval_with_g1_hidings   src/building_block/field/polynomial.rs:271-281
+// The reference runs n double-and-add scalar multiplications and n affine additions
+// strictly sequentially.  The group element is the same whatever the summation order,
+// and the result leaves as a canonical affine point, so this is bit-compatible.
+//
+// MI355X-first design:
+//  * bases are device-resident (a CRS is uploaded once and reused by every proof) and,
+//    because HBM is 288 GB, every base is stored together with its window multiples
+//    2^(c*w) * P_i  (nwin * n affine points, 96 B each).  All windows then share ONE set
+//    of 2^(c-1) buckets: there is no per-window bucket reduction and no final Horner
+//    chain of 256 serial doublings — on this machine a serial Fq multiply costs ~1.1 us
+//    per lane, so serial chains, not FLOPs, are what must be designed away.
+//  * signed c-bit digits (scalars used as-is, 256 bits: macros.rs:10-21), counting sort of
+//    (bucket, point) pairs, one bucket per lane accumulating in XYZZ coordinates with
+//    complete mixed additions (P+P, P+(-P), infinity: macros.rs:43-63), gather of 96-byte
+//    affine points, then a two-level bucket reduction built from short trees.
+#include "abi.h"
+#include "zkt_internal.h"
+
+namespace zkt {
+
+typedef Xyzz<FqOps> XY;
+static constexpr int XYW = 48;   // u32 words of an XYZZ point in memory
+
+__device__ inline XY ld_xy(const uint32_t* p) { XY r; r.X = ld_raw<FqC>(p); r.Y = ld_raw<FqC>(p + 12); r.ZZ = ld_raw<FqC>(p + 24); r.ZZZ = ld_raw<FqC>(p + 36); return r; }
+__device__ inline void st_xy(uint32_t* p, const XY& a) { st_raw<FqC>(p, a.X); st_raw<FqC>(p + 12, a.Y); st_raw<FqC>(p + 24, a.ZZ); st_raw<FqC>(p + 36, a.ZZZ); }
+
+// ---------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------
+MsmPlan msm_plan(size_t n) {
+  MsmPlan p; p.n = n;
+  int lg = 0; while ((size_t(1) << (lg + 1)) <= (n ? n : 1)) ++lg;   // floor(log2 n)
+  int c = lg;                       // 2^(c-1) buckets ~ n/2: ~2*nwin ~ 26 points per bucket at 2^20
+  if (c < 4) c = 4;
+  if (c > 20) c = 20;
+  p.c = c; p.nwin = (256 + 1 + c - 1) / c; p.nbuckets = size_t(1) << (c - 1);
+  size_t ent = (size_t)p.nwin * n;
+  size_t b = 0;
+  b += (p.nbuckets + 1) * 4 * 3;          // counts, offsets, cursor
+  b += ent * 4;                            // entries
+  b += p.nbuckets * XYW * 4;               // bucket sums
+  b += (2048 + 64) * XYW * 4;              // row/col sums, bit classes
+  b += 4096;
+  p.ws_bytes = b;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------
+// layout conversion and window-multiple precomputation
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_to_kernel_layout(const uint32_t* __restrict__ abi, uint32_t* __restrict__ mont,
+                                                          uint8_t* __restrict__ inf, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  Aff<FqOps> p = PtIO<FqOps>::ld(abi + i * ABI_G1_WORDS);
+  st_raw<FqC>(mont + i * 24, p.x); st_raw<FqC>(mont + i * 24 + 12, p.y);
+  inf[i] = p.inf ? 1 : 0;
+}
+hipError_t launch_g1_to_kernel_layout(const uint32_t* abi, uint32_t* mont, uint8_t* inf, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_to_kernel_layout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, abi, mont, inf, n);
+  return hipGetLastError();
+}
+
+// table[w*n + i] = 2^(c*w) * P_i (affine, Montgomery); infinity flags likewise.
+__global__ void __launch_bounds__(64) k_precompute(uint32_t* __restrict__ table, uint8_t* __restrict__ inf, size_t n, int c, int nwin) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Aff<FqOps> a; a.x = ld_raw<FqC>(table + i * 24); a.y = ld_raw<FqC>(table + i * 24 + 12); a.inf = inf[i] != 0;
+  Jac<FqOps> j = jac_from_aff(a);
+  for (int w = 1; w < nwin; ++w) {
+    for (int d = 0; d < c; ++d) j = jac_dbl(j);
+    Aff<FqOps> r = jac_to_aff(j);
+    size_t o = (size_t)w * n + i;
+    st_raw<FqC>(table + o * 24, r.x); st_raw<FqC>(table + o * 24 + 12, r.y);
+    inf[o] = r.inf ? 1 : 0;
+    if (!r.inf) { j.X = r.x; j.Y = r.y; j.Z = fp_one<FqC>(); }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// signed-digit decomposition, counting sort by bucket
+// ---------------------------------------------------------------------------------
+__device__ inline uint32_t window_bits(const uint32_t* k, int w, int c) {
+  int o = w * c, word = o >> 5, sh = o & 31;
+  if (word >= 8) return 0;
+  uint64_t v = k[word];
+  if (word + 1 < 8) v |= (uint64_t)k[word + 1] << 32;
+  return (uint32_t)(v >> sh) & ((1u << c) - 1);
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t n, int c, int nwin,
+                                                uint32_t* __restrict__ counts_or_cursor, const uint32_t* __restrict__ offsets,
+                                                uint32_t* __restrict__ entries) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t k[8];
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+  uint4 lo = sp[0], hi = sp[1];
+  k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+  const uint32_t half = 1u << (c - 1);
+  uint32_t carry = 0;
+  for (int w = 0; w < nwin; ++w) {
+    uint32_t raw = window_bits(k, w, c) + carry;
+    uint32_t neg = raw > half;
+    uint32_t mag = neg ? (1u << c) - raw : raw;     // |digit| in [0, 2^(c-1)]
+    carry = neg;
+    if (mag == 0) continue;
+    size_t src = (size_t)w * n + i;
+    if (inf[src]) continue;                          // infinity contributes nothing
+    uint32_t b = mag - 1;
+    if (!SCATTER) {
+      atomicAdd(&counts_or_cursor[b], 1u);
+    } else {
+      uint32_t pos = atomicAdd(&counts_or_cursor[b], 1u);
+      entries[offsets[b] + pos] = (uint32_t)src | (neg << 31);
+    }
+  }
+}
+
+// exclusive scan of counts[0..m) into offsets[0..m]; single block (m <= 2^19 + 1)
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, size_t m) {
+  __shared__ uint32_t part[1024];
+  const int t = threadIdx.x;
+  size_t chunk = (m + 1023) / 1024, lo = (size_t)t * chunk, hi = lo + chunk < m ? lo + chunk : m;
+  uint32_t s = 0;
+  for (size_t i = lo; i < hi; ++i) s += counts[i];
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint32_t v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = t ? part[t - 1] : 0;
+  for (size_t i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
+  if (t == 1023) offsets[m] = part[1023];
+}
+
+// ---------------------------------------------------------------------------------
+// bucket accumulation: one bucket per lane
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ table, const uint32_t* __restrict__ entries,
+                                                   const uint32_t* __restrict__ offsets, size_t nbuckets, uint32_t* __restrict__ sums) {
+  size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= nbuckets) return;
+  uint32_t beg = offsets[b], end = offsets[b + 1];
+  XY acc = xyzz_inf<FqOps>();
+  for (uint32_t e = beg; e < end; ++e) {
+    uint32_t ent = entries[e];
+    const uint32_t* p = table + (size_t)(ent & 0x7fffffffu) * 24;
+    Fq x = ld_raw<FqC>(p), y = ld_raw<FqC>(p + 12);
+    if (ent >> 31) y = fp_neg(y);
+    acc = xyzz_add_aff<FqOps>(acc, x, y);
+  }
+  st_xy(sums + b * XYW, acc);
+}
+
+// ---------------------------------------------------------------------------------
+// bucket reduction  sum_b (b+1) S_b, b = hi*NLO + lo:
+//   = sum_lo (lo+1) C_lo + NLO * sum_hi hi * R_hi,   C_lo = sum_hi S, R_hi = sum_lo S
+// ---------------------------------------------------------------------------------
+// wave-level tree sum of one XYZZ per lane through LDS (64 lanes -> lane 0)
+__device__ inline XY wave_tree_sum(XY v, uint32_t* lds /* 64*XYW words */) {
+  const int lane = threadIdx.x & 63;
+  for (int d = 32; d >= 1; d >>= 1) {
+    if (lane >= d && lane < 2 * d) st_xy(lds + (lane - d) * XYW, v);
+    __syncthreads();
+    if (lane < d) v = xyzz_add<FqOps>(v, ld_xy(lds + lane * XYW));
+    __syncthreads();
+  }
+  return v;
+}
+// one 64-lane block per output: out[o] = sum_{j<count} in[o*stride_o + j*stride_j]
+__global__ void __launch_bounds__(64) k_strided_sums(const uint32_t* __restrict__ in, size_t count, size_t stride_o, size_t stride_j,
+                                                     uint32_t* __restrict__ out) {
+  __shared__ uint32_t lds[64 * XYW];
+  const size_t o = blockIdx.x; const int lane = threadIdx.x;
+  XY acc = xyzz_inf<FqOps>();
+  for (size_t j = lane; j < count; j += 64) acc = xyzz_add<FqOps>(acc, ld_xy(in + (o * stride_o + j * stride_j) * XYW));
+  acc = wave_tree_sum(acc, lds);
+  if (lane == 0) st_xy(out + o * XYW, acc);
+}
+// block `bit`: classes[bit] = sum of in[i] over i < m whose weight (i + woff) has that bit set
+__global__ void __launch_bounds__(64) k_weight_bits(const uint32_t* __restrict__ in, size_t m, uint32_t woff, uint32_t* __restrict__ classes) {
+  __shared__ uint32_t lds[64 * XYW];
+  const int bit = blockIdx.x, lane = threadIdx.x;
+  XY acc = xyzz_inf<FqOps>();
+  for (size_t i = lane; i < m; i += 64)
+    if (((uint32_t)i + woff) >> bit & 1) acc = xyzz_add<FqOps>(acc, ld_xy(in + i * XYW));
+  acc = wave_tree_sum(acc, lds);
+  if (lane == 0) st_xy(classes + bit * XYW, acc);
+}
+// result = sum_bit 2^bit classesA[bit]  +  2^shift * sum_bit 2^bit classesB[bit]   (Jacobian out)
+__global__ void k_combine(const uint32_t* __restrict__ clsA, int nbA, const uint32_t* __restrict__ clsB, int nbB, int shift,
+                          uint32_t* __restrict__ out_jac) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  XY hi = xyzz_inf<FqOps>();
+  for (int b = nbB - 1; b >= 0; --b) { hi = xyzz_dbl<FqOps>(hi); hi = xyzz_add<FqOps>(hi, ld_xy(clsB + b * XYW)); }
+  // total = sum_{b<shift} 2^b A_b + 2^shift (A_shift + B): one Horner chain from the top
+  if (nbA > shift) hi = xyzz_add<FqOps>(hi, ld_xy(clsA + shift * XYW));
+  XY acc = hi;
+  for (int b = shift - 1; b >= 0; --b) {
+    acc = xyzz_dbl<FqOps>(acc);
+    if (b < nbA) acc = xyzz_add<FqOps>(acc, ld_xy(clsA + b * XYW));
+  }
+  Jac<FqOps> j = xyzz_to_jac<FqOps>(acc);
+  st_raw<FqC>(out_jac, j.X); st_raw<FqC>(out_jac + 12, j.Y); st_raw<FqC>(out_jac + 24, j.Z);
+}
+
+hipError_t launch_g1_msm(const MsmPlan& P, const uint32_t* table, const uint8_t* inf, const uint32_t* scalars, void* workspace,
+                         uint32_t* dev_result_jac, hipStream_t s, float* accum_ms) {
+  const size_t B = P.nbuckets, n = P.n;
+  uint8_t* ws = (uint8_t*)workspace;
+  uint32_t* counts = (uint32_t*)ws; ws += (B + 1) * 4;
+  uint32_t* offsets = (uint32_t*)ws; ws += (B + 1) * 4;
+  uint32_t* cursor = (uint32_t*)ws; ws += (B + 1) * 4;
+  ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  uint32_t* entries = (uint32_t*)ws; ws += (size_t)P.nwin * n * 4;
+  ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  uint32_t* sums = (uint32_t*)ws; ws += B * XYW * 4;
+  uint32_t* colsum = (uint32_t*)ws; ws += 1024 * XYW * 4;
+  uint32_t* rowsum = (uint32_t*)ws; ws += 1024 * XYW * 4;
+  uint32_t* clsA = (uint32_t*)ws; ws += 32 * XYW * 4;
+  uint32_t* clsB = (uint32_t*)ws; ws += 32 * XYW * 4;
+
+  hipError_t e;
+  if ((e = hipMemsetAsync(counts, 0, (B + 1) * 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(cursor, 0, (B + 1) * 4, s)) != hipSuccess) return e;
+  if (n) {
+    const unsigned g = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_digits<false>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, counts, offsets, B);
+    hipLaunchKernelGGL(k_digits<true>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, cursor, offsets, entries);
+  } else {
+    if ((e = hipMemsetAsync(offsets, 0, (B + 1) * 4, s)) != hipSuccess) return e;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (accum_ms) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); }
+  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, table, entries, offsets, B, sums);
+  if (accum_ms) hipEventRecord(e1, s);
+
+  // two-level reduction: b = hi*NLO + lo
+  const size_t NLO = B < 1024 ? B : 1024, NHI = B / NLO;
+  int lo_bits = 0; while ((size_t(1) << lo_bits) < NLO) ++lo_bits;
+  int hi_bits = 0; while ((size_t(1) << hi_bits) < NHI) ++hi_bits;
+  // C_lo = sum_hi S[hi*NLO+lo];  R_hi = sum_lo S[hi*NLO+lo]
+  hipLaunchKernelGGL(k_strided_sums, dim3((unsigned)NLO), dim3(64), 0, s, sums, NHI, (size_t)1, NLO, colsum);
+  hipLaunchKernelGGL(k_weight_bits, dim3((unsigned)(lo_bits + 1)), dim3(64), 0, s, colsum, NLO, 1u, clsA);   // weights lo+1 in [1, NLO]
+  int nbB = 0;
+  if (NHI > 1) {
+    hipLaunchKernelGGL(k_strided_sums, dim3((unsigned)NHI), dim3(64), 0, s, sums, NLO, NLO, (size_t)1, rowsum);
+    hipLaunchKernelGGL(k_weight_bits, dim3((unsigned)hi_bits), dim3(64), 0, s, rowsum, NHI, 0u, clsB);        // weights hi in [0, NHI)
+    nbB = hi_bits;
+  }
+  // total = sum_b 2^b clsA[b] + 2^lo_bits * sum_b 2^b clsB[b];  clsA has lo_bits+1 classes (weight NLO = 2^lo_bits)
+  hipLaunchKernelGGL(k_combine, dim3(1), dim3(64), 0, s, clsA, lo_bits + 1, clsB, nbB, lo_bits, dev_result_jac);
+  e = hipGetLastError();
+  if (accum_ms) {
+    hipEventSynchronize(e1); hipEventElapsedTime(accum_ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+  return e;
+}
+
+// precompute launcher (declared here to keep the MSM layout private to this file)
+hipError_t launch_g1_precompute(uint32_t* table, uint8_t* inf, size_t n, int c, int nwin, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_precompute, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, table, inf, n, c, nwin);
+  return hipGetLastError();
+}
+
+// combine step of a sharded MSM + affine normalisation
+__global__ void k_jac_sum_to_affine(const uint32_t* __restrict__ parts, size_t count, uint32_t* __restrict__ out_abi) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Jac<FqOps> acc = jac_inf<FqOps>();
+  for (size_t i = 0; i < count; ++i) {
+    Jac<FqOps> p; p.X = ld_raw<FqC>(parts + i * 36); p.Y = ld_raw<FqC>(parts + i * 36 + 12); p.Z = ld_raw<FqC>(parts + i * 36 + 24);
+    acc = jac_add<FqOps>(acc, p);
+  }
+  PtIO<FqOps>::st(out_abi, jac_to_aff(acc));
+}
+hipError_t launch_g1_jac_sum_to_affine(const uint32_t* parts, size_t count, uint32_t* out_abi, hipStream_t s) {
+  hipLaunchKernelGGL(k_jac_sum_to_affine, dim3(1), dim3(64), 0, s, parts, count, out_abi);
+  return hipGetLastError();
+}
+
+}  // namespace zkt
