@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py — G1 MSM throughput at 2^20 bases per GPU (BASELINE.json configs[1]), plus the
+Tate-pairing rate, on MI355X.  Contract: python bench.py --gpus N --steps K --warmup W
+(N>1 under torch.distributed.run, one rank per GPU, RCCL).  One JSON line on rank 0.
+
+step  = one MSM over 2^20 device-resident bases (a CRS) and 2^20 device-resident 255-bit
+        scalars, result normalised to an affine point on the host.
+N>1   = each rank owns a 2^20-term shard of one N*2^20-term MSM (weak scaling); the only
+        exchange is an all_gather of the 144-byte Jacobian partial sums + a local add.
+value = total scalar-muls per second over all ranks (terms / wall time, max over ranks)."""
+import argparse, ctypes, importlib, json, os, sys, time
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MSM_BYTES_PER_TERM = 128       # 96 B affine base + 32 B scalar
+PAIRING_BYTES = 864            # 96 + 192 in, 576 out
+
+
+def rand_scalars_mod_r(seed, n):
+    """n uniform scalars in [0, r) as (n,4) u64 — 255-bit draws with rejection (vectorised)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    r_limbs = [(R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    out = np.zeros((0, 4), dtype=np.uint64)
+    while out.shape[0] < n:
+        c = rng.integers(0, 2**64, size=(int((n - out.shape[0]) * 1.2) + 16, 4), dtype=np.uint64)
+        c[:, 3] &= np.uint64(0x7FFFFFFFFFFFFFFF)
+        lt = np.zeros(c.shape[0], dtype=bool); eq = np.ones(c.shape[0], dtype=bool)
+        for i in (3, 2, 1, 0):
+            lt |= eq & (c[:, i] < np.uint64(r_limbs[i])); eq &= c[:, i] == np.uint64(r_limbs[i])
+        out = np.concatenate([out, c[lt]])
+    return np.ascontiguousarray(out[:n])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--pairings", type=int, default=1 << 14, help="pairings in the secondary measurement (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    zk = importlib.import_module("zk-toolkit_amd")
+    zk.init(local)
+    L = zk.lib()
+    stream = torch.cuda.current_stream()
+    sp = ctypes.c_void_p(stream.cuda_stream)
+    n = 1 << args.log2n
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    # ---- synthetic inputs, resident in HBM: P_i = k_i * G1 (seed 3 + rank), s_i uniform in [0,r) (seed 4 + rank)
+    from zkt_testlib import G1_GEN, int_to_limbs
+    gen = np.zeros((1, 13), dtype=np.uint64); gen[0, :6] = int_to_limbs(G1_GEN[0], 6); gen[0, 6:12] = int_to_limbs(G1_GEN[1], 6)
+    d_gen = torch.from_numpy(np.repeat(gen, n, axis=0).view(np.int64)).to(dev)
+    d_k = torch.from_numpy(rand_scalars_mod_r(3 + 1000 * rank, n).view(np.int64)).to(dev)
+    d_bases = torch.empty((n, 13), dtype=torch.int64, device=dev)
+    zk.check(L.zkt_g1_mul_batch_dev(vp(d_gen), vp(d_k), 4, vp(d_bases), n, sp))
+    torch.cuda.synchronize()
+    h = ctypes.c_void_p()
+    t0 = time.perf_counter()
+    zk.check(L.zkt_g1_bases_from_device(vp(d_bases), n, sp, ctypes.byref(h)))
+    setup_s = time.perf_counter() - t0
+    del d_gen
+    h_scalars = rand_scalars_mod_r(4 + 1000 * rank, n)
+    d_scalars = torch.from_numpy(h_scalars.view(np.int64)).to(dev)
+    d_partial = torch.zeros(36, dtype=torch.int32, device=dev)
+    d_gather = torch.zeros((world, 36), dtype=torch.int32, device=dev)
+    out = np.zeros((1, 13), dtype=np.uint64)
+    outp = out.ctypes.data_as(ctypes.c_void_p)
+
+    def step():
+        if world == 1:
+            zk.check(L.zkt_g1_msm_dev(h, vp(d_scalars), n, sp, outp, None))
+        else:
+            zk.check(L.zkt_g1_msm_dev(h, vp(d_scalars), n, sp, None, vp(d_partial)))
+            dist.all_gather_into_tensor(d_gather, d_partial)
+            zk.check(L.zkt_g1_jac_sum_dev(vp(d_gather), world, sp, outp))
+        return L.zkt_last_kernel_ms()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kern_ms = []
+    for _ in range(args.steps):
+        kern_ms.append(step())
+    torch.cuda.synchronize()
+    if world > 1: dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n * args.steps / elapsed
+    k_ms = float(np.mean(kern_ms))
+
+    result = {
+        "metric": "G1 MSM scalar-muls/sec at 2^%d bases per GPU (BLS12-381)" % args.log2n,
+        "value": value, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 limbs (384-bit Montgomery integer)", "data": "synthetic",
+        "config": {"workload": "Batched G1 Pippenger MSM, 2^%d random bases/scalars per GPU, bases device-resident with window multiples" % args.log2n,
+                   "terms_per_gpu": n, "scalar_bits": 255, "sharding": "index range per rank; all_gather of 144-B partial sums" if world > 1 else "none",
+                   "bases_setup_s": round(setup_s, 3)},
+        "roofline": {"bound": "hbm", "kernel": L.zkt_last_kernel_name().decode(),
+                     "achieved": MSM_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": MSM_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": MSM_BYTES_PER_TERM * n,
+                     "note": "integer-VALU bound by construction (SURVEY §8d); see DESIGN.md for the VALU roofline"},
+    }
+
+    if rank == 0:
+        # parity spot check of the timed configuration: result == (sum k_i s_i mod r) * G, computed independently
+        if world == 1:
+            from zkt_testlib import oracle, ptr, limbs_to_int
+            O = oracle()
+            hk = d_k.cpu().numpy().view(np.uint64)
+            tot = 0
+            for a, b in zip(hk, h_scalars):
+                tot += limbs_to_int(a) * limbs_to_int(b)
+            tot %= R_MOD
+            want = np.zeros((1, 13), dtype=np.uint64); k1 = np.array([int_to_limbs(tot, 4)], dtype=np.uint64)
+            assert O.zkto_g1_mul_batch(ptr(gen), ptr(k1), 4, ptr(want), 1, 1) == 0
+            result["config"]["full_size_check"] = "ok" if (want == out).all() else "MISMATCH"
+
+        # secondary metric: Tate pairings/s
+        if args.pairings > 0:
+            m = args.pairings
+            from zkt_testlib import G2_GEN
+            g2 = np.zeros((1, 25), dtype=np.uint64)
+            (x1, x0), (y1, y0) = G2_GEN
+            g2[0, 0:6] = int_to_limbs(x1, 6); g2[0, 6:12] = int_to_limbs(x0, 6); g2[0, 12:18] = int_to_limbs(y1, 6); g2[0, 18:24] = int_to_limbs(y0, 6)
+            d_g2 = torch.from_numpy(np.repeat(g2, m, axis=0).view(np.int64)).to(dev)
+            d_kq = torch.from_numpy(rand_scalars_mod_r(6, m).view(np.int64)).to(dev)
+            d_q = torch.empty((m, 25), dtype=torch.int64, device=dev)
+            zk.check(L.zkt_g2_mul_batch_dev(vp(d_g2), vp(d_kq), 4, vp(d_q), m, sp))
+            d_p = d_bases[:m].contiguous()
+            d_e = torch.empty((m, 72), dtype=torch.int64, device=dev)
+            zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), m, sp))   # warm
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), m, sp))
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            result["pairing"] = {"metric": "Tate pairings/sec", "value": m / dt, "batch": m, "kernel_ms": L.zkt_last_kernel_ms(),
+                                 "hbm_achieved_GBs": PAIRING_BYTES * m / dt / 1e9, "hbm_frac": PAIRING_BYTES * m / dt / 1e9 / HBM_PEAK_GBS}
+
+        # CPU baseline: the oracle (faithful restatement of the reference algorithm) on a bounded sample
+        if world == 1 and not args.no_cpu:
+            from zkt_testlib import oracle, ptr
+            O = oracle()
+            cores = min(os.cpu_count() or 1, 16)      # the GPU box's CPU share for one GPU is 16 cores
+            m = 128 * cores
+            pts = d_bases[:m].cpu().numpy().view(np.uint64).copy(); sc = h_scalars[:m].copy()
+            tmp = np.zeros_like(pts); acc = np.zeros((1, 13), dtype=np.uint64); acc[0, 12] = 1
+            t0 = time.perf_counter()
+            assert O.zkto_g1_mul_batch(ptr(pts), ptr(sc), 4, ptr(tmp), m, cores) == 0      # n scalar-muls (macros.rs:1-32) on all cores
+            for i in range(m):                                                             # n sequential affine adds (polynomial.rs:277-279)
+                O.zkto_g1_add_batch(ptr(acc), ptr(tmp[i:i + 1]), ptr(acc), 1)
+            dt = time.perf_counter() - t0
+            result["cpu_baseline"] = {"value": m / dt, "unit": "scalar-muls/s", "cores": cores, "kind": "port",
+                                      "sample": "%d-term MSM by the oracle's reference algorithm (per-term double-and-add on %d threads + sequential affine adds), %.1f s" % (m, cores, dt)}
+        print(json.dumps(result))
+    L.zkt_g1_bases_free(h)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(the HIP library is the only compute path, there is no CPU fallback)")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7.  Importing torch first makes
+        # this library's DT_NEEDED libamdhip64.so.7 resolve to the copy torch already mapped, so device
+        # pointers and streams are shared.  (A C/C++/Rust host without torch simply uses /opt/rocm's.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         L.zkt_strerror.restype = ctypes.c_char_p
         L.zkt_last_error_index.restype = ctypes.c_size_t
