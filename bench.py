@@ -38,8 +38,8 @@ def rand_scalars_mod_r(seed, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--pairings", type=int, default=1 << 14, help="pairings in the secondary measurement (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -56,6 +56,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     zk = importlib.import_module("zk-toolkit_amd")
+    sharded = importlib.import_module("zk-toolkit_amd.sharded")
     zk.init(local)
     L = zk.lib()
     stream = torch.cuda.current_stream()
@@ -79,27 +80,42 @@ def main():
     h_scalars = rand_scalars_mod_r(4 + 1000 * rank, n)
     d_scalars = torch.from_numpy(h_scalars.view(np.int64)).to(dev)
     d_partial = torch.zeros(36, dtype=torch.int32, device=dev)
-    d_gather = torch.zeros((world, 36), dtype=torch.int32, device=dev)
     out = np.zeros((1, 13), dtype=np.uint64)
     outp = out.ctypes.data_as(ctypes.c_void_p)
 
-    def step():
+    DEPTH = int(os.environ.get("ZKT_BENCH_DEPTH", "3"))   # MSMs in flight: sort / accumulate / reduce-tail of consecutive MSMs overlap
+    NSLOT = 8          # ZKT_MSM_SLOTS
+
+    def finish(slot):
+        """collect one MSM; for N>1 also the exchange step: all_gather of the 144-B partials + local add."""
         if world == 1:
-            zk.check(L.zkt_g1_msm_dev(h, vp(d_scalars), n, sp, outp, None))
+            zk.check(L.zkt_g1_msm_collect(h, slot, outp, None))
         else:
-            zk.check(L.zkt_g1_msm_dev(h, vp(d_scalars), n, sp, None, vp(d_partial)))
-            dist.all_gather_into_tensor(d_gather, d_partial)
-            zk.check(L.zkt_g1_jac_sum_dev(vp(d_gather), world, sp, outp))
+            zk.check(L.zkt_g1_msm_collect(h, slot, None, vp(d_partial)))
+            g = sharded.sharded_sum(d_partial, lambda stack: stack.contiguous())      # RCCL all_gather of the 144-B partials
+            torch.cuda.current_stream().synchronize()
+            zk.check(L.zkt_g1_jac_sum_dev(vp(g), world, sp, outp))
         return L.zkt_last_kernel_ms()
 
-    for _ in range(args.warmup):
-        step()
+    def run(steps):
+        """exactly `steps` MSMs, submitted back to back, each collected (result on the host) before returning"""
+        kms = []
+        for i in range(steps + DEPTH):
+            if i >= DEPTH:
+                kms.append(finish((i - DEPTH) % NSLOT))
+            if i < steps:
+                zk.check(L.zkt_g1_msm_submit(h, vp(d_scalars), n, sp, i % NSLOT))
+        return kms
+
+    run(args.warmup)
+    # single-MSM latency (blocking call, nothing else in flight)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    zk.check(L.zkt_g1_msm_dev(h, vp(d_scalars), n, sp, outp, None) if world == 1 else 0)
+    latency_ms = (time.perf_counter() - t0) * 1e3
     if world > 1: dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kern_ms = []
-    for _ in range(args.steps):
-        kern_ms.append(step())
+    kern_ms = run(args.steps)
     torch.cuda.synchronize()
     if world > 1: dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -118,7 +134,8 @@ def main():
         "dtype": "u32 limbs (384-bit Montgomery integer)", "data": "synthetic",
         "config": {"workload": "Batched G1 Pippenger MSM, 2^%d random bases/scalars per GPU, bases device-resident with window multiples" % args.log2n,
                    "terms_per_gpu": n, "scalar_bits": 255, "sharding": "index range per rank; all_gather of 144-B partial sums" if world > 1 else "none",
-                   "bases_setup_s": round(setup_s, 3)},
+                   "bases_setup_s": round(setup_s, 3), "msms_in_flight": DEPTH,
+                   "single_msm_latency_ms": round(latency_ms, 3) if world == 1 else None},
         "roofline": {"bound": "hbm", "kernel": L.zkt_last_kernel_name().decode(),
                      "achieved": MSM_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": MSM_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,

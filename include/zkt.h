@@ -125,6 +125,14 @@ void zkt_g1_bases_free(zkt_g1_bases* b);
  * multi-GPU combine (see zkt_g1_jac_sum_dev). */
 int zkt_g1_msm_dev(const zkt_g1_bases* bases, const uint64_t* dev_scalars, size_t n, void* stream,
                    zkt_g1_affine* out, uint32_t* dev_partial_jac);
+/* Pipelined form: up to ZKT_MSM_SLOTS (8) MSMs over the same bases in flight, each on its own internal
+ * stream and workspace, so the digit sort of one, the bucket accumulation of the next and the
+ * latency-bound reduction tail of a third overlap on the chip.  submit() orders the slot behind
+ * everything already enqueued on `stream` (where the scalars are produced) and returns at once;
+ * collect() blocks until that slot's affine result (and optional Jacobian partial) is available. */
+#define ZKT_MSM_SLOTS 8
+int zkt_g1_msm_submit(zkt_g1_bases* bases, const uint64_t* dev_scalars, size_t n, void* stream, int slot);
+int zkt_g1_msm_collect(zkt_g1_bases* bases, int slot, zkt_g1_affine* out, uint32_t* dev_partial_jac);
 /* combine step of a sharded MSM: sum `count` Jacobian partials (36 u32 words each, device)
  * and normalise to affine on the host */
 int zkt_g1_jac_sum_dev(const uint32_t* dev_partials, size_t count, void* stream, zkt_g1_affine* out);

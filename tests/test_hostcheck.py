@@ -37,9 +37,11 @@ def test_field_ops(H, field, mod, w, pre):
         o = np.zeros_like(a)
         assert H.zkt_hostcheck_fp(field, op, p32(a), p32(b), p32(o), len(xs)) == 0
         assert arr_to_ints(o) == [f(x, y) for x, y in zip(xs, ys)], op
-    nz = ints_to_arr([x for x in xs if x], w); o = np.zeros_like(nz)
-    assert H.zkt_hostcheck_fp(field, 5, p32(nz), None, p32(o), len(nz)) == 0
-    assert arr_to_ints(o) == [pow(x, -1, mod) for x in arr_to_ints(nz)]
+    nz = ints_to_arr([x for x in xs if x] + [2**k for k in (1, 31, 32, 33, 64, 200)] + [mod - 2**k for k in (0, 1, 32, 100)], w)
+    for op in (5, 6):                                  # binary-Euclid inverse and Fermat inverse
+        o = np.zeros_like(nz)
+        assert H.zkt_hostcheck_fp(field, op, p32(nz), None, p32(o), len(nz)) == 0
+        assert arr_to_ints(o) == [pow(x, -1, mod) for x in arr_to_ints(nz)], op
 
 
 @pytest.mark.parametrize("field,mod", [(2, SECP_P), (3, SECP_N)])
@@ -52,6 +54,10 @@ def test_field_ops_256bit_moduli(H, field, mod):
         o = np.zeros_like(a)
         assert H.zkt_hostcheck_fp(field, op, p32(a), p32(b), p32(o), len(xs)) == 0
         assert arr_to_ints(o) == [f(x, y) for x, y in zip(xs, ys)], op
+    for op in (5, 6):
+        o = np.zeros_like(a)
+        assert H.zkt_hostcheck_fp(field, op, p32(a), None, p32(o), len(xs)) == 0
+        assert arr_to_ints(o) == [pow(x, -1, mod) for x in xs], op
 
 
 def _rand_tower(rng, w):

@@ -7,7 +7,7 @@
 using namespace zkt;
 
 extern "C" {
-// op: 0 add 1 sub 2 mul 3 sqr 4 neg 5 inv
+// op: 0 add 1 sub 2 mul 3 sqr 4 neg 5 inv (binary Euclid) 6 inv (Fermat)
 int zkt_hostcheck_fp(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n) {
   auto run = [&](auto tag) {
     typedef decltype(tag) C;
@@ -15,7 +15,7 @@ int zkt_hostcheck_fp(int field, int op, const uint32_t* a, const uint32_t* b, ui
       Fp<C> x = ld_fp<C>(a + i * C::N), y = b ? ld_fp<C>(b + i * C::N) : fp_zero<C>(), r;
       switch (op) {
         case 0: r = fp_add(x, y); break; case 1: r = fp_sub(x, y); break; case 2: r = fp_mul(x, y); break;
-        case 3: r = fp_sqr(x); break; case 4: r = fp_neg(x); break; default: r = fp_inv(x);
+        case 3: r = fp_sqr(x); break; case 4: r = fp_neg(x); break; case 6: r = fp_inv_fermat(x); break; default: r = fp_inv(x);
       }
       st_fp<C>(o + i * C::N, r);
     }

@@ -101,15 +101,34 @@ size_t pt_bytes(int grp) { return grp == G_G1 ? sizeof(zkt_g1_affine) : grp == G
 
 }  // namespace
 
+static constexpr int MSM_SLOTS = 8;
+struct MsmSlot {                      // one in-flight MSM: own stream, workspace and result buffers
+  hipStream_t stream = nullptr;
+  hipEvent_t e_in = nullptr, e_acc0 = nullptr, e_acc1 = nullptr;
+  void* workspace = nullptr;
+  uint32_t* d_result_jac = nullptr;   // 36 words
+  uint32_t* d_out_abi = nullptr;      // 26 words
+  zkt_g1_affine* h_out = nullptr;     // pinned
+  bool busy = false;
+};
 struct zkt_g1_bases {
   size_t n = 0;
   MsmPlan plan{};
   uint32_t* table = nullptr;     // nwin*n x 24 words
   uint8_t* inf = nullptr;        // nwin*n flags
-  void* workspace = nullptr;
-  uint32_t* d_result_jac = nullptr;   // 36 words
-  uint32_t* d_out_abi = nullptr;      // 26 words
+  MsmSlot slot[MSM_SLOTS];
 };
+static int slot_ready(zkt_g1_bases* h, int k) {   // lazily create the slot's stream/workspace
+  MsmSlot& S = h->slot[k];
+  if (S.stream) return ZKT_OK;
+  HIPCHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&S.e_in)); HIPCHK(hipEventCreate(&S.e_acc0)); HIPCHK(hipEventCreate(&S.e_acc1));
+  HIPCHK(hipMalloc(&S.workspace, h->plan.ws_bytes));
+  HIPCHK(hipMalloc((void**)&S.d_result_jac, 36 * 4));
+  HIPCHK(hipMalloc((void**)&S.d_out_abi, 26 * 4));
+  HIPCHK(hipHostMalloc((void**)&S.h_out, sizeof(zkt_g1_affine), hipHostMallocDefault));
+  return ZKT_OK;
+}
 
 extern "C" {
 
@@ -261,9 +280,6 @@ static int bases_build(zkt_g1_bases* h, const uint32_t* dev_abi, hipStream_t s) 
   const size_t tot = (size_t)h->plan.nwin * (n ? n : 1);
   HIPCHK(hipMalloc((void**)&h->table, tot * 96));
   HIPCHK(hipMalloc((void**)&h->inf, tot));
-  HIPCHK(hipMalloc(&h->workspace, h->plan.ws_bytes));
-  HIPCHK(hipMalloc((void**)&h->d_result_jac, 36 * 4));
-  HIPCHK(hipMalloc((void**)&h->d_out_abi, 26 * 4));
   HIPCHK(launch_g1_to_kernel_layout(dev_abi, h->table, h->inf, n, s));
   HIPCHK(launch_g1_precompute(h->table, h->inf, n, h->plan.c, h->plan.nwin, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -291,26 +307,51 @@ int zkt_g1_bases_upload(const zkt_g1_affine* host, size_t n, zkt_g1_bases** out)
 size_t zkt_g1_bases_len(const zkt_g1_bases* b) { return b ? b->n : 0; }
 void zkt_g1_bases_free(zkt_g1_bases* h) {
   if (!h) return;
-  if (h->table) hipFree(h->table); if (h->inf) hipFree(h->inf); if (h->workspace) hipFree(h->workspace);
-  if (h->d_result_jac) hipFree(h->d_result_jac); if (h->d_out_abi) hipFree(h->d_out_abi);
+  if (h->table) hipFree(h->table);
+  if (h->inf) hipFree(h->inf);
+  for (MsmSlot& S : h->slot) {
+    if (S.stream) { hipStreamSynchronize(S.stream); hipStreamDestroy(S.stream); }
+    if (S.e_in) hipEventDestroy(S.e_in); if (S.e_acc0) hipEventDestroy(S.e_acc0); if (S.e_acc1) hipEventDestroy(S.e_acc1);
+    if (S.workspace) hipFree(S.workspace); if (S.d_result_jac) hipFree(S.d_result_jac); if (S.d_out_abi) hipFree(S.d_out_abi);
+    if (S.h_out) hipHostFree(S.h_out);
+  }
   delete h;
 }
 size_t zkt_g1_msm_workspace_bytes(size_t n) { MsmPlan p = msm_plan(n); return p.ws_bytes + (size_t)p.nwin * n * 97; }
 
-int zkt_g1_msm_dev(const zkt_g1_bases* h, const uint64_t* dev_scalars, size_t n, void* stream, zkt_g1_affine* out, uint32_t* dev_partial_jac) {
+int zkt_g1_msm_submit(zkt_g1_bases* h, const uint64_t* dev_scalars, size_t n, void* stream, int slot) {
   if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
-  if (!h || n != h->n || (n && !dev_scalars) || (!out && !dev_partial_jac)) return ZKT_ERR_SHAPE;
-  hipStream_t s = (hipStream_t)stream;
-  float ms = 0.f;
-  HIPCHK(launch_g1_msm(h->plan, h->table, h->inf, (const uint32_t*)dev_scalars, h->workspace, h->d_result_jac, s, &ms));
-  t_kernel_ms = ms; t_kernel_name = "k_accumulate";
-  if (dev_partial_jac) HIPCHK(hipMemcpyAsync(dev_partial_jac, h->d_result_jac, 36 * 4, hipMemcpyDeviceToDevice, s));
-  if (out) {
-    HIPCHK(launch_g1_jac_sum_to_affine(h->d_result_jac, 1, h->d_out_abi, s));
-    HIPCHK(hipMemcpyAsync(out, h->d_out_abi, sizeof(zkt_g1_affine), hipMemcpyDeviceToHost, s));
-  }
-  HIPCHK(hipStreamSynchronize(s));
+  if (!h || n != h->n || (n && !dev_scalars) || slot < 0 || slot >= MSM_SLOTS) return ZKT_ERR_SHAPE;
+  if (h->slot[slot].busy) return ZKT_ERR_SHAPE;          // collect it first
+  int rc = slot_ready(h, slot); if (rc) return rc;
+  MsmSlot& S = h->slot[slot];
+  // inputs are produced on the caller's stream: order this slot's stream behind it
+  HIPCHK(hipEventRecord(S.e_in, (hipStream_t)stream));
+  HIPCHK(hipStreamWaitEvent(S.stream, S.e_in, 0));
+  HIPCHK(launch_g1_msm(h->plan, h->table, h->inf, (const uint32_t*)dev_scalars, S.workspace, S.d_result_jac, S.stream, S.e_acc0, S.e_acc1));
+  HIPCHK(launch_g1_jac_sum_to_affine(S.d_result_jac, 1, S.d_out_abi, S.stream));
+  HIPCHK(hipMemcpyAsync(S.h_out, S.d_out_abi, sizeof(zkt_g1_affine), hipMemcpyDeviceToHost, S.stream));
+  S.busy = true;
   return ZKT_OK;
+}
+int zkt_g1_msm_collect(zkt_g1_bases* h, int slot, zkt_g1_affine* out, uint32_t* dev_partial_jac) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!h || slot < 0 || slot >= MSM_SLOTS || !h->slot[slot].busy) return ZKT_ERR_SHAPE;
+  MsmSlot& S = h->slot[slot];
+  if (dev_partial_jac) HIPCHK(hipMemcpyAsync(dev_partial_jac, S.d_result_jac, 36 * 4, hipMemcpyDeviceToDevice, S.stream));
+  HIPCHK(hipStreamSynchronize(S.stream));
+  if (out) *out = *S.h_out;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, S.e_acc0, S.e_acc1) == hipSuccess) { t_kernel_ms = ms; t_kernel_name = "k_accumulate"; }
+  S.busy = false;
+  return ZKT_OK;
+}
+int zkt_g1_msm_dev(const zkt_g1_bases* h, const uint64_t* dev_scalars, size_t n, void* stream, zkt_g1_affine* out, uint32_t* dev_partial_jac) {
+  if (!out && !dev_partial_jac) return ZKT_ERR_SHAPE;
+  zkt_g1_bases* hh = const_cast<zkt_g1_bases*>(h);
+  int rc = zkt_g1_msm_submit(hh, dev_scalars, n, stream, 0);
+  if (rc) return rc;
+  return zkt_g1_msm_collect(hh, 0, out, dev_partial_jac);
 }
 int zkt_g1_jac_sum_dev(const uint32_t* dev_partials, size_t count, void* stream, zkt_g1_affine* out) {
   if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;

@@ -42,6 +42,7 @@ MsmPlan msm_plan(size_t n) {
   b += ent * 4;                            // entries
   b += p.nbuckets * XYW * 4;               // bucket sums
   b += (2048 + 64) * XYW * 4;              // row/col sums, bit classes
+  b += p.nbuckets * 4 + (1024 + 3 * 1025) * 4; // size order, scan scratch, size bins
   b += 4096;
   p.ws_bytes = b;
   return p;
@@ -121,33 +122,97 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
   }
 }
 
-// exclusive scan of counts[0..m) into offsets[0..m]; single block (m <= 2^19 + 1)
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, size_t m) {
-  __shared__ uint32_t part[1024];
+// exclusive scan of counts[0..m) into offsets[0..m]: per-block sums, scan of the block sums, per-block scan.
+static constexpr int SCAN_TPB = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_TPB * SCAN_ITEMS;
+__device__ inline uint32_t block_excl_scan_256(uint32_t v, uint32_t* lds /*256*/, uint32_t& total) {
   const int t = threadIdx.x;
-  size_t chunk = (m + 1023) / 1024, lo = (size_t)t * chunk, hi = lo + chunk < m ? lo + chunk : m;
-  uint32_t s = 0;
-  for (size_t i = lo; i < hi; ++i) s += counts[i];
-  part[t] = s;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    uint32_t v = t >= d ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  lds[t] = v; __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t x = t >= d ? lds[t - d] : 0; __syncthreads();
+    lds[t] += x; __syncthreads();
   }
-  uint32_t run = t ? part[t - 1] : 0;
-  for (size_t i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
-  if (t == 1023) offsets[m] = part[1023];
+  total = lds[255];
+  uint32_t excl = t ? lds[t - 1] : 0;
+  __syncthreads();
+  return excl;
+}
+__global__ void __launch_bounds__(256) k_scan_sums(const uint32_t* __restrict__ in, size_t m, uint32_t* __restrict__ blocksum) {
+  __shared__ uint32_t lds[256];
+  size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < m) s += in[base + k];
+  uint32_t tot; (void)block_excl_scan_256(s, lds, tot);
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) k_scan_top(uint32_t* __restrict__ blocksum, int nblk, uint32_t* __restrict__ grand_total) {
+  __shared__ uint32_t lds[256];
+  uint32_t run = 0;
+  for (int base = 0; base < nblk; base += 256) {          // nblk <= 2^19/2048 = 256 in practice
+    int i = base + threadIdx.x;
+    uint32_t v = i < nblk ? blocksum[i] : 0, tot;
+    uint32_t ex = block_excl_scan_256(v, lds, tot);
+    if (i < nblk) blocksum[i] = run + ex;
+    run += tot;
+  }
+  if (threadIdx.x == 0) *grand_total = run;
+}
+__global__ void __launch_bounds__(256) k_scan_final(const uint32_t* __restrict__ in, size_t m, const uint32_t* __restrict__ blocksum,
+                                                    uint32_t* __restrict__ out) {
+  __shared__ uint32_t lds[256];
+  size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = base + k < m ? in[base + k] : 0; s += v[k]; }
+  uint32_t tot; uint32_t run = block_excl_scan_256(s, lds, tot) + blocksum[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < m) out[base + k] = run; run += v[k]; }
+}
+// out[0..m) = exclusive scan of in, out[m] = total.  scratch: >= ceil(m/2048) words
+static void launch_scan(const uint32_t* in, uint32_t* out, size_t m, uint32_t* scratch, hipStream_t s) {
+  int nblk = (int)((m + SCAN_TILE - 1) / SCAN_TILE);
+  hipLaunchKernelGGL(k_scan_sums, dim3(nblk), dim3(256), 0, s, in, m, scratch);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, scratch, nblk, out + m);
+  hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(256), 0, s, in, m, (const uint32_t*)scratch, out);
+}
+
+// bucket ids ordered by population (largest first) so the 64 lanes of a wave run equally long lists;
+// a counting sort over min(count, SIZE_BINS-1).
+static constexpr int SIZE_BINS = 1024;
+__global__ void __launch_bounds__(256) k_size_hist(const uint32_t* __restrict__ counts, size_t m, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[SIZE_BINS];
+  for (int i = threadIdx.x; i < SIZE_BINS; i += 256) h[i] = 0;
+  __syncthreads();
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < m) { uint32_t c = counts[i]; atomicAdd(&h[SIZE_BINS - 1 - (c < SIZE_BINS ? c : SIZE_BINS - 1)], 1u); }   // bin 0 = largest
+  __syncthreads();
+  for (int k = threadIdx.x; k < SIZE_BINS; k += 256) if (h[k]) atomicAdd(&hist[k], h[k]);
+}
+__global__ void __launch_bounds__(256) k_size_scatter(const uint32_t* __restrict__ counts, size_t m, const uint32_t* __restrict__ binoff,
+                                                      uint32_t* __restrict__ bincur, uint32_t* __restrict__ order) {
+  // rank inside the block with LDS atomics, then ONE global atomic per (block, non-empty bin):
+  // ~50 distinct sizes are shared by 2^19 buckets, so per-element global atomics would serialise.
+  __shared__ uint32_t h[SIZE_BINS], base[SIZE_BINS];
+  for (int i = threadIdx.x; i < SIZE_BINS; i += 256) h[i] = 0;
+  __syncthreads();
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t bin = 0, rank = 0;
+  if (i < m) { uint32_t c = counts[i]; bin = SIZE_BINS - 1 - (c < SIZE_BINS ? c : SIZE_BINS - 1); rank = atomicAdd(&h[bin], 1u); }
+  __syncthreads();
+  for (int k = threadIdx.x; k < SIZE_BINS; k += 256) if (h[k]) base[k] = binoff[k] + atomicAdd(&bincur[k], h[k]);
+  __syncthreads();
+  if (i < m) order[base[bin] + rank] = (uint32_t)i;
 }
 
 // ---------------------------------------------------------------------------------
 // bucket accumulation: one bucket per lane
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ table, const uint32_t* __restrict__ entries,
-                                                   const uint32_t* __restrict__ offsets, size_t nbuckets, uint32_t* __restrict__ sums) {
-  size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= nbuckets) return;
+                                                   const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ order,
+                                                   size_t nbuckets, uint32_t* __restrict__ sums) {
+  size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (t >= nbuckets) return;
+  const size_t b = order[t];
   uint32_t beg = offsets[b], end = offsets[b + 1];
   XY acc = xyzz_inf<FqOps>();
   for (uint32_t e = beg; e < end; ++e) {
@@ -164,10 +229,11 @@ __global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ 
 // bucket reduction  sum_b (b+1) S_b, b = hi*NLO + lo:
 //   = sum_lo (lo+1) C_lo + NLO * sum_hi hi * R_hi,   C_lo = sum_hi S, R_hi = sum_lo S
 // ---------------------------------------------------------------------------------
-// wave-level tree sum of one XYZZ per lane through LDS (64 lanes -> lane 0)
-__device__ inline XY wave_tree_sum(XY v, uint32_t* lds /* 64*XYW words */) {
-  const int lane = threadIdx.x & 63;
-  for (int d = 32; d >= 1; d >>= 1) {
+// block-level tree sum of one XYZZ per lane through LDS (RED_TPB lanes -> lane 0): log2 depth
+static constexpr int RED_TPB = 256;
+__device__ inline XY block_tree_sum(XY v, uint32_t* lds /* RED_TPB/2 * XYW words */) {
+  const int lane = threadIdx.x;
+  for (int d = RED_TPB / 2; d >= 1; d >>= 1) {
     if (lane >= d && lane < 2 * d) st_xy(lds + (lane - d) * XYW, v);
     __syncthreads();
     if (lane < d) v = xyzz_add<FqOps>(v, ld_xy(lds + lane * XYW));
@@ -175,24 +241,25 @@ __device__ inline XY wave_tree_sum(XY v, uint32_t* lds /* 64*XYW words */) {
   }
   return v;
 }
-// one 64-lane block per output: out[o] = sum_{j<count} in[o*stride_o + j*stride_j]
-__global__ void __launch_bounds__(64) k_strided_sums(const uint32_t* __restrict__ in, size_t count, size_t stride_o, size_t stride_j,
-                                                     uint32_t* __restrict__ out) {
-  __shared__ uint32_t lds[64 * XYW];
+// one block per output: out[o] = sum_{j<count} in[o*stride_o + j*stride_j]
+__global__ void __launch_bounds__(RED_TPB) k_strided_sums(const uint32_t* __restrict__ in, size_t count, size_t stride_o, size_t stride_j,
+                                                          uint32_t* __restrict__ out) {
+  __shared__ uint32_t lds[RED_TPB / 2 * XYW];
   const size_t o = blockIdx.x; const int lane = threadIdx.x;
   XY acc = xyzz_inf<FqOps>();
-  for (size_t j = lane; j < count; j += 64) acc = xyzz_add<FqOps>(acc, ld_xy(in + (o * stride_o + j * stride_j) * XYW));
-  acc = wave_tree_sum(acc, lds);
+  for (size_t j = lane; j < count; j += RED_TPB) acc = xyzz_add<FqOps>(acc, ld_xy(in + (o * stride_o + j * stride_j) * XYW));
+  acc = block_tree_sum(acc, lds);
   if (lane == 0) st_xy(out + o * XYW, acc);
 }
 // block `bit`: classes[bit] = sum of in[i] over i < m whose weight (i + woff) has that bit set
-__global__ void __launch_bounds__(64) k_weight_bits(const uint32_t* __restrict__ in, size_t m, uint32_t woff, uint32_t* __restrict__ classes) {
-  __shared__ uint32_t lds[64 * XYW];
+__global__ void __launch_bounds__(RED_TPB) k_weight_bits(const uint32_t* __restrict__ in, size_t m, uint32_t woff, uint32_t* __restrict__ classes) {
+  __shared__ uint32_t lds[RED_TPB / 2 * XYW];
   const int bit = blockIdx.x, lane = threadIdx.x;
   XY acc = xyzz_inf<FqOps>();
-  for (size_t i = lane; i < m; i += 64)
+  // the j-th element with this bit set: i = ((j >> bit) << (bit+1)) | (1 << bit) | (j & ((1<<bit)-1)), shifted by woff
+  for (size_t i = lane; i < m; i += RED_TPB)
     if (((uint32_t)i + woff) >> bit & 1) acc = xyzz_add<FqOps>(acc, ld_xy(in + i * XYW));
-  acc = wave_tree_sum(acc, lds);
+  acc = block_tree_sum(acc, lds);
   if (lane == 0) st_xy(classes + bit * XYW, acc);
 }
 // result = sum_bit 2^bit classesA[bit]  +  2^shift * sum_bit 2^bit classesB[bit]   (Jacobian out)
@@ -213,7 +280,7 @@ __global__ void k_combine(const uint32_t* __restrict__ clsA, int nbA, const uint
 }
 
 hipError_t launch_g1_msm(const MsmPlan& P, const uint32_t* table, const uint8_t* inf, const uint32_t* scalars, void* workspace,
-                         uint32_t* dev_result_jac, hipStream_t s, float* accum_ms) {
+                         uint32_t* dev_result_jac, hipStream_t s, hipEvent_t ev_acc0, hipEvent_t ev_acc1) {
   const size_t B = P.nbuckets, n = P.n;
   uint8_t* ws = (uint8_t*)workspace;
   uint32_t* counts = (uint32_t*)ws; ws += (B + 1) * 4;
@@ -227,6 +294,11 @@ hipError_t launch_g1_msm(const MsmPlan& P, const uint32_t* table, const uint8_t*
   uint32_t* rowsum = (uint32_t*)ws; ws += 1024 * XYW * 4;
   uint32_t* clsA = (uint32_t*)ws; ws += 32 * XYW * 4;
   uint32_t* clsB = (uint32_t*)ws; ws += 32 * XYW * 4;
+  uint32_t* order = (uint32_t*)ws; ws += B * 4;
+  uint32_t* scan_tmp = (uint32_t*)ws; ws += 1024 * 4;
+  uint32_t* size_hist = (uint32_t*)ws; ws += (SIZE_BINS + 1) * 4;
+  uint32_t* size_off = (uint32_t*)ws; ws += (SIZE_BINS + 1) * 4;
+  uint32_t* size_cur = (uint32_t*)ws; ws += (SIZE_BINS + 1) * 4;
 
   hipError_t e;
   if ((e = hipMemsetAsync(counts, 0, (B + 1) * 4, s)) != hipSuccess) return e;
@@ -234,37 +306,36 @@ hipError_t launch_g1_msm(const MsmPlan& P, const uint32_t* table, const uint8_t*
   if (n) {
     const unsigned g = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_digits<false>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, counts, offsets, B);
+    launch_scan(counts, offsets, B, scan_tmp, s);
     hipLaunchKernelGGL(k_digits<true>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, cursor, offsets, entries);
   } else {
     if ((e = hipMemsetAsync(offsets, 0, (B + 1) * 4, s)) != hipSuccess) return e;
   }
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (accum_ms) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); }
-  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, table, entries, offsets, B, sums);
-  if (accum_ms) hipEventRecord(e1, s);
+  // bucket order by population
+  if ((e = hipMemsetAsync(size_hist, 0, (SIZE_BINS + 1) * 4 * 3, s)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_size_hist, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)counts, B, size_hist);
+  launch_scan(size_hist, size_off, SIZE_BINS, scan_tmp, s);
+  hipLaunchKernelGGL(k_size_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)counts, B, (const uint32_t*)size_off, size_cur, order);
+  if (ev_acc0) hipEventRecord(ev_acc0, s);
+  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, table, entries, offsets, (const uint32_t*)order, B, sums);
+  if (ev_acc1) hipEventRecord(ev_acc1, s);
 
   // two-level reduction: b = hi*NLO + lo
   const size_t NLO = B < 1024 ? B : 1024, NHI = B / NLO;
   int lo_bits = 0; while ((size_t(1) << lo_bits) < NLO) ++lo_bits;
   int hi_bits = 0; while ((size_t(1) << hi_bits) < NHI) ++hi_bits;
   // C_lo = sum_hi S[hi*NLO+lo];  R_hi = sum_lo S[hi*NLO+lo]
-  hipLaunchKernelGGL(k_strided_sums, dim3((unsigned)NLO), dim3(64), 0, s, sums, NHI, (size_t)1, NLO, colsum);
-  hipLaunchKernelGGL(k_weight_bits, dim3((unsigned)(lo_bits + 1)), dim3(64), 0, s, colsum, NLO, 1u, clsA);   // weights lo+1 in [1, NLO]
+  hipLaunchKernelGGL(k_strided_sums, dim3((unsigned)NLO), dim3(RED_TPB), 0, s, sums, NHI, (size_t)1, NLO, colsum);
+  hipLaunchKernelGGL(k_weight_bits, dim3((unsigned)(lo_bits + 1)), dim3(RED_TPB), 0, s, colsum, NLO, 1u, clsA);   // weights lo+1 in [1, NLO]
   int nbB = 0;
   if (NHI > 1) {
-    hipLaunchKernelGGL(k_strided_sums, dim3((unsigned)NHI), dim3(64), 0, s, sums, NLO, NLO, (size_t)1, rowsum);
-    hipLaunchKernelGGL(k_weight_bits, dim3((unsigned)hi_bits), dim3(64), 0, s, rowsum, NHI, 0u, clsB);        // weights hi in [0, NHI)
+    hipLaunchKernelGGL(k_strided_sums, dim3((unsigned)NHI), dim3(RED_TPB), 0, s, sums, NLO, NLO, (size_t)1, rowsum);
+    hipLaunchKernelGGL(k_weight_bits, dim3((unsigned)hi_bits), dim3(RED_TPB), 0, s, rowsum, NHI, 0u, clsB);        // weights hi in [0, NHI)
     nbB = hi_bits;
   }
   // total = sum_b 2^b clsA[b] + 2^lo_bits * sum_b 2^b clsB[b];  clsA has lo_bits+1 classes (weight NLO = 2^lo_bits)
   hipLaunchKernelGGL(k_combine, dim3(1), dim3(64), 0, s, clsA, lo_bits + 1, clsB, nbB, lo_bits, dev_result_jac);
-  e = hipGetLastError();
-  if (accum_ms) {
-    hipEventSynchronize(e1); hipEventElapsedTime(accum_ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
-  }
-  return e;
+  return hipGetLastError();
 }
 
 // precompute launcher (declared here to keep the MSM layout private to this file)
