@@ -106,10 +106,42 @@ int zkt_secp_mul_batch(const zkt_secp_affine* points, const uint64_t* scalars, i
  * scalars are 4 limbs (256 bits) each, used as-is */
 int zkt_g1_msm(const zkt_g1_affine* bases, const uint64_t* scalars, size_t n, zkt_g1_affine* out);
 
+/* f-1 and the secp256k1 vector form: Polynomial::eval_with_g2_hidings polynomial.rs:283-293;
+ * (AffinePoints * PrimeFieldElems).sum() secp256k1/affine_points.rs:25-31,123-144.  4-limb scalars, used as-is. */
+int zkt_g2_msm(const zkt_g2_affine* bases, const uint64_t* scalars, size_t n, zkt_g2_affine* out);
+int zkt_secp_msm(const zkt_secp_affine* bases, const uint64_t* scalars, size_t n, zkt_secp_affine* out);
+
 /* a10–a13: Pairing::tate pairing.rs:86-100 — out[i] = Fq12 of tate(g1[i], g2[i]) */
 int zkt_tate_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out_fq12, size_t n);
 /* a15: GTPoint == gt_point.rs:33-39 (all 12 coefficients); returns 1/0, or <0 = -status */
 int zkt_gt_eq(const uint64_t* a_fq12, const uint64_t* b_fq12);
+
+/* a17: Groth16 over the kernels above — CRS (crs.rs:17-43), CRS::new crs.rs:49-146, Prover::prove prover.rs:96-147,
+ * Verifier::verify verifier.rs:30-54.  The reference samples alpha,beta,gamma,delta,x (crs.rs:59-63) and r,s
+ * (prover.rs:100-101) from OS entropy; here they are arguments (4-limb Fr, non-zero).  QAP polynomials ui/vi/wi are
+ * (m+1) x n dense Fr coefficient arrays, low degree first (Prover.ui/vi/wi prover.rs:44-46); wires = a_0..a_m
+ * (wires.rs:12-39), statement = a_0..a_l; h = quotient polynomial coefficients (prover.rs:64-71), h_len <= n. */
+typedef struct {
+  size_t n, l, m;                       /* constraints, last statement wire, last wire (prover.rs:36-38) */
+  zkt_g1_affine *g1_alpha, *g1_beta, *g1_delta, *g1_xi /*n*/, *g1_uvw_stmt /*l+1*/, *g1_uvw_wit /*m-l*/, *g1_xt_by_delta /*n*/;
+  zkt_g2_affine *g2_beta, *g2_gamma, *g2_delta, *g2_xi /*n*/;
+  uint64_t* gt_alpha_beta;              /* 72 limbs */
+} zkt_groth16_crs;
+int zkt_groth16_setup(zkt_groth16_crs* crs, const uint64_t* ui, const uint64_t* vi, const uint64_t* wi,
+                      const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma, const uint64_t* delta, const uint64_t* x);
+int zkt_groth16_prove(const zkt_groth16_crs* crs, const uint64_t* ui, const uint64_t* vi, const uint64_t* wires,
+                      const uint64_t* h, size_t h_len, const uint64_t* r, const uint64_t* s,
+                      zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* C);
+/* returns 1 accept, 0 reject, negative = -status (a pairing argument at infinity panics in the reference) */
+int zkt_groth16_verify(const zkt_groth16_crs* crs, const zkt_g1_affine* A, const zkt_g2_affine* B, const zkt_g1_affine* C,
+                       const uint64_t* stmt_wires, size_t n_stmt);
+
+/* a18: Bulletproofs::inner_product_argument bulletproofs.rs:19-55 over secp256k1; n a power of two; a, b are 4-limb
+ * residues mod the group order; xs = one challenge per level (the reference draws them at bulletproofs.rs:42).
+ * out_trace (optional): per level {L, R, P'}.  Returns 1/0 like the reference's bool, negative = -status. */
+int zkt_bp_inner_product_argument(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u,
+                                  const zkt_secp_affine* P, const uint64_t* a, const uint64_t* b, const uint64_t* xs,
+                                  zkt_secp_affine* out_trace);
 
 /* ---- device-resident entry points (inputs/outputs already in HBM) -------------------- */
 /* Bases kept on the device in kernel layout (Montgomery x,y, 96 B each) — the analogue of

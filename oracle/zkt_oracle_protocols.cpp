@@ -1,0 +1,195 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE.  Oracle restatement of the two callers of the hot path:
+//   Groth16  src/zk/w_trusted_setup/groth16/zktoolkit_based/{crs.rs:49-146, prover.rs:96-147, verifier.rs:30-54}
+//   Bulletproofs inner-product argument  src/zk/wo_trusted_setup/bulletproofs.rs:19-55 (secp256k1)
+// The reference samples every random value from OS entropy (prime_field.rs:73-85, random_number.rs:8-13);
+// here they are INJECTED (alpha,beta,gamma,delta,x,r,s and the IPA challenges) so that results are comparable.
+// QAP polynomials arrive as dense coefficient arrays (low degree first), n coefficients each; the reference's
+// Polynomial trims trailing zeros, which only removes terms that contribute the point at infinity.
+#include "zkt_oracle.hpp"
+using namespace zkto;
+
+namespace {
+const int FQ = 6, FR = 4, G1W = 13, G2W = 25, FQ12 = 72;
+Fr ldr(const uint64_t* p) { return Fr::from_limbs(p, FR); }
+Fq2 ld2(const uint64_t* p) { return Fq2(Fq1::from_limbs(p, FQ), Fq1::from_limbs(p + FQ, FQ)); }
+void st2(uint64_t* p, const Fq2& v) { for (int i = 0; i < FQ; ++i) { p[i] = v.u1.l[i]; p[FQ + i] = v.u0.l[i]; } }
+G1Point ldg1(const uint64_t* p) { if (p[12] & 0xffffffffu) return G1Point::infinity(); return G1Point(Fq1::from_limbs(p, FQ), Fq1::from_limbs(p + FQ, FQ)); }
+void stg1(uint64_t* p, const G1Point& v) {
+  if (v.inf) { for (int i = 0; i < 12; ++i) p[i] = 0; p[12] = 1; return; }
+  for (int i = 0; i < FQ; ++i) { p[i] = v.x.l[i]; p[FQ + i] = v.y.l[i]; } p[12] = 0;
+}
+G2Point ldg2(const uint64_t* p) { if (p[24] & 0xffffffffu) return G2Point::infinity(); return G2Point(ld2(p), ld2(p + 12)); }
+void stg2(uint64_t* p, const G2Point& v) {
+  if (v.inf) { for (int i = 0; i < 24; ++i) p[i] = 0; p[24] = 1; return; }
+  st2(p, v.x); st2(p + 12, v.y); p[24] = 0;
+}
+void st12(uint64_t* p, const Fq12& v) {
+  const Fq6* six[2] = {&v.w1, &v.w0};
+  for (int s = 0; s < 2; ++s) { const Fq2* c[3] = {&six[s]->v2, &six[s]->v1, &six[s]->v0}; for (int k = 0; k < 3; ++k) st2(p + s * 36 + k * 12, *c[k]); }
+}
+Fq12 ld12(const uint64_t* p) {
+  Fq6 s[2]; for (int k = 0; k < 2; ++k) s[k] = Fq6(ld2(p + k * 36), ld2(p + k * 36 + 12), ld2(p + k * 36 + 24));
+  return Fq12(s[0], s[1]);
+}
+template <class P> P mul_fr(const P& p, const Fr& k) { return scalar_mul(p, k.l, FR); }   // G * Fq1-like scalar (macros.rs:1-32)
+
+// Polynomial::eval_at (field/polynomial.rs:240-249)
+Fr poly_eval(const uint64_t* coeffs, size_t n, const Fr& x) {
+  Fr acc(0), xp(1);
+  for (size_t i = 0; i < n; ++i) { acc = acc + ldr(coeffs + i * FR) * xp; xp = xp * x; }
+  return acc;
+}
+// QAP::build_t(f, n).eval_at(x): t = prod_{i=1..n} (x - i)   (qap/qap.rs:115-135)
+Fr t_eval(size_t n, const Fr& x) { Fr t(1); for (size_t i = 1; i <= n; ++i) t = t * (x - Fr((uint64_t)i)); return t; }
+}  // namespace
+
+struct zkto_groth16_crs {   // same field order as zkt_groth16_crs in include/zkt.h
+  size_t n, l, m;
+  uint64_t *g1_alpha, *g1_beta, *g1_delta, *g1_xi, *g1_uvw_stmt, *g1_uvw_wit, *g1_xt_by_delta;
+  uint64_t *g2_beta, *g2_gamma, *g2_delta, *g2_xi;
+  uint64_t* gt_alpha_beta;
+};
+
+extern "C" {
+
+// CRS::new (crs.rs:49-146) with the trapdoors injected
+int zkto_groth16_setup(zkto_groth16_crs* c, const uint64_t* ui, const uint64_t* vi, const uint64_t* wi,
+                       const uint64_t* alpha_, const uint64_t* beta_, const uint64_t* gamma_, const uint64_t* delta_, const uint64_t* x_) {
+  init_fields();
+  const size_t n = c->n, l = c->l, m = c->m;
+  G1Point g = g1_generator(); G2Point h = g2_generator();
+  Fr alpha = ldr(alpha_), beta = ldr(beta_), gamma = ldr(gamma_), delta = ldr(delta_), x = ldr(x_);
+  auto uvw_div = [&](size_t from, size_t to, const Fr& div, uint64_t* out) {     // calc_uvw_div! crs.rs:65-83
+    for (size_t i = from; i <= to; ++i) {
+      Fr u = beta * poly_eval(ui + i * n * FR, n, x);
+      Fr v = alpha * poly_eval(vi + i * n * FR, n, x);
+      Fr w = poly_eval(wi + i * n * FR, n, x);
+      Fr y = (u + v + w) * div;
+      stg1(out + (i - from) * G1W, mul_fr(g, y));
+    }
+  };
+  uvw_div(0, l, gamma.inv(), c->g1_uvw_stmt);
+  uvw_div(l + 1, m, delta.inv(), c->g1_uvw_wit);
+  Fr xp(1);
+  for (size_t k = 0; k < n; ++k) { stg1(c->g1_xi + k * G1W, mul_fr(g, xp)); xp = xp * x; }          // calc_n_pows! crs.rs:88-104
+  Fr t = t_eval(n, x); xp = Fr(1);
+  for (size_t k = 0; k < n; ++k) { stg1(c->g1_xt_by_delta + k * G1W, mul_fr(g, xp * t * delta.inv())); xp = xp * x; }   // crs.rs:106-116
+  stg1(c->g1_alpha, mul_fr(g, alpha)); stg1(c->g1_beta, mul_fr(g, beta)); stg1(c->g1_delta, mul_fr(g, delta));
+  xp = Fr(1);
+  for (size_t k = 0; k < n; ++k) { stg2(c->g2_xi + k * G2W, mul_fr(h, xp)); xp = xp * x; }
+  stg2(c->g2_beta, mul_fr(h, beta)); stg2(c->g2_gamma, mul_fr(h, gamma)); stg2(c->g2_delta, mul_fr(h, delta));
+  static Pairing pr;
+  st12(c->gt_alpha_beta, pr.tate(ldg1(c->g1_alpha), ldg2(c->g2_beta)));                               // crs.rs:137-139
+  return 0;
+}
+
+// Prover::prove (prover.rs:96-147) with r, s injected.  literal != 0: the reference's loop — per wire three MSMs, each
+// followed by a scalar multiplication by a_i; literal == 0: the same group elements via one MSM per output
+// (A = alpha + (sum a_i u_i)(x) G + r delta), used for sizes where the literal loop would take hours.
+int zkto_groth16_prove(const zkto_groth16_crs* c, const uint64_t* ui, const uint64_t* vi, const uint64_t* wires,
+                       const uint64_t* hcoef, size_t h_len, const uint64_t* r_, const uint64_t* s_, int literal,
+                       uint64_t* A_, uint64_t* B_, uint64_t* C_) {
+  init_fields();
+  const size_t n = c->n, l = c->l, m = c->m;
+  Fr r = ldr(r_), s = ldr(s_);
+  std::vector<G1Point> xi1(n), xtd(n); std::vector<G2Point> xi2(n);
+  for (size_t k = 0; k < n; ++k) { xi1[k] = ldg1(c->g1_xi + k * G1W); xi2[k] = ldg2(c->g2_xi + k * G2W); xtd[k] = ldg1(c->g1_xt_by_delta + k * G1W); }
+  G1Point sumA = G1Point::infinity(), sumB1 = G1Point::infinity(); G2Point sumB = G2Point::infinity();
+  if (literal) {
+    for (size_t i = 0; i <= m; ++i) {                                          // prover.rs:107-117
+      Fr ai = ldr(wires + i * FR);
+      G1Point up = mul_fr(msm_naive(xi1.data(), ui + i * n * FR, FR, n), ai);
+      G2Point vp = mul_fr(msm_naive(xi2.data(), vi + i * n * FR, FR, n), ai);
+      G1Point vp1 = mul_fr(msm_naive(xi1.data(), vi + i * n * FR, FR, n), ai);
+      sumA = affine_add(sumA, up); sumB = affine_add(sumB, vp); sumB1 = affine_add(sumB1, vp1);
+    }
+  } else {
+    std::vector<uint64_t> U(n * FR), V(n * FR);
+    for (size_t k = 0; k < n; ++k) {
+      Fr u(0), v(0);
+      for (size_t i = 0; i <= m; ++i) { Fr ai = ldr(wires + i * FR); u = u + ai * ldr(ui + (i * n + k) * FR); v = v + ai * ldr(vi + (i * n + k) * FR); }
+      for (int j = 0; j < FR; ++j) { U[k * FR + j] = u.l[j]; V[k * FR + j] = v.l[j]; }
+    }
+    sumA = msm_naive(xi1.data(), U.data(), FR, n); sumB = msm_naive(xi2.data(), V.data(), FR, n); sumB1 = msm_naive(xi1.data(), V.data(), FR, n);
+  }
+  G1Point d1 = ldg1(c->g1_delta);
+  G1Point A = affine_add(affine_add(ldg1(c->g1_alpha), sumA), mul_fr(d1, r));                 // prover.rs:118
+  G2Point B = affine_add(affine_add(ldg2(c->g2_beta), sumB), mul_fr(ldg2(c->g2_delta), s));    // :119
+  G1Point B1 = affine_add(affine_add(ldg1(c->g1_beta), sumB1), mul_fr(d1, s));                 // :120
+  G1Point sum = G1Point::infinity();
+  for (size_t i = l + 1; i <= m; ++i) sum = affine_add(sum, mul_fr(ldg1(c->g1_uvw_wit + (i - l - 1) * G1W), ldr(wires + i * FR)));   // :127-131
+  G1Point ht = msm_naive(xtd.data(), hcoef, FR, h_len);                                          // :133
+  G1Point C = affine_add(affine_add(affine_add(affine_add(sum, ht), mul_fr(A, s)), mul_fr(B1, r)), mul_fr(mul_fr(d1, r), s).neg());   // :135-140
+  stg1(A_, A); stg2(B_, B); stg1(C_, C);
+  return 0;
+}
+
+// Verifier::verify (verifier.rs:30-54); returns 1/0, -2 if a pairing argument is at infinity (the reference panics)
+int zkto_groth16_verify(const zkto_groth16_crs* c, const uint64_t* A_, const uint64_t* B_, const uint64_t* C_,
+                        const uint64_t* stmt_wires, size_t n_stmt) {
+  init_fields();
+  static Pairing pr;
+  try {
+    Fq12 lhs = pr.tate(ldg1(A_), ldg2(B_));
+    G1Point sum = G1Point::infinity();
+    for (size_t i = 0; i < n_stmt; ++i) sum = affine_add(sum, mul_fr(ldg1(c->g1_uvw_stmt + i * G1W), ldr(stmt_wires + i * FR)));
+    Fq12 rhs = ld12(c->gt_alpha_beta) * pr.tate(sum, ldg2(c->g2_gamma)) * pr.tate(ldg1(C_), ldg2(c->g2_delta));
+    return lhs == rhs ? 1 : 0;
+  } catch (const std::domain_error&) { return -2; }
+}
+
+// ---- Bulletproofs::inner_product_argument (bulletproofs.rs:19-55), challenges injected (xs[level]) -----------
+typedef Fp<SpTag> Sp; typedef Fp<SnTag> Sn;
+static SecpPoint ldsp(const uint64_t* p) { if (p[8] & 0xffffffffu) return SecpPoint::infinity(); return SecpPoint(Sp::from_limbs(p, 4), Sp::from_limbs(p + 4, 4)); }
+static void stsp(uint64_t* p, const SecpPoint& v) {
+  if (v.inf) { for (int i = 0; i < 8; ++i) p[i] = 0; p[8] = 1; return; }
+  for (int i = 0; i < 4; ++i) { p[i] = v.x.l[i]; p[4 + i] = v.y.l[i]; } p[8] = 0;
+}
+static SecpPoint smul(const SecpPoint& p, const Sn& k) { return scalar_mul(p, k.l, 4); }
+static SecpPoint vec_msm(const std::vector<SecpPoint>& g, size_t g0, const std::vector<Sn>& a, size_t a0, size_t cnt) {   // (gg * a).sum(), affine_points.rs:123-144,25-31
+  SecpPoint s = SecpPoint::infinity();
+  for (size_t i = 0; i < cnt; ++i) s = affine_add(s, smul(g[g0 + i], a[a0 + i]));
+  return s;
+}
+// out_trace (optional): per level L,R (2 points) then the folded P' — lets the GPU path be compared level by level.
+int zkto_bp_ipa(size_t n, const uint64_t* gg_, const uint64_t* hh_, const uint64_t* u_, const uint64_t* P_,
+                const uint64_t* a_, const uint64_t* b_, const uint64_t* xs, uint64_t* out_trace) {
+  init_fields();
+  std::vector<SecpPoint> gg(n), hh(n); std::vector<Sn> a(n), b(n);
+  for (size_t i = 0; i < n; ++i) { gg[i] = ldsp(gg_ + i * 9); hh[i] = ldsp(hh_ + i * 9); a[i] = Sn::from_limbs(a_ + i * 4, 4); b[i] = Sn::from_limbs(b_ + i * 4, 4); }
+  SecpPoint u = ldsp(u_), P = ldsp(P_);
+  size_t level = 0;
+  while (n > 1) {
+    size_t np = n / 2;
+    Sn cL(0), cR(0);
+    for (size_t i = 0; i < np; ++i) { cL = cL + a[i] * b[np + i]; cR = cR + a[np + i] * b[i]; }                                  // :36-37
+    SecpPoint L = affine_add(affine_add(vec_msm(gg, np, a, 0, np), vec_msm(hh, 0, b, np, np)), smul(u, cL));                      // :39
+    SecpPoint R = affine_add(affine_add(vec_msm(gg, 0, a, np, np), vec_msm(hh, np, b, 0, np)), smul(u, cR));                      // :40
+    Sn x = Sn::from_limbs(xs + level * 4, 4), xi = x.inv();                                                                        // :42 (injected)
+    std::vector<SecpPoint> g2(np), h2(np); std::vector<Sn> a2(np), b2(np);
+    for (size_t i = 0; i < np; ++i) {
+      g2[i] = affine_add(smul(gg[i], xi), smul(gg[np + i], x));                                                                    // :44
+      h2[i] = affine_add(smul(hh[i], x), smul(hh[np + i], xi));                                                                    // :45
+      a2[i] = a[i] * x + a[np + i] * xi; b2[i] = b[i] * xi + b[np + i] * x;                                                        // :49-50
+    }
+    P = affine_add(affine_add(smul(L, x.sq()), P), smul(R, x.sq().inv()));                                                         // :47
+    if (out_trace) { stsp(out_trace + level * 27, L); stsp(out_trace + level * 27 + 9, R); stsp(out_trace + level * 27 + 18, P); }
+    gg.swap(g2); hh.swap(h2); a.swap(a2); b.swap(b2); n = np; ++level;
+  }
+  Sn c = a[0] * b[0];                                                                                                              // :28-32
+  SecpPoint rhs = affine_add(affine_add(smul(gg[0], a[0]), smul(hh[0], b[0])), smul(u, c));
+  return P == rhs ? 1 : 0;
+}
+// helper for the tests: P = g^a h^b u^<a,b> (bulletproofs.rs:17)
+int zkto_bp_commit(size_t n, const uint64_t* gg_, const uint64_t* hh_, const uint64_t* u_, const uint64_t* a_, const uint64_t* b_, uint64_t* P_) {
+  init_fields();
+  std::vector<SecpPoint> gg(n), hh(n); std::vector<Sn> a(n), b(n);
+  Sn c(0);
+  for (size_t i = 0; i < n; ++i) { gg[i] = ldsp(gg_ + i * 9); hh[i] = ldsp(hh_ + i * 9); a[i] = Sn::from_limbs(a_ + i * 4, 4); b[i] = Sn::from_limbs(b_ + i * 4, 4); c = c + a[i] * b[i]; }
+  stsp(P_, affine_add(affine_add(vec_msm(gg, 0, a, 0, n), vec_msm(hh, 0, b, 0, n)), smul(ldsp(u_), c)));
+  return 0;
+}
+// Fr / secp-n helpers the python harness uses to build QAPs and challenges (field only)
+int zkto_sn_inv(const uint64_t* a, uint64_t* o) { init_fields(); Sn r; if (!Sn::from_limbs(a, 4).safe_inv(r)) return 1; for (int i = 0; i < 4; ++i) o[i] = r.l[i]; return 0; }
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+"""GPU parity for the two callers of the hot path against the oracle's
+restatement with the same injected randomness: CRS points, proof points (A,B,C) and IPA transcripts must be
+bit-identical; accept/reject decisions must agree."""
+import ctypes, importlib
+import numpy as np
+import pytest
+from zkt_testlib import *
+from qap_util import *
+
+pytestmark = pytest.mark.gpu
+zk = importlib.import_module("zk-toolkit_amd")
+O = oracle()
+fr = lambda v: ints_to_arr([v], 4)
+
+
+@pytest.fixture(scope="module")
+def L():
+    zk.init()
+    return zk.lib()
+
+
+@pytest.mark.parametrize("n", [1, 3, 16, 100])
+def test_g2_and_secp_msm_vs_oracle(L, n):           # polynomial.rs:283-293; secp256k1/affine_points.rs:25-31,123-144
+    rng = SplitMix64(500 + n)
+    for name, W, order, gen in (("g2", G2W, R, O.zkto_g2_generator), ("secp", 9, SECP_N, O.zkto_secp_generator)):
+        g = np.zeros((1, W), np.uint64); gen(ptr(g))
+        bases = np.zeros((n, W), np.uint64)
+        zk.check(getattr(L, f"zkt_{name}_mul_batch")(ptr(np.repeat(g, n, axis=0)), ptr(ints_to_arr([rng.below(order) for _ in range(n)], 4)), 4, ptr(bases), n))
+        ss = [rng.below(order) for _ in range(n)]
+        if n > 2: ss[1] = 0
+        sc = ints_to_arr(ss, 4)
+        got = np.zeros((1, W), np.uint64); zk.check(getattr(L, f"zkt_{name}_msm")(ptr(bases), ptr(sc), n, ptr(got)))
+        # oracle: n scalar muls then sequential adds
+        tmp = np.zeros_like(bases); assert getattr(O, f"zkto_{name}_mul_batch")(ptr(bases), ptr(sc), 4, ptr(tmp), n, 8) == 0
+        acc = np.zeros((1, W), np.uint64); acc[0, W - 1] = 1
+        for i in range(n):
+            nxt = np.zeros_like(acc); assert getattr(O, f"zkto_{name}_add_batch")(ptr(acc), ptr(tmp[i:i + 1].copy()), ptr(nxt), 1) == 0; acc = nxt
+        assert (got == acc).all(), (name, n)
+
+
+def run_both(L, A, B, C, wit, l, seed, literal):
+    n, m = len(A), len(wit) - 1
+    ui, vi, wi, h, _ = qap_from_r1cs(A, B, C, wit)
+    U, V, W = dense(ui, n), dense(vi, n), dense(wi, n)
+    rng = SplitMix64(seed)
+    trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+    r, s = fr(rng.below(R - 1) + 1), fr(rng.below(R - 1) + 1)
+    wires = ints_to_arr(wit, 4); H = ints_to_arr(h, 4)
+    ocrs, obuf = alloc_crs(n, l, m); gcrs, gbuf = alloc_crs(n, l, m)
+    assert O.zkto_groth16_setup(ctypes.byref(ocrs), ptr(U), ptr(V), ptr(W), *[ptr(t) for t in trap]) == 0
+    zk.check(L.zkt_groth16_setup(ctypes.byref(gcrs), ptr(U), ptr(V), ptr(W), *[ptr(t) for t in trap]))
+    for k in obuf:
+        assert (obuf[k] == gbuf[k]).all(), f"CRS field {k} differs"
+    op = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+    gp = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+    assert O.zkto_groth16_prove(ctypes.byref(ocrs), ptr(U), ptr(V), ptr(wires), ptr(H), len(h), ptr(r), ptr(s), literal, *[ptr(x) for x in op]) == 0
+    zk.check(L.zkt_groth16_prove(ctypes.byref(gcrs), ptr(U), ptr(V), ptr(wires), ptr(H), len(h), ptr(r), ptr(s), *[ptr(x) for x in gp]))
+    for a, b, name in zip(op, gp, "ABC"):
+        assert (a == b).all(), f"proof element {name} differs"
+    stmt = ints_to_arr(wit[:l + 1], 4)
+    assert L.zkt_groth16_verify(ctypes.byref(gcrs), *[ptr(x) for x in gp], ptr(stmt), l + 1) == 1
+    assert O.zkto_groth16_verify(ctypes.byref(ocrs), *[ptr(x) for x in gp], ptr(stmt), l + 1) == 1
+    bad = stmt.copy(); bad[l, 0] ^= 1
+    assert L.zkt_groth16_verify(ctypes.byref(gcrs), *[ptr(x) for x in gp], ptr(bad), l + 1) == 0
+    tam = gp[2].copy(); tam[0, :12] = gp[0][0, :12]                      # C := A
+    assert L.zkt_groth16_verify(ctypes.byref(gcrs), ptr(gp[0]), ptr(gp[1]), ptr(tam), ptr(stmt), l + 1) == 0
+
+
+def test_groth16_reference_example(L):              # prover.rs:159-192, literal per-wire loop in the oracle
+    run_both(L, *example_cubic(), seed=11, literal=1)
+
+
+@pytest.mark.parametrize("n", [16, 64])
+def test_groth16_chain_circuit(L, n):               # SURVEY §8d C4 generator at parity sizes
+    run_both(L, *chain_circuit(n), seed=12 + n, literal=0)
+
+
+def test_groth16_verify_infinity_is_error(L):       # verifier.rs:40-49: tate with the point at infinity panics
+    A, B, C, wit, l = example_cubic()
+    n, m = len(A), len(wit) - 1
+    ui, vi, wi, h, _ = qap_from_r1cs(A, B, C, wit)
+    crs, buf = alloc_crs(n, l, m)
+    rng = SplitMix64(3); trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+    zk.check(L.zkt_groth16_setup(ctypes.byref(crs), ptr(dense(ui, n)), ptr(dense(vi, n)), ptr(dense(wi, n)), *[ptr(t) for t in trap]))
+    inf1 = g1_arr([None]); g2 = buf["g2_beta"]
+    assert L.zkt_groth16_verify(ctypes.byref(crs), ptr(inf1), ptr(g2), ptr(buf["g1_alpha"]), ptr(ints_to_arr(wit[:l + 1], 4)), l + 1) == -ZKT_ERR_INFINITY
+
+
+def ipa_instance(L, n, seed):
+    rng = SplitMix64(seed)
+    g = np.zeros((1, 9), np.uint64); O.zkto_secp_generator(ptr(g))
+    ks = ints_to_arr([rng.below(SECP_N - 1) + 1 for _ in range(2 * n + 1)], 4)
+    pts = np.zeros((2 * n + 1, 9), np.uint64)
+    zk.check(L.zkt_secp_mul_batch(ptr(np.repeat(g, 2 * n + 1, axis=0)), ptr(ks), 4, ptr(pts), 2 * n + 1))
+    gg, hh, u = pts[:n].copy(), pts[n:2 * n].copy(), pts[2 * n:].copy()
+    av = [rng.below(SECP_N) for _ in range(n)]; bv = [rng.below(SECP_N) for _ in range(n)]
+    a, b = ints_to_arr(av, 4), ints_to_arr(bv, 4)
+    # P = g^a h^b u^<a,b> (bulletproofs.rs:17) through the GPU MSM
+    c = sum(x * y for x, y in zip(av, bv)) % SECP_N
+    P = np.zeros((1, 9), np.uint64)
+    zk.check(L.zkt_secp_msm(ptr(np.concatenate([gg, hh, u])), ptr(np.concatenate([a, b, ints_to_arr([c], 4)])), 2 * n + 1, ptr(P)))
+    levels = max(n.bit_length() - 1, 1)
+    xs = ints_to_arr([rng.below(SECP_N - 1) + 1 for _ in range(levels)], 4)
+    return gg, hh, u, P, a, b, xs, levels
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 64])
+def test_ipa_transcript_vs_oracle(L, n):            # bulletproofs.rs:19-55, level by level
+    gg, hh, u, P, a, b, xs, levels = ipa_instance(L, n, 600 + n)
+    want_P = np.zeros((1, 9), np.uint64); assert O.zkto_bp_commit(n, ptr(gg), ptr(hh), ptr(u), ptr(a), ptr(b), ptr(want_P)) == 0
+    assert (P == want_P).all()
+    gt, ot = np.zeros((levels * 3, 9), np.uint64), np.zeros((levels * 3, 9), np.uint64)
+    assert L.zkt_bp_inner_product_argument(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b), ptr(xs), ptr(gt)) == 1
+    assert O.zkto_bp_ipa(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b), ptr(xs), ptr(ot)) == 1
+    if n > 1: assert (gt == ot).all()
+    b2 = b.copy(); b2[0, 0] ^= 1
+    assert L.zkt_bp_inner_product_argument(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b2), ptr(xs), None) == 0
+
+
+def test_ipa_full_size_accepts(L):                  # BASELINE config 5 shape: n = 64*1024 generators, 16 levels
+    n = 1 << 16
+    gg, hh, u, P, a, b, xs, levels = ipa_instance(L, n, 77)
+    assert levels == 16
+    assert L.zkt_bp_inner_product_argument(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b), ptr(xs), None) == 1
+    a2 = a.copy(); a2[n - 1, 0] ^= 1
+    assert L.zkt_bp_inner_product_argument(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a2), ptr(b), ptr(xs), None) == 0

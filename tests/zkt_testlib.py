@@ -37,7 +37,7 @@ def oracle():
     global _oracle
     if _oracle is None:
         so = os.path.join(ROOT, "oracle", "libzkt_oracle.so")
-        srcs = [os.path.join(ROOT, "oracle", f) for f in ("zkt_oracle.cpp", "zkt_oracle_capi.cpp", "zkt_oracle.hpp")]
+        srcs = [os.path.join(ROOT, "oracle", f) for f in ("zkt_oracle.cpp", "zkt_oracle_capi.cpp", "zkt_oracle_protocols.cpp", "zkt_oracle.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
         _oracle = ctypes.CDLL(so)

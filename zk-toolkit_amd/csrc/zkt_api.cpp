@@ -130,6 +130,8 @@ static int slot_ready(zkt_g1_bases* h, int k) {   // lazily create the slot's st
   return ZKT_OK;
 }
 
+int zkt_internal_ready() { return ensure_ready(); }
+
 extern "C" {
 
 int zkt_version(void) { return 1; }

@@ -1,0 +1,289 @@
+// The two callers of the hot path, orchestrated on the device (rows a17, a18 of SURVEY §8):
+//   Groth16   src/zk/w_trusted_setup/groth16/zktoolkit_based/{crs.rs:49-146, prover.rs:96-147, verifier.rs:30-54}
+//   Bulletproofs inner-product argument   src/zk/wo_trusted_setup/bulletproofs.rs:19-55 (secp256k1)
+// Random values the reference draws from OS entropy (alpha..x, r, s, the IPA challenges) are arguments.
+// Fr / secp-n scalar algebra runs in small kernels here; every group operation goes through the batched
+// kernels of zkt_group.hip / zkt_msm.hip / zkt_pairing.hip.  Host code only moves buffers and sequences launches.
+#include <vector>
+#include <cstring>
+#include "abi.h"
+#include "zkt_internal.h"
+#include "../../include/zkt.h"
+
+namespace zkt {
+
+// ---- small scalar-field kernels (C = FrC for Groth16, SnC for Bulletproofs) -----------------------------
+// out[k] = sum_i a[i] * P[i*n + k]    (the combination sum_i a_i u_i of prover.rs:107-117, done in Fr first)
+template <class C>
+__global__ void __launch_bounds__(256) k_lincomb(const uint32_t* __restrict__ P, const uint32_t* __restrict__ a, size_t rows, size_t n, uint32_t* __restrict__ out) {
+  size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  Fp<C> acc = fp_zero<C>();
+  for (size_t i = 0; i < rows; ++i) acc = fp_add(acc, fp_mul(ld_fp<C>(a + i * C::N), ld_raw<C>(P + (i * n + k) * C::N)));   // aR * p * R^-1 = a p
+  st_raw<C>(out + k * C::N, acc);
+}
+// out[i] = P_i(x) for `rows` dense polynomials of n coefficients (Polynomial::eval_at, polynomial.rs:240-249)
+template <class C>
+__global__ void __launch_bounds__(64) k_poly_eval(const uint32_t* __restrict__ P, size_t rows, size_t n, const uint32_t* __restrict__ x, uint32_t* __restrict__ out_mont) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= rows) return;
+  Fp<C> xm = ld_fp<C>(x), acc = fp_zero<C>();
+  for (size_t k = n; k-- > 0;) acc = fp_add(fp_mul(acc, xm), ld_fp<C>(P + (i * n + k) * C::N));     // Horner, Montgomery domain
+  st_raw<C>(out_mont + i * C::N, acc);
+}
+// CRS::new scalar stage (crs.rs:59-116): y_i = (beta u_i(x) + alpha v_i(x) + w_i(x)) / (gamma | delta), x^k, x^k t(x)/delta
+__global__ void k_groth16_setup_scalars(const uint32_t* __restrict__ ue, const uint32_t* __restrict__ ve, const uint32_t* __restrict__ we,
+                                        const uint32_t* __restrict__ trap /*alpha,beta,gamma,delta,x canonical*/, size_t n, size_t l, size_t m,
+                                        uint32_t* __restrict__ y /*m+1*/, uint32_t* __restrict__ xpow /*n*/, uint32_t* __restrict__ xt /*n*/) {
+  typedef FrC C;
+  if (threadIdx.x || blockIdx.x) return;
+  Fp<C> alpha = ld_fp<C>(trap), beta = ld_fp<C>(trap + 8), gamma = ld_fp<C>(trap + 16), delta = ld_fp<C>(trap + 24), x = ld_fp<C>(trap + 32);
+  Fp<C> ginv = fp_inv(gamma), dinv = fp_inv(delta);
+  for (size_t i = 0; i <= m; ++i) {
+    Fp<C> s = fp_add(fp_add(fp_mul(beta, ld_raw<C>(ue + i * 8)), fp_mul(alpha, ld_raw<C>(ve + i * 8))), ld_raw<C>(we + i * 8));
+    st_fp<C>(y + i * 8, fp_mul(s, i <= l ? ginv : dinv));
+  }
+  Fp<C> t = fp_one<C>(), one = fp_one<C>(), ii = fp_zero<C>();
+  for (size_t i = 1; i <= n; ++i) { ii = fp_add(ii, one); t = fp_mul(t, fp_sub(x, ii)); }       // QAP::build_t(f,n).eval_at(x), qap.rs:115-135
+  Fp<C> td = fp_mul(t, dinv), xp = one;
+  for (size_t k = 0; k < n; ++k) { st_fp<C>(xpow + k * 8, xp); st_fp<C>(xt + k * 8, fp_mul(xp, td)); xp = fp_mul(xp, x); }
+}
+// r*s etc. are group-side in the reference (delta*r*s = two scalar muls), nothing to do here.
+
+// IPA scalar stage: [x, x^-1, x^2, x^-2] canonical
+__global__ void k_ipa_challenge(const uint32_t* __restrict__ x, uint32_t* __restrict__ out4) {
+  typedef SnC C;
+  if (threadIdx.x || blockIdx.x) return;
+  Fp<C> xm = ld_fp<C>(x), xi = fp_inv(xm), x2 = fp_sqr(xm), x2i = fp_inv(x2);
+  st_fp<C>(out4, xm); st_fp<C>(out4 + 8, xi); st_fp<C>(out4 + 16, x2); st_fp<C>(out4 + 24, x2i);
+}
+// dot = sum_i a[i]*b[i] (one block); PrimeFieldElems * PrimeFieldElems then sum (prime_field_elems.rs:90-174)
+template <class C>
+__global__ void __launch_bounds__(256) k_dot(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n, uint32_t* __restrict__ out) {
+  __shared__ uint32_t lds[256 * C::N];
+  const int t = threadIdx.x;
+  Fp<C> acc = fp_zero<C>();
+  for (size_t i = t; i < n; i += 256) acc = fp_add(acc, fp_mul(ld_fp<C>(a + i * C::N), ld_raw<C>(b + i * C::N)));
+  st_raw<C>(lds + t * C::N, acc); __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (t < d) { acc = fp_add(acc, ld_raw<C>(lds + (t + d) * C::N)); st_raw<C>(lds + t * C::N, acc); }
+    __syncthreads();
+  }
+  if (t == 0) st_raw<C>(out, acc);
+}
+// out[i] = a[i]*s0 + b[i]*s1 (a' = a_lo x + a_hi x^-1, bulletproofs.rs:49-50)
+template <class C>
+__global__ void __launch_bounds__(256) k_fold(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ s0,
+                                              const uint32_t* __restrict__ s1, size_t n, uint32_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  Fp<C> r = fp_add(fp_mul(ld_fp<C>(s0), ld_raw<C>(a + i * C::N)), fp_mul(ld_fp<C>(s1), ld_raw<C>(b + i * C::N)));
+  st_raw<C>(out + i * C::N, r);
+}
+
+}  // namespace zkt
+
+using namespace zkt;
+
+namespace {
+struct Dev {   // tiny RAII device buffer
+  void* p = nullptr;
+  explicit Dev(size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) p = nullptr; }
+  ~Dev() { if (p) hipFree(p); }
+  uint32_t* w() const { return (uint32_t*)p; }
+  Dev(const Dev&) = delete; Dev& operator=(const Dev&) = delete;
+};
+#define PCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return ZKT_ERR_DEVICE; } while (0)
+int up(Dev& d, const void* h, size_t bytes, hipStream_t s) { if (!d.p) return ZKT_ERR_DEVICE; if (bytes) PCHK(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, s)); return ZKT_OK; }
+int down(void* h, const void* d, size_t bytes, hipStream_t s) { PCHK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s)); return ZKT_OK; }
+const size_t G1B = sizeof(zkt_g1_affine), G2B = sizeof(zkt_g2_affine), SPB = sizeof(zkt_secp_affine), FRB = 32;
+const uint64_t G1_GEN[13] = {0xfb3af00adb22c6bbull, 0x6c55e83ff97a1aefull, 0xa14e3a3f171bac58ull, 0xc3688c4f9774b905ull, 0x2695638c4fa9ac0full, 0x17f1d3a73197d794ull,
+                             0x0caa232946c5e7e1ull, 0xd03cc744a2888ae4ull, 0x00db18cb2c04b3edull, 0xfcf5e095d5d00af6ull, 0xa09e30ed741d8ae4ull, 0x08b3f481e3aaa0f1ull, 0};   // g1_point.rs:38-47
+const uint64_t G2_GEN[25] = {0xe5ac7d055d042b7eull, 0x334cf11213945d57ull, 0xb5da61bbdc7f5049ull, 0x596bd0d09920b61aull, 0x7dacd3a088274f65ull, 0x13e02b6052719f60ull,
+                             0xd48056c8c121bdb8ull, 0x0bac0326a805bbefull, 0xb4510b647ae3d177ull, 0xc6e47ad4fa403b02ull, 0x260805272dc51051ull, 0x024aa2b2f08f0a91ull,
+                             0xaaa9075ff05f79beull, 0x3f370d275cec1da1ull, 0x267492ab572e99abull, 0xcb3e287e85a763afull, 0x32acd2b02bc28b99ull, 0x0606c4a02ea734ccull,
+                             0xe193548608b82801ull, 0x923ac9cc3baca289ull, 0x6d429a695160d12cull, 0xadfd9baa8cbdd3a7ull, 0x8cc9cdc6da2e351aull, 0x0ce5d527727d6e11ull, 0};   // g2_point.rs:36-46 {x.u1,x.u0,y.u1,y.u0}
+}  // namespace
+
+extern int zkt_internal_ready();   // zkt_api.cpp
+
+extern "C" {
+
+// eval_with_g2_hidings (polynomial.rs:283-293) and the secp256k1 vector form (affine_points.rs:25-31,123-144):
+// n scalar multiplications then a pairwise-tree sum.  (G1 has the Pippenger path in zkt_msm.hip.)
+static int msm_simple(int grp, const void* bases, const uint64_t* scalars, size_t n, void* out) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  const size_t PB = grp == G_G2 ? G2B : SPB;
+  if (!out || (n && (!bases || !scalars))) return ZKT_ERR_SHAPE;
+  if (n == 0) { memset(out, 0, PB); ((uint32_t*)out)[PB / 4 - 2] = 1; return ZKT_OK; }
+  hipStream_t s = nullptr;
+  Dev db(n * PB), dk(n * FRB), dt(n * PB);
+  int rc; if ((rc = up(db, bases, n * PB, s)) || (rc = up(dk, scalars, n * FRB, s))) return rc;
+  if (!dt.p) return ZKT_ERR_DEVICE;
+  PCHK(launch_group_mul(grp, db.w(), dk.w(), 8, dt.w(), n, s));
+  PCHK(launch_group_sum_inplace(grp, dt.w(), n, s));
+  if ((rc = down(out, dt.p, PB, s))) return rc;
+  PCHK(hipStreamSynchronize(s));
+  return ZKT_OK;
+}
+int zkt_g2_msm(const zkt_g2_affine* bases, const uint64_t* scalars, size_t n, zkt_g2_affine* out) { return msm_simple(G_G2, bases, scalars, n, out); }
+int zkt_secp_msm(const zkt_secp_affine* bases, const uint64_t* scalars, size_t n, zkt_secp_affine* out) { return msm_simple(G_SECP, bases, scalars, n, out); }
+
+// CRS::new (crs.rs:49-146), trapdoors injected.  ui/vi/wi: (m+1) x n Fr coefficients, low degree first.
+int zkt_groth16_setup(zkt_groth16_crs* c, const uint64_t* ui, const uint64_t* vi, const uint64_t* wi,
+                      const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma, const uint64_t* delta, const uint64_t* x) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!c || !ui || !vi || !wi || !alpha || !beta || !gamma || !delta || !x || c->n == 0 || c->l > c->m) return ZKT_ERR_SHAPE;
+  const size_t n = c->n, l = c->l, m = c->m, rows = m + 1;
+  hipStream_t s = nullptr;
+  uint64_t trap[20]; memcpy(trap, alpha, 32); memcpy(trap + 4, beta, 32); memcpy(trap + 8, gamma, 32); memcpy(trap + 12, delta, 32); memcpy(trap + 16, x, 32);
+  for (int k = 0; k < 5; ++k) { bool z = true; for (int j = 0; j < 4; ++j) z = z && trap[4 * k + j] == 0; if (z) return ZKT_ERR_INV_ZERO; }   // rand_elem(true): non-zero (crs.rs:59-63)
+  Dev dP(rows * n * FRB), dtrap(160), due(rows * FRB), dve(rows * FRB), dwe(rows * FRB), dy(rows * FRB), dxp(n * FRB), dxt(n * FRB);
+  Dev dgen1(G1B), dgen2(G2B), dout1((rows + 2 * n + 3) * G1B), dout2((n + 3) * G2B), dgt(576), derr(8);
+  int rc;
+  if ((rc = up(dtrap, trap, 160, s)) || (rc = up(dgen1, G1_GEN, G1B, s)) || (rc = up(dgen2, G2_GEN, G2B, s))) return rc;
+  const uint64_t* polys[3] = {ui, vi, wi}; Dev* evals[3] = {&due, &dve, &dwe};
+  for (int k = 0; k < 3; ++k) {
+    if ((rc = up(dP, polys[k], rows * n * FRB, s))) return rc;
+    hipLaunchKernelGGL(k_poly_eval<FrC>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, (const uint32_t*)dP.w(), rows, n, (const uint32_t*)(dtrap.w() + 32), evals[k]->w());
+  }
+  hipLaunchKernelGGL(k_groth16_setup_scalars, dim3(1), dim3(64), 0, s, (const uint32_t*)due.w(), (const uint32_t*)dve.w(), (const uint32_t*)dwe.w(),
+                     (const uint32_t*)dtrap.w(), n, l, m, dy.w(), dxp.w(), dxt.w());
+  // fixed-base multiplications g * y (crs.rs:85-135): [uvw (m+1) | xi (n) | xt_by_delta (n) | alpha beta delta]
+  uint32_t* o1 = dout1.w();
+  PCHK(launch_group_mul(G_G1, dgen1.w(), dy.w(), 8, o1, rows, s, true));
+  PCHK(launch_group_mul(G_G1, dgen1.w(), dxp.w(), 8, o1 + rows * 26, n, s, true));
+  PCHK(launch_group_mul(G_G1, dgen1.w(), dxt.w(), 8, o1 + (rows + n) * 26, n, s, true));
+  PCHK(launch_group_mul(G_G1, dgen1.w(), dtrap.w(), 8, o1 + (rows + 2 * n) * 26, 1, s, true));            // alpha
+  PCHK(launch_group_mul(G_G1, dgen1.w(), dtrap.w() + 8, 8, o1 + (rows + 2 * n + 1) * 26, 1, s, true));    // beta
+  PCHK(launch_group_mul(G_G1, dgen1.w(), dtrap.w() + 24, 8, o1 + (rows + 2 * n + 2) * 26, 1, s, true));   // delta
+  uint32_t* o2 = dout2.w();
+  PCHK(launch_group_mul(G_G2, dgen2.w(), dxp.w(), 8, o2, n, s, true));
+  PCHK(launch_group_mul(G_G2, dgen2.w(), dtrap.w() + 8, 8, o2 + n * 50, 1, s, true));          // beta
+  PCHK(launch_group_mul(G_G2, dgen2.w(), dtrap.w() + 16, 8, o2 + (n + 1) * 50, 1, s, true));   // gamma
+  PCHK(launch_group_mul(G_G2, dgen2.w(), dtrap.w() + 24, 8, o2 + (n + 2) * 50, 1, s, true));   // delta
+  unsigned long long noerr = NO_ERR; if ((rc = up(derr, &noerr, 8, s))) return rc;
+  PCHK(launch_tate(o1 + (rows + 2 * n) * 26, o2 + n * 50, dgt.w(), 1, (unsigned long long*)derr.p, s));   // crs.rs:137-139
+  if ((rc = down(c->g1_uvw_stmt, o1, (l + 1) * G1B, s)) || (rc = down(c->g1_uvw_wit, o1 + (l + 1) * 26, (m - l) * G1B, s)) ||
+      (rc = down(c->g1_xi, o1 + rows * 26, n * G1B, s)) || (rc = down(c->g1_xt_by_delta, o1 + (rows + n) * 26, n * G1B, s)) ||
+      (rc = down(c->g1_alpha, o1 + (rows + 2 * n) * 26, G1B, s)) || (rc = down(c->g1_beta, o1 + (rows + 2 * n + 1) * 26, G1B, s)) ||
+      (rc = down(c->g1_delta, o1 + (rows + 2 * n + 2) * 26, G1B, s)) || (rc = down(c->g2_xi, o2, n * G2B, s)) ||
+      (rc = down(c->g2_beta, o2 + n * 50, G2B, s)) || (rc = down(c->g2_gamma, o2 + (n + 1) * 50, G2B, s)) ||
+      (rc = down(c->g2_delta, o2 + (n + 2) * 50, G2B, s)) || (rc = down(c->gt_alpha_beta, dgt.p, 576, s))) return rc;
+  PCHK(hipStreamSynchronize(s));
+  return ZKT_OK;
+}
+
+// Prover::prove (prover.rs:96-147), r and s injected.
+// A = alpha + (sum_i a_i u_i)(x) G + r delta is one MSM over crs.g1.xi once the polynomials are combined in Fr
+// (the reference does (m+1) MSMs and multiplies each by a_i — the same group element).
+int zkt_groth16_prove(const zkt_groth16_crs* c, const uint64_t* ui, const uint64_t* vi, const uint64_t* wires,
+                      const uint64_t* h, size_t h_len, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* C) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!c || !ui || !vi || !wires || !r || !s_ || !A || !B || !C || (h_len && !h) || h_len > c->n || c->l > c->m) return ZKT_ERR_SHAPE;   // h_len > n would index-panic (polynomial.rs:277-279)
+  const size_t n = c->n, l = c->l, m = c->m, rows = m + 1, nw = m - l;
+  hipStream_t s = nullptr;
+  Dev dP(rows * n * FRB), dw(rows * FRB), dU(n * FRB), dV(n * FRB);
+  int rc; if ((rc = up(dw, wires, rows * FRB, s))) return rc;
+  if ((rc = up(dP, ui, rows * n * FRB, s))) return rc;
+  hipLaunchKernelGGL(k_lincomb<FrC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)dP.w(), (const uint32_t*)dw.w(), rows, n, dU.w());
+  if ((rc = up(dP, vi, rows * n * FRB, s))) return rc;
+  hipLaunchKernelGGL(k_lincomb<FrC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)dP.w(), (const uint32_t*)dw.w(), rows, n, dV.w());
+  std::vector<uint64_t> U(n * 4), V(n * 4);
+  if ((rc = down(U.data(), dU.p, n * FRB, s)) || (rc = down(V.data(), dV.p, n * FRB, s))) return rc;
+  PCHK(hipStreamSynchronize(s));
+  zkt_g1_affine sumA, sumB1, sumW, ht; zkt_g2_affine sumB;
+  if ((rc = zkt_g1_msm(c->g1_xi, U.data(), n, &sumA)) || (rc = zkt_g2_msm(c->g2_xi, V.data(), n, &sumB)) || (rc = zkt_g1_msm(c->g1_xi, V.data(), n, &sumB1))) return rc;
+  if ((rc = zkt_g1_msm(c->g1_uvw_wit, wires + (l + 1) * 4, nw, &sumW)) || (rc = zkt_g1_msm(c->g1_xt_by_delta, h, h_len, &ht))) return rc;
+  // the seven single scalar multiplications and the final sums (prover.rs:118-140)
+  zkt_g1_affine dr, ds, As, Br, drs, t1, t2;
+  if ((rc = zkt_g1_mul_batch(c->g1_delta, r, 4, &dr, 1)) || (rc = zkt_g1_mul_batch(c->g1_delta, s_, 4, &ds, 1))) return rc;
+  zkt_g2_affine d2s; if ((rc = zkt_g2_mul_batch(c->g2_delta, s_, 4, &d2s, 1))) return rc;
+  if ((rc = zkt_g1_add_batch(c->g1_alpha, &sumA, &t1, 1)) || (rc = zkt_g1_add_batch(&t1, &dr, A, 1))) return rc;               // A
+  zkt_g2_affine t3; if ((rc = zkt_g2_add_batch(c->g2_beta, &sumB, &t3, 1)) || (rc = zkt_g2_add_batch(&t3, &d2s, B, 1))) return rc;   // B
+  zkt_g1_affine B1; if ((rc = zkt_g1_add_batch(c->g1_beta, &sumB1, &t1, 1)) || (rc = zkt_g1_add_batch(&t1, &ds, &B1, 1))) return rc; // B_g1
+  if ((rc = zkt_g1_mul_batch(A, s_, 4, &As, 1)) || (rc = zkt_g1_mul_batch(&B1, r, 4, &Br, 1)) || (rc = zkt_g1_mul_batch(&dr, s_, 4, &drs, 1))) return rc;
+  zkt_g1_affine ndrs; if ((rc = zkt_g1_neg_batch(&drs, &ndrs, 1))) return rc;
+  if ((rc = zkt_g1_add_batch(&sumW, &ht, &t1, 1)) || (rc = zkt_g1_add_batch(&t1, &As, &t2, 1)) || (rc = zkt_g1_add_batch(&t2, &Br, &t1, 1)) ||
+      (rc = zkt_g1_add_batch(&t1, &ndrs, C, 1))) return rc;                                                                        // C
+  return ZKT_OK;
+}
+
+// Verifier::verify (verifier.rs:30-54): 1 = accept, 0 = reject, negative = -status (pairing with infinity panics in the reference)
+int zkt_groth16_verify(const zkt_groth16_crs* c, const zkt_g1_affine* A, const zkt_g2_affine* B, const zkt_g1_affine* C,
+                       const uint64_t* stmt_wires, size_t n_stmt) {
+  if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
+  if (!c || !A || !B || !C || (n_stmt && !stmt_wires) || n_stmt > c->l + 1) return -ZKT_ERR_SHAPE;
+  zkt_g1_affine sum; int rc;
+  if ((rc = zkt_g1_msm(c->g1_uvw_stmt, stmt_wires, n_stmt, &sum))) return -rc;
+  zkt_g1_affine p[3] = {*A, sum, *C}; zkt_g2_affine q[3] = {*B, *c->g2_gamma, *c->g2_delta};
+  uint64_t e[3 * 72], t[72], rhs[72];
+  if ((rc = zkt_tate_batch(p, q, e, 3))) return -rc;
+  if ((rc = zkt_fq12_mul_batch(c->gt_alpha_beta, e + 72, t, 1)) || (rc = zkt_fq12_mul_batch(t, e + 144, rhs, 1))) return -rc;
+  return zkt_gt_eq(e, rhs);
+}
+
+// Bulletproofs::inner_product_argument (bulletproofs.rs:19-55); xs = one injected challenge per level (log2 n of them).
+// out_trace (optional, host): per level L, R and the folded P' (3 zkt_secp_affine) for level-by-level parity.
+int zkt_bp_inner_product_argument(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u, const zkt_secp_affine* P,
+                                  const uint64_t* a, const uint64_t* b, const uint64_t* xs, zkt_secp_affine* out_trace) {
+  if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
+  if (n == 0 || (n & (n - 1)) || !gg || !hh || !u || !P || !a || !b || (n > 1 && !xs)) return -ZKT_ERR_SHAPE;
+  hipStream_t s = nullptr;
+  const int PW = 18;
+  Dev dg(n * SPB), dh(n * SPB), da(n * FRB), db(n * FRB), du(SPB), dPp(SPB), dx(FRB), dch(4 * FRB), dc(2 * FRB);
+  Dev tmp((n + 2) * SPB), tmp2((n + 2) * SPB), dLR(2 * SPB), da2(n * FRB), db2(n * FRB);
+  int rc;
+  if ((rc = up(dg, gg, n * SPB, s)) || (rc = up(dh, hh, n * SPB, s)) || (rc = up(da, a, n * FRB, s)) || (rc = up(db, b, n * FRB, s)) ||
+      (rc = up(du, u, SPB, s)) || (rc = up(dPp, P, SPB, s))) return -rc;
+  if (!tmp.p || !tmp2.p || !dLR.p || !da2.p || !db2.p || !dch.p || !dc.p || !dx.p) return -ZKT_ERR_DEVICE;
+  uint32_t *G = dg.w(), *H = dh.w(), *Av = da.w(), *Bv = db.w(), *A2 = da2.w(), *B2 = db2.w();
+  size_t level = 0;
+  while (n > 1) {
+    const size_t np = n / 2;
+    // cL = <a_lo, b_hi>, cR = <a_hi, b_lo>  (:36-37)
+    hipLaunchKernelGGL(k_dot<SnC>, dim3(1), dim3(256), 0, s, (const uint32_t*)Av, (const uint32_t*)(Bv + np * 8), np, dc.w());
+    hipLaunchKernelGGL(k_dot<SnC>, dim3(1), dim3(256), 0, s, (const uint32_t*)(Av + np * 8), (const uint32_t*)Bv, np, dc.w() + 8);
+    // L = (gg_hi * a_lo).sum() + (hh_lo * b_hi).sum() + u * cL   (:39)
+    uint32_t* T = tmp.w();
+    if (launch_group_mul(G_SECP, G + np * PW, Av, 8, T, np, s) || launch_group_mul(G_SECP, H, Bv + np * 8, 8, T + np * PW, np, s) ||
+        launch_group_mul(G_SECP, du.w(), dc.w(), 8, T + 2 * np * PW, 1, s) || launch_group_sum_inplace(G_SECP, T, 2 * np + 1, s)) return -ZKT_ERR_DEVICE;
+    if (hipMemcpyAsync(dLR.w(), T, SPB, hipMemcpyDeviceToDevice, s) != hipSuccess) return -ZKT_ERR_DEVICE;
+    // R = (gg_lo * a_hi).sum() + (hh_hi * b_lo).sum() + u * cR   (:40)
+    if (launch_group_mul(G_SECP, G, Av + np * 8, 8, T, np, s) || launch_group_mul(G_SECP, H + np * PW, Bv, 8, T + np * PW, np, s) ||
+        launch_group_mul(G_SECP, du.w(), dc.w() + 8, 8, T + 2 * np * PW, 1, s) || launch_group_sum_inplace(G_SECP, T, 2 * np + 1, s)) return -ZKT_ERR_DEVICE;
+    if (hipMemcpyAsync(dLR.w() + PW, T, SPB, hipMemcpyDeviceToDevice, s) != hipSuccess) return -ZKT_ERR_DEVICE;
+    // challenge x (:42, injected) -> x, x^-1, x^2, x^-2
+    bool zero = true; for (int j = 0; j < 4; ++j) zero = zero && xs[level * 4 + j] == 0;
+    if (zero) return -ZKT_ERR_INV_ZERO;
+    if ((rc = up(dx, xs + level * 4, FRB, s))) return -rc;
+    hipLaunchKernelGGL(k_ipa_challenge, dim3(1), dim3(64), 0, s, (const uint32_t*)dx.w(), dch.w());
+    const uint32_t *X = dch.w(), *XI = dch.w() + 8, *X2 = dch.w() + 16, *X2I = dch.w() + 24;
+    // gg' = gg_lo * x^-1 + gg_hi * x ; hh' = hh_lo * x + hh_hi * x^-1   (:44-45)
+    uint32_t* T2 = tmp2.w();
+    if (launch_group_mul(G_SECP, G, XI, 8, T, np, s, false, true) || launch_group_mul(G_SECP, G + np * PW, X, 8, T2, np, s, false, true) ||
+        launch_group_add(G_SECP, T, T2, G, np, s)) return -ZKT_ERR_DEVICE;
+    if (launch_group_mul(G_SECP, H, X, 8, T, np, s, false, true) || launch_group_mul(G_SECP, H + np * PW, XI, 8, T2, np, s, false, true) ||
+        launch_group_add(G_SECP, T, T2, H, np, s)) return -ZKT_ERR_DEVICE;
+    // P' = L x^2 + P + R x^-2   (:47)
+    if (launch_group_mul(G_SECP, dLR.w(), X2, 8, T, 1, s) || launch_group_add(G_SECP, T, dPp.w(), T, 1, s) ||
+        launch_group_mul(G_SECP, dLR.w() + PW, X2I, 8, T2, 1, s) || launch_group_add(G_SECP, T, T2, dPp.w(), 1, s)) return -ZKT_ERR_DEVICE;
+    // a' = a_lo x + a_hi x^-1 ; b' = b_lo x^-1 + b_hi x   (:49-50)
+    hipLaunchKernelGGL(k_fold<SnC>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const uint32_t*)Av, (const uint32_t*)(Av + np * 8), X, XI, np, A2);
+    hipLaunchKernelGGL(k_fold<SnC>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const uint32_t*)Bv, (const uint32_t*)(Bv + np * 8), XI, X, np, B2);
+    std::swap(Av, A2); std::swap(Bv, B2);
+    if (out_trace) { if ((rc = down(out_trace + level * 3, dLR.p, 2 * SPB, s)) || (rc = down(out_trace + level * 3 + 2, dPp.p, SPB, s))) return -rc; }
+    n = np; ++level;
+  }
+  // base case (:28-32): c = a*b; P == g*a + h*b + u*c
+  hipLaunchKernelGGL(k_dot<SnC>, dim3(1), dim3(256), 0, s, (const uint32_t*)Av, (const uint32_t*)Bv, (size_t)1, dc.w());
+  uint32_t* T = tmp.w();
+  if (launch_group_mul(G_SECP, G, Av, 8, T, 1, s) || launch_group_mul(G_SECP, H, Bv, 8, T + PW, 1, s) || launch_group_mul(G_SECP, du.w(), dc.w(), 8, T + 2 * PW, 1, s) ||
+      launch_group_sum_inplace(G_SECP, T, 3, s)) return -ZKT_ERR_DEVICE;
+  zkt_secp_affine rhs, lhs;
+  if ((rc = down(&rhs, T, SPB, s)) || (rc = down(&lhs, dPp.p, SPB, s))) return -rc;
+  if (hipStreamSynchronize(s) != hipSuccess) return -ZKT_ERR_DEVICE;
+  return memcmp(&rhs, &lhs, SPB) == 0 ? 1 : 0;
+}
+
+}  // extern "C"
