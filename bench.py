@@ -9,6 +9,7 @@ N>1   = each rank owns a 2^20-term shard of one N*2^20-term MSM (weak scaling); 
         exchange is an all_gather of the 144-byte Jacobian partial sums + a local add.
 value = total scalar-muls per second over all ranks (terms / wall time, max over ranks)."""
 import argparse, ctypes, importlib, json, os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the MSM pipeline wants its three stage streams on distinct hardware queues
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

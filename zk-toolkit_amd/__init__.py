@@ -5,6 +5,8 @@ The HIP library is the only compute path: if libzkt_hip.so is missing or no GPU 
 `lib()` / `init()` raise — there is no CPU fallback."""
 import ctypes, os
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # read by the HIP runtime at first use: stage streams on distinct HW queues
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkt_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "zkt.h")

@@ -102,9 +102,8 @@ size_t pt_bytes(int grp) { return grp == G_G1 ? sizeof(zkt_g1_affine) : grp == G
 }  // namespace
 
 static constexpr int MSM_SLOTS = 8;
-struct MsmSlot {                      // one in-flight MSM: own stream, workspace and result buffers
-  hipStream_t stream = nullptr;
-  hipEvent_t e_in = nullptr, e_acc0 = nullptr, e_acc1 = nullptr;
+struct MsmSlot {                      // one in-flight MSM: workspace, result buffers, stage events
+  hipEvent_t e_in = nullptr, e_sorted = nullptr, e_acc0 = nullptr, e_acc1 = nullptr, e_done = nullptr;
   void* workspace = nullptr;
   uint32_t* d_result_jac = nullptr;   // 36 words
   uint32_t* d_out_abi = nullptr;      // 26 words
@@ -116,13 +115,27 @@ struct zkt_g1_bases {
   MsmPlan plan{};
   uint32_t* table = nullptr;     // nwin*n x 24 words
   uint8_t* inf = nullptr;        // nwin*n flags
+  // software pipeline: the three stages of consecutive MSMs run on three streams (sort | accumulate | reduce),
+  // chained by events, so the atomic-bound sort and the latency-bound reduce of neighbours hide under the
+  // VALU-bound accumulation of the current one.
+  hipStream_t s_sort = nullptr, s_acc = nullptr, s_tail = nullptr;
   MsmSlot slot[MSM_SLOTS];
 };
-static int slot_ready(zkt_g1_bases* h, int k) {   // lazily create the slot's stream/workspace
+static int streams_ready(zkt_g1_bases* h) {
+  if (h->s_acc) return ZKT_OK;
+  int lo = 0, hi = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));        // hi = numerically smallest = highest priority
+  HIPCHK(hipStreamCreateWithPriority(&h->s_sort, hipStreamNonBlocking, hi));
+  HIPCHK(hipStreamCreateWithPriority(&h->s_acc, hipStreamNonBlocking, lo));
+  HIPCHK(hipStreamCreateWithPriority(&h->s_tail, hipStreamNonBlocking, hi));
+  return ZKT_OK;
+}
+static int slot_ready(zkt_g1_bases* h, int k) {   // lazily create the slot's workspace
+  int rc = streams_ready(h); if (rc) return rc;
   MsmSlot& S = h->slot[k];
-  if (S.stream) return ZKT_OK;
-  HIPCHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreate(&S.e_in)); HIPCHK(hipEventCreate(&S.e_acc0)); HIPCHK(hipEventCreate(&S.e_acc1));
+  if (S.workspace) return ZKT_OK;
+  HIPCHK(hipEventCreateWithFlags(&S.e_in, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&S.e_sorted, hipEventDisableTiming));
+  HIPCHK(hipEventCreate(&S.e_acc0)); HIPCHK(hipEventCreate(&S.e_acc1)); HIPCHK(hipEventCreateWithFlags(&S.e_done, hipEventDisableTiming));
   HIPCHK(hipMalloc(&S.workspace, h->plan.ws_bytes));
   HIPCHK(hipMalloc((void**)&S.d_result_jac, 36 * 4));
   HIPCHK(hipMalloc((void**)&S.d_out_abi, 26 * 4));
@@ -311,9 +324,9 @@ void zkt_g1_bases_free(zkt_g1_bases* h) {
   if (!h) return;
   if (h->table) hipFree(h->table);
   if (h->inf) hipFree(h->inf);
+  for (hipStream_t st : {h->s_sort, h->s_acc, h->s_tail}) if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
   for (MsmSlot& S : h->slot) {
-    if (S.stream) { hipStreamSynchronize(S.stream); hipStreamDestroy(S.stream); }
-    if (S.e_in) hipEventDestroy(S.e_in); if (S.e_acc0) hipEventDestroy(S.e_acc0); if (S.e_acc1) hipEventDestroy(S.e_acc1);
+    for (hipEvent_t ev : {S.e_in, S.e_sorted, S.e_acc0, S.e_acc1, S.e_done}) if (ev) hipEventDestroy(ev);
     if (S.workspace) hipFree(S.workspace); if (S.d_result_jac) hipFree(S.d_result_jac); if (S.d_out_abi) hipFree(S.d_out_abi);
     if (S.h_out) hipHostFree(S.h_out);
   }
@@ -327,12 +340,19 @@ int zkt_g1_msm_submit(zkt_g1_bases* h, const uint64_t* dev_scalars, size_t n, vo
   if (h->slot[slot].busy) return ZKT_ERR_SHAPE;          // collect it first
   int rc = slot_ready(h, slot); if (rc) return rc;
   MsmSlot& S = h->slot[slot];
-  // inputs are produced on the caller's stream: order this slot's stream behind it
+  // inputs are produced on the caller's stream: order the sort stage behind it
   HIPCHK(hipEventRecord(S.e_in, (hipStream_t)stream));
-  HIPCHK(hipStreamWaitEvent(S.stream, S.e_in, 0));
-  HIPCHK(launch_g1_msm(h->plan, h->table, h->inf, (const uint32_t*)dev_scalars, S.workspace, S.d_result_jac, S.stream, S.e_acc0, S.e_acc1));
-  HIPCHK(launch_g1_jac_sum_to_affine(S.d_result_jac, 1, S.d_out_abi, S.stream));
-  HIPCHK(hipMemcpyAsync(S.h_out, S.d_out_abi, sizeof(zkt_g1_affine), hipMemcpyDeviceToHost, S.stream));
+  HIPCHK(hipStreamWaitEvent(h->s_sort, S.e_in, 0));
+  HIPCHK(launch_g1_msm_sort(h->plan, h->inf, (const uint32_t*)dev_scalars, S.workspace, h->s_sort));
+  HIPCHK(hipEventRecord(S.e_sorted, h->s_sort));
+  HIPCHK(hipStreamWaitEvent(h->s_acc, S.e_sorted, 0));
+  HIPCHK(hipEventRecord(S.e_acc0, h->s_acc));
+  HIPCHK(launch_g1_msm_accumulate(h->plan, h->table, S.workspace, h->s_acc));
+  HIPCHK(hipEventRecord(S.e_acc1, h->s_acc));
+  HIPCHK(hipStreamWaitEvent(h->s_tail, S.e_acc1, 0));
+  HIPCHK(launch_g1_msm_reduce(h->plan, S.workspace, S.d_result_jac, S.d_out_abi, h->s_tail));
+  HIPCHK(hipMemcpyAsync(S.h_out, S.d_out_abi, sizeof(zkt_g1_affine), hipMemcpyDeviceToHost, h->s_tail));
+  HIPCHK(hipEventRecord(S.e_done, h->s_tail));
   S.busy = true;
   return ZKT_OK;
 }
@@ -340,8 +360,8 @@ int zkt_g1_msm_collect(zkt_g1_bases* h, int slot, zkt_g1_affine* out, uint32_t* 
   if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
   if (!h || slot < 0 || slot >= MSM_SLOTS || !h->slot[slot].busy) return ZKT_ERR_SHAPE;
   MsmSlot& S = h->slot[slot];
-  if (dev_partial_jac) HIPCHK(hipMemcpyAsync(dev_partial_jac, S.d_result_jac, 36 * 4, hipMemcpyDeviceToDevice, S.stream));
-  HIPCHK(hipStreamSynchronize(S.stream));
+  HIPCHK(hipEventSynchronize(S.e_done));
+  if (dev_partial_jac) HIPCHK(hipMemcpy(dev_partial_jac, S.d_result_jac, 36 * 4, hipMemcpyDeviceToDevice));
   if (out) *out = *S.h_out;
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, S.e_acc0, S.e_acc1) == hipSuccess) { t_kernel_ms = ms; t_kernel_name = "k_accumulate"; }

@@ -35,10 +35,12 @@ struct MsmPlan {
   size_t ws_bytes;     // workspace bytes
 };
 MsmPlan msm_plan(size_t n);
-// bases_mont: n x 24 u32 (x,y Montgomery), base_inf: n bytes or nullptr.  scalars: n x 8 u32.
-// result: Jacobian X,Y,Z Montgomery (36 u32) written to dev_result.
-hipError_t launch_g1_msm(const MsmPlan& plan, const uint32_t* bases_mont, const uint8_t* base_inf, const uint32_t* scalars,
-                         void* workspace, uint32_t* dev_result_jac, hipStream_t s, hipEvent_t ev_acc_begin, hipEvent_t ev_acc_end);
+// table: nwin*n x 24 u32 (x,y Montgomery, window multiples), inf: nwin*n bytes.  scalars: n x 8 u32.
+// Three stages so the API layer can run them on three streams (sort | accumulate | reduce) and overlap
+// consecutive MSMs; the result is a Jacobian partial (36 u32) and optionally the affine ABI point.
+hipError_t launch_g1_msm_sort(const MsmPlan& plan, const uint8_t* base_inf, const uint32_t* scalars, void* workspace, hipStream_t s);
+hipError_t launch_g1_msm_accumulate(const MsmPlan& plan, const uint32_t* table, void* workspace, hipStream_t s);
+hipError_t launch_g1_msm_reduce(const MsmPlan& plan, void* workspace, uint32_t* dev_result_jac, uint32_t* dev_out_abi, hipStream_t s);
 hipError_t launch_g1_to_kernel_layout(const uint32_t* abi_pts, uint32_t* bases_mont, uint8_t* base_inf, size_t n, hipStream_t s);
 hipError_t launch_g1_jac_sum_to_affine(const uint32_t* jac_partials, size_t count, uint32_t* out_abi_pt, hipStream_t s);
 

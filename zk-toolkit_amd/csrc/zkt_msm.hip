@@ -15,6 +15,7 @@
 //    (bucket, point) pairs, one bucket per lane accumulating in XYZZ coordinates with
 //    complete mixed additions (P+P, P+(-P), infinity: macros.rs:43-63), gather of 96-byte
 //    affine points, then a two-level bucket reduction built from short trees.
+#include <cstdlib>
 #include "abi.h"
 #include "zkt_internal.h"
 
@@ -230,7 +231,7 @@ __global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ 
 //   = sum_lo (lo+1) C_lo + NLO * sum_hi hi * R_hi,   C_lo = sum_hi S, R_hi = sum_lo S
 // ---------------------------------------------------------------------------------
 // block-level tree sum of one XYZZ per lane through LDS (RED_TPB lanes -> lane 0): log2 depth
-static constexpr int RED_TPB = 256;
+static constexpr int RED_TPB = 64;
 __device__ inline XY block_tree_sum(XY v, uint32_t* lds /* RED_TPB/2 * XYW words */) {
   const int lane = threadIdx.x;
   for (int d = RED_TPB / 2; d >= 1; d >>= 1) {
@@ -241,100 +242,128 @@ __device__ inline XY block_tree_sum(XY v, uint32_t* lds /* RED_TPB/2 * XYW words
   }
   return v;
 }
-// one block per output: out[o] = sum_{j<count} in[o*stride_o + j*stride_j]
-__global__ void __launch_bounds__(RED_TPB) k_strided_sums(const uint32_t* __restrict__ in, size_t count, size_t stride_o, size_t stride_j,
-                                                          uint32_t* __restrict__ out) {
+// Both marginals of the NHI x NLO bucket matrix in ONE launch: blocks [0,NLO) produce the column sums
+// C_lo = sum_hi S[hi][lo]; blocks [NLO, NLO+NHI) the row sums R_hi = sum_lo S[hi][lo].
+__global__ void __launch_bounds__(RED_TPB) k_marginals(const uint32_t* __restrict__ in, size_t NLO, size_t NHI,
+                                                       uint32_t* __restrict__ colsum, uint32_t* __restrict__ rowsum) {
   __shared__ uint32_t lds[RED_TPB / 2 * XYW];
-  const size_t o = blockIdx.x; const int lane = threadIdx.x;
+  const int lane = threadIdx.x;
+  const bool is_col = blockIdx.x < NLO;
+  const size_t o = is_col ? blockIdx.x : blockIdx.x - NLO;
+  const size_t count = is_col ? NHI : NLO, stride_o = is_col ? 1 : NLO, stride_j = is_col ? NLO : 1;
   XY acc = xyzz_inf<FqOps>();
   for (size_t j = lane; j < count; j += RED_TPB) acc = xyzz_add<FqOps>(acc, ld_xy(in + (o * stride_o + j * stride_j) * XYW));
   acc = block_tree_sum(acc, lds);
-  if (lane == 0) st_xy(out + o * XYW, acc);
+  if (lane == 0) st_xy((is_col ? colsum : rowsum) + o * XYW, acc);
 }
-// block `bit`: classes[bit] = sum of in[i] over i < m whose weight (i + woff) has that bit set
-__global__ void __launch_bounds__(RED_TPB) k_weight_bits(const uint32_t* __restrict__ in, size_t m, uint32_t woff, uint32_t* __restrict__ classes) {
+// Bit classes of both weighted sums in one launch: blocks [0,nbA) slice colsum by the bits of (lo+1),
+// blocks [nbA, nbA+nbB) slice rowsum by the bits of hi.  D[t] for the final combine: t = bit (A) or lo_bits + bit (B).
+__global__ void __launch_bounds__(RED_TPB) k_weight_bits(const uint32_t* __restrict__ colsum, size_t NLO, int nbA,
+                                                         const uint32_t* __restrict__ rowsum, size_t NHI, uint32_t* __restrict__ clsA, uint32_t* __restrict__ clsB) {
   __shared__ uint32_t lds[RED_TPB / 2 * XYW];
-  const int bit = blockIdx.x, lane = threadIdx.x;
+  const int lane = threadIdx.x;
+  const bool isA = (int)blockIdx.x < nbA;
+  const int bit = isA ? blockIdx.x : blockIdx.x - nbA;
+  const uint32_t* in = isA ? colsum : rowsum; const size_t m = isA ? NLO : NHI; const uint32_t woff = isA ? 1u : 0u;
   XY acc = xyzz_inf<FqOps>();
-  // the j-th element with this bit set: i = ((j >> bit) << (bit+1)) | (1 << bit) | (j & ((1<<bit)-1)), shifted by woff
   for (size_t i = lane; i < m; i += RED_TPB)
     if (((uint32_t)i + woff) >> bit & 1) acc = xyzz_add<FqOps>(acc, ld_xy(in + i * XYW));
   acc = block_tree_sum(acc, lds);
-  if (lane == 0) st_xy(classes + bit * XYW, acc);
+  if (lane == 0) st_xy((isA ? clsA : clsB) + bit * XYW, acc);
 }
-// result = sum_bit 2^bit classesA[bit]  +  2^shift * sum_bit 2^bit classesB[bit]   (Jacobian out)
-__global__ void k_combine(const uint32_t* __restrict__ clsA, int nbA, const uint32_t* __restrict__ clsB, int nbB, int shift,
-                          uint32_t* __restrict__ out_jac) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  XY hi = xyzz_inf<FqOps>();
-  for (int b = nbB - 1; b >= 0; --b) { hi = xyzz_dbl<FqOps>(hi); hi = xyzz_add<FqOps>(hi, ld_xy(clsB + b * XYW)); }
-  // total = sum_{b<shift} 2^b A_b + 2^shift (A_shift + B): one Horner chain from the top
-  if (nbA > shift) hi = xyzz_add<FqOps>(hi, ld_xy(clsA + shift * XYW));
-  XY acc = hi;
-  for (int b = shift - 1; b >= 0; --b) {
-    acc = xyzz_dbl<FqOps>(acc);
-    if (b < nbA) acc = xyzz_add<FqOps>(acc, ld_xy(clsA + b * XYW));
+// total = sum_{b<=shift} 2^b A_b + 2^shift sum_b 2^b B_b = sum_t 2^t D_t with D_t = A_t (t<=shift) (+) B_{t-shift} (t>=shift).
+// One wave: lane t doubles D_t t times (<= 19 doublings instead of a 40-step serial Horner), then an LDS tree;
+// lane 0 writes the Jacobian sum and its affine normalisation.
+__global__ void __launch_bounds__(64) k_combine(const uint32_t* __restrict__ clsA, int nbA, const uint32_t* __restrict__ clsB, int nbB, int shift,
+                                                uint32_t* __restrict__ out_jac, uint32_t* __restrict__ out_abi) {
+  __shared__ uint32_t lds[32 * XYW];
+  const int t = threadIdx.x;
+  XY v = xyzz_inf<FqOps>();
+  if (t < nbA) v = ld_xy(clsA + t * XYW);
+  if (t >= shift && t - shift < nbB) v = xyzz_add<FqOps>(v, ld_xy(clsB + (t - shift) * XYW));
+  for (int d = 0; d < t && t < 32; ++d) v = xyzz_dbl<FqOps>(v);
+  for (int d = 16; d >= 1; d >>= 1) {
+    if (t >= d && t < 2 * d) st_xy(lds + (t - d) * XYW, v);
+    __syncthreads();
+    if (t < d) v = xyzz_add<FqOps>(v, ld_xy(lds + t * XYW));
+    __syncthreads();
   }
-  Jac<FqOps> j = xyzz_to_jac<FqOps>(acc);
-  st_raw<FqC>(out_jac, j.X); st_raw<FqC>(out_jac + 12, j.Y); st_raw<FqC>(out_jac + 24, j.Z);
+  if (t == 0) {
+    Jac<FqOps> j = xyzz_to_jac<FqOps>(v);
+    st_raw<FqC>(out_jac, j.X); st_raw<FqC>(out_jac + 12, j.Y); st_raw<FqC>(out_jac + 24, j.Z);
+    if (out_abi) PtIO<FqOps>::st(out_abi, xyzz_to_aff<FqOps>(v));
+  }
 }
 
-hipError_t launch_g1_msm(const MsmPlan& P, const uint32_t* table, const uint8_t* inf, const uint32_t* scalars, void* workspace,
-                         uint32_t* dev_result_jac, hipStream_t s, hipEvent_t ev_acc0, hipEvent_t ev_acc1) {
-  const size_t B = P.nbuckets, n = P.n;
+namespace {
+struct MsmWs {   // workspace carve-up (one per in-flight MSM)
+  uint32_t *zero_begin, *counts, *cursor, *size_hist, *size_off, *size_cur, *zero_end;   // [zero_begin, zero_end) is cleared per MSM
+  uint32_t *offsets, *entries, *sums, *colsum, *rowsum, *clsA, *clsB, *order, *scan_tmp;
+};
+MsmWs carve(const MsmPlan& P, void* workspace) {
+  const size_t B = P.nbuckets;
   uint8_t* ws = (uint8_t*)workspace;
-  uint32_t* counts = (uint32_t*)ws; ws += (B + 1) * 4;
-  uint32_t* offsets = (uint32_t*)ws; ws += (B + 1) * 4;
-  uint32_t* cursor = (uint32_t*)ws; ws += (B + 1) * 4;
+  MsmWs w;
+  w.zero_begin = (uint32_t*)ws;
+  w.counts = (uint32_t*)ws; ws += (B + 1) * 4;
+  w.cursor = (uint32_t*)ws; ws += (B + 1) * 4;
+  w.size_hist = (uint32_t*)ws; ws += (SIZE_BINS + 1) * 4;
+  w.size_off = (uint32_t*)ws; ws += (SIZE_BINS + 1) * 4;
+  w.size_cur = (uint32_t*)ws; ws += (SIZE_BINS + 1) * 4;
+  w.zero_end = (uint32_t*)ws;
+  w.offsets = (uint32_t*)ws; ws += (B + 1) * 4;
   ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  uint32_t* entries = (uint32_t*)ws; ws += (size_t)P.nwin * n * 4;
+  w.entries = (uint32_t*)ws; ws += (size_t)P.nwin * P.n * 4;
   ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  uint32_t* sums = (uint32_t*)ws; ws += B * XYW * 4;
-  uint32_t* colsum = (uint32_t*)ws; ws += 1024 * XYW * 4;
-  uint32_t* rowsum = (uint32_t*)ws; ws += 1024 * XYW * 4;
-  uint32_t* clsA = (uint32_t*)ws; ws += 32 * XYW * 4;
-  uint32_t* clsB = (uint32_t*)ws; ws += 32 * XYW * 4;
-  uint32_t* order = (uint32_t*)ws; ws += B * 4;
-  uint32_t* scan_tmp = (uint32_t*)ws; ws += 1024 * 4;
-  uint32_t* size_hist = (uint32_t*)ws; ws += (SIZE_BINS + 1) * 4;
-  uint32_t* size_off = (uint32_t*)ws; ws += (SIZE_BINS + 1) * 4;
-  uint32_t* size_cur = (uint32_t*)ws; ws += (SIZE_BINS + 1) * 4;
+  w.sums = (uint32_t*)ws; ws += B * XYW * 4;
+  w.colsum = (uint32_t*)ws; ws += 1024 * XYW * 4;
+  w.rowsum = (uint32_t*)ws; ws += 1024 * XYW * 4;
+  w.clsA = (uint32_t*)ws; ws += 32 * XYW * 4;
+  w.clsB = (uint32_t*)ws; ws += 32 * XYW * 4;
+  w.order = (uint32_t*)ws; ws += B * 4;
+  w.scan_tmp = (uint32_t*)ws; ws += 1024 * 4;
+  return w;
+}
+}  // namespace
 
+// stage 1 (atomic/memory bound): signed digits, counting sort by bucket, bucket order by population
+hipError_t launch_g1_msm_sort(const MsmPlan& P, const uint8_t* inf, const uint32_t* scalars, void* workspace, hipStream_t s) {
+  const size_t B = P.nbuckets, n = P.n;
+  MsmWs w = carve(P, workspace);
   hipError_t e;
-  if ((e = hipMemsetAsync(counts, 0, (B + 1) * 4, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(cursor, 0, (B + 1) * 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(w.zero_begin, 0, (uint8_t*)w.zero_end - (uint8_t*)w.zero_begin, s)) != hipSuccess) return e;
   if (n) {
     const unsigned g = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_digits<false>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
-    launch_scan(counts, offsets, B, scan_tmp, s);
-    hipLaunchKernelGGL(k_digits<true>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, cursor, offsets, entries);
+    hipLaunchKernelGGL(k_digits<false>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, w.counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    launch_scan(w.counts, w.offsets, B, w.scan_tmp, s);
+    hipLaunchKernelGGL(k_digits<true>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, w.cursor, (const uint32_t*)w.offsets, w.entries);
   } else {
-    if ((e = hipMemsetAsync(offsets, 0, (B + 1) * 4, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(w.offsets, 0, (B + 1) * 4, s)) != hipSuccess) return e;
   }
-  // bucket order by population
-  if ((e = hipMemsetAsync(size_hist, 0, (SIZE_BINS + 1) * 4 * 3, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_size_hist, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)counts, B, size_hist);
-  launch_scan(size_hist, size_off, SIZE_BINS, scan_tmp, s);
-  hipLaunchKernelGGL(k_size_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)counts, B, (const uint32_t*)size_off, size_cur, order);
-  if (ev_acc0) hipEventRecord(ev_acc0, s);
-  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, table, entries, offsets, (const uint32_t*)order, B, sums);
-  if (ev_acc1) hipEventRecord(ev_acc1, s);
-
-  // two-level reduction: b = hi*NLO + lo
+  hipLaunchKernelGGL(k_size_hist, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, w.size_hist);
+  launch_scan(w.size_hist, w.size_off, SIZE_BINS, w.scan_tmp, s);
+  hipLaunchKernelGGL(k_size_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, (const uint32_t*)w.size_off, w.size_cur, w.order);
+  return hipGetLastError();
+}
+// stage 2 (VALU bound, the dominant kernel): one bucket per lane
+hipError_t launch_g1_msm_accumulate(const MsmPlan& P, const uint32_t* table, void* workspace, hipStream_t s) {
+  MsmWs w = carve(P, workspace);
+  static const int acc_lds = getenv("ZKT_ACC_LDS") ? atoi(getenv("ZKT_ACC_LDS")) : 0;   // experiment: cap occupancy through dynamic LDS
+  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((P.nbuckets + 63) / 64)), dim3(64), acc_lds, s, table, (const uint32_t*)w.entries,
+                     (const uint32_t*)w.offsets, (const uint32_t*)w.order, P.nbuckets, w.sums);
+  return hipGetLastError();
+}
+// stage 3 (latency bound): sum_b (b+1) S_b, b = hi*NLO + lo  ->  Jacobian partial (+ affine point if out_abi)
+hipError_t launch_g1_msm_reduce(const MsmPlan& P, void* workspace, uint32_t* dev_result_jac, uint32_t* dev_out_abi, hipStream_t s) {
+  const size_t B = P.nbuckets;
+  MsmWs w = carve(P, workspace);
   const size_t NLO = B < 1024 ? B : 1024, NHI = B / NLO;
   int lo_bits = 0; while ((size_t(1) << lo_bits) < NLO) ++lo_bits;
   int hi_bits = 0; while ((size_t(1) << hi_bits) < NHI) ++hi_bits;
-  // C_lo = sum_hi S[hi*NLO+lo];  R_hi = sum_lo S[hi*NLO+lo]
-  hipLaunchKernelGGL(k_strided_sums, dim3((unsigned)NLO), dim3(RED_TPB), 0, s, sums, NHI, (size_t)1, NLO, colsum);
-  hipLaunchKernelGGL(k_weight_bits, dim3((unsigned)(lo_bits + 1)), dim3(RED_TPB), 0, s, colsum, NLO, 1u, clsA);   // weights lo+1 in [1, NLO]
-  int nbB = 0;
-  if (NHI > 1) {
-    hipLaunchKernelGGL(k_strided_sums, dim3((unsigned)NHI), dim3(RED_TPB), 0, s, sums, NLO, NLO, (size_t)1, rowsum);
-    hipLaunchKernelGGL(k_weight_bits, dim3((unsigned)hi_bits), dim3(RED_TPB), 0, s, rowsum, NHI, 0u, clsB);        // weights hi in [0, NHI)
-    nbB = hi_bits;
-  }
-  // total = sum_b 2^b clsA[b] + 2^lo_bits * sum_b 2^b clsB[b];  clsA has lo_bits+1 classes (weight NLO = 2^lo_bits)
-  hipLaunchKernelGGL(k_combine, dim3(1), dim3(64), 0, s, clsA, lo_bits + 1, clsB, nbB, lo_bits, dev_result_jac);
+  const int nbA = lo_bits + 1, nbB = NHI > 1 ? hi_bits : 0;     // weights lo+1 in [1,NLO]; hi in [0,NHI)
+  hipLaunchKernelGGL(k_marginals, dim3((unsigned)(NLO + (NHI > 1 ? NHI : 0))), dim3(RED_TPB), 0, s, (const uint32_t*)w.sums, NLO, NHI, w.colsum, w.rowsum);
+  hipLaunchKernelGGL(k_weight_bits, dim3((unsigned)(nbA + nbB)), dim3(RED_TPB), 0, s, (const uint32_t*)w.colsum, NLO, nbA, (const uint32_t*)w.rowsum, NHI, w.clsA, w.clsB);
+  hipLaunchKernelGGL(k_combine, dim3(1), dim3(64), 0, s, (const uint32_t*)w.clsA, nbA, (const uint32_t*)w.clsB, nbB, lo_bits, dev_result_jac, dev_out_abi);
   return hipGetLastError();
 }
 
