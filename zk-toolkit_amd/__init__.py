@@ -8,7 +8,7 @@ import ctypes, os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # read by the HIP runtime at first use: stage streams on distinct HW queues
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkt_hip.so")
+LIB_PATH = os.environ.get("ZKT_LIB_PATH", os.path.join(_HERE, "libzkt_hip.so"))   # override only for A/B experiments
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "zkt.h")
 
 ZKT_OK, ZKT_ERR_INV_ZERO, ZKT_ERR_INFINITY, ZKT_ERR_SHAPE, ZKT_ERR_DEVICE = 0, 1, 2, 3, 4

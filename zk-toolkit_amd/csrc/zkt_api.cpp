@@ -118,7 +118,8 @@ struct zkt_g1_bases {
   // software pipeline: the three stages of consecutive MSMs run on three streams (sort | accumulate | reduce),
   // chained by events, so the atomic-bound sort and the latency-bound reduce of neighbours hide under the
   // VALU-bound accumulation of the current one.
-  hipStream_t s_sort = nullptr, s_acc = nullptr, s_tail = nullptr;
+  static constexpr int NTAIL = 2;   // reduce chains of alternate MSMs run side by side: each is latency-bound, not throughput-bound
+  hipStream_t s_sort = nullptr, s_acc = nullptr, s_tail[NTAIL] = {nullptr, nullptr};
   MsmSlot slot[MSM_SLOTS];
 };
 static int streams_ready(zkt_g1_bases* h) {
@@ -127,7 +128,7 @@ static int streams_ready(zkt_g1_bases* h) {
   HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));        // hi = numerically smallest = highest priority
   HIPCHK(hipStreamCreateWithPriority(&h->s_sort, hipStreamNonBlocking, hi));
   HIPCHK(hipStreamCreateWithPriority(&h->s_acc, hipStreamNonBlocking, lo));
-  HIPCHK(hipStreamCreateWithPriority(&h->s_tail, hipStreamNonBlocking, hi));
+  for (int k = 0; k < zkt_g1_bases::NTAIL; ++k) HIPCHK(hipStreamCreateWithPriority(&h->s_tail[k], hipStreamNonBlocking, hi));
   return ZKT_OK;
 }
 static int slot_ready(zkt_g1_bases* h, int k) {   // lazily create the slot's workspace
@@ -324,7 +325,7 @@ void zkt_g1_bases_free(zkt_g1_bases* h) {
   if (!h) return;
   if (h->table) hipFree(h->table);
   if (h->inf) hipFree(h->inf);
-  for (hipStream_t st : {h->s_sort, h->s_acc, h->s_tail}) if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+  for (hipStream_t st : {h->s_sort, h->s_acc, h->s_tail[0], h->s_tail[1]}) if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
   for (MsmSlot& S : h->slot) {
     for (hipEvent_t ev : {S.e_in, S.e_sorted, S.e_acc0, S.e_acc1, S.e_done}) if (ev) hipEventDestroy(ev);
     if (S.workspace) hipFree(S.workspace); if (S.d_result_jac) hipFree(S.d_result_jac); if (S.d_out_abi) hipFree(S.d_out_abi);
@@ -349,10 +350,11 @@ int zkt_g1_msm_submit(zkt_g1_bases* h, const uint64_t* dev_scalars, size_t n, vo
   HIPCHK(hipEventRecord(S.e_acc0, h->s_acc));
   HIPCHK(launch_g1_msm_accumulate(h->plan, h->table, S.workspace, h->s_acc));
   HIPCHK(hipEventRecord(S.e_acc1, h->s_acc));
-  HIPCHK(hipStreamWaitEvent(h->s_tail, S.e_acc1, 0));
-  HIPCHK(launch_g1_msm_reduce(h->plan, S.workspace, S.d_result_jac, S.d_out_abi, h->s_tail));
-  HIPCHK(hipMemcpyAsync(S.h_out, S.d_out_abi, sizeof(zkt_g1_affine), hipMemcpyDeviceToHost, h->s_tail));
-  HIPCHK(hipEventRecord(S.e_done, h->s_tail));
+  hipStream_t st = h->s_tail[slot % zkt_g1_bases::NTAIL];
+  HIPCHK(hipStreamWaitEvent(st, S.e_acc1, 0));
+  HIPCHK(launch_g1_msm_reduce(h->plan, S.workspace, S.d_result_jac, S.d_out_abi, st));
+  HIPCHK(hipMemcpyAsync(S.h_out, S.d_out_abi, sizeof(zkt_g1_affine), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(S.e_done, st));
   S.busy = true;
   return ZKT_OK;
 }
