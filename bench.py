@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--log2n", type=int, default=20)
-    ap.add_argument("--pairings", type=int, default=1 << 14, help="pairings in the secondary measurement (0 = skip)")
+    ap.add_argument("--pairings", type=int, default=1 << 16, help="pairings in the secondary measurement (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
@@ -128,6 +128,13 @@ def main():
     value = world * n * args.steps / elapsed
     k_ms = float(np.mean(kern_ms))
 
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (committed summary), never from this run
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")) as f:
+            traffic = json.load(f)["k_accumulate_hbm_bytes_per_launch"]["uncorrected"] if args.log2n == 20 else None
+    except Exception:
+        traffic = None
     result = {
         "metric": "G1 MSM scalar-muls/sec at 2^%d bases per GPU (BLS12-381)" % args.log2n,
         "value": value, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -139,7 +146,8 @@ def main():
                    "single_msm_latency_ms": round(latency_ms, 3) if world == 1 else None},
         "roofline": {"bound": "hbm", "kernel": L.zkt_last_kernel_name().decode(),
                      "achieved": MSM_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": MSM_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "frac": MSM_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_note": "FETCH_SIZE+WRITE_SIZE per launch from profiles/r01_hbm_traffic_pmc.json; 13x the algorithmic bytes by design: every term is gathered once per window from the resident window-multiple table (DESIGN.md §4)",
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": MSM_BYTES_PER_TERM * n,
                      "note": "integer-VALU bound by construction (SURVEY §8d); see DESIGN.md for the VALU roofline"},
     }

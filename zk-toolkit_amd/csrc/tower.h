@@ -13,6 +13,13 @@
 
 namespace zkt {
 
+// Fq2 products are inlined into their Fq6/Fq12 callers by default (operands stay in VGPRs across the 6 products
+// of an Fq6 multiply instead of being re-read from scratch); -DZKT_FQ2_CALLS makes them real functions.
+#ifdef ZKT_FQ2_CALLS
+#define ZKT_FQ2 ZKT_FN
+#else
+#define ZKT_FQ2 ZKT_HD
+#endif
 struct Fq2 { Fq c0, c1; };
 struct Fq6 { Fq2 c0, c1, c2; };
 struct Fq12 { Fq6 c0, c1; };
@@ -28,12 +35,12 @@ ZKT_HD Fq2 fq2_neg(const Fq2& a) { return Fq2{fp_neg(a.c0), fp_neg(a.c1)}; }    
 ZKT_HD Fq2 fq2_dbl(const Fq2& a) { return Fq2{fp_dbl(a.c0), fp_dbl(a.c1)}; }
 ZKT_HD Fq2 fq2_conj(const Fq2& a) { return Fq2{a.c0, fp_neg(a.c1)}; }
 // fq2.rs:134-146 computes the 4-product schoolbook; Karatsuba gives the same element
-ZKT_FN Fq2 fq2_mul(const Fq2& a, const Fq2& b) {
+ZKT_FQ2 Fq2 fq2_mul(const Fq2& a, const Fq2& b) {
   Fq v0 = fp_mul(a.c0, b.c0), v1 = fp_mul(a.c1, b.c1);
   Fq s = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
   return Fq2{fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
 }
-ZKT_FN Fq2 fq2_sqr(const Fq2& a) {                                      // fq2.rs:34-36
+ZKT_FQ2 Fq2 fq2_sqr(const Fq2& a) {                                      // fq2.rs:34-36
   Fq t = fp_mul(a.c0, a.c1);
   return Fq2{fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_dbl(t)};
 }
