@@ -51,10 +51,18 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("ZKT_BENCH_BACKEND", "nccl")     # "gloo" only to rehearse the N>1 control flow on a 1-GPU box
+    if backend == "nccl":
+        assert local < ndev, f"LOCAL_RANK {local} but only {ndev} GPUs visible"
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     zk = importlib.import_module("zk-toolkit_amd")
     sharded = importlib.import_module("zk-toolkit_amd.sharded")
@@ -93,7 +101,10 @@ def main():
             zk.check(L.zkt_g1_msm_collect(h, slot, outp, None))
         else:
             zk.check(L.zkt_g1_msm_collect(h, slot, None, vp(d_partial)))
-            g = sharded.sharded_sum(d_partial, lambda stack: stack.contiguous())      # RCCL all_gather of the 144-B partials
+            if backend == "nccl":
+                g = sharded.sharded_sum(d_partial, lambda stack: stack.contiguous())      # RCCL all_gather of the 144-B partials
+            else:
+                g = sharded.sharded_sum(d_partial.cpu(), lambda stack: stack.contiguous()).to(dev)
             torch.cuda.current_stream().synchronize()
             zk.check(L.zkt_g1_jac_sum_dev(vp(g), world, sp, outp))
         return L.zkt_last_kernel_ms()
@@ -121,7 +132,7 @@ def main():
     if world > 1: dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -152,19 +163,24 @@ def main():
                      "note": "integer-VALU bound by construction (SURVEY §8d); see DESIGN.md for the VALU roofline"},
     }
 
+    # parity check of the timed configuration at full size, by linearity: bases are k_i*G, so the MSM over all ranks
+    # must equal (sum_i k_i s_i mod r)*G — python integers + ONE oracle scalar-mul, independent of the HIP path
+    from zkt_testlib import limbs_to_int
+    hk = d_k.cpu().numpy().view(np.uint64)
+    tot = 0
+    for a, b in zip(hk, h_scalars):
+        tot += limbs_to_int(a) * limbs_to_int(b)
+    tot %= R_MOD
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, tot)
+        tot = sum(parts) % R_MOD
     if rank == 0:
-        # parity spot check of the timed configuration: result == (sum k_i s_i mod r) * G, computed independently
-        if world == 1:
-            from zkt_testlib import oracle, ptr, limbs_to_int
-            O = oracle()
-            hk = d_k.cpu().numpy().view(np.uint64)
-            tot = 0
-            for a, b in zip(hk, h_scalars):
-                tot += limbs_to_int(a) * limbs_to_int(b)
-            tot %= R_MOD
-            want = np.zeros((1, 13), dtype=np.uint64); k1 = np.array([int_to_limbs(tot, 4)], dtype=np.uint64)
-            assert O.zkto_g1_mul_batch(ptr(gen), ptr(k1), 4, ptr(want), 1, 1) == 0
-            result["config"]["full_size_check"] = "ok" if (want == out).all() else "MISMATCH"
+        from zkt_testlib import oracle, ptr
+        O = oracle()
+        want = np.zeros((1, 13), dtype=np.uint64); k1 = np.array([int_to_limbs(tot, 4)], dtype=np.uint64)
+        assert O.zkto_g1_mul_batch(ptr(gen), ptr(k1), 4, ptr(want), 1, 1) == 0
+        result["config"]["full_size_check"] = "ok" if (want == out).all() else "MISMATCH"
 
         # secondary metric: Tate pairings/s
         if args.pairings > 0:
