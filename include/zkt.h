@@ -113,6 +113,11 @@ int zkt_secp_msm(const zkt_secp_affine* bases, const uint64_t* scalars, size_t n
 
 /* a10–a13: Pairing::tate pairing.rs:86-100 — out[i] = Fq12 of tate(g1[i], g2[i]) */
 int zkt_tate_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out_fq12, size_t n);
+/* a12, a14: raw Miller values and the Weil pairing, bit-exact (the reference uses them in its tests only):
+ * Pairing::calc_g1_g2 pairing.rs:54, calc_g2_g1 pairing.rs:55, weil = calc_g1_g2(P,Q) * calc_g2_g1(Q,P)^-1 pairing.rs:75-84 */
+int zkt_miller_g1g2_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out_fq12, size_t n);
+int zkt_miller_g2g1_batch(const zkt_g2_affine* g2, const zkt_g1_affine* g1, uint64_t* out_fq12, size_t n);
+int zkt_weil_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out_fq12, size_t n);
 /* a15: GTPoint == gt_point.rs:33-39 (all 12 coefficients); returns 1/0, or <0 = -status */
 int zkt_gt_eq(const uint64_t* a_fq12, const uint64_t* b_fq12);
 

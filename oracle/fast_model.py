@@ -151,3 +151,89 @@ def final_exp_fast(f):
 
 def tate_fast(P, Qp):
     return final_exp_fast(miller_fast(P, Qp))
+
+
+# ---- raw Miller values, bit-exact with the reference (pairing.rs:20-55) --------------------------
+# calc_g1_g2 / calc_g2_g1 / weil are NOT normalisation independent, so the projective loop
+# tracks numerator N, denominator D (Fq12, sparse updates) and the Fq / Fq2 scale factors exactly, and divides
+# once at the end: f = (N * ns) / (D * ds).
+def f12_scale2(a, s):      # Fq12 * Fq2 scalar
+    return tuple(tuple(f2_mul(c, s) for c in six) for six in a)
+
+
+def calc_g1_g2_exact(P, Qp):
+    xp, yp = P
+    Xq = f2_mul(Qp[0], XI_INV); Yq = f2_mul(Qp[1], XI_INV)
+    X, Y, Z = xp, yp, 1
+    N = F12_1; D = F12_1; ns = 1; ds = 1
+    def line(a, b, c): return (((a, 0), F2_0, b), (F2_0, c, F2_0))          # a + b v^2 + c v w
+    def vert(a, b): return (((a, 0), F2_0, b), F6_0)                        # a + b v^2
+    for bit in L_BITS:
+        A = X * X % Q; B = Y * Y % Q; C = B * B % Q; ZZ = Z * Z % Q
+        Dd = 2 * ((X + B) ** 2 - A - C) % Q; E = 3 * A % Q
+        X3 = (E * E - 2 * Dd) % Q; Y3 = (E * (Dd - X3) - 8 * C) % Q; Z3 = 2 * Y * Z % Q
+        # tangent l = l'/s, s = 2YZ^3 = Z3*ZZ ; vertical at 2V: v = v'/Z3^2, v' = Z3^2 X' - X3
+        lp = line((E * X - 2 * B) % Q, f2_muls(Xq, -E * ZZ % Q), f2_muls(Yq, Z3 * ZZ % Q))
+        Z3Z3 = Z3 * Z3 % Q
+        vp = vert(-X3 % Q, f2_muls(Xq, Z3Z3))
+        N = f12_mul(f12_sqr(N), lp); D = f12_mul(f12_sqr(D), vp)
+        ns = ns * ns % Q * Z3Z3 % Q; ds = ds * ds % Q * (Z3 * ZZ % Q) % Q
+        X, Y, Z = X3, Y3, Z3
+        if bit:
+            ZZ = Z * Z % Q; H = (xp * ZZ - X) % Q; Rr = (yp * ZZ * Z - Y) % Q
+            HH = H * H % Q; HHH = H * HH % Q; V = X * HH % Q
+            X3 = (Rr * Rr - HHH - 2 * V) % Q; Y3 = (Rr * (V - X3) - Y * HHH) % Q; Z3 = Z * H % Q
+            # chord through V and P: slope = Rr/Z3; l = l'/Z3 with l' = (Rr xp - Z3 yp) - Rr X' + Z3 Y'
+            lp = line((Rr * xp - Z3 * yp) % Q, f2_muls(Xq, -Rr % Q), f2_muls(Yq, Z3))
+            Z3Z3 = Z3 * Z3 % Q
+            vp = vert(-X3 % Q, f2_muls(Xq, Z3Z3))
+            N = f12_mul(N, lp); D = f12_mul(D, vp)
+            ns = ns * Z3Z3 % Q; ds = ds * Z3 % Q
+            X, Y, Z = X3, Y3, Z3
+    num = f12_scale2(N, (ns, 0)); den = f12_scale2(D, (ds, 0))
+    return f12_mul(num, f12_inv(den))
+
+
+def calc_g2_g1_exact(Qp, P):
+    """Miller loop on the G2 point (Fq2 Jacobian), evaluated at the embedded G1 point (pairing.rs:55).
+    Untwisted coordinates: x' = (x/xi) v^2, y' = (y/xi) v w, so an affine slope lam becomes (lam/xi) v^2 w and
+      line(P)     = yp + [(lam x1 - y1)/xi] v w + [-(lam/xi) xp] v^2 w
+      vertical(P) = xp - (x/xi) v^2."""
+    xp, yp = P
+    xq, yq = Qp
+    X, Y, Z = xq, yq, F2_1
+    N = F12_1; D = F12_1; ns = F2_1; ds = F2_1
+    def line(a, b, c): return (((a, 0), F2_0, F2_0), (F2_0, b, c))          # a + b v w + c v^2 w
+    def vert(a, b): return (((a, 0), F2_0, b), F6_0)                        # a + b v^2
+    m = f2_mul; sq = f2_sqr; sub = f2_sub; add = f2_add
+    def k(a, n): return f2_muls(a, n % Q)
+    for bit in L_BITS:
+        A = sq(X); B = sq(Y); C = sq(B); ZZ = sq(Z)
+        Dd = k(sub(sub(sq(add(X, B)), A), C), 2); E = k(A, 3)
+        X3 = sub(sq(E), k(Dd, 2)); Y3 = sub(m(E, sub(Dd, X3)), k(C, 8)); Z3 = k(m(Y, Z), 2)
+        # affine slope lam = E/Z3 (3x^2/2y with x=X/Z^2,y=Y/Z^3 -> 3X^2/(2YZ)); scale s = Z3*ZZ:
+        #   s*(lam x1 - y1) = E X - 2B ;  s*lam = E*ZZ
+        s = m(Z3, ZZ)
+        lp = line(yp, m(sub(m(E, X), k(B, 2)), XI_INV), k(m(m(E, ZZ), XI_INV), -xp))
+        lp = (((f2_muls(s, yp)), F2_0, F2_0), lp[1])        # a-slot carries s*yp (an Fq2 now)
+        Z3Z3 = sq(Z3)
+        vp = ((f2_muls(Z3Z3, xp), F2_0, f2_neg(m(X3, XI_INV))), F6_0)
+        N = f12_mul(f12_sqr(N), lp); D = f12_mul(f12_sqr(D), vp)
+        ns = m(sq(ns), Z3Z3); ds = m(sq(ds), s)
+        X, Y, Z = X3, Y3, Z3
+        if bit:
+            ZZ = sq(Z); H = sub(m(xq, ZZ), X); Rr = sub(m(m(yq, ZZ), Z), Y)
+            HH = sq(H); HHH = m(H, HH); V = m(X, HH)
+            X3 = sub(sub(sq(Rr), HHH), k(V, 2)); Y3 = sub(m(Rr, sub(V, X3)), m(Y, HHH)); Z3 = m(Z, H)
+            # chord through V and Q: lam = Rr/Z3, through the affine point (xq,yq): Z3*(lam xq - yq) = Rr xq - Z3 yq
+            lp = ((f2_muls(Z3, yp), F2_0, F2_0), (F2_0, m(sub(m(Rr, xq), m(Z3, yq)), XI_INV), k(m(Rr, XI_INV), -xp)))
+            Z3Z3 = sq(Z3)
+            vp = ((f2_muls(Z3Z3, xp), F2_0, f2_neg(m(X3, XI_INV))), F6_0)
+            N = f12_mul(N, lp); D = f12_mul(D, vp)
+            ns = m(ns, Z3Z3); ds = m(ds, Z3)
+            X, Y, Z = X3, Y3, Z3
+    return f12_mul(f12_scale2(N, ns), f12_inv(f12_scale2(D, ds)))
+
+
+def weil_exact(P, Qp):
+    return f12_mul(calc_g1_g2_exact(P, Qp), f12_inv(calc_g2_g1_exact(Qp, P)))

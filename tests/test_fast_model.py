@@ -31,3 +31,17 @@ def test_fast_tate_matches_oracle():
     for i in range(3):
         got = fm.to_ref_order(fm.tate_fast(*_pq(ps[i], qs[i])))
         assert tuple(got) == want[i]
+
+
+def test_exact_miller_values_and_weil_match_oracle():
+    """raw calc_g1_g2 / calc_g2_g1 (pairing.rs:54-55) and weil (pairing.rs:75-84), bit for bit"""
+    rng = SplitMix64(23)
+    ps = [g1_gen(), g1_mul(g1_gen(), rng.below(R))]
+    qs = [g2_gen(), g2_mul(g2_gen(), rng.below(R))]
+    P, Qa = np.concatenate(ps), np.concatenate(qs)
+    for which, fn in ((0, lambda p, q: fm.calc_g1_g2_exact(p, q)), (1, lambda p, q: fm.calc_g2_g1_exact(q, p)), (2, fm.weil_exact)):
+        rc, o, _ = pair(which, P, Qa)
+        assert rc == 0
+        want = fq12_from_arr(o)
+        for i in range(2):
+            assert tuple(fm.to_ref_order(fn(*_pq(ps[i], qs[i])))) == want[i], (which, i)

@@ -250,3 +250,18 @@ def test_g1_msm_edge_cases(L):
     got = np.zeros((1, G1W), dtype=np.uint64)
     zk.check(L.zkt_g1_msm(ptr(bases), ptr(sc), 0, ptr(got)))
     assert g1_from_arr(got) == [None]                 # empty sum = G1Point::zero() (polynomial.rs:275)
+
+
+def test_raw_miller_values_and_weil_vs_oracle(L):    # pairing.rs:54-55,75-84; bilinearity of weil as in pairing.rs:107-151
+    n = 4
+    rng = SplitMix64(700)
+    P, Qp = np.zeros((n, G1W), np.uint64), np.zeros((n, G2W), np.uint64)
+    assert O.zkto_g1_mul_batch(ptr(np.repeat(_gen(0), n, axis=0)), ptr(ints_to_arr([1] + [rng.below(R) for _ in range(n - 1)], 4)), 4, ptr(P), n, 4) == 0
+    assert O.zkto_g2_mul_batch(ptr(np.repeat(_gen(1), n, axis=0)), ptr(ints_to_arr([1] + [rng.below(R) for _ in range(n - 1)], 4)), 4, ptr(Qp), n, 4) == 0
+    for which, fn, swap in ((0, L.zkt_miller_g1g2_batch, False), (1, L.zkt_miller_g2g1_batch, True), (2, L.zkt_weil_batch, False)):
+        got, want = np.zeros((n, FQ12), np.uint64), np.zeros((n, FQ12), np.uint64)
+        zk.check(fn(ptr(Qp), ptr(P), ptr(got), n) if swap else fn(ptr(P), ptr(Qp), ptr(got), n))
+        assert O.zkto_pairing_batch(which, ptr(P), ptr(Qp), ptr(want), n, 8, None) == 0
+        assert (got == want).all(), which
+    inf = P.copy(); inf[2, :] = 0; inf[2, 12] = 1
+    assert L.zkt_weil_batch(ptr(inf), ptr(Qp), ptr(got), n) == ZKT_ERR_INFINITY and L.zkt_last_error_index() == 2

@@ -130,3 +130,14 @@ def test_tate_vs_oracle(H):
         assert H.zkt_hostcheck_tate(p32(ps[i:i + 1]), p32(qs[i:i + 1]), p32(got)) == 0
         assert (got[0] == want[i]).all()
     assert H.zkt_hostcheck_tate(p32(g1_arr([None])), p32(qs[0:1]), p32(np.zeros((1, 72), dtype=np.uint64))) == 2
+
+
+def test_exact_miller_and_weil_vs_oracle(H):         # pairing.rs:54-55,75-84 raw values
+    rng = SplitMix64(81)
+    p = g1_mul(g1_gen(), rng.below(R)); q = g2_mul(g2_gen(), rng.below(R))
+    for which in (0, 1, 2):
+        rc, want, _ = pair(which, p, q, threads=1)
+        assert rc == 0
+        got = np.zeros((1, 72), dtype=np.uint64)
+        assert H.zkt_hostcheck_miller_exact(which, p32(p), p32(q), p32(got)) == 0
+        assert (got[0] == want[0]).all(), which

@@ -76,6 +76,17 @@ int zkt_hostcheck_group(int grp, int op, const uint32_t* a, const uint32_t* b, i
   else { if (op == 0) pt_add<SpOps>(a, b, o); else if (op == 1) pt_add_full<SpOps>(a, b, o); else pt_mul<SpOps>(a, b, klimbs, o); }
   return 0;
 }
+// which: 0 calc_g1_g2, 1 calc_g2_g1, 2 weil
+int zkt_hostcheck_miller_exact(int which, const uint32_t* g1, const uint32_t* g2, uint32_t* o) {
+  Aff<FqOps> p = PtIO<FqOps>::ld(g1); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2);
+  if (p.inf || q.inf) return 2;
+  Fq12 r;
+  if (which == 0) r = miller_g1_g2_exact(p.x, p.y, q.x, q.y);
+  else if (which == 1) r = miller_g2_g1_exact(q.x, q.y, p.x, p.y);
+  else r = fq12_mul(miller_g1_g2_exact(p.x, p.y, q.x, q.y), fq12_inv(miller_g2_g1_exact(q.x, q.y, p.x, p.y)));
+  st_fq12(o, r);
+  return 0;
+}
 int zkt_hostcheck_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* o) {
   Aff<FqOps> p = PtIO<FqOps>::ld(g1); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2);
   if (p.inf || q.inf) return 2;

@@ -99,4 +99,109 @@ ZKT_FN Fq12 final_exponentiation(const Fq12& f) {
   return fq12_mul(c, g);
 }
 
+
+// ---- raw Miller values and the Weil pairing, bit-exact (row a14) ------------------------------------
+//   calc_g1_g2 / calc_g2_g1   pairing.rs:20-55      weil   pairing.rs:75-84
+// These are NOT normalisation independent, so the projective loop keeps a numerator N and a denominator D
+// (Fq12) plus the exact Fq / Fq2 scale factors of every line and vertical, and divides once at the end:
+// f = (N*ns)/(D*ds) is the very element the reference builds with one Fq12 inversion per step
+// (python model: oracle/fast_model.py calc_g1_g2_exact / calc_g2_g1_exact, tests/test_fast_model.py).
+// Used by the reference's tests only, so the sparse structure is not exploited: dense Fq12 products.
+ZKT_HD Fq12 fq12_sparse(const Fq2& c00, const Fq2& c02, const Fq2& c11, const Fq2& c12) {   // c00 + c02 v^2 + c11 v w + c12 v^2 w
+  Fq12 r; r.c0 = Fq6{c00, fq2_zero(), c02}; r.c1 = Fq6{fq2_zero(), c11, c12}; return r;
+}
+ZKT_FN Fq12 fq12_scale_fq2(const Fq12& a, const Fq2& s) {
+  Fq12 r;
+  r.c0 = Fq6{fq2_mul(a.c0.c0, s), fq2_mul(a.c0.c1, s), fq2_mul(a.c0.c2, s)};
+  r.c1 = Fq6{fq2_mul(a.c1.c0, s), fq2_mul(a.c1.c1, s), fq2_mul(a.c1.c2, s)};
+  return r;
+}
+ZKT_HD bool miller_bit(int i) {
+  uint32_t w = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w = (j == (i >> 5)) ? miller_bits_word(j) : w;
+  return (w >> (i & 31)) & 1;
+}
+ZKT_HD Fq2 fq2_from_fq(const Fq& a) { return Fq2{a, fp_zero<FqC>()}; }
+
+// calc_g1_g2(P, Q): Miller loop on P in G1 (Fq Jacobian), evaluated at the untwisted Q
+ZKT_FN Fq12 miller_g1_g2_exact(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq) {
+  const Fq2 xi_inv = xi_inv_const();
+  const Fq2 Xq = fq2_mul(xq, xi_inv), Yq = fq2_mul(yq, xi_inv);
+  Fq X = xp, Y = yp, Z = fp_one<FqC>();
+  Fq12 N = fq12_one(), D = fq12_one();
+  Fq ns = fp_one<FqC>(), ds = fp_one<FqC>();
+  for (int i = 0; i < MILLER_NBITS; ++i) {
+    {
+      Fq A = fp_sqr(X), B = fp_sqr(Y), C = fp_sqr(B), ZZ = fp_sqr(Z);
+      Fq Dd = fp_dbl(fp_sub(fp_sub(fp_sqr(fp_add(X, B)), A), C));
+      Fq E = fp_add(fp_dbl(A), A);
+      Fq X3 = fp_sub(fp_sqr(E), fp_dbl(Dd));
+      Fq Y3 = fp_sub(fp_mul(E, fp_sub(Dd, X3)), fp_dbl(fp_dbl(fp_dbl(C))));
+      Fq Z3 = fp_dbl(fp_mul(Y, Z));
+      Fq s = fp_mul(Z3, ZZ), Z3Z3 = fp_sqr(Z3);
+      Fq12 lp = fq12_sparse(fq2_from_fq(fp_sub(fp_mul(E, X), fp_dbl(B))), fq2_mul_fq(Xq, fp_neg(fp_mul(E, ZZ))), fq2_mul_fq(Yq, s), fq2_zero());
+      Fq12 vp = fq12_sparse(fq2_from_fq(fp_neg(X3)), fq2_mul_fq(Xq, Z3Z3), fq2_zero(), fq2_zero());
+      N = fq12_mul(fq12_sqr(N), lp); D = fq12_mul(fq12_sqr(D), vp);
+      ns = fp_mul(fp_sqr(ns), Z3Z3); ds = fp_mul(fp_sqr(ds), s);
+      X = X3; Y = Y3; Z = Z3;
+    }
+    if (miller_bit(i)) {
+      Fq ZZ = fp_sqr(Z), H = fp_sub(fp_mul(xp, ZZ), X), Rr = fp_sub(fp_mul(fp_mul(yp, ZZ), Z), Y);
+      Fq HH = fp_sqr(H), HHH = fp_mul(H, HH), V = fp_mul(X, HH);
+      Fq X3 = fp_sub(fp_sub(fp_sqr(Rr), HHH), fp_dbl(V));
+      Fq Y3 = fp_sub(fp_mul(Rr, fp_sub(V, X3)), fp_mul(Y, HHH));
+      Fq Z3 = fp_mul(Z, H), Z3Z3 = fp_sqr(Z3);
+      Fq12 lp = fq12_sparse(fq2_from_fq(fp_sub(fp_mul(Rr, xp), fp_mul(Z3, yp))), fq2_mul_fq(Xq, fp_neg(Rr)), fq2_mul_fq(Yq, Z3), fq2_zero());
+      Fq12 vp = fq12_sparse(fq2_from_fq(fp_neg(X3)), fq2_mul_fq(Xq, Z3Z3), fq2_zero(), fq2_zero());
+      N = fq12_mul(N, lp); D = fq12_mul(D, vp);
+      ns = fp_mul(ns, Z3Z3); ds = fp_mul(ds, Z3);
+      X = X3; Y = Y3; Z = Z3;
+    }
+  }
+  return fq12_mul(fq12_scale_fq2(N, fq2_from_fq(ns)), fq12_inv(fq12_scale_fq2(D, fq2_from_fq(ds))));
+}
+
+// calc_g2_g1(Q, P): Miller loop on Q in G2 (Fq2 Jacobian), evaluated at the embedded P.  With x' = (x/xi) v^2 and
+// y' = (y/xi) v w an affine slope lam becomes (lam/xi) v^2 w, so
+//   line(P) = yp + [(lam x1 - y1)/xi] v w + [-(lam/xi) xp] v^2 w,   vertical(P) = xp - (x/xi) v^2.
+ZKT_FN Fq12 miller_g2_g1_exact(const Fq2& xq, const Fq2& yq, const Fq& xp, const Fq& yp) {
+  const Fq2 xi_inv = xi_inv_const();
+  const Fq nxp = fp_neg(xp);
+  Fq2 X = xq, Y = yq, Z = fq2_one();
+  Fq12 N = fq12_one(), D = fq12_one();
+  Fq2 ns = fq2_one(), ds = fq2_one();
+  for (int i = 0; i < MILLER_NBITS; ++i) {
+    {
+      Fq2 A = fq2_sqr(X), B = fq2_sqr(Y), C = fq2_sqr(B), ZZ = fq2_sqr(Z);
+      Fq2 Dd = fq2_dbl(fq2_sub(fq2_sub(fq2_sqr(fq2_add(X, B)), A), C));
+      Fq2 E = fq2_add(fq2_dbl(A), A);
+      Fq2 X3 = fq2_sub(fq2_sqr(E), fq2_dbl(Dd));
+      Fq2 Y3 = fq2_sub(fq2_mul(E, fq2_sub(Dd, X3)), fq2_dbl(fq2_dbl(fq2_dbl(C))));
+      Fq2 Z3 = fq2_dbl(fq2_mul(Y, Z));
+      Fq2 s = fq2_mul(Z3, ZZ), Z3Z3 = fq2_sqr(Z3);
+      Fq12 lp = fq12_sparse(fq2_mul_fq(s, yp), fq2_zero(), fq2_mul(fq2_sub(fq2_mul(E, X), fq2_dbl(B)), xi_inv),
+                            fq2_mul_fq(fq2_mul(fq2_mul(E, ZZ), xi_inv), nxp));
+      Fq12 vp = fq12_sparse(fq2_mul_fq(Z3Z3, xp), fq2_neg(fq2_mul(X3, xi_inv)), fq2_zero(), fq2_zero());
+      N = fq12_mul(fq12_sqr(N), lp); D = fq12_mul(fq12_sqr(D), vp);
+      ns = fq2_mul(fq2_sqr(ns), Z3Z3); ds = fq2_mul(fq2_sqr(ds), s);
+      X = X3; Y = Y3; Z = Z3;
+    }
+    if (miller_bit(i)) {
+      Fq2 ZZ = fq2_sqr(Z), H = fq2_sub(fq2_mul(xq, ZZ), X), Rr = fq2_sub(fq2_mul(fq2_mul(yq, ZZ), Z), Y);
+      Fq2 HH = fq2_sqr(H), HHH = fq2_mul(H, HH), V = fq2_mul(X, HH);
+      Fq2 X3 = fq2_sub(fq2_sub(fq2_sqr(Rr), HHH), fq2_dbl(V));
+      Fq2 Y3 = fq2_sub(fq2_mul(Rr, fq2_sub(V, X3)), fq2_mul(Y, HHH));
+      Fq2 Z3 = fq2_mul(Z, H), Z3Z3 = fq2_sqr(Z3);
+      Fq12 lp = fq12_sparse(fq2_mul_fq(Z3, yp), fq2_zero(), fq2_mul(fq2_sub(fq2_mul(Rr, xq), fq2_mul(Z3, yq)), xi_inv),
+                            fq2_mul_fq(fq2_mul(Rr, xi_inv), nxp));
+      Fq12 vp = fq12_sparse(fq2_mul_fq(Z3Z3, xp), fq2_neg(fq2_mul(X3, xi_inv)), fq2_zero(), fq2_zero());
+      N = fq12_mul(N, lp); D = fq12_mul(D, vp);
+      ns = fq2_mul(ns, Z3Z3); ds = fq2_mul(ds, Z3);
+      X = X3; Y = Y3; Z = Z3;
+    }
+  }
+  return fq12_mul(fq12_scale_fq2(N, ns), fq12_inv(fq12_scale_fq2(D, ds)));
+}
+
 }  // namespace zkt

@@ -252,6 +252,13 @@ int zkt_tate_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* o
   return staged(g1, sizeof(zkt_g1_affine), g2, sizeof(zkt_g2_affine), out, 576, n, ZKT_ERR_INFINITY,
                 [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_tate(da, db, dout, n, g.d_err, s); });
 }
+static int miller_exact(int which, const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out, size_t n) {
+  return staged(g1, sizeof(zkt_g1_affine), g2, sizeof(zkt_g2_affine), out, 576, n, ZKT_ERR_INFINITY,
+                [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_miller_exact(which, da, db, dout, n, g.d_err, s); });
+}
+int zkt_miller_g1g2_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out, size_t n) { return miller_exact(0, g1, g2, out, n); }
+int zkt_miller_g2g1_batch(const zkt_g2_affine* g2, const zkt_g1_affine* g1, uint64_t* out, size_t n) { return miller_exact(1, g1, g2, out, n); }
+int zkt_weil_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out, size_t n) { return miller_exact(2, g1, g2, out, n); }
 int zkt_gt_eq(const uint64_t* a, const uint64_t* b) {
   if (!a || !b) return -ZKT_ERR_SHAPE;
   return memcmp(a, b, 576) == 0 ? 1 : 0;   // canonical residues: memcmp equality <=> Fq12 equality (fq12.rs:88-93)

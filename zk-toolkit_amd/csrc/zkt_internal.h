@@ -24,6 +24,7 @@ hipError_t launch_group_add(int grp, const uint32_t* a, const uint32_t* b, uint3
 hipError_t launch_group_neg(int grp, const uint32_t* a, uint32_t* out, size_t n, hipStream_t s);
 hipError_t launch_group_mul(int grp, const uint32_t* pts, const uint32_t* scalars, int scalar_words, uint32_t* out, size_t n, hipStream_t s, bool fixed_base = false, bool fixed_scalar = false);
 hipError_t launch_group_sum_inplace(int grp, uint32_t* pts, size_t n, hipStream_t s);
+hipError_t launch_miller_exact(int which, const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s);
 hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s);
 
 // ---- MSM (zkt_msm.hip) ---------------------------------------------------------
