@@ -148,6 +148,13 @@ int zkt_bp_inner_product_argument(size_t n, const zkt_secp_affine* gg, const zkt
                                   const zkt_secp_affine* P, const uint64_t* a, const uint64_t* b, const uint64_t* xs,
                                   zkt_secp_affine* out_trace);
 
+/* a18: Bulletproofs::range_proof bulletproofs.rs:58-147 (n = bit length, a power of two; aL = the value's bits).  rnd =
+ * alpha, rho, y, z, tau1, tau2, x, sL[n], sR[n] (the values the reference draws at :76,:79-81,:84-85,:97-98,:102);
+ * u = the random point of :137 and xs the inner-product challenges (only with use_ipa).  out_pts (optional) = A,S,T1,T2,P. */
+int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, const uint64_t* gamma, const zkt_secp_affine* g,
+                       const zkt_secp_affine* h, const zkt_secp_affine* gg, const zkt_secp_affine* hh, int use_ipa,
+                       const uint64_t* rnd, const zkt_secp_affine* u, const uint64_t* xs, zkt_secp_affine* out_pts);
+
 /* ---- device-resident entry points (inputs/outputs already in HBM) -------------------- */
 /* Bases kept on the device in kernel layout (Montgomery x,y, 96 B each) — the analogue of
  * a CRS that is uploaded once (crs.rs:85-135) and reused by every prove call. */

@@ -193,3 +193,66 @@ int zkto_bp_commit(size_t n, const uint64_t* gg_, const uint64_t* hh_, const uin
 int zkto_sn_inv(const uint64_t* a, uint64_t* o) { init_fields(); Sn r; if (!Sn::from_limbs(a, 4).safe_inv(r)) return 1; for (int i = 0; i < 4; ++i) o[i] = r.l[i]; return 0; }
 
 }  // extern "C"
+
+// ---- Bulletproofs::range_proof (bulletproofs.rs:58-147), every random draw injected ------------------------
+// rnd layout (4-limb residues mod the secp256k1 group order): alpha, rho, y, z, tau1, tau2, x, then sL[n], sR[n].
+// u = the random point of :137 (used only with the inner-product argument), xs = the IPA challenges.
+// out_pts (optional): A, S, T1, T2, P  (5 points) for parity with the GPU path.
+extern "C" int zkto_bp_range_proof(size_t n, const uint64_t* V_, const uint64_t* aL_, const uint64_t* gamma_, const uint64_t* g_, const uint64_t* h_,
+                                   const uint64_t* gg_, const uint64_t* hh_, int use_ipa, const uint64_t* rnd, const uint64_t* u_, const uint64_t* xs,
+                                   uint64_t* out_pts) {
+  init_fields();
+  typedef std::vector<Sn> Vec;
+  auto ldv = [&](const uint64_t* p, size_t cnt) { Vec v(cnt); for (size_t i = 0; i < cnt; ++i) v[i] = Sn::from_limbs(p + i * 4, 4); return v; };
+  auto had = [](const Vec& a, const Vec& b) { Vec r(a.size()); for (size_t i = 0; i < a.size(); ++i) r[i] = a[i] * b[i]; return r; };
+  auto add = [](const Vec& a, const Vec& b) { Vec r(a.size()); for (size_t i = 0; i < a.size(); ++i) r[i] = a[i] + b[i]; return r; };
+  auto sub = [](const Vec& a, const Vec& b) { Vec r(a.size()); for (size_t i = 0; i < a.size(); ++i) r[i] = a[i] - b[i]; return r; };
+  auto scl = [](const Vec& a, const Sn& s) { Vec r(a.size()); for (size_t i = 0; i < a.size(); ++i) r[i] = a[i] * s; return r; };
+  auto sum = [](const Vec& a) { Sn s(0); for (const Sn& x : a) s = s + x; return s; };
+  auto powseq = [&](const Sn& b) { Vec r(n); Sn x(1); for (size_t i = 0; i < n; ++i) { r[i] = x; x = x * b; } return r; };   // pow_seq, prime_field_elem.rs:346-361
+  std::vector<SecpPoint> gg(n), hh(n);
+  for (size_t i = 0; i < n; ++i) { gg[i] = ldsp(gg_ + i * 9); hh[i] = ldsp(hh_ + i * 9); }
+  auto msm = [&](const std::vector<SecpPoint>& pts, const Vec& k) { return vec_msm(pts, 0, k, 0, n); };
+  SecpPoint V = ldsp(V_), g = ldsp(g_), h = ldsp(h_);
+  Vec aL = ldv(aL_, n);
+  Sn gamma = Sn::from_limbs(gamma_, 4);
+  Sn alpha = Sn::from_limbs(rnd, 4), rho = Sn::from_limbs(rnd + 4, 4), y = Sn::from_limbs(rnd + 8, 4), z = Sn::from_limbs(rnd + 12, 4),
+     tau1 = Sn::from_limbs(rnd + 16, 4), tau2 = Sn::from_limbs(rnd + 20, 4), x = Sn::from_limbs(rnd + 24, 4);
+  Vec sL = ldv(rnd + 28, n), sR = ldv(rnd + 28 + 4 * n, n);
+
+  Vec one_n = powseq(Sn(1)), two_n = powseq(Sn(2));                                   // :72-73
+  Vec aR = sub(aL, one_n);                                                             // :75
+  SecpPoint A = affine_add(affine_add(smul(h, alpha), msm(gg, aL)), msm(hh, aR));      // :77
+  SecpPoint S = affine_add(affine_add(smul(h, rho), msm(gg, sL)), msm(hh, sR));        // :82
+  Vec y_n = powseq(y);                                                                 // :87
+  Vec l0 = sub(aL, scl(one_n, z)), l1 = sL;                                            // :88-89
+  Vec r0 = add(had(y_n, add(aR, scl(one_n, z))), scl(two_n, z.sq())), r1 = had(y_n, sR);   // :90-91
+  Sn t0 = sum(had(l0, r0)), t1 = sum(had(l1, r0)) + sum(had(l0, r1)), t2 = sum(had(l1, r1));   // :93-95
+  SecpPoint T1 = affine_add(smul(g, t1), smul(h, tau1)), T2 = affine_add(smul(g, t2), smul(h, tau2));   // :99-100
+  Sn t_hat = t0 + t1 * x + t2 * x.sq();                                                // :104
+  Sn tau_x = tau2 * x.sq() + tau1 * x + z.sq() * gamma;                                // :105
+  Sn mu = alpha + rho * x;                                                             // :106
+  Vec yinv_n = powseq(y.inv());
+  std::vector<SecpPoint> hhp(n);
+  for (size_t i = 0; i < n; ++i) hhp[i] = smul(hh[i], yinv_n[i]);                      // :109
+  Sn delta_yz = (z - z.sq()) * sum(had(one_n, y_n)) - (z.sq() * z) * sum(had(one_n, two_n));   // :112
+  SecpPoint lhs65 = affine_add(smul(g, t_hat), smul(h, tau_x));                        // :114
+  SecpPoint rhs65 = affine_add(affine_add(affine_add(smul(V, z.sq()), smul(g, delta_yz)), smul(T1, x)), smul(T2, x.sq()));   // :115
+  Vec l = add(sub(aL, scl(one_n, z)), scl(sL, x));                                     // :121
+  Vec r = add(had(y_n, add(add(aR, scl(one_n, z)), scl(sR, x))), scl(two_n, z.sq()));  // :122
+  SecpPoint P = affine_add(affine_add(affine_add(A, smul(S, x)), msm(gg, scl(one_n, z.negate()))),
+                           msm(hhp, add(scl(y_n, z), scl(two_n, z.sq()))));            // :124-128
+  if (out_pts) { stsp(out_pts, A); stsp(out_pts + 9, S); stsp(out_pts + 18, T1); stsp(out_pts + 27, T2); stsp(out_pts + 36, P); }
+  if (!(lhs65 == rhs65)) return 0;                                                     // :116-118
+  if (use_ipa) {
+    SecpPoint u = ldsp(u_);
+    SecpPoint Pp = affine_add(affine_add(P, smul(h, mu.negate())), smul(u, sum(had(l, r))));   // :138
+    std::vector<uint64_t> ggb(n * 9), hhb(n * 9), lb(n * 4), rb(n * 4); uint64_t ub[9], pb[9];
+    for (size_t i = 0; i < n; ++i) { stsp(ggb.data() + i * 9, gg[i]); stsp(hhb.data() + i * 9, hhp[i]); for (int j = 0; j < 4; ++j) { lb[i * 4 + j] = l[i].l[j]; rb[i * 4 + j] = r[i].l[j]; } }
+    stsp(ub, u); stsp(pb, Pp);
+    return zkto_bp_ipa(n, ggb.data(), hhb.data(), ub, pb, lb.data(), rb.data(), xs, nullptr);   // :139
+  }
+  SecpPoint rhs6667 = affine_add(affine_add(smul(h, mu), msm(gg, l)), msm(hhp, r));    // :142
+  if (!(P == rhs6667)) return 0;
+  return t_hat == sum(had(l, r)) ? 1 : 0;                                              // :147-149
+}

@@ -124,3 +124,17 @@ def test_ipa_full_size_accepts(L):                  # BASELINE config 5 shape: n
     assert L.zkt_bp_inner_product_argument(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b), ptr(xs), None) == 1
     a2 = a.copy(); a2[n - 1, 0] ^= 1
     assert L.zkt_bp_inner_product_argument(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a2), ptr(b), ptr(xs), None) == 0
+
+
+@pytest.mark.parametrize("n,value", [(4, 9), (64, 0xDEADBEEFCAFEF00D)])
+def test_range_proof_vs_oracle(L, n, value):          # bulletproofs.rs:58-147 / test at :248-282 (n = 4, value 9)
+    from test_oracle_protocols import range_proof_instance
+    V, aL, gamma, g, h, gg, hh, rnd, u, xs = range_proof_instance(n, value, 40 + n)
+    for use_ipa in (0, 1):
+        gp, op = np.zeros((5, 9), np.uint64), np.zeros((5, 9), np.uint64)
+        want = O.zkto_bp_range_proof(n, ptr(V), ptr(aL), ptr(gamma), ptr(g), ptr(h), ptr(gg), ptr(hh), use_ipa, ptr(rnd), ptr(u), ptr(xs), ptr(op))
+        got = L.zkt_bp_range_proof(n, ptr(V), ptr(aL), ptr(gamma), ptr(g), ptr(h), ptr(gg), ptr(hh), use_ipa, ptr(rnd), ptr(u), ptr(xs), ptr(gp))
+        assert want == 1 and got == 1
+        assert (gp == op).all()                       # A, S, T1, T2, P identical
+        bad = aL.copy(); bad[1, 0] ^= 1
+        assert L.zkt_bp_range_proof(n, ptr(V), ptr(bad), ptr(gamma), ptr(g), ptr(h), ptr(gg), ptr(hh), use_ipa, ptr(rnd), ptr(u), ptr(xs), None) == 0

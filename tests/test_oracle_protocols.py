@@ -64,3 +64,29 @@ def test_ipa_accepts_honest_and_rejects_tampered():    # bulletproofs.rs:231-246
     gg[1] = gg[0]
     assert O.zkto_bp_commit(2, ptr(gg), ptr(hh), ptr(u), ptr(a), ptr(b), ptr(P)) == 0
     assert O.zkto_bp_ipa(2, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b), ptr(xs), None) == 1
+
+
+def range_proof_instance(n, value, seed):
+    rng = SplitMix64(seed)
+    g0 = np.zeros((1, 9), np.uint64); O.zkto_secp_generator(ptr(g0))
+    ks = ints_to_arr([rng.below(SECP_N - 1) + 1 for _ in range(2 * n + 3)], 4)
+    pts = np.zeros((2 * n + 3, 9), np.uint64)
+    assert O.zkto_secp_mul_batch(ptr(np.repeat(g0, 2 * n + 3, axis=0)), ptr(ks), 4, ptr(pts), 2 * n + 3, 8) == 0
+    gg, hh, g, h, u = pts[:n].copy(), pts[n:2 * n].copy(), pts[2 * n:2 * n + 1].copy(), pts[2 * n + 1:2 * n + 2].copy(), pts[2 * n + 2:].copy()
+    aL = ints_to_arr([(value >> i) & 1 for i in range(n)], 4)            # bits of the value (bulletproofs.rs:258-262)
+    gamma = ints_to_arr([rng.below(SECP_N - 1) + 1], 4)
+    V = np.zeros((1, 9), np.uint64)                                         # V = g^v h^gamma
+    tmp = np.zeros((2, 9), np.uint64)
+    assert O.zkto_secp_mul_batch(ptr(np.concatenate([g, h])), ptr(np.concatenate([ints_to_arr([value], 4), gamma])), 4, ptr(tmp), 2, 1) == 0
+    assert O.zkto_secp_add_batch(ptr(tmp[0:1].copy()), ptr(tmp[1:2].copy()), ptr(V), 1) == 0
+    rnd = ints_to_arr([rng.below(SECP_N - 1) + 1 for _ in range(7 + 2 * n)], 4)
+    xs = ints_to_arr([rng.below(SECP_N - 1) + 1 for _ in range(max(n.bit_length() - 1, 1))], 4)
+    return V, aL, gamma, g, h, gg, hh, rnd, u, xs
+
+
+def test_range_proof_accepts_in_range_value():      # bulletproofs.rs:248-282: n = 4, value 9, with and without the IPA
+    for use_ipa in (0, 1):
+        V, aL, gamma, g, h, gg, hh, rnd, u, xs = range_proof_instance(4, 9, 31)
+        assert O.zkto_bp_range_proof(4, ptr(V), ptr(aL), ptr(gamma), ptr(g), ptr(h), ptr(gg), ptr(hh), use_ipa, ptr(rnd), ptr(u), ptr(xs), None) == 1
+        bad = aL.copy(); bad[0, 0] ^= 1                                    # opening that does not match V
+        assert O.zkto_bp_range_proof(4, ptr(V), ptr(bad), ptr(gamma), ptr(g), ptr(h), ptr(gg), ptr(hh), use_ipa, ptr(rnd), ptr(u), ptr(xs), None) == 0

@@ -81,6 +81,35 @@ __global__ void __launch_bounds__(256) k_fold(const uint32_t* __restrict__ a, co
   st_raw<C>(out + i * C::N, r);
 }
 
+// out[i] = s  (PrimeFieldElem::repeat, prime_field_elem.rs:363-376) / out[i] = base^i (pow_seq, :346-361)
+template <class C>
+__global__ void __launch_bounds__(256) k_powseq(const uint32_t* __restrict__ base, size_t n, uint32_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  Fp<C> b = ld_fp<C>(base), r = fp_one<C>();
+  for (size_t e = i; e; e >>= 1) { if (e & 1) r = fp_mul(r, b); b = fp_sqr(b); }
+  st_fp<C>(out + i * C::N, r);
+}
+template <class C>
+__global__ void __launch_bounds__(256) k_scale(const uint32_t* __restrict__ a, const uint32_t* __restrict__ s, size_t n, uint32_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  st_raw<C>(out + i * C::N, fp_mul(ld_fp<C>(s), ld_raw<C>(a + i * C::N)));
+}
+template <class C>
+__global__ void __launch_bounds__(256) k_sum(const uint32_t* __restrict__ a, size_t n, uint32_t* __restrict__ out) {
+  __shared__ uint32_t lds[256 * C::N];
+  const int t = threadIdx.x;
+  Fp<C> acc = fp_zero<C>();
+  for (size_t i = t; i < n; i += 256) acc = fp_add(acc, ld_raw<C>(a + i * C::N));
+  st_raw<C>(lds + t * C::N, acc); __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (t < d) { acc = fp_add(acc, ld_raw<C>(lds + (t + d) * C::N)); st_raw<C>(lds + t * C::N, acc); }
+    __syncthreads();
+  }
+  if (t == 0) st_raw<C>(out, acc);
+}
+
 }  // namespace zkt
 
 using namespace zkt;
@@ -284,6 +313,124 @@ int zkt_bp_inner_product_argument(size_t n, const zkt_secp_affine* gg, const zkt
   if ((rc = down(&rhs, T, SPB, s)) || (rc = down(&lhs, dPp.p, SPB, s))) return -rc;
   if (hipStreamSynchronize(s) != hipSuccess) return -ZKT_ERR_DEVICE;
   return memcmp(&rhs, &lhs, SPB) == 0 ? 1 : 0;
+}
+
+
+// Bulletproofs::range_proof (bulletproofs.rs:58-147) over secp256k1, every random draw injected.
+// rnd = alpha, rho, y, z, tau1, tau2, x, sL[n], sR[n] (4-limb residues mod the group order); u = the random point of :137;
+// xs = IPA challenges.  out_pts (optional) = A, S, T1, T2, P.  Returns 1/0 like the reference's bool, negative = -status.
+int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, const uint64_t* gamma, const zkt_secp_affine* g, const zkt_secp_affine* h,
+                       const zkt_secp_affine* gg, const zkt_secp_affine* hh, int use_ipa, const uint64_t* rnd, const zkt_secp_affine* u, const uint64_t* xs,
+                       zkt_secp_affine* out_pts) {
+  if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
+  if (n == 0 || (n & (n - 1)) || !V || !aL || !gamma || !g || !h || !gg || !hh || !rnd || (use_ipa && (!u || (n > 1 && !xs)))) return -ZKT_ERR_SHAPE;
+  hipStream_t s = nullptr;
+  const int PW = 18;
+  unsigned long long* noerr = nullptr;
+  // scalar-field vectors on the device (canonical residues), simple arena of n-vectors and scalars
+  const int NV = 32, NS = 64;
+  Dev vec((size_t)NV * n * FRB), sc((size_t)NS * FRB), derr(8);
+  if (!vec.p || !sc.p || !derr.p) return -ZKT_ERR_DEVICE;
+  noerr = (unsigned long long*)derr.p;
+  int vi = 0, si = 0;
+  auto newv = [&]() { return vec.w() + (size_t)(vi++) * n * 8; };
+  auto news = [&]() { return sc.w() + (size_t)(si++) * 8; };
+  auto op = [&](int o, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t cnt) { return launch_fp_op(F_SN, o, a, b, out, cnt, noerr, s) == hipSuccess; };
+  auto vadd = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = newv(); op(OP_ADD, a, b, o, n); return o; };
+  auto vsub = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = newv(); op(OP_SUB, a, b, o, n); return o; };
+  auto vhad = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = newv(); op(OP_MUL, a, b, o, n); return o; };
+  auto vscl = [&](const uint32_t* a, const uint32_t* k) { uint32_t* o = newv(); hipLaunchKernelGGL(k_scale<SnC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, k, n, o); return o; };
+  auto vpow = [&](const uint32_t* b) { uint32_t* o = newv(); hipLaunchKernelGGL(k_powseq<SnC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, b, n, o); return o; };
+  auto vsum = [&](const uint32_t* a) { uint32_t* o = news(); hipLaunchKernelGGL(k_sum<SnC>, dim3(1), dim3(256), 0, s, a, n, o); return o; };
+  auto vdot = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = news(); hipLaunchKernelGGL(k_dot<SnC>, dim3(1), dim3(256), 0, s, a, b, n, o); return o; };
+  auto sadd = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = news(); op(OP_ADD, a, b, o, 1); return o; };
+  auto ssub = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = news(); op(OP_SUB, a, b, o, 1); return o; };
+  auto smul = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = news(); op(OP_MUL, a, b, o, 1); return o; };
+  auto sneg = [&](const uint32_t* a) { uint32_t* o = news(); op(OP_NEG, a, nullptr, o, 1); return o; };
+  auto sinv = [&](const uint32_t* a) { uint32_t* o = news(); op(OP_INV, a, nullptr, o, 1); return o; };
+  auto sput = [&](const uint64_t* hsrc) { uint32_t* o = news(); hipMemcpyAsync(o, hsrc, FRB, hipMemcpyHostToDevice, s); return o; };
+  auto vput = [&](const uint64_t* hsrc) { uint32_t* o = newv(); hipMemcpyAsync(o, hsrc, n * FRB, hipMemcpyHostToDevice, s); return o; };
+  unsigned long long ne = NO_ERR; hipMemcpyAsync(derr.p, &ne, 8, hipMemcpyHostToDevice, s);
+  const uint64_t one64[4] = {1, 0, 0, 0}, two64[4] = {2, 0, 0, 0};
+  if ((rnd[8] | rnd[9] | rnd[10] | rnd[11]) == 0) return -ZKT_ERR_INV_ZERO;   // y must be invertible (:109); the reference draws non-zero values
+  // points on the device: [gg | hh | hhp | g h V u | scratch]
+  Dev pts((3 * n + 8) * SPB), tmp((2 * n + 8) * SPB), res(16 * SPB);
+  if (!pts.p || !tmp.p || !res.p) return -ZKT_ERR_DEVICE;
+  uint32_t *GG = pts.w(), *HH = GG + n * PW, *HHP = HH + n * PW, *Gp = HHP + n * PW, *Hp = Gp + PW, *Vp = Hp + PW, *Up = Vp + PW;
+  hipMemcpyAsync(GG, gg, n * SPB, hipMemcpyHostToDevice, s); hipMemcpyAsync(HH, hh, n * SPB, hipMemcpyHostToDevice, s);
+  hipMemcpyAsync(Gp, g, SPB, hipMemcpyHostToDevice, s); hipMemcpyAsync(Hp, h, SPB, hipMemcpyHostToDevice, s); hipMemcpyAsync(Vp, V, SPB, hipMemcpyHostToDevice, s);
+  if (use_ipa) hipMemcpyAsync(Up, u, SPB, hipMemcpyHostToDevice, s);
+  uint32_t* R = res.w(); int ri = 0;
+  auto newp = [&]() { return R + (size_t)(ri++) * PW; };
+  // sum_i pts[i]*k[i] (+ extra terms): scalar-mul batch then pairwise tree (AffinePoints * PrimeFieldElems).sum()
+  auto msm = [&](const uint32_t* P, const uint32_t* k) { uint32_t* T = tmp.w(); launch_group_mul(G_SECP, P, k, 8, T, n, s); launch_group_sum_inplace(G_SECP, T, n, s);
+                                                         uint32_t* o = newp(); hipMemcpyAsync(o, T, SPB, hipMemcpyDeviceToDevice, s); return o; };
+  auto pmul = [&](const uint32_t* P, const uint32_t* k) { uint32_t* o = newp(); launch_group_mul(G_SECP, P, k, 8, o, 1, s); return o; };
+  auto padd = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = newp(); launch_group_add(G_SECP, a, b, o, 1, s); return o; };
+
+  uint32_t *d_aL = vput(aL), *d_sL = vput(rnd + 28), *d_sR = vput(rnd + 28 + 4 * n);
+  uint32_t *alpha = sput(rnd), *rho = sput(rnd + 4), *y = sput(rnd + 8), *z = sput(rnd + 12), *tau1 = sput(rnd + 16), *tau2 = sput(rnd + 20), *x = sput(rnd + 24);
+  uint32_t *d_gamma = sput(gamma), *one = sput(one64), *two = sput(two64);
+  uint32_t *one_n = vpow(one), *two_n = vpow(two);                                   // :72-73
+  uint32_t* aR = vsub(d_aL, one_n);                                                   // :75
+  uint32_t* A = padd(padd(pmul(Hp, alpha), msm(GG, d_aL)), msm(HH, aR));              // :77
+  ri = 0; uint32_t* Ak = newp(); hipMemcpyAsync(Ak, A, SPB, hipMemcpyDeviceToDevice, s);
+  uint32_t* S = padd(padd(pmul(Hp, rho), msm(GG, d_sL)), msm(HH, d_sR));              // :82
+  ri = 1; uint32_t* Sk = newp(); hipMemcpyAsync(Sk, S, SPB, hipMemcpyDeviceToDevice, s);
+  uint32_t* y_n = vpow(y);                                                            // :87
+  uint32_t* z2 = smul(z, z);
+  uint32_t* onez = vscl(one_n, z);
+  uint32_t* l0 = vsub(d_aL, onez);                                                    // :88
+  uint32_t* aRz = vadd(aR, onez);
+  uint32_t* twoz2 = vscl(two_n, z2);
+  uint32_t* r0 = vadd(vhad(y_n, aRz), twoz2);                                         // :90
+  uint32_t* r1 = vhad(y_n, d_sR);                                                     // :91
+  uint32_t *t0 = vdot(l0, r0), *t1 = sadd(vdot(d_sL, r0), vdot(l0, r1)), *t2 = vdot(d_sL, r1);   // :93-95
+  ri = 2;
+  uint32_t* T1 = padd(pmul(Gp, t1), pmul(Hp, tau1)); ri = 2; uint32_t* T1k = newp(); hipMemcpyAsync(T1k, T1, SPB, hipMemcpyDeviceToDevice, s);   // :99
+  uint32_t* T2 = padd(pmul(Gp, t2), pmul(Hp, tau2)); ri = 3; uint32_t* T2k = newp(); hipMemcpyAsync(T2k, T2, SPB, hipMemcpyDeviceToDevice, s);   // :100
+  uint32_t* x2 = smul(x, x);
+  uint32_t* t_hat = sadd(sadd(t0, smul(t1, x)), smul(t2, x2));                        // :104
+  uint32_t* tau_x = sadd(sadd(smul(tau2, x2), smul(tau1, x)), smul(z2, d_gamma));     // :105
+  uint32_t* mu = sadd(alpha, smul(rho, x));                                           // :106
+  uint32_t* yinv_n = vpow(sinv(y));
+  launch_group_mul(G_SECP, HH, yinv_n, 8, HHP, n, s);                                 // :109 hh' = hh * y^-i
+  uint32_t* z3 = smul(z2, z);
+  uint32_t* delta_yz = ssub(smul(ssub(z, z2), vsum(y_n)), smul(z3, vsum(two_n)));     // :112 (one_n o v = v)
+  ri = 4;
+  uint32_t* lhs65 = padd(pmul(Gp, t_hat), pmul(Hp, tau_x));                           // :114
+  uint32_t* lhsk = R + 12 * PW; hipMemcpyAsync(lhsk, lhs65, SPB, hipMemcpyDeviceToDevice, s);
+  ri = 4;
+  uint32_t* rhs65 = padd(padd(padd(pmul(Vp, z2), pmul(Gp, delta_yz)), pmul(T1k, x)), pmul(T2k, x2));   // :115
+  uint32_t* rhsk = R + 13 * PW; hipMemcpyAsync(rhsk, rhs65, SPB, hipMemcpyDeviceToDevice, s);
+  uint32_t* l = vadd(l0, vscl(d_sL, x));                                              // :121
+  uint32_t* r = vadd(vhad(y_n, vadd(aRz, vscl(d_sR, x))), twoz2);                     // :122
+  ri = 4;
+  uint32_t* Pm = padd(padd(padd(Ak, pmul(Sk, x)), msm(GG, vscl(one_n, sneg(z)))), msm(HHP, vadd(vscl(y_n, z), twoz2)));   // :124-128
+  uint32_t* Pk = R + 4 * PW; hipMemcpyAsync(Pk, Pm, SPB, hipMemcpyDeviceToDevice, s);
+  zkt_secp_affine hl, hr;
+  int rc;
+  if ((rc = down(&hl, lhsk, SPB, s)) || (rc = down(&hr, rhsk, SPB, s))) return -rc;
+  if (out_pts && (rc = down(out_pts, R, 5 * SPB, s))) return -rc;
+  if (hipStreamSynchronize(s) != hipSuccess || vi > NV || si > NS) return -ZKT_ERR_DEVICE;
+  if (memcmp(&hl, &hr, SPB) != 0) return 0;                                           // :116-118
+  if (use_ipa) {
+    ri = 5;
+    uint32_t* Pp = padd(padd(Pk, pmul(Hp, sneg(mu))), pmul(Up, vdot(l, r)));          // :138
+    std::vector<zkt_secp_affine> hgg(n), hhhp(n); std::vector<uint64_t> hl2(n * 4), hr2(n * 4); zkt_secp_affine hu, hP;
+    if ((rc = down(hgg.data(), GG, n * SPB, s)) || (rc = down(hhhp.data(), HHP, n * SPB, s)) || (rc = down(hl2.data(), l, n * FRB, s)) ||
+        (rc = down(hr2.data(), r, n * FRB, s)) || (rc = down(&hu, Up, SPB, s)) || (rc = down(&hP, Pp, SPB, s))) return -rc;
+    if (hipStreamSynchronize(s) != hipSuccess || si > NS) return -ZKT_ERR_DEVICE;
+    return zkt_bp_inner_product_argument(n, hgg.data(), hhhp.data(), &hu, &hP, hl2.data(), hr2.data(), xs, nullptr);   // :139
+  }
+  ri = 5;
+  uint32_t* rhs = padd(padd(pmul(Hp, mu), msm(GG, l)), msm(HHP, r));                  // :142
+  uint32_t* lr = vdot(l, r);
+  zkt_secp_affine hP, hrhs; uint64_t hth[4], hlr[4];
+  if ((rc = down(&hP, Pk, SPB, s)) || (rc = down(&hrhs, rhs, SPB, s)) || (rc = down(hth, t_hat, FRB, s)) || (rc = down(hlr, lr, FRB, s))) return -rc;
+  if (hipStreamSynchronize(s) != hipSuccess || si > NS) return -ZKT_ERR_DEVICE;
+  if (memcmp(&hP, &hrhs, SPB) != 0) return 0;
+  return memcmp(hth, hlr, FRB) == 0 ? 1 : 0;                                          // :147-149
 }
 
 }  // extern "C"
