@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--pairings", type=int, default=1 << 16, help="pairings in the secondary measurement (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--scalar-dist", default="uniform", choices=["uniform", "ones", "bits"],
+                    help="uniform in [0,r) (the metric) | all ones | random 0/1 (skew stress: one hot bucket)")
     args = ap.parse_args()
 
     import torch
@@ -87,6 +89,10 @@ def main():
     setup_s = time.perf_counter() - t0
     del d_gen
     h_scalars = rand_scalars_mod_r(4 + 1000 * rank, n)
+    if args.scalar_dist == "ones":
+        h_scalars[:] = 0; h_scalars[:, 0] = 1
+    elif args.scalar_dist == "bits":
+        h_scalars[:, 1:] = 0; h_scalars[:, 0] &= np.uint64(1)
     d_scalars = torch.from_numpy(h_scalars.view(np.int64)).to(dev)
     d_partial = torch.zeros(36, dtype=torch.int32, device=dev)
     out = np.zeros((1, 13), dtype=np.uint64)
@@ -152,7 +158,7 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32 limbs (384-bit Montgomery integer)", "data": "synthetic",
         "config": {"workload": "Batched G1 Pippenger MSM, 2^%d random bases/scalars per GPU, bases device-resident with window multiples" % args.log2n,
-                   "terms_per_gpu": n, "scalar_bits": 255, "sharding": "index range per rank; all_gather of 144-B partial sums" if world > 1 else "none",
+                   "terms_per_gpu": n, "scalar_bits": 255, "scalar_dist": args.scalar_dist, "sharding": "index range per rank; all_gather of 144-B partial sums" if world > 1 else "none",
                    "bases_setup_s": round(setup_s, 3), "msms_in_flight": DEPTH,
                    "single_msm_latency_ms": round(latency_ms, 3) if world == 1 else None},
         "roofline": {"bound": "hbm", "kernel": L.zkt_last_kernel_name().decode(),

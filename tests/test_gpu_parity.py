@@ -265,3 +265,26 @@ def test_raw_miller_values_and_weil_vs_oracle(L):    # pairing.rs:54-55,75-84; b
         assert (got == want).all(), which
     inf = P.copy(); inf[2, :] = 0; inf[2, 12] = 1
     assert L.zkt_weil_batch(ptr(inf), ptr(Qp), ptr(got), n) == ZKT_ERR_INFINITY and L.zkt_last_error_index() == 2
+
+
+@pytest.mark.parametrize("kind", ["ones", "small", "equal", "few_big"])
+def test_g1_msm_skewed_scalars(L, kind):
+    """Skewed scalar distributions put thousands of terms in one bucket (a real witness is full of 0/1): the hot
+    buckets are split into <=128-entry tasks and merged; the sum must not change."""
+    n = 4096
+    rng = SplitMix64(900)
+    g = np.repeat(_gen(0), n, axis=0); bases = np.zeros_like(g)
+    zk.check(L.zkt_g1_mul_batch(ptr(g), ptr(ints_to_arr([rng.below(R) for _ in range(n)], 4)), 4, ptr(bases), n))
+    if kind == "ones": ss = [1] * n
+    elif kind == "small": ss = [rng.below(4) for _ in range(n)]
+    elif kind == "equal": ss = [rng.below(R)] * n
+    else: ss = [1] * n; ss[7] = R - 1; ss[100] = (1 << 256) - 1; ss[4095] = 0
+    sc = ints_to_arr(ss, 4)
+    got = np.zeros((1, G1W), dtype=np.uint64)
+    zk.check(L.zkt_g1_msm(ptr(bases), ptr(sc), n, ptr(got)))
+    if kind == "equal":                                # sum_i s*P_i = s * sum_i P_i : keeps the oracle side cheap
+        acc = np.zeros((1, G1W), np.uint64); assert O.zkto_g1_msm(ptr(bases), ptr(ints_to_arr([1] * n, 4)), 4, n, ptr(acc)) == 0
+        want = np.zeros((1, G1W), np.uint64); assert O.zkto_g1_mul_batch(ptr(acc), ptr(sc[:1].copy()), 4, ptr(want), 1, 1) == 0
+    else:
+        want = _msm_oracle(bases, sc, n)
+    assert (got == want).all(), kind

@@ -43,7 +43,8 @@ MsmPlan msm_plan(size_t n) {
   b += ent * 4;                            // entries
   b += p.nbuckets * XYW * 4;               // bucket sums
   b += (2048 + 64) * XYW * 4;              // row/col sums, bit classes
-  b += p.nbuckets * 4 + (1024 + 3 * 1025) * 4; // size order, scan scratch, size bins
+  b += (1024 + 3 * 1025) * 4 + 2 * (p.nbuckets + 1) * 4;          // scan scratch, size bins, task counts/offsets
+  b += (p.nbuckets + ent / 128 + 2) * (8 + XYW * 4);              // task list + partial sums of split buckets
   b += 4096;
   p.ws_bytes = b;
   return p;
@@ -93,32 +94,51 @@ __device__ inline uint32_t window_bits(const uint32_t* k, int w, int c) {
   return (uint32_t)(v >> sh) & ((1u << c) - 1);
 }
 
+// One atomic per (scalar, window) on the bucket counter; the returned value is the entry's slot inside its bucket.
+// Skewed inputs (a witness full of 0/1) send most lanes of a wave to the SAME counter, which would serialise a million
+// atomics on one address: up to two rounds of wave-level aggregation elect a leader for the most common bucket id among
+// the active lanes (one atomicAdd of the population count, ranks by prefix popcount); the rest go individually.
 template <bool SCATTER>
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t n, int c, int nwin,
                                                 uint32_t* __restrict__ counts_or_cursor, const uint32_t* __restrict__ offsets,
                                                 uint32_t* __restrict__ entries) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  uint32_t k[8];
-  const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
-  uint4 lo = sp[0], hi = sp[1];
-  k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+  const bool live = i < n;
+  uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (live) {
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8);
+    uint4 lo = sp[0], hi = sp[1];
+    k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+  }
   const uint32_t half = 1u << (c - 1);
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   uint32_t carry = 0;
-  for (int w = 0; w < nwin; ++w) {
+  for (int w = 0; w < nwin; ++w) {                      // wave-uniform trip count: the ballots below need every lane here
     uint32_t raw = window_bits(k, w, c) + carry;
     uint32_t neg = raw > half;
-    uint32_t mag = neg ? (1u << c) - raw : raw;     // |digit| in [0, 2^(c-1)]
+    uint32_t mag = neg ? (1u << c) - raw : raw;         // |digit| in [0, 2^(c-1)]
     carry = neg;
-    if (mag == 0) continue;
     size_t src = (size_t)w * n + i;
-    if (inf[src]) continue;                          // infinity contributes nothing
-    uint32_t b = mag - 1;
-    if (!SCATTER) {
-      atomicAdd(&counts_or_cursor[b], 1u);
-    } else {
-      uint32_t pos = atomicAdd(&counts_or_cursor[b], 1u);
-      entries[offsets[b] + pos] = (uint32_t)src | (neg << 31);
+    bool todo = live && mag != 0 && !inf[live ? src : 0];   // infinity and zero digits contribute nothing
+    const uint32_t b = mag - 1;
+    uint32_t pos = 0;
+    for (int round = 0; round < 2; ++round) {
+      unsigned long long act = __ballot(todo);
+      if (act == 0) break;
+      int leader = __ffsll((long long)act) - 1;
+      uint32_t lb = __shfl(b, leader);
+      unsigned long long same = __ballot(todo && b == lb);
+      int cnt = __popcll(same);
+      if (cnt < 4) break;                               // nothing worth aggregating: fall through to individual atomics
+      uint32_t base = 0;
+      if ((int)lane == leader) base = atomicAdd(&counts_or_cursor[lb], (uint32_t)cnt);
+      base = __shfl(base, leader);
+      if (todo && b == lb) { pos = base + (uint32_t)__popcll(same & lt_mask); if (SCATTER) entries[offsets[b] + pos] = (uint32_t)src | (neg << 31); todo = false; }
+    }
+    if (todo) {
+      pos = atomicAdd(&counts_or_cursor[b], 1u);
+      if (SCATTER) entries[offsets[b] + pos] = (uint32_t)src | (neg << 31);
     }
   }
 }
@@ -177,44 +197,63 @@ static void launch_scan(const uint32_t* in, uint32_t* out, size_t m, uint32_t* s
   hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(256), 0, s, in, m, (const uint32_t*)scratch, out);
 }
 
-// bucket ids ordered by population (largest first) so the 64 lanes of a wave run equally long lists;
-// a counting sort over min(count, SIZE_BINS-1).
-static constexpr int SIZE_BINS = 1024;
-__global__ void __launch_bounds__(256) k_size_hist(const uint32_t* __restrict__ counts, size_t m, uint32_t* __restrict__ hist) {
+// Work list.  A bucket is processed in chunks of at most CHUNK entries, one chunk per lane ("task"), so one lane never
+// runs an unbounded list: with random scalars every bucket (~26 entries at 2^20) is a single task, while skewed inputs
+// (many equal scalars: a real witness is full of 0/1) split their hot buckets over many lanes, whose partial sums are
+// merged afterwards.  Tasks are ordered by size (largest first) by a counting sort, so the 64 lanes of a wave run
+// equally long lists.
+static constexpr uint32_t CHUNK = 128;
+static constexpr int SIZE_BINS = CHUNK + 1;      // bin k holds tasks of size CHUNK - k
+__device__ inline uint32_t ntasks_of(uint32_t c) { return c <= CHUNK ? 1u : (c + CHUNK - 1) / CHUNK; }
+__global__ void __launch_bounds__(256) k_task_count(const uint32_t* __restrict__ counts, size_t m, uint32_t* __restrict__ ntask, uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[SIZE_BINS];
   for (int i = threadIdx.x; i < SIZE_BINS; i += 256) h[i] = 0;
   __syncthreads();
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < m) { uint32_t c = counts[i]; atomicAdd(&h[SIZE_BINS - 1 - (c < SIZE_BINS ? c : SIZE_BINS - 1)], 1u); }   // bin 0 = largest
+  if (i < m) {
+    uint32_t c = counts[i], nt = ntasks_of(c), last = c - (nt - 1) * CHUNK;
+    ntask[i] = nt;
+    atomicAdd(&h[CHUNK - last], 1u);
+    if (nt > 1) atomicAdd(&h[0], nt - 1);
+  }
   __syncthreads();
   for (int k = threadIdx.x; k < SIZE_BINS; k += 256) if (h[k]) atomicAdd(&hist[k], h[k]);
 }
-__global__ void __launch_bounds__(256) k_size_scatter(const uint32_t* __restrict__ counts, size_t m, const uint32_t* __restrict__ binoff,
-                                                      uint32_t* __restrict__ bincur, uint32_t* __restrict__ order) {
-  // rank inside the block with LDS atomics, then ONE global atomic per (block, non-empty bin):
-  // ~50 distinct sizes are shared by 2^19 buckets, so per-element global atomics would serialise.
+__global__ void __launch_bounds__(256) k_task_scatter(const uint32_t* __restrict__ counts, size_t m, const uint32_t* __restrict__ binoff,
+                                                      uint32_t* __restrict__ bincur, uint2* __restrict__ order) {
+  // rank inside the block with LDS atomics, then ONE global atomic per (block, non-empty bin): ~50 distinct sizes
+  // are shared by 2^19 buckets, so per-element global atomics would serialise.
   __shared__ uint32_t h[SIZE_BINS], base[SIZE_BINS];
   for (int i = threadIdx.x; i < SIZE_BINS; i += 256) h[i] = 0;
   __syncthreads();
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  uint32_t bin = 0, rank = 0;
-  if (i < m) { uint32_t c = counts[i]; bin = SIZE_BINS - 1 - (c < SIZE_BINS ? c : SIZE_BINS - 1); rank = atomicAdd(&h[bin], 1u); }
+  uint32_t bin = 0, rank = 0, nt = 1;
+  if (i < m) { uint32_t c = counts[i]; nt = ntasks_of(c); bin = CHUNK - (c - (nt - 1) * CHUNK); rank = atomicAdd(&h[bin], 1u); }
   __syncthreads();
   for (int k = threadIdx.x; k < SIZE_BINS; k += 256) if (h[k]) base[k] = binoff[k] + atomicAdd(&bincur[k], h[k]);
   __syncthreads();
-  if (i < m) order[base[bin] + rank] = (uint32_t)i;
+  if (i < m) {
+    order[base[bin] + rank] = make_uint2((uint32_t)i, nt - 1);                       // the last (possibly short) chunk
+    if (nt > 1) {                                                                    // full chunks of a hot bucket (rare)
+      uint32_t b0 = binoff[0] + atomicAdd(&bincur[0], nt - 1);
+      for (uint32_t k = 0; k + 1 < nt; ++k) order[b0 + k] = make_uint2((uint32_t)i, k);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------
-// bucket accumulation: one bucket per lane
+// bucket accumulation: one task (bucket chunk) per lane — the dominant kernel
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ table, const uint32_t* __restrict__ entries,
-                                                   const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ order,
-                                                   size_t nbuckets, uint32_t* __restrict__ sums) {
+                                                   const uint32_t* __restrict__ offsets, const uint2* __restrict__ order,
+                                                   const uint32_t* __restrict__ task_off, size_t nbuckets,
+                                                   uint32_t* __restrict__ sums, uint32_t* __restrict__ partial) {
   size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (t >= nbuckets) return;
-  const size_t b = order[t];
-  uint32_t beg = offsets[b], end = offsets[b + 1];
+  if (t >= task_off[nbuckets]) return;
+  const uint2 tk = order[t];
+  const size_t b = tk.x;
+  uint32_t beg = offsets[b] + tk.y * CHUNK, end = offsets[b + 1];
+  if (end - beg > CHUNK) end = beg + CHUNK;
   XY acc = xyzz_inf<FqOps>();
   for (uint32_t e = beg; e < end; ++e) {
     uint32_t ent = entries[e];
@@ -223,7 +262,8 @@ __global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ 
     if (ent >> 31) y = fp_neg(y);
     acc = xyzz_add_aff<FqOps>(acc, x, y);
   }
-  st_xy(sums + b * XYW, acc);
+  const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
+  st_xy(nt == 1 ? sums + b * XYW : partial + (size_t)(t0 + tk.y) * XYW, acc);
 }
 
 // ---------------------------------------------------------------------------------
@@ -242,6 +282,21 @@ __device__ inline XY block_tree_sum(XY v, uint32_t* lds /* RED_TPB/2 * XYW words
   }
   return v;
 }
+// hot buckets (more than one task): sums[b] = sum of the bucket's partials.  Blocks stride over the buckets; the test is
+// block-uniform, so the barrier inside the tree is safe.
+__global__ void __launch_bounds__(RED_TPB) k_merge_partials(const uint32_t* __restrict__ task_off, size_t nbuckets, const uint32_t* __restrict__ partial,
+                                                            uint32_t* __restrict__ sums) {
+  __shared__ uint32_t lds[RED_TPB / 2 * XYW];
+  for (size_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+    const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
+    if (nt == 1) continue;
+    XY acc = xyzz_inf<FqOps>();
+    for (uint32_t k = threadIdx.x; k < nt; k += RED_TPB) acc = xyzz_add<FqOps>(acc, ld_xy(partial + (size_t)(t0 + k) * XYW));
+    acc = block_tree_sum(acc, lds);
+    if (threadIdx.x == 0) st_xy(sums + b * XYW, acc);
+  }
+}
+
 // Both marginals of the NHI x NLO bucket matrix in ONE launch: blocks [0,NLO) produce the column sums
 // C_lo = sum_hi S[hi][lo]; blocks [NLO, NLO+NHI) the row sums R_hi = sum_lo S[hi][lo].
 __global__ void __launch_bounds__(RED_TPB) k_marginals(const uint32_t* __restrict__ in, size_t NLO, size_t NHI,
@@ -298,7 +353,8 @@ __global__ void __launch_bounds__(64) k_combine(const uint32_t* __restrict__ cls
 namespace {
 struct MsmWs {   // workspace carve-up (one per in-flight MSM)
   uint32_t *zero_begin, *counts, *cursor, *size_hist, *size_off, *size_cur, *zero_end;   // [zero_begin, zero_end) is cleared per MSM
-  uint32_t *offsets, *entries, *sums, *colsum, *rowsum, *clsA, *clsB, *order, *scan_tmp;
+  uint32_t *offsets, *entries, *sums, *colsum, *rowsum, *clsA, *clsB, *scan_tmp, *ntask, *task_off, *partial;
+  uint2* order; size_t max_tasks;
 };
 MsmWs carve(const MsmPlan& P, void* workspace) {
   const size_t B = P.nbuckets;
@@ -320,8 +376,13 @@ MsmWs carve(const MsmPlan& P, void* workspace) {
   w.rowsum = (uint32_t*)ws; ws += 1024 * XYW * 4;
   w.clsA = (uint32_t*)ws; ws += 32 * XYW * 4;
   w.clsB = (uint32_t*)ws; ws += 32 * XYW * 4;
-  w.order = (uint32_t*)ws; ws += B * 4;
   w.scan_tmp = (uint32_t*)ws; ws += 1024 * 4;
+  w.ntask = (uint32_t*)ws; ws += (B + 1) * 4;
+  w.task_off = (uint32_t*)ws; ws += (B + 1) * 4;
+  w.max_tasks = B + (size_t)P.nwin * P.n / CHUNK + 1;
+  ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  w.order = (uint2*)ws; ws += w.max_tasks * 8;
+  w.partial = (uint32_t*)ws; ws += w.max_tasks * XYW * 4;
   return w;
 }
 }  // namespace
@@ -340,17 +401,18 @@ hipError_t launch_g1_msm_sort(const MsmPlan& P, const uint8_t* inf, const uint32
   } else {
     if ((e = hipMemsetAsync(w.offsets, 0, (B + 1) * 4, s)) != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_size_hist, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, w.size_hist);
+  hipLaunchKernelGGL(k_task_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, w.ntask, w.size_hist);
+  launch_scan(w.ntask, w.task_off, B, w.scan_tmp, s);
   launch_scan(w.size_hist, w.size_off, SIZE_BINS, w.scan_tmp, s);
-  hipLaunchKernelGGL(k_size_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, (const uint32_t*)w.size_off, w.size_cur, w.order);
+  hipLaunchKernelGGL(k_task_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, (const uint32_t*)w.size_off, w.size_cur, w.order);
   return hipGetLastError();
 }
 // stage 2 (VALU bound, the dominant kernel): one bucket per lane
 hipError_t launch_g1_msm_accumulate(const MsmPlan& P, const uint32_t* table, void* workspace, hipStream_t s) {
   MsmWs w = carve(P, workspace);
   static const int acc_lds = getenv("ZKT_ACC_LDS") ? atoi(getenv("ZKT_ACC_LDS")) : 0;   // experiment: cap occupancy through dynamic LDS
-  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((P.nbuckets + 63) / 64)), dim3(64), acc_lds, s, table, (const uint32_t*)w.entries,
-                     (const uint32_t*)w.offsets, (const uint32_t*)w.order, P.nbuckets, w.sums);
+  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((w.max_tasks + 63) / 64)), dim3(64), acc_lds, s, table, (const uint32_t*)w.entries,
+                     (const uint32_t*)w.offsets, (const uint2*)w.order, (const uint32_t*)w.task_off, P.nbuckets, w.sums, w.partial);
   return hipGetLastError();
 }
 // stage 3 (latency bound): sum_b (b+1) S_b, b = hi*NLO + lo  ->  Jacobian partial (+ affine point if out_abi)
@@ -361,6 +423,7 @@ hipError_t launch_g1_msm_reduce(const MsmPlan& P, void* workspace, uint32_t* dev
   int lo_bits = 0; while ((size_t(1) << lo_bits) < NLO) ++lo_bits;
   int hi_bits = 0; while ((size_t(1) << hi_bits) < NHI) ++hi_bits;
   const int nbA = lo_bits + 1, nbB = NHI > 1 ? hi_bits : 0;     // weights lo+1 in [1,NLO]; hi in [0,NHI)
+  hipLaunchKernelGGL(k_merge_partials, dim3((unsigned)(B < 2048 ? B : 2048)), dim3(RED_TPB), 0, s, (const uint32_t*)w.task_off, B, (const uint32_t*)w.partial, w.sums);
   hipLaunchKernelGGL(k_marginals, dim3((unsigned)(NLO + (NHI > 1 ? NHI : 0))), dim3(RED_TPB), 0, s, (const uint32_t*)w.sums, NLO, NHI, w.colsum, w.rowsum);
   hipLaunchKernelGGL(k_weight_bits, dim3((unsigned)(nbA + nbB)), dim3(RED_TPB), 0, s, (const uint32_t*)w.colsum, NLO, nbA, (const uint32_t*)w.rowsum, NHI, w.clsA, w.clsB);
   hipLaunchKernelGGL(k_combine, dim3(1), dim3(64), 0, s, (const uint32_t*)w.clsA, nbA, (const uint32_t*)w.clsB, nbB, lo_bits, dev_result_jac, dev_out_abi);
