@@ -98,7 +98,7 @@ def main():
     out = np.zeros((1, 13), dtype=np.uint64)
     outp = out.ctypes.data_as(ctypes.c_void_p)
 
-    DEPTH = int(os.environ.get("ZKT_BENCH_DEPTH", "3"))   # MSMs in flight: sort / accumulate / reduce-tail of consecutive MSMs overlap
+    DEPTH = int(os.environ.get("ZKT_BENCH_DEPTH", "5"))   # MSMs in flight: sort / accumulate / reduce-tail of consecutive MSMs overlap
     NSLOT = 8          # ZKT_MSM_SLOTS
 
     def finish(slot):
