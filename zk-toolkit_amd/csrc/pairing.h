@@ -31,44 +31,58 @@ ZKT_HD Fq2 xi_inv_const() {
   return g;
 }
 
+// One Miller step on the G1 side as its own function: its Fq temporaries live in a transient frame instead of the
+// Miller loop's, which must stay small (<4 KB per lane keeps the whole grid's Fq12 working set inside the 256 MB MALL).
+struct MillerLine { Fq a; Fq2 b, c; };     // a + b v^2 + c v w
+struct MillerPt { Fq X, Y, Z; };
+// tangent at V scaled by 2YZ^3: (3X^3 - 2Y^2) - 3X^2 Z^2 * X' + Z3 Z^2 * Y';  V <- 2V
+ZKT_FN void miller_dbl_step(MillerPt& V, const Fq2& Xq, const Fq2& Yq, MillerLine& l) {
+  const Fq X = V.X, Y = V.Y, Z = V.Z;
+  Fq A = fp_sqr(X), B = fp_sqr(Y), C = fp_sqr(B), ZZ = fp_sqr(Z);
+  Fq t = fp_sqr(fp_add(X, B));
+  Fq D = fp_dbl(fp_sub(fp_sub(t, A), C));
+  Fq E = fp_add(fp_dbl(A), A);
+  Fq X3 = fp_sub(fp_sqr(E), fp_dbl(D));
+  Fq Y3 = fp_sub(fp_mul(E, fp_sub(D, X3)), fp_dbl(fp_dbl(fp_dbl(C))));
+  Fq Z3 = fp_dbl(fp_mul(Y, Z));
+  l.a = fp_sub(fp_mul(E, X), fp_dbl(B));
+  l.b = fq2_mul_fq(Xq, fp_neg(fp_mul(E, ZZ)));
+  l.c = fq2_mul_fq(Yq, fp_mul(Z3, ZZ));
+  V.X = X3; V.Y = Y3; V.Z = Z3;
+}
+// chord through V and P scaled by Z*H: (R xp - Z3 yp) - R X' + Z3 Y';  V <- V + P
+ZKT_FN void miller_add_step(MillerPt& V, const Fq& xp, const Fq& yp, const Fq2& Xq, const Fq2& Yq, MillerLine& l) {
+  const Fq X = V.X, Y = V.Y, Z = V.Z;
+  Fq ZZ = fp_sqr(Z), H = fp_sub(fp_mul(xp, ZZ), X), Rr = fp_sub(fp_mul(fp_mul(yp, ZZ), Z), Y);
+  Fq HH = fp_sqr(H), HHH = fp_mul(H, HH), Vv = fp_mul(X, HH);
+  Fq X3 = fp_sub(fp_sub(fp_sqr(Rr), HHH), fp_dbl(Vv));
+  Fq Y3 = fp_sub(fp_mul(Rr, fp_sub(Vv, X3)), fp_mul(Y, HHH));
+  Fq Z3 = fp_mul(Z, H);
+  l.a = fp_sub(fp_mul(Rr, xp), fp_mul(Z3, yp));
+  l.b = fq2_mul_fq(Xq, fp_neg(Rr));
+  l.c = fq2_mul_fq(Yq, Z3);
+  V.X = X3; V.Y = Y3; V.Z = Z3;
+}
+
 // f_{r-1,P}(untwist(Q)) up to Fq6 factors.  P, Q affine, Montgomery domain, neither at infinity.
 ZKT_FN Fq12 miller_g1_g2(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq) {
   const Fq2 xi_inv = xi_inv_const();
   const Fq2 Xq = fq2_mul(xq, xi_inv), Yq = fq2_mul(yq, xi_inv);
-  Fq X = xp, Y = yp, Z = fp_one<FqC>();
-  Fq12 f = fq12_one();
+  MillerPt V{xp, yp, fp_one<FqC>()};
+  MillerLine l;
+  Fq12 f = fq12_one(), ft;          // ping-pong f <-> ft: a destination never aliases a source
   for (int i = 0; i < MILLER_NBITS; ++i) {
     uint32_t w = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) w = (j == (i >> 5)) ? miller_bits_word(j) : w;
     const bool bit = (w >> (i & 31)) & 1;          // wave-uniform (compile-time table)
-    {
-      // tangent at V scaled by 2YZ^3: (3X^3 - 2Y^2) - 3X^2 Z^2 * X' + Z3 Z^2 * Y'
-      Fq A = fp_sqr(X), B = fp_sqr(Y), C = fp_sqr(B), ZZ = fp_sqr(Z);
-      Fq t = fp_sqr(fp_add(X, B));
-      Fq D = fp_dbl(fp_sub(fp_sub(t, A), C));
-      Fq E = fp_add(fp_dbl(A), A);
-      Fq X3 = fp_sub(fp_sqr(E), fp_dbl(D));
-      Fq Y3 = fp_sub(fp_mul(E, fp_sub(D, X3)), fp_dbl(fp_dbl(fp_dbl(C))));
-      Fq Z3 = fp_dbl(fp_mul(Y, Z));
-      Fq a = fp_sub(fp_mul(E, X), fp_dbl(B));
-      Fq2 b = fq2_mul_fq(Xq, fp_neg(fp_mul(E, ZZ)));
-      Fq2 c = fq2_mul_fq(Yq, fp_mul(Z3, ZZ));
-      f = fq12_mul_line(fq12_sqr(f), a, b, c);
-      X = X3; Y = Y3; Z = Z3;
-    }
+    miller_dbl_step(V, Xq, Yq, l);
+    ft = fq12_sqr(f);
+    f = fq12_mul_line(ft, l.a, l.b, l.c);
     if (bit) {
-      // chord through V and P scaled by Z*H: (R xp - Z3 yp) - R X' + Z3 Y'
-      Fq ZZ = fp_sqr(Z), H = fp_sub(fp_mul(xp, ZZ), X), Rr = fp_sub(fp_mul(fp_mul(yp, ZZ), Z), Y);
-      Fq HH = fp_sqr(H), HHH = fp_mul(H, HH), V = fp_mul(X, HH);
-      Fq X3 = fp_sub(fp_sub(fp_sqr(Rr), HHH), fp_dbl(V));
-      Fq Y3 = fp_sub(fp_mul(Rr, fp_sub(V, X3)), fp_mul(Y, HHH));
-      Fq Z3 = fp_mul(Z, H);
-      Fq a = fp_sub(fp_mul(Rr, xp), fp_mul(Z3, yp));
-      Fq2 b = fq2_mul_fq(Xq, fp_neg(Rr));
-      Fq2 c = fq2_mul_fq(Yq, Z3);
-      f = fq12_mul_line(f, a, b, c);
-      X = X3; Y = Y3; Z = Z3;
+      miller_add_step(V, xp, yp, Xq, Yq, l);
+      ft = fq12_mul_line(f, l.a, l.b, l.c);
+      f = ft;
     }
   }
   return f;
@@ -86,19 +100,30 @@ ZKT_FN Fq12 fq12_pow_xabs(const Fq12& a) {
 // a^x for x = -|x|, a in the cyclotomic subgroup (inverse = conjugate)
 ZKT_HD Fq12 fq12_pow_x(const Fq12& a) { return fq12_conj(fq12_pow_xabs(a)); }
 
-// f^((q^12-1)/r), exact.
+// f^((q^12-1)/r), exact.  Four named Fq12 buffers (g, a, b, t) are reused; a destination never aliases a source.
 ZKT_FN Fq12 final_exponentiation(const Fq12& f) {
-  Fq12 g = fq12_mul(fq12_conj(f), fq12_inv(f));          // ^(q^6-1)
-  g = fq12_mul(fq12_frob<2>(g), g);                      // ^(q^2+1)
   uint32_t e1[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) e1[i] = e1_limb(i);
-  Fq12 a = fq12_pow(g, e1, 4);                           // ^e1
-  Fq12 b = fq12_mul(fq12_pow_x(a), fq12_frob<1>(a));     // ^(x+q)
-  Fq12 c = fq12_mul(fq12_mul(fq12_pow_x(fq12_pow_x(b)), fq12_frob<2>(b)), fq12_conj(b));   // ^(x^2+q^2-1)
-  return fq12_mul(c, g);
+  Fq12 g, a, b, t;
+  t = fq12_inv(f);
+  a = fq12_conj(f);
+  g = fq12_mul(a, t);                      // ^(q^6-1)
+  t = fq12_frob<2>(g);
+  a = fq12_mul(t, g);                      // ^(q^2+1): easy part, now in a
+  g = a;
+  a = fq12_pow(g, e1, 4);                  // ^e1
+  t = fq12_pow_xabs(a); t = fq12_conj(t);  // a^x (x < 0: conjugate = inverse in the cyclotomic subgroup)
+  b = fq12_frob<1>(a);
+  a = fq12_mul(t, b);                      // a := ^(x+q)
+  t = fq12_pow_xabs(a); t = fq12_conj(t);
+  b = fq12_pow_xabs(t); b = fq12_conj(b);  // b = a^(x^2)
+  t = fq12_frob<2>(a);
+  b = fq12_mul(b, t) ;                     // (aliasing a source here costs one temporary; kept for clarity)
+  t = fq12_conj(a);
+  a = fq12_mul(b, t);                      // ^(x^2+q^2-1)
+  return fq12_mul(a, g);
 }
-
 
 // ---- raw Miller values and the Weil pairing, bit-exact (row a14) ------------------------------------
 //   calc_g1_g2 / calc_g2_g1   pairing.rs:20-55      weil   pairing.rs:75-84
