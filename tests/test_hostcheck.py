@@ -141,3 +141,17 @@ def test_exact_miller_and_weil_vs_oracle(H):         # pairing.rs:54-55,75-84 ra
         got = np.zeros((1, 72), dtype=np.uint64)
         assert H.zkt_hostcheck_miller_exact(which, p32(p), p32(q), p32(got)) == 0
         assert (got[0] == want[0]).all(), which
+
+
+def test_cyclotomic_square_matches_generic_square(H):
+    """Granger-Scott squaring == plain squaring on elements of the cyclotomic subgroup (a^((q^6-1)(q^2+1)))."""
+    rng = SplitMix64(61)
+    u32 = lambda v: np.array([(v >> (32 * i)) & 0xFFFFFFFF for i in range((v.bit_length() + 31) // 32)], dtype=np.uint32)
+    e = u32((Q**6 - 1) * (Q**2 + 1))
+    for _ in range(2):
+        a = _rand_tower(rng, 72); c = np.zeros((1, 72), dtype=np.uint64)
+        assert O.zkto_fq12_pow(ptr(a), p32(e), len(e), ptr(c)) == 0
+        want = np.zeros((1, 72), dtype=np.uint64); got = np.zeros((1, 72), dtype=np.uint64)
+        assert O.zkto_fq12_op(2, ptr(c), ptr(c), ptr(want), 1) == 0
+        assert H.zkt_hostcheck_tower(12, 10, p32(c), None, p32(got)) == 0
+        assert (want == got).all()

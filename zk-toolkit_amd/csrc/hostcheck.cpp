@@ -39,7 +39,7 @@ int zkt_hostcheck_tower(int deg, int op, const uint32_t* a, const uint32_t* b, u
     Fq12 x = ld_fq12(a), y = b ? ld_fq12(b) : fq12_one(), r;
     switch (op) { case 0: r = fq12_add(x, y); break; case 1: r = fq12_sub(x, y); break; case 2: r = fq12_mul(x, y); break;
       case 3: r = fq12_inv(x); break; case 4: r = fq12_neg(x); break; case 6: r = fq12_sqr(x); break;
-      case 7: r = fq12_frob<1>(x); break; case 8: r = fq12_frob<2>(x); break; default: r = fq12_conj(x); }
+      case 7: r = fq12_frob<1>(x); break; case 8: r = fq12_frob<2>(x); break; case 10: r = fq12_cyclotomic_sqr(x); break; default: r = fq12_conj(x); }
     st_fq12(o, r);
   }
   return 0;

@@ -89,11 +89,12 @@ ZKT_FN Fq12 miller_g1_g2(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& y
 }
 
 // a^|x| , |x| = 0xd201000000010000 (bits 63,62,60,57,48,16)
+// (a in the cyclotomic subgroup: Granger-Scott squarings)
 ZKT_FN Fq12 fq12_pow_xabs(const Fq12& a) {
-  Fq12 r = a;
+  Fq12 r = a, t;
   for (int i = 62; i >= 0; --i) {
-    r = fq12_sqr(r);
-    if ((BLS_X_ABS >> i) & 1) r = fq12_mul(r, a);
+    t = fq12_cyclotomic_sqr(r); r = t;
+    if ((BLS_X_ABS >> i) & 1) { t = fq12_mul(r, a); r = t; }
   }
   return r;
 }
@@ -112,7 +113,7 @@ ZKT_FN Fq12 final_exponentiation(const Fq12& f) {
   t = fq12_frob<2>(g);
   a = fq12_mul(t, g);                      // ^(q^2+1): easy part, now in a
   g = a;
-  a = fq12_pow(g, e1, 4);                  // ^e1
+  a = fq12_cyclotomic_pow(g, e1, 4);       // ^e1
   t = fq12_pow_xabs(a); t = fq12_conj(t);  // a^x (x < 0: conjugate = inverse in the cyclotomic subgroup)
   b = fq12_frob<1>(a);
   a = fq12_mul(t, b);                      // a := ^(x+q)

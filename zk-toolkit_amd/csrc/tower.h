@@ -99,6 +99,30 @@ ZKT_FN Fq12 fq12_inv(const Fq12& a) {                                    // fq12
   return Fq12{fq6_mul(a.c0, t), fq6_neg(fq6_mul(a.c1, t))};
 }
 
+// Squaring in the cyclotomic subgroup G_{phi6}(q^2) (Granger-Scott): valid after the easy part of the final
+// exponentiation, where a^(q^6+1) = 1.  Three Fq4 squarings = 9 Fq2 squarings instead of the 12 Fq2 products of the
+// complex squaring; the result is the same field element as fq12_sqr on such inputs (tests/test_hostcheck.py).
+ZKT_HD void fq4_sqr(const Fq2& a, const Fq2& b, Fq2& c0, Fq2& c1) {
+  Fq2 t0 = fq2_sqr(a), t1 = fq2_sqr(b);
+  c0 = fq2_add(fq2_mul_xi(t1), t0);
+  c1 = fq2_sub(fq2_sub(fq2_sqr(fq2_add(a, b)), t0), t1);
+}
+ZKT_FN Fq12 fq12_cyclotomic_sqr(const Fq12& f) {
+  Fq2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
+  Fq2 t0, t1, t2, t3;
+  auto three_minus_two = [](const Fq2& t, const Fq2& z) { Fq2 d = fq2_sub(t, z); return fq2_add(fq2_dbl(d), t); };   // 3t - 2z
+  auto three_plus_two = [](const Fq2& t, const Fq2& z) { Fq2 d = fq2_add(t, z); return fq2_add(fq2_dbl(d), t); };     // 3t + 2z
+  fq4_sqr(z0, z1, t0, t1);
+  z0 = three_minus_two(t0, z0); z1 = three_plus_two(t1, z1);
+  fq4_sqr(z2, z3, t0, t1);
+  fq4_sqr(z4, z5, t2, t3);
+  z4 = three_minus_two(t0, z4); z5 = three_plus_two(t1, z5);
+  t0 = fq2_mul_xi(t3);
+  z2 = three_plus_two(t0, z2); z3 = three_minus_two(t2, z3);
+  Fq12 r; r.c0 = Fq6{z0, z4, z3}; r.c1 = Fq6{z2, z1, z5};
+  return r;
+}
+
 // Frobenius pi^K, K in {1,2}: conj^K on every Fq2 coefficient of w^i times gamma_i^(K)
 template <int K> ZKT_HD Fq2 frob_const(int idx) {
   Fq2 g;
@@ -148,6 +172,16 @@ ZKT_FN Fq12 fq12_pow(const Fq12& a, const uint32_t* e, int nlimbs) {
   for (int i = nlimbs * 32 - 1; i >= 0; --i) {
     if (started) r = fq12_sqr(r);
     if ((e[i >> 5] >> (i & 31)) & 1) { r = started ? fq12_mul(r, a) : a; started = true; }
+  }
+  return r;
+}
+
+// same, for elements of the cyclotomic subgroup (final exponentiation hard part)
+ZKT_FN Fq12 fq12_cyclotomic_pow(const Fq12& a, const uint32_t* e, int nlimbs) {
+  Fq12 r = fq12_one(), t; bool started = false;
+  for (int i = nlimbs * 32 - 1; i >= 0; --i) {
+    if (started) { t = fq12_cyclotomic_sqr(r); r = t; }
+    if ((e[i >> 5] >> (i & 31)) & 1) { if (started) { t = fq12_mul(r, a); r = t; } else { r = a; started = true; } }
   }
   return r;
 }
