@@ -61,13 +61,21 @@ ZKT_HD Fq6 fq6_sub(const Fq6& a, const Fq6& b) { return Fq6{fq2_sub(a.c0, b.c0),
 ZKT_HD Fq6 fq6_neg(const Fq6& a) { return Fq6{fq2_neg(a.c0), fq2_neg(a.c1), fq2_neg(a.c2)}; }
 ZKT_HD Fq6 fq6_mul_v(const Fq6& a) { return Fq6{fq2_mul_xi(a.c2), a.c0, a.c1}; }                 // Fq6::reduce, fq6.rs:54-62
 // fq6.rs:148-166 is the 9-product schoolbook; Karatsuba (6 products) gives the same element
-ZKT_FN Fq6 fq6_mul(const Fq6& a, const Fq6& b) {
+ZKT_HD Fq6 fq6_mul_inl(const Fq6& a, const Fq6& b) {
   Fq2 v0 = fq2_mul(a.c0, b.c0), v1 = fq2_mul(a.c1, b.c1), v2 = fq2_mul(a.c2, b.c2);
   Fq2 t0 = fq2_sub(fq2_sub(fq2_mul(fq2_add(a.c1, a.c2), fq2_add(b.c1, b.c2)), v1), v2);
   Fq2 t1 = fq2_sub(fq2_sub(fq2_mul(fq2_add(a.c0, a.c1), fq2_add(b.c0, b.c1)), v0), v1);
   Fq2 t2 = fq2_sub(fq2_sub(fq2_mul(fq2_add(a.c0, a.c2), fq2_add(b.c0, b.c2)), v0), v2);
   return Fq6{fq2_add(v0, fq2_mul_xi(t0)), fq2_add(t1, fq2_mul_xi(v2)), fq2_add(t2, v1)};
 }
+ZKT_FN Fq6 fq6_mul(const Fq6& a, const Fq6& b) { return fq6_mul_inl(a, b); }
+// inside the Fq12 square/product the Fq6 products are inlined (ZKT_FQ6_INLINE): operands and partial results stay in the
+// 512-entry register file instead of round-tripping through scratch between calls
+#ifdef ZKT_FQ6_CALLS
+#define FQ6_MUL12 fq6_mul
+#else
+#define FQ6_MUL12 fq6_mul_inl
+#endif
 ZKT_FN Fq6 fq6_inv(const Fq6& a) {                                      // fq6.rs:23-37
   Fq2 t0 = fq2_sub(fq2_sqr(a.c0), fq2_mul_xi(fq2_mul(a.c1, a.c2)));
   Fq2 t1 = fq2_sub(fq2_mul_xi(fq2_sqr(a.c2)), fq2_mul(a.c0, a.c1));
@@ -84,14 +92,14 @@ ZKT_HD Fq12 fq12_neg(const Fq12& a) { return Fq12{fq6_neg(a.c0), fq6_neg(a.c1)};
 ZKT_HD Fq12 fq12_conj(const Fq12& a) { return Fq12{a.c0, fq6_neg(a.c1)}; }
 // fq12.rs:135-147 is 4 Fq6 products; Karatsuba (3) gives the same element
 ZKT_FN Fq12 fq12_mul(const Fq12& a, const Fq12& b) {
-  Fq6 v0 = fq6_mul(a.c0, b.c0), v1 = fq6_mul(a.c1, b.c1);
-  Fq6 s = fq6_mul(fq6_add(a.c0, a.c1), fq6_add(b.c0, b.c1));
+  Fq6 v0 = FQ6_MUL12(a.c0, b.c0), v1 = FQ6_MUL12(a.c1, b.c1);
+  Fq6 s = FQ6_MUL12(fq6_add(a.c0, a.c1), fq6_add(b.c0, b.c1));
   return Fq12{fq6_add(v0, fq6_mul_v(v1)), fq6_sub(fq6_sub(s, v0), v1)};
 }
 // complex squaring: (a0 + a1 w)^2 = (a0+a1)(a0+v a1) - v0 - v v0 + 2 v0 w,  v0 = a0 a1
 ZKT_FN Fq12 fq12_sqr(const Fq12& a) {
-  Fq6 v0 = fq6_mul(a.c0, a.c1);
-  Fq6 t = fq6_mul(fq6_add(a.c0, a.c1), fq6_add(a.c0, fq6_mul_v(a.c1)));
+  Fq6 v0 = FQ6_MUL12(a.c0, a.c1);
+  Fq6 t = FQ6_MUL12(fq6_add(a.c0, a.c1), fq6_add(a.c0, fq6_mul_v(a.c1)));
   return Fq12{fq6_sub(fq6_sub(t, v0), fq6_mul_v(v0)), fq6_add(v0, v0)};
 }
 ZKT_FN Fq12 fq12_inv(const Fq12& a) {                                    // fq12.rs:31-40
