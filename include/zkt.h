@@ -137,6 +137,10 @@ int zkt_groth16_setup(zkt_groth16_crs* crs, const uint64_t* ui, const uint64_t* 
 int zkt_groth16_prove(const zkt_groth16_crs* crs, const uint64_t* ui, const uint64_t* vi, const uint64_t* wires,
                       const uint64_t* h, size_t h_len, const uint64_t* r, const uint64_t* s,
                       zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* C);
+/* f-2: many proofs against one CRS, one proof per lane; the three pairings of a proof share one Miller squaring chain and
+ * one final exponentiation (the decision is a bool, so this is parity-safe).  stmt_wires: n_proofs x n_stmt.  ok[i] = 1/0. */
+int zkt_groth16_verify_batch(const zkt_groth16_crs* crs, const zkt_g1_affine* A, const zkt_g2_affine* B, const zkt_g1_affine* C,
+                             const uint64_t* stmt_wires, size_t n_stmt, size_t n_proofs, uint32_t* ok);
 /* returns 1 accept, 0 reject, negative = -status (a pairing argument at infinity panics in the reference) */
 int zkt_groth16_verify(const zkt_groth16_crs* crs, const zkt_g1_affine* A, const zkt_g2_affine* B, const zkt_g1_affine* C,
                        const uint64_t* stmt_wires, size_t n_stmt);

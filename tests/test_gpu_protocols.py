@@ -138,3 +138,27 @@ def test_range_proof_vs_oracle(L, n, value):          # bulletproofs.rs:58-147 /
         assert (gp == op).all()                       # A, S, T1, T2, P identical
         bad = aL.copy(); bad[1, 0] ^= 1
         assert L.zkt_bp_range_proof(n, ptr(V), ptr(bad), ptr(gamma), ptr(g), ptr(h), ptr(gg), ptr(hh), use_ipa, ptr(rnd), ptr(u), ptr(xs), None) == 0
+
+
+def test_groth16_verify_batch_mixed(L):              # f-2: fused 3-pairing verification, many proofs per launch
+    A_, B_, C_, wit, l = example_cubic()
+    n, m = len(A_), len(wit) - 1
+    ui, vi, wi, h, _ = qap_from_r1cs(A_, B_, C_, wit)
+    U, V, W = dense(ui, n), dense(vi, n), dense(wi, n)
+    rng = SplitMix64(71); trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+    crs, buf = alloc_crs(n, l, m)
+    zk.check(L.zkt_groth16_setup(ctypes.byref(crs), ptr(U), ptr(V), ptr(W), *[ptr(t) for t in trap]))
+    wires = ints_to_arr(wit, 4); H = ints_to_arr(h, 4)
+    k = 6
+    As, Bs, Cs = np.zeros((k, G1W), np.uint64), np.zeros((k, G2W), np.uint64), np.zeros((k, G1W), np.uint64)
+    for i in range(k):                                  # k proofs of the same statement with different prover randomness
+        r, s = fr(rng.below(R - 1) + 1), fr(rng.below(R - 1) + 1)
+        zk.check(L.zkt_groth16_prove(ctypes.byref(crs), ptr(U), ptr(V), ptr(wires), ptr(H), len(h), ptr(r), ptr(s), ptr(As[i:i + 1]), ptr(Bs[i:i + 1]), ptr(Cs[i:i + 1])))
+    stmts = np.repeat(ints_to_arr(wit[:l + 1], 4).reshape(1, -1), k, axis=0).copy()
+    stmts[2].reshape(l + 1, 4)[l, 0] ^= 1              # proof 2: wrong statement
+    Cs[4, :12] = As[4, :12]                            # proof 4: tampered C
+    ok = np.zeros(k, np.uint32)
+    zk.check(L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(stmts), l + 1, k, ok.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+    assert ok.tolist() == [1, 1, 0, 1, 0, 1]
+    for i in range(k):                                  # the oracle's verifier (three separate tate calls) agrees
+        assert O.zkto_groth16_verify(ctypes.byref(crs), ptr(As[i:i + 1].copy()), ptr(Bs[i:i + 1].copy()), ptr(Cs[i:i + 1].copy()), ptr(stmts[i:i + 1].copy()), l + 1) == int(ok[i])

@@ -46,6 +46,10 @@ def lib():
         L.zkt_g1_bases_len.restype = ctypes.c_size_t
         L.zkt_g1_msm_workspace_bytes.restype = ctypes.c_size_t
         L.zkt_g1_msm_workspace_bytes.argtypes = [ctypes.c_size_t]
+        # size_t arguments beyond the sixth travel on the stack: declare them, or ctypes pushes a 32-bit int with garbage above it
+        vp = ctypes.c_void_p
+        L.zkt_groth16_verify_batch.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, ctypes.c_size_t, vp]
+        L.zkt_groth16_prove.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 

@@ -88,6 +88,35 @@ ZKT_FN Fq12 miller_g1_g2(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& y
   return f;
 }
 
+// prod_k f_{r-1,P_k}(untwist(Q_k)) for K pairs sharing ONE squaring chain (row f-2: the Groth16 verifier's three pairings,
+// verifier.rs:30-54, as a single multi-Miller loop + a single final exponentiation).
+template <int K>
+ZKT_FN Fq12 miller_g1_g2_multi(const Fq* xp, const Fq* yp, const Fq2* xq, const Fq2* yq) {
+  const Fq2 xi_inv = xi_inv_const();
+  Fq2 Xq[K], Yq[K]; MillerPt V[K];
+  for (int k = 0; k < K; ++k) { Xq[k] = fq2_mul(xq[k], xi_inv); Yq[k] = fq2_mul(yq[k], xi_inv); V[k] = MillerPt{xp[k], yp[k], fp_one<FqC>()}; }
+  MillerLine l;
+  Fq12 f = fq12_one(), ft;
+  for (int i = 0; i < MILLER_NBITS; ++i) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w = (j == (i >> 5)) ? miller_bits_word(j) : w;
+    const bool bit = (w >> (i & 31)) & 1;
+    ft = fq12_sqr(f); f = ft;
+    for (int k = 0; k < K; ++k) {
+      miller_dbl_step(V[k], Xq[k], Yq[k], l);
+      ft = fq12_mul_line(f, l.a, l.b, l.c); f = ft;
+    }
+    if (bit) {
+      for (int k = 0; k < K; ++k) {
+        miller_add_step(V[k], xp[k], yp[k], Xq[k], Yq[k], l);
+        ft = fq12_mul_line(f, l.a, l.b, l.c); f = ft;
+      }
+    }
+  }
+  return f;
+}
+
 // a^|x| , |x| = 0xd201000000010000 (bits 63,62,60,57,48,16)
 // (a in the cyclotomic subgroup: Granger-Scott squarings)
 ZKT_FN Fq12 fq12_pow_xabs(const Fq12& a) {

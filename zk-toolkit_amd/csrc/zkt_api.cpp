@@ -145,6 +145,7 @@ static int slot_ready(zkt_g1_bases* h, int k) {   // lazily create the slot's wo
 }
 
 int zkt_internal_ready() { return ensure_ready(); }
+void zkt_internal_set_error_index(size_t i) { t_err_index = i; }
 
 extern "C" {
 

@@ -40,6 +40,40 @@ hipError_t launch_miller_exact(int which, const uint32_t* g1, const uint32_t* g2
   return hipGetLastError();
 }
 
+// Groth16 verification, one proof per lane (verifier.rs:30-54 / SURVEY §8 f-2):
+//   e(A,B) == alpha_beta * e(S,gamma) * e(C,delta)   <=>   tate-product(A,B; -S,gamma; -C,delta) == alpha_beta
+// (e(-P,Q) = e(P,Q)^-1 exactly).  S_i = sum_j stmt[i][j] * uvw_stmt[j] is formed here too.  ok[i] = 1 / 0.
+__global__ void __launch_bounds__(64) k_groth16_verify(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, const uint32_t* __restrict__ C,
+                                                       const uint32_t* __restrict__ uvw_stmt, const uint32_t* __restrict__ stmt, int n_stmt,
+                                                       const uint32_t* __restrict__ gamma, const uint32_t* __restrict__ delta,
+                                                       const uint32_t* __restrict__ alpha_beta, uint32_t* __restrict__ ok, size_t n, unsigned long long* err) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Jac<FqOps> acc = jac_inf<FqOps>();
+  for (int j = 0; j < n_stmt; ++j) {                                   // verifier.rs:41-45
+    Aff<FqOps> u = PtIO<FqOps>::ld(uvw_stmt + (size_t)j * ABI_G1_WORDS);
+    acc = jac_add(acc, scalar_mul_aff<FqOps>(u, stmt + ((size_t)i * n_stmt + j) * 8, 8));
+  }
+  Aff<FqOps> S = jac_to_aff(acc);
+  Aff<FqOps> a = PtIO<FqOps>::ld(A + i * ABI_G1_WORDS), c = PtIO<FqOps>::ld(C + i * ABI_G1_WORDS);
+  Aff<Fq2Ops> b = PtIO<Fq2Ops>::ld(B + i * ABI_G2_WORDS), g = PtIO<Fq2Ops>::ld(gamma), d = PtIO<Fq2Ops>::ld(delta);
+  if (a.inf || b.inf || c.inf || S.inf || g.inf || d.inf) { atomicMin(err, (unsigned long long)i); ok[i] = 0; return; }   // tate() with infinity panics
+  Fq xp[3] = {a.x, S.x, c.x}, yp[3] = {a.y, fp_neg(S.y), fp_neg(c.y)};
+  Fq2 xq[3] = {b.x, g.x, d.x}, yq[3] = {b.y, g.y, d.y};
+  Fq12 e = final_exponentiation(miller_g1_g2_multi<3>(xp, yp, xq, yq));
+  uint32_t got[144]; st_fq12(got, e);
+  uint32_t diff = 0;
+  for (int k = 0; k < 144; ++k) diff |= got[k] ^ alpha_beta[k];
+  ok[i] = diff == 0;
+}
+hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
+                                 const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* ok, size_t n,
+                                 unsigned long long* err, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_groth16_verify, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err);
+  return hipGetLastError();
+}
+
 hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_tate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);

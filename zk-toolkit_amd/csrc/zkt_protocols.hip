@@ -6,6 +6,7 @@
 // kernels of zkt_group.hip / zkt_msm.hip / zkt_pairing.hip.  Host code only moves buffers and sequences launches.
 #include <vector>
 #include <cstring>
+#include <cstdio>
 #include "abi.h"
 #include "zkt_internal.h"
 #include "../../include/zkt.h"
@@ -122,7 +123,7 @@ struct Dev {   // tiny RAII device buffer
   uint32_t* w() const { return (uint32_t*)p; }
   Dev(const Dev&) = delete; Dev& operator=(const Dev&) = delete;
 };
-#define PCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return ZKT_ERR_DEVICE; } while (0)
+#define PCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[zkt] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return ZKT_ERR_DEVICE; } } while (0)
 int up(Dev& d, const void* h, size_t bytes, hipStream_t s) { if (!d.p) return ZKT_ERR_DEVICE; if (bytes) PCHK(hipMemcpyAsync(d.p, h, bytes, hipMemcpyHostToDevice, s)); return ZKT_OK; }
 int down(void* h, const void* d, size_t bytes, hipStream_t s) { PCHK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s)); return ZKT_OK; }
 const size_t G1B = sizeof(zkt_g1_affine), G2B = sizeof(zkt_g2_affine), SPB = sizeof(zkt_secp_affine), FRB = 32;
@@ -135,6 +136,7 @@ const uint64_t G2_GEN[25] = {0xe5ac7d055d042b7eull, 0x334cf11213945d57ull, 0xb5d
 }  // namespace
 
 extern int zkt_internal_ready();   // zkt_api.cpp
+extern void zkt_internal_set_error_index(size_t i);
 
 extern "C" {
 
@@ -238,18 +240,37 @@ int zkt_groth16_prove(const zkt_groth16_crs* c, const uint64_t* ui, const uint64
   return ZKT_OK;
 }
 
-// Verifier::verify (verifier.rs:30-54): 1 = accept, 0 = reject, negative = -status (pairing with infinity panics in the reference)
+// Verifier::verify (verifier.rs:30-54) for a batch of proofs against one CRS, one proof per lane: the three pairings of a
+// proof share one Miller squaring chain and one final exponentiation.  stmt_wires: n_proofs x n_stmt Fr.
+// ok[i] = 1 accept / 0 reject.  Returns ZKT_OK, or ZKT_ERR_INFINITY (+index) if some pairing argument is the point at infinity.
+int zkt_groth16_verify_batch(const zkt_groth16_crs* c, const zkt_g1_affine* A, const zkt_g2_affine* B, const zkt_g1_affine* C,
+                             const uint64_t* stmt_wires, size_t n_stmt, size_t n_proofs, uint32_t* ok) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!c || !A || !B || !C || !ok || (n_stmt && !stmt_wires) || n_stmt > c->l + 1) return ZKT_ERR_SHAPE;
+  if (n_proofs == 0) return ZKT_OK;
+  hipStream_t s = nullptr;
+  Dev dA(n_proofs * G1B), dB(n_proofs * G2B), dC(n_proofs * G1B), dU((n_stmt ? n_stmt : 1) * G1B), dW((n_proofs * n_stmt ? n_proofs * n_stmt : 1) * FRB),
+      dg(G2B), dd(G2B), dab(576), dok(n_proofs * 4), derr(8);
+  int rc;
+  if ((rc = up(dA, A, n_proofs * G1B, s)) || (rc = up(dB, B, n_proofs * G2B, s)) || (rc = up(dC, C, n_proofs * G1B, s)) ||
+      (rc = up(dU, c->g1_uvw_stmt, n_stmt * G1B, s)) || (rc = up(dW, stmt_wires, n_proofs * n_stmt * FRB, s)) ||
+      (rc = up(dg, c->g2_gamma, G2B, s)) || (rc = up(dd, c->g2_delta, G2B, s)) || (rc = up(dab, c->gt_alpha_beta, 576, s))) return rc;
+  unsigned long long noerr = NO_ERR; if ((rc = up(derr, &noerr, 8, s))) return rc;
+  if (!dok.p) return ZKT_ERR_DEVICE;
+  PCHK(launch_groth16_verify(dA.w(), dB.w(), dC.w(), dU.w(), dW.w(), (int)n_stmt, dg.w(), dd.w(), dab.w(), dok.w(), n_proofs, (unsigned long long*)derr.p, s));
+  unsigned long long e = NO_ERR;
+  if ((rc = down(ok, dok.p, n_proofs * 4, s)) || (rc = down(&e, derr.p, 8, s))) return rc;
+  PCHK(hipStreamSynchronize(s));
+  if (e != NO_ERR) { zkt_internal_set_error_index((size_t)e); return ZKT_ERR_INFINITY; }
+  return ZKT_OK;
+}
+// single proof: 1 = accept, 0 = reject, negative = -status (a pairing argument at infinity panics in the reference)
 int zkt_groth16_verify(const zkt_groth16_crs* c, const zkt_g1_affine* A, const zkt_g2_affine* B, const zkt_g1_affine* C,
                        const uint64_t* stmt_wires, size_t n_stmt) {
-  if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
-  if (!c || !A || !B || !C || (n_stmt && !stmt_wires) || n_stmt > c->l + 1) return -ZKT_ERR_SHAPE;
-  zkt_g1_affine sum; int rc;
-  if ((rc = zkt_g1_msm(c->g1_uvw_stmt, stmt_wires, n_stmt, &sum))) return -rc;
-  zkt_g1_affine p[3] = {*A, sum, *C}; zkt_g2_affine q[3] = {*B, *c->g2_gamma, *c->g2_delta};
-  uint64_t e[3 * 72], t[72], rhs[72];
-  if ((rc = zkt_tate_batch(p, q, e, 3))) return -rc;
-  if ((rc = zkt_fq12_mul_batch(c->gt_alpha_beta, e + 72, t, 1)) || (rc = zkt_fq12_mul_batch(t, e + 144, rhs, 1))) return -rc;
-  return zkt_gt_eq(e, rhs);
+  uint32_t ok = 0;
+  int rc = zkt_groth16_verify_batch(c, A, B, C, stmt_wires, n_stmt, 1, &ok);
+  if (rc != ZKT_OK) return -rc;
+  return (int)ok;
 }
 
 // Bulletproofs::inner_product_argument (bulletproofs.rs:19-55); xs = one injected challenge per level (log2 n of them).
