@@ -107,7 +107,8 @@ int zkt_secp_mul_batch(const zkt_secp_affine* points, const uint64_t* scalars, i
 int zkt_g1_msm(const zkt_g1_affine* bases, const uint64_t* scalars, size_t n, zkt_g1_affine* out);
 
 /* f-1 and the secp256k1 vector form: Polynomial::eval_with_g2_hidings polynomial.rs:283-293;
- * (AffinePoints * PrimeFieldElems).sum() secp256k1/affine_points.rs:25-31,123-144.  4-limb scalars, used as-is. */
+ * (AffinePoints * PrimeFieldElems).sum() secp256k1/affine_points.rs:25-31,123-144.  4-limb scalars, used as-is.
+ * Same Pippenger pipeline as G1, instantiated over Fq2 / the secp256k1 field. */
 int zkt_g2_msm(const zkt_g2_affine* bases, const uint64_t* scalars, size_t n, zkt_g2_affine* out);
 int zkt_secp_msm(const zkt_secp_affine* bases, const uint64_t* scalars, size_t n, zkt_secp_affine* out);
 
@@ -186,6 +187,26 @@ int zkt_g1_msm_collect(zkt_g1_bases* bases, int slot, zkt_g1_affine* out, uint32
 int zkt_g1_jac_sum_dev(const uint32_t* dev_partials, size_t count, void* stream, zkt_g1_affine* out);
 /* bytes of device workspace a zkt_g1_msm_dev of n terms allocates once and keeps */
 size_t zkt_g1_msm_workspace_bytes(size_t n);
+
+/* the same resident-bases / pipelined MSM interface for G2 and secp256k1 (Jacobian partial = 72 / 24 u32 words) */
+typedef struct zkt_g2_bases zkt_g2_bases;
+typedef struct zkt_secp_bases zkt_secp_bases;
+int zkt_g2_bases_upload(const zkt_g2_affine* host_bases, size_t n, zkt_g2_bases** out);
+int zkt_g2_bases_from_device(const zkt_g2_affine* dev_bases, size_t n, void* stream, zkt_g2_bases** out);
+size_t zkt_g2_bases_len(const zkt_g2_bases* b);
+void zkt_g2_bases_free(zkt_g2_bases* b);
+int zkt_g2_msm_dev(const zkt_g2_bases* bases, const uint64_t* dev_scalars, size_t n, void* stream, zkt_g2_affine* out, uint32_t* dev_partial_jac);
+int zkt_g2_msm_submit(zkt_g2_bases* bases, const uint64_t* dev_scalars, size_t n, void* stream, int slot);
+int zkt_g2_msm_collect(zkt_g2_bases* bases, int slot, zkt_g2_affine* out, uint32_t* dev_partial_jac);
+int zkt_g2_jac_sum_dev(const uint32_t* dev_partials, size_t count, void* stream, zkt_g2_affine* out);
+int zkt_secp_bases_upload(const zkt_secp_affine* host_bases, size_t n, zkt_secp_bases** out);
+int zkt_secp_bases_from_device(const zkt_secp_affine* dev_bases, size_t n, void* stream, zkt_secp_bases** out);
+size_t zkt_secp_bases_len(const zkt_secp_bases* b);
+void zkt_secp_bases_free(zkt_secp_bases* b);
+int zkt_secp_msm_dev(const zkt_secp_bases* bases, const uint64_t* dev_scalars, size_t n, void* stream, zkt_secp_affine* out, uint32_t* dev_partial_jac);
+int zkt_secp_msm_submit(zkt_secp_bases* bases, const uint64_t* dev_scalars, size_t n, void* stream, int slot);
+int zkt_secp_msm_collect(zkt_secp_bases* bases, int slot, zkt_secp_affine* out, uint32_t* dev_partial_jac);
+int zkt_secp_jac_sum_dev(const uint32_t* dev_partials, size_t count, void* stream, zkt_secp_affine* out);
 
 int zkt_g1_mul_batch_dev(const zkt_g1_affine* dev_points, const uint64_t* dev_scalars, int scalar_limbs,
                          zkt_g1_affine* dev_out, size_t n, void* stream);

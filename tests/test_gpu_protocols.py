@@ -162,3 +162,26 @@ def test_groth16_verify_batch_mixed(L):              # f-2: fused 3-pairing veri
     assert ok.tolist() == [1, 1, 0, 1, 0, 1]
     for i in range(k):                                  # the oracle's verifier (three separate tate calls) agrees
         assert O.zkto_groth16_verify(ctypes.byref(crs), ptr(As[i:i + 1].copy()), ptr(Bs[i:i + 1].copy()), ptr(Cs[i:i + 1].copy()), ptr(stmts[i:i + 1].copy()), l + 1) == int(ok[i])
+
+
+@pytest.mark.parametrize("name,W,order,gen_fn,n", [("g2", G2W, R, "zkto_g2_generator", 1 << 13), ("secp", 9, SECP_N, "zkto_secp_generator", 1 << 14)])
+def test_g2_secp_msm_large_by_linearity(L, name, W, order, gen_fn, n):
+    """Pippenger over Fq2 / secp256k1 at a size the oracle cannot sum term by term: bases k_i*G, so the MSM must equal
+    (sum k_i s_i mod order)*G — python integers plus one oracle scalar multiplication."""
+    import time
+    rng = np.random.Generator(np.random.PCG64(123))
+    ks = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64); ks[:, 3] >>= np.uint64(2)
+    ss = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64); ss[:, 3] >>= np.uint64(2)
+    ss[5] = 0; ss[6] = [1, 0, 0, 0]
+    g = np.zeros((1, W), np.uint64); getattr(O, gen_fn)(ptr(g))
+    bases = np.zeros((n, W), np.uint64)
+    zk.check(getattr(L, f"zkt_{name}_mul_batch")(ptr(np.repeat(g, n, axis=0)), ptr(ks), 4, ptr(bases), n))
+    got = np.zeros((1, W), np.uint64)
+    t0 = time.perf_counter()
+    zk.check(getattr(L, f"zkt_{name}_msm")(ptr(bases), ptr(ss), n, ptr(got)))
+    dt = time.perf_counter() - t0
+    tot = sum(limbs_to_int(a) * limbs_to_int(b) for a, b in zip(ks, ss)) % order
+    want = np.zeros((1, W), np.uint64)
+    assert getattr(O, f"zkto_{name}_mul_batch")(ptr(g), ptr(ints_to_arr([tot], 4)), 4, ptr(want), 1, 1) == 0
+    assert (got == want).all()
+    print(f"{name} one-shot MSM n={n}: {dt*1e3:.1f} ms (incl. upload + window-multiple table build)")

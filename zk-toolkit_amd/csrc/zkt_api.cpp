@@ -11,10 +11,6 @@
 
 using namespace zkt;
 
-namespace zkt {
-hipError_t launch_g1_precompute(uint32_t* table, uint8_t* inf, size_t n, int c, int nwin, hipStream_t s);
-}
-
 namespace {
 
 struct Ctx {
@@ -105,13 +101,14 @@ static constexpr int MSM_SLOTS = 8;
 struct MsmSlot {                      // one in-flight MSM: workspace, result buffers, stage events
   hipEvent_t e_in = nullptr, e_sorted = nullptr, e_acc0 = nullptr, e_acc1 = nullptr, e_done = nullptr;
   void* workspace = nullptr;
-  uint32_t* d_result_jac = nullptr;   // 36 words
-  uint32_t* d_out_abi = nullptr;      // 26 words
-  zkt_g1_affine* h_out = nullptr;     // pinned
+  uint32_t* d_result_jac = nullptr;   // 3 coordinates (Jacobian partial)
+  uint32_t* d_out_abi = nullptr;      // one ABI point
+  uint8_t* h_out = nullptr;           // pinned, one ABI point
   bool busy = false;
 };
-struct zkt_g1_bases {
+struct zkt_bases_impl {               // one resident base set of any group; zkt_g1_bases / zkt_g2_bases / zkt_secp_bases are this
   size_t n = 0;
+  int grp = G_G1;
   MsmPlan plan{};
   uint32_t* table = nullptr;     // nwin*n x 24 words
   uint8_t* inf = nullptr;        // nwin*n flags
@@ -122,25 +119,30 @@ struct zkt_g1_bases {
   hipStream_t s_sort = nullptr, s_acc = nullptr, s_tail[NTAIL] = {nullptr, nullptr};
   MsmSlot slot[MSM_SLOTS];
 };
-static int streams_ready(zkt_g1_bases* h) {
+struct zkt_g1_bases : zkt_bases_impl {};
+struct zkt_g2_bases : zkt_bases_impl {};
+struct zkt_secp_bases : zkt_bases_impl {};
+static size_t grp_pt_bytes(int grp) { return grp == G_G1 ? sizeof(zkt_g1_affine) : grp == G_G2 ? sizeof(zkt_g2_affine) : sizeof(zkt_secp_affine); }
+static size_t grp_coord_bytes(int grp) { return grp == G_G1 ? 48 : grp == G_G2 ? 96 : 32; }
+static int streams_ready(zkt_bases_impl* h) {
   if (h->s_acc) return ZKT_OK;
   int lo = 0, hi = 0;
   HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));        // hi = numerically smallest = highest priority
   HIPCHK(hipStreamCreateWithPriority(&h->s_sort, hipStreamNonBlocking, hi));
   HIPCHK(hipStreamCreateWithPriority(&h->s_acc, hipStreamNonBlocking, lo));
-  for (int k = 0; k < zkt_g1_bases::NTAIL; ++k) HIPCHK(hipStreamCreateWithPriority(&h->s_tail[k], hipStreamNonBlocking, hi));
+  for (int k = 0; k < zkt_bases_impl::NTAIL; ++k) HIPCHK(hipStreamCreateWithPriority(&h->s_tail[k], hipStreamNonBlocking, hi));
   return ZKT_OK;
 }
-static int slot_ready(zkt_g1_bases* h, int k) {   // lazily create the slot's workspace
+static int slot_ready(zkt_bases_impl* h, int k) {   // lazily create the slot's workspace
   int rc = streams_ready(h); if (rc) return rc;
   MsmSlot& S = h->slot[k];
   if (S.workspace) return ZKT_OK;
   HIPCHK(hipEventCreateWithFlags(&S.e_in, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&S.e_sorted, hipEventDisableTiming));
   HIPCHK(hipEventCreate(&S.e_acc0)); HIPCHK(hipEventCreate(&S.e_acc1)); HIPCHK(hipEventCreateWithFlags(&S.e_done, hipEventDisableTiming));
   HIPCHK(hipMalloc(&S.workspace, h->plan.ws_bytes));
-  HIPCHK(hipMalloc((void**)&S.d_result_jac, 36 * 4));
-  HIPCHK(hipMalloc((void**)&S.d_out_abi, 26 * 4));
-  HIPCHK(hipHostMalloc((void**)&S.h_out, sizeof(zkt_g1_affine), hipHostMallocDefault));
+  HIPCHK(hipMalloc((void**)&S.d_result_jac, 3 * grp_coord_bytes(h->grp)));
+  HIPCHK(hipMalloc((void**)&S.d_out_abi, grp_pt_bytes(h->grp)));
+  HIPCHK(hipHostMalloc((void**)&S.h_out, grp_pt_bytes(h->grp), hipHostMallocDefault));
   return ZKT_OK;
 }
 
@@ -298,38 +300,18 @@ int zkt_tate_batch_dev(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_
   return rc;
 }
 
-static int bases_build(zkt_g1_bases* h, const uint32_t* dev_abi, hipStream_t s) {
+static int bases_build(zkt_bases_impl* h, const uint32_t* dev_abi, hipStream_t s) {
   const size_t n = h->n;
-  h->plan = msm_plan(n);
+  h->plan = msm_plan(n, h->grp);
   const size_t tot = (size_t)h->plan.nwin * (n ? n : 1);
-  HIPCHK(hipMalloc((void**)&h->table, tot * 96));
+  HIPCHK(hipMalloc((void**)&h->table, tot * 2 * grp_coord_bytes(h->grp)));
   HIPCHK(hipMalloc((void**)&h->inf, tot));
-  HIPCHK(launch_g1_to_kernel_layout(dev_abi, h->table, h->inf, n, s));
-  HIPCHK(launch_g1_precompute(h->table, h->inf, n, h->plan.c, h->plan.nwin, s));
+  HIPCHK(launch_msm_to_kernel_layout(h->grp, dev_abi, h->table, h->inf, n, s));
+  HIPCHK(launch_msm_precompute(h->grp, h->table, h->inf, n, h->plan.c, h->plan.nwin, s));
   HIPCHK(hipStreamSynchronize(s));
   return ZKT_OK;
 }
-int zkt_g1_bases_from_device(const zkt_g1_affine* dev_bases, size_t n, void* stream, zkt_g1_bases** out) {
-  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
-  if (!out || (n && !dev_bases) || n >= (size_t(1) << 26)) return ZKT_ERR_SHAPE;
-  zkt_g1_bases* h = new zkt_g1_bases(); h->n = n;
-  int rc = bases_build(h, (const uint32_t*)dev_bases, (hipStream_t)stream);
-  if (rc) { zkt_g1_bases_free(h); return rc; }
-  *out = h; return ZKT_OK;
-}
-int zkt_g1_bases_upload(const zkt_g1_affine* host, size_t n, zkt_g1_bases** out) {
-  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
-  if (!out || (n && !host)) return ZKT_ERR_SHAPE;
-  HIPCHK(hipSetDevice(g.device));
-  uint32_t* tmp = nullptr;
-  HIPCHK(hipMalloc((void**)&tmp, (n ? n : 1) * sizeof(zkt_g1_affine)));
-  if (n) HIPCHK(hipMemcpy(tmp, host, n * sizeof(zkt_g1_affine), hipMemcpyHostToDevice));
-  int rc = zkt_g1_bases_from_device((const zkt_g1_affine*)tmp, n, g.stream, out);
-  hipFree(tmp);
-  return rc;
-}
-size_t zkt_g1_bases_len(const zkt_g1_bases* b) { return b ? b->n : 0; }
-void zkt_g1_bases_free(zkt_g1_bases* h) {
+static void bases_free(zkt_bases_impl* h) {
   if (!h) return;
   if (h->table) hipFree(h->table);
   if (h->inf) hipFree(h->inf);
@@ -341,9 +323,26 @@ void zkt_g1_bases_free(zkt_g1_bases* h) {
   }
   delete h;
 }
-size_t zkt_g1_msm_workspace_bytes(size_t n) { MsmPlan p = msm_plan(n); return p.ws_bytes + (size_t)p.nwin * n * 97; }
-
-int zkt_g1_msm_submit(zkt_g1_bases* h, const uint64_t* dev_scalars, size_t n, void* stream, int slot) {
+static int bases_from_device(int grp, const void* dev_bases, size_t n, void* stream, zkt_bases_impl** out) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!out || (n && !dev_bases) || n >= (size_t(1) << 26)) return ZKT_ERR_SHAPE;
+  zkt_bases_impl* h = new zkt_bases_impl(); h->n = n; h->grp = grp;
+  int rc = bases_build(h, (const uint32_t*)dev_bases, (hipStream_t)stream);
+  if (rc) { bases_free(h); return rc; }
+  *out = h; return ZKT_OK;
+}
+static int bases_upload(int grp, const void* host, size_t n, zkt_bases_impl** out) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!out || (n && !host)) return ZKT_ERR_SHAPE;
+  HIPCHK(hipSetDevice(g.device));
+  uint32_t* tmp = nullptr;
+  HIPCHK(hipMalloc((void**)&tmp, (n ? n : 1) * grp_pt_bytes(grp)));
+  if (n) HIPCHK(hipMemcpy(tmp, host, n * grp_pt_bytes(grp), hipMemcpyHostToDevice));
+  int rc = bases_from_device(grp, tmp, n, g.stream, out);
+  hipFree(tmp);
+  return rc;
+}
+static int msm_submit(zkt_bases_impl* h, const uint64_t* dev_scalars, size_t n, void* stream, int slot) {
   if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
   if (!h || n != h->n || (n && !dev_scalars) || slot < 0 || slot >= MSM_SLOTS) return ZKT_ERR_SHAPE;
   if (h->slot[slot].busy) return ZKT_ERR_SHAPE;          // collect it first
@@ -352,64 +351,81 @@ int zkt_g1_msm_submit(zkt_g1_bases* h, const uint64_t* dev_scalars, size_t n, vo
   // inputs are produced on the caller's stream: order the sort stage behind it
   HIPCHK(hipEventRecord(S.e_in, (hipStream_t)stream));
   HIPCHK(hipStreamWaitEvent(h->s_sort, S.e_in, 0));
-  HIPCHK(launch_g1_msm_sort(h->plan, h->inf, (const uint32_t*)dev_scalars, S.workspace, h->s_sort));
+  HIPCHK(launch_msm_sort(h->plan, h->inf, (const uint32_t*)dev_scalars, S.workspace, h->s_sort));
   HIPCHK(hipEventRecord(S.e_sorted, h->s_sort));
   HIPCHK(hipStreamWaitEvent(h->s_acc, S.e_sorted, 0));
   HIPCHK(hipEventRecord(S.e_acc0, h->s_acc));
-  HIPCHK(launch_g1_msm_accumulate(h->plan, h->table, S.workspace, h->s_acc));
+  HIPCHK(launch_msm_accumulate(h->plan, h->table, S.workspace, h->s_acc));
   HIPCHK(hipEventRecord(S.e_acc1, h->s_acc));
-  hipStream_t st = h->s_tail[slot % zkt_g1_bases::NTAIL];
+  hipStream_t st = h->s_tail[slot % zkt_bases_impl::NTAIL];
   HIPCHK(hipStreamWaitEvent(st, S.e_acc1, 0));
-  HIPCHK(launch_g1_msm_reduce(h->plan, S.workspace, S.d_result_jac, S.d_out_abi, st));
-  HIPCHK(hipMemcpyAsync(S.h_out, S.d_out_abi, sizeof(zkt_g1_affine), hipMemcpyDeviceToHost, st));
+  HIPCHK(launch_msm_reduce(h->plan, S.workspace, S.d_result_jac, S.d_out_abi, st));
+  HIPCHK(hipMemcpyAsync(S.h_out, S.d_out_abi, grp_pt_bytes(h->grp), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(S.e_done, st));
   S.busy = true;
   return ZKT_OK;
 }
-int zkt_g1_msm_collect(zkt_g1_bases* h, int slot, zkt_g1_affine* out, uint32_t* dev_partial_jac) {
+static int msm_collect(zkt_bases_impl* h, int slot, void* out, uint32_t* dev_partial_jac) {
   if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
   if (!h || slot < 0 || slot >= MSM_SLOTS || !h->slot[slot].busy) return ZKT_ERR_SHAPE;
   MsmSlot& S = h->slot[slot];
   HIPCHK(hipEventSynchronize(S.e_done));
-  if (dev_partial_jac) HIPCHK(hipMemcpy(dev_partial_jac, S.d_result_jac, 36 * 4, hipMemcpyDeviceToDevice));
-  if (out) *out = *S.h_out;
+  if (dev_partial_jac) HIPCHK(hipMemcpy(dev_partial_jac, S.d_result_jac, 3 * grp_coord_bytes(h->grp), hipMemcpyDeviceToDevice));
+  if (out) memcpy(out, S.h_out, grp_pt_bytes(h->grp));
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, S.e_acc0, S.e_acc1) == hipSuccess) { t_kernel_ms = ms; t_kernel_name = "k_accumulate"; }
   S.busy = false;
   return ZKT_OK;
 }
-int zkt_g1_msm_dev(const zkt_g1_bases* h, const uint64_t* dev_scalars, size_t n, void* stream, zkt_g1_affine* out, uint32_t* dev_partial_jac) {
+static int msm_dev(zkt_bases_impl* h, const uint64_t* dev_scalars, size_t n, void* stream, void* out, uint32_t* dev_partial_jac) {
   if (!out && !dev_partial_jac) return ZKT_ERR_SHAPE;
-  zkt_g1_bases* hh = const_cast<zkt_g1_bases*>(h);
-  int rc = zkt_g1_msm_submit(hh, dev_scalars, n, stream, 0);
+  int rc = msm_submit(h, dev_scalars, n, stream, 0);
   if (rc) return rc;
-  return zkt_g1_msm_collect(hh, 0, out, dev_partial_jac);
+  return msm_collect(h, 0, out, dev_partial_jac);
 }
-int zkt_g1_jac_sum_dev(const uint32_t* dev_partials, size_t count, void* stream, zkt_g1_affine* out) {
+static int jac_sum_dev(int grp, const uint32_t* dev_partials, size_t count, void* stream, void* out) {
   if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
   if (!dev_partials || !out || count == 0) return ZKT_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   uint32_t* d_out = nullptr;
-  HIPCHK(hipMalloc((void**)&d_out, 26 * 4));
-  HIPCHK(launch_g1_jac_sum_to_affine(dev_partials, count, d_out, s));
-  HIPCHK(hipMemcpyAsync(out, d_out, sizeof(zkt_g1_affine), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMalloc((void**)&d_out, grp_pt_bytes(grp)));
+  HIPCHK(launch_msm_jac_sum_to_affine(grp, dev_partials, count, d_out, s));
+  HIPCHK(hipMemcpyAsync(out, d_out, grp_pt_bytes(grp), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   hipFree(d_out);
   return ZKT_OK;
 }
-int zkt_g1_msm(const zkt_g1_affine* bases, const uint64_t* scalars, size_t n, zkt_g1_affine* out) {
+// one-shot host-pointer MSM: upload, build the window-multiple table, run, free
+static int msm_host(int grp, const void* bases, const uint64_t* scalars, size_t n, void* out) {
   if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
   if (!out || (n && (!bases || !scalars))) return ZKT_ERR_SHAPE;
-  if (n == 0) { memset(out, 0, sizeof(*out)); out->is_infinity = 1; return ZKT_OK; }
-  zkt_g1_bases* h = nullptr;
-  int rc = zkt_g1_bases_upload(bases, n, &h);
+  if (n == 0) { memset(out, 0, grp_pt_bytes(grp)); ((uint32_t*)out)[grp_pt_bytes(grp) / 4 - 2] = 1; return ZKT_OK; }
+  zkt_bases_impl* h = nullptr;
+  int rc = bases_upload(grp, bases, n, &h);
   if (rc) return rc;
   uint64_t* d_s = nullptr;
-  if (hipMalloc((void**)&d_s, n * 32) != hipSuccess) { zkt_g1_bases_free(h); return ZKT_ERR_DEVICE; }
+  if (hipMalloc((void**)&d_s, n * 32) != hipSuccess) { bases_free(h); return ZKT_ERR_DEVICE; }
   hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice);
-  rc = zkt_g1_msm_dev(h, d_s, n, g.stream, out, nullptr);
-  hipFree(d_s); zkt_g1_bases_free(h);
+  rc = msm_dev(h, d_s, n, g.stream, out, nullptr);
+  hipFree(d_s); bases_free(h);
   return rc;
 }
+
+#define ZKT_BASES_API(NAME, GRP, PT)                                                                                             \
+  int zkt_##NAME##_bases_from_device(const PT* dev, size_t n, void* stream, zkt_##NAME##_bases** out) {                          \
+    return bases_from_device(GRP, dev, n, stream, (zkt_bases_impl**)out); }                                                     \
+  int zkt_##NAME##_bases_upload(const PT* host, size_t n, zkt_##NAME##_bases** out) { return bases_upload(GRP, host, n, (zkt_bases_impl**)out); } \
+  size_t zkt_##NAME##_bases_len(const zkt_##NAME##_bases* b) { return b ? b->n : 0; }                                             \
+  void zkt_##NAME##_bases_free(zkt_##NAME##_bases* b) { bases_free(b); }                                                          \
+  int zkt_##NAME##_msm_submit(zkt_##NAME##_bases* b, const uint64_t* k, size_t n, void* stream, int slot) { return msm_submit(b, k, n, stream, slot); } \
+  int zkt_##NAME##_msm_collect(zkt_##NAME##_bases* b, int slot, PT* out, uint32_t* partial) { return msm_collect(b, slot, out, partial); } \
+  int zkt_##NAME##_msm_dev(const zkt_##NAME##_bases* b, const uint64_t* k, size_t n, void* stream, PT* out, uint32_t* partial) { \
+    return msm_dev(const_cast<zkt_##NAME##_bases*>(b), k, n, stream, out, partial); }                                              \
+  int zkt_##NAME##_jac_sum_dev(const uint32_t* partials, size_t count, void* stream, PT* out) { return jac_sum_dev(GRP, partials, count, stream, out); } \
+  int zkt_##NAME##_msm(const PT* bases, const uint64_t* scalars, size_t n, PT* out) { return msm_host(GRP, bases, scalars, n, out); }
+ZKT_BASES_API(g1, G_G1, zkt_g1_affine)
+ZKT_BASES_API(g2, G_G2, zkt_g2_affine)
+ZKT_BASES_API(secp, G_SECP, zkt_secp_affine)
+size_t zkt_g1_msm_workspace_bytes(size_t n) { MsmPlan p = msm_plan(n, G_G1); return p.ws_bytes + (size_t)p.nwin * n * 97; }
 
 }  // extern "C"

@@ -30,22 +30,24 @@ hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uin
                                  unsigned long long* err, hipStream_t s);
 hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s);
 
-// ---- MSM (zkt_msm.hip) ---------------------------------------------------------
+// ---- MSM (zkt_msm.hip), generic over the group (G_G1, G_G2, G_SECP) ------------------------------------------
 struct MsmPlan {
   size_t n;            // terms
+  int grp;             // GroupId
   int c;               // window bits
   int nwin;            // windows
-  size_t nbuckets;     // buckets per window = 2^(c-1)
-  size_t ws_bytes;     // workspace bytes
+  size_t nbuckets;     // 2^(c-1), shared by all windows (window multiples are precomputed)
+  size_t ws_bytes;     // workspace bytes per in-flight MSM
 };
-MsmPlan msm_plan(size_t n);
-// table: nwin*n x 24 u32 (x,y Montgomery, window multiples), inf: nwin*n bytes.  scalars: n x 8 u32.
+MsmPlan msm_plan(size_t n, int grp);
+// table: nwin*n affine points (x,y raw Montgomery coordinates), inf: nwin*n bytes.  scalars: n x 8 u32.
 // Three stages so the API layer can run them on three streams (sort | accumulate | reduce) and overlap
-// consecutive MSMs; the result is a Jacobian partial (36 u32) and optionally the affine ABI point.
-hipError_t launch_g1_msm_sort(const MsmPlan& plan, const uint8_t* base_inf, const uint32_t* scalars, void* workspace, hipStream_t s);
-hipError_t launch_g1_msm_accumulate(const MsmPlan& plan, const uint32_t* table, void* workspace, hipStream_t s);
-hipError_t launch_g1_msm_reduce(const MsmPlan& plan, void* workspace, uint32_t* dev_result_jac, uint32_t* dev_out_abi, hipStream_t s);
-hipError_t launch_g1_to_kernel_layout(const uint32_t* abi_pts, uint32_t* bases_mont, uint8_t* base_inf, size_t n, hipStream_t s);
-hipError_t launch_g1_jac_sum_to_affine(const uint32_t* jac_partials, size_t count, uint32_t* out_abi_pt, hipStream_t s);
+// consecutive MSMs; the result is a Jacobian partial (3 coordinates) and optionally the affine ABI point.
+hipError_t launch_msm_to_kernel_layout(int grp, const uint32_t* abi_pts, uint32_t* table, uint8_t* base_inf, size_t n, hipStream_t s);
+hipError_t launch_msm_precompute(int grp, uint32_t* table, uint8_t* inf, size_t n, int c, int nwin, hipStream_t s);
+hipError_t launch_msm_sort(const MsmPlan& plan, const uint8_t* base_inf, const uint32_t* scalars, void* workspace, hipStream_t s);
+hipError_t launch_msm_accumulate(const MsmPlan& plan, const uint32_t* table, void* workspace, hipStream_t s);
+hipError_t launch_msm_reduce(const MsmPlan& plan, void* workspace, uint32_t* dev_result_jac, uint32_t* dev_out_abi, hipStream_t s);
+hipError_t launch_msm_jac_sum_to_affine(int grp, const uint32_t* jac_partials, size_t count, uint32_t* out_abi_pt, hipStream_t s);
 
 }  // namespace zkt

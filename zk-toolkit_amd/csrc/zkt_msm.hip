@@ -21,17 +21,37 @@
 
 namespace zkt {
 
-typedef Xyzz<FqOps> XY;
-static constexpr int XYW = 48;   // u32 words of an XYZZ point in memory
-
-__device__ inline XY ld_xy(const uint32_t* p) { XY r; r.X = ld_raw<FqC>(p); r.Y = ld_raw<FqC>(p + 12); r.ZZ = ld_raw<FqC>(p + 24); r.ZZZ = ld_raw<FqC>(p + 36); return r; }
-__device__ inline void st_xy(uint32_t* p, const XY& a) { st_raw<FqC>(p, a.X); st_raw<FqC>(p + 12, a.Y); st_raw<FqC>(p + 24, a.ZZ); st_raw<FqC>(p + 36, a.ZZZ); }
+// The pipeline is generic over the group: G1 over Fq (FqOps), G2 over Fq2 (Fq2Ops, row f-1: eval_with_g2_hidings,
+// polynomial.rs:283-293) and secp256k1 (SpOps: (AffinePoints * PrimeFieldElems).sum(), secp256k1/affine_points.rs:25-31,123-144).
+// Coordinates are stored raw (Montgomery) with CW words each: affine point = 2*CW, XYZZ = 4*CW, Jacobian partial = 3*CW.
+template <class F> struct Coord;
+template <class C> struct Coord<PrimeOps<C>> {
+  static constexpr int CW = C::N;
+  __device__ static Fp<C> ld(const uint32_t* p) { return ld_raw<C>(p); }
+  __device__ static void st(uint32_t* p, const Fp<C>& a) { st_raw<C>(p, a); }
+};
+template <> struct Coord<Fq2Ops> {
+  static constexpr int CW = 24;
+  __device__ static Fq2 ld(const uint32_t* p) { Fq2 r; r.c0 = ld_raw<FqC>(p); r.c1 = ld_raw<FqC>(p + 12); return r; }
+  __device__ static void st(uint32_t* p, const Fq2& a) { st_raw<FqC>(p, a.c0); st_raw<FqC>(p + 12, a.c1); }
+};
+template <class F> __device__ inline Xyzz<F> ld_xy(const uint32_t* p) {
+  constexpr int CW = Coord<F>::CW; Xyzz<F> r;
+  r.X = Coord<F>::ld(p); r.Y = Coord<F>::ld(p + CW); r.ZZ = Coord<F>::ld(p + 2 * CW); r.ZZZ = Coord<F>::ld(p + 3 * CW); return r;
+}
+template <class F> __device__ inline void st_xy(uint32_t* p, const Xyzz<F>& a) {
+  constexpr int CW = Coord<F>::CW;
+  Coord<F>::st(p, a.X); Coord<F>::st(p + CW, a.Y); Coord<F>::st(p + 2 * CW, a.ZZ); Coord<F>::st(p + 3 * CW, a.ZZZ);
+}
+static int coord_words(int grp) { return grp == G_G1 ? 12 : grp == G_G2 ? 24 : 8; }
 
 // ---------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------
-MsmPlan msm_plan(size_t n) {
-  MsmPlan p; p.n = n;
+#if defined(ZKT_MSM_PART_G1)
+MsmPlan msm_plan(size_t n, int grp) {
+  MsmPlan p; p.n = n; p.grp = grp;
+  const size_t XYW = 4 * (size_t)coord_words(grp);
   int lg = 0; while ((size_t(1) << (lg + 1)) <= (n ? n : 1)) ++lg;   // floor(log2 n)
   int c = lg;                       // 2^(c-1) buckets ~ n/2: ~2*nwin ~ 26 points per bucket at 2^20
   if (c < 4) c = 4;
@@ -49,37 +69,53 @@ MsmPlan msm_plan(size_t n) {
   p.ws_bytes = b;
   return p;
 }
+#endif
 
 // ---------------------------------------------------------------------------------
 // layout conversion and window-multiple precomputation
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_to_kernel_layout(const uint32_t* __restrict__ abi, uint32_t* __restrict__ mont,
-                                                          uint8_t* __restrict__ inf, size_t n) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+template <class F>
+__global__ void __launch_bounds__(64) k_to_kernel_layout(const uint32_t* __restrict__ abi, uint32_t* __restrict__ mont,
+                                                         uint8_t* __restrict__ inf, size_t n) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
-  Aff<FqOps> p = PtIO<FqOps>::ld(abi + i * ABI_G1_WORDS);
-  st_raw<FqC>(mont + i * 24, p.x); st_raw<FqC>(mont + i * 24 + 12, p.y);
+  constexpr int CW = Coord<F>::CW;
+  Aff<F> p = PtIO<F>::ld(abi + i * PtIO<F>::WORDS);
+  Coord<F>::st(mont + i * 2 * CW, p.x); Coord<F>::st(mont + i * 2 * CW + CW, p.y);
   inf[i] = p.inf ? 1 : 0;
 }
-hipError_t launch_g1_to_kernel_layout(const uint32_t* abi, uint32_t* mont, uint8_t* inf, size_t n, hipStream_t s) {
+// This file is compiled twice (Makefile): -DZKT_MSM_PART_G1 -DZKT_INLINE_MUL instantiates the G1 kernels with the field
+// multiply inlined (the headline path) and defines the public launch_msm_* dispatchers; -DZKT_MSM_PART_OTHER instantiates
+// G2 and secp256k1 with a called multiply (an inlined Fq2 XYZZ add would be ~200 KB of code and minutes of compile time).
+#if defined(ZKT_MSM_PART_G1)
+#define MSM_DISPATCH(grp, CALL) switch (grp) { case G_G1: { typedef FqOps F; CALL; } break; default: return hipErrorInvalidValue; }
+#define PART(x) x##_g1
+#else
+#define MSM_DISPATCH(grp, CALL) switch (grp) { case G_G2: { typedef Fq2Ops F; CALL; } break; case G_SECP: { typedef SpOps F; CALL; } break; \
+                                               default: return hipErrorInvalidValue; }
+#define PART(x) x##_other
+#endif
+hipError_t PART(launch_msm_to_kernel_layout)(int grp, const uint32_t* abi, uint32_t* mont, uint8_t* inf, size_t n, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_to_kernel_layout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, abi, mont, inf, n);
+  MSM_DISPATCH(grp, hipLaunchKernelGGL(k_to_kernel_layout<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, abi, mont, inf, n));
   return hipGetLastError();
 }
 
 // table[w*n + i] = 2^(c*w) * P_i (affine, Montgomery); infinity flags likewise.
+template <class F>
 __global__ void __launch_bounds__(64) k_precompute(uint32_t* __restrict__ table, uint8_t* __restrict__ inf, size_t n, int c, int nwin) {
   size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
-  Aff<FqOps> a; a.x = ld_raw<FqC>(table + i * 24); a.y = ld_raw<FqC>(table + i * 24 + 12); a.inf = inf[i] != 0;
-  Jac<FqOps> j = jac_from_aff(a);
+  constexpr int CW = Coord<F>::CW, PW = 2 * CW;
+  Aff<F> a; a.x = Coord<F>::ld(table + i * PW); a.y = Coord<F>::ld(table + i * PW + CW); a.inf = inf[i] != 0;
+  Jac<F> j = jac_from_aff(a);
   for (int w = 1; w < nwin; ++w) {
     for (int d = 0; d < c; ++d) j = jac_dbl(j);
-    Aff<FqOps> r = jac_to_aff(j);
+    Aff<F> r = jac_to_aff(j);
     size_t o = (size_t)w * n + i;
-    st_raw<FqC>(table + o * 24, r.x); st_raw<FqC>(table + o * 24 + 12, r.y);
+    Coord<F>::st(table + o * PW, r.x); Coord<F>::st(table + o * PW + CW, r.y);
     inf[o] = r.inf ? 1 : 0;
-    if (!r.inf) { j.X = r.x; j.Y = r.y; j.Z = fp_one<FqC>(); }
+    if (!r.inf) { j.X = r.x; j.Y = r.y; j.Z = F::one(); }
   }
 }
 
@@ -99,7 +135,7 @@ __device__ inline uint32_t window_bits(const uint32_t* k, int w, int c) {
 // atomics on one address: up to two rounds of wave-level aggregation elect a leader for the most common bucket id among
 // the active lanes (one atomicAdd of the population count, ranks by prefix popcount); the rest go individually.
 template <bool SCATTER>
-__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t n, int c, int nwin,
+static __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t n, int c, int nwin,
                                                 uint32_t* __restrict__ counts_or_cursor, const uint32_t* __restrict__ offsets,
                                                 uint32_t* __restrict__ entries) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -157,7 +193,7 @@ __device__ inline uint32_t block_excl_scan_256(uint32_t v, uint32_t* lds /*256*/
   __syncthreads();
   return excl;
 }
-__global__ void __launch_bounds__(256) k_scan_sums(const uint32_t* __restrict__ in, size_t m, uint32_t* __restrict__ blocksum) {
+static __global__ void __launch_bounds__(256) k_scan_sums(const uint32_t* __restrict__ in, size_t m, uint32_t* __restrict__ blocksum) {
   __shared__ uint32_t lds[256];
   size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
   uint32_t s = 0;
@@ -166,7 +202,7 @@ __global__ void __launch_bounds__(256) k_scan_sums(const uint32_t* __restrict__ 
   uint32_t tot; (void)block_excl_scan_256(s, lds, tot);
   if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
 }
-__global__ void __launch_bounds__(256) k_scan_top(uint32_t* __restrict__ blocksum, int nblk, uint32_t* __restrict__ grand_total) {
+static __global__ void __launch_bounds__(256) k_scan_top(uint32_t* __restrict__ blocksum, int nblk, uint32_t* __restrict__ grand_total) {
   __shared__ uint32_t lds[256];
   uint32_t run = 0;
   for (int base = 0; base < nblk; base += 256) {          // nblk <= 2^19/2048 = 256 in practice
@@ -178,7 +214,7 @@ __global__ void __launch_bounds__(256) k_scan_top(uint32_t* __restrict__ blocksu
   }
   if (threadIdx.x == 0) *grand_total = run;
 }
-__global__ void __launch_bounds__(256) k_scan_final(const uint32_t* __restrict__ in, size_t m, const uint32_t* __restrict__ blocksum,
+static __global__ void __launch_bounds__(256) k_scan_final(const uint32_t* __restrict__ in, size_t m, const uint32_t* __restrict__ blocksum,
                                                     uint32_t* __restrict__ out) {
   __shared__ uint32_t lds[256];
   size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
@@ -205,7 +241,7 @@ static void launch_scan(const uint32_t* in, uint32_t* out, size_t m, uint32_t* s
 static constexpr uint32_t CHUNK = 128;
 static constexpr int SIZE_BINS = CHUNK + 1;      // bin k holds tasks of size CHUNK - k
 __device__ inline uint32_t ntasks_of(uint32_t c) { return c <= CHUNK ? 1u : (c + CHUNK - 1) / CHUNK; }
-__global__ void __launch_bounds__(256) k_task_count(const uint32_t* __restrict__ counts, size_t m, uint32_t* __restrict__ ntask, uint32_t* __restrict__ hist) {
+static __global__ void __launch_bounds__(256) k_task_count(const uint32_t* __restrict__ counts, size_t m, uint32_t* __restrict__ ntask, uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[SIZE_BINS];
   for (int i = threadIdx.x; i < SIZE_BINS; i += 256) h[i] = 0;
   __syncthreads();
@@ -219,7 +255,7 @@ __global__ void __launch_bounds__(256) k_task_count(const uint32_t* __restrict__
   __syncthreads();
   for (int k = threadIdx.x; k < SIZE_BINS; k += 256) if (h[k]) atomicAdd(&hist[k], h[k]);
 }
-__global__ void __launch_bounds__(256) k_task_scatter(const uint32_t* __restrict__ counts, size_t m, const uint32_t* __restrict__ binoff,
+static __global__ void __launch_bounds__(256) k_task_scatter(const uint32_t* __restrict__ counts, size_t m, const uint32_t* __restrict__ binoff,
                                                       uint32_t* __restrict__ bincur, uint2* __restrict__ order) {
   // rank inside the block with LDS atomics, then ONE global atomic per (block, non-empty bin): ~50 distinct sizes
   // are shared by 2^19 buckets, so per-element global atomics would serialise.
@@ -244,6 +280,7 @@ __global__ void __launch_bounds__(256) k_task_scatter(const uint32_t* __restrict
 // ---------------------------------------------------------------------------------
 // bucket accumulation: one task (bucket chunk) per lane — the dominant kernel
 // ---------------------------------------------------------------------------------
+template <class F>
 __global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ table, const uint32_t* __restrict__ entries,
                                                    const uint32_t* __restrict__ offsets, const uint2* __restrict__ order,
                                                    const uint32_t* __restrict__ task_off, size_t nbuckets,
@@ -254,16 +291,17 @@ __global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ 
   const size_t b = tk.x;
   uint32_t beg = offsets[b] + tk.y * CHUNK, end = offsets[b + 1];
   if (end - beg > CHUNK) end = beg + CHUNK;
-  XY acc = xyzz_inf<FqOps>();
+  constexpr int CW = Coord<F>::CW, XYW = 4 * CW;
+  Xyzz<F> acc = xyzz_inf<F>();
   for (uint32_t e = beg; e < end; ++e) {
     uint32_t ent = entries[e];
-    const uint32_t* p = table + (size_t)(ent & 0x7fffffffu) * 24;
-    Fq x = ld_raw<FqC>(p), y = ld_raw<FqC>(p + 12);
-    if (ent >> 31) y = fp_neg(y);
-    acc = xyzz_add_aff<FqOps>(acc, x, y);
+    const uint32_t* p = table + (size_t)(ent & 0x7fffffffu) * (2 * CW);
+    typename F::E x = Coord<F>::ld(p), y = Coord<F>::ld(p + CW);
+    if (ent >> 31) y = F::neg(y);
+    acc = xyzz_add_aff<F>(acc, x, y);
   }
   const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
-  st_xy(nt == 1 ? sums + b * XYW : partial + (size_t)(t0 + tk.y) * XYW, acc);
+  st_xy<F>(nt == 1 ? sums + b * XYW : partial + (size_t)(t0 + tk.y) * XYW, acc);
 }
 
 // ---------------------------------------------------------------------------------
@@ -272,81 +310,90 @@ __global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ 
 // ---------------------------------------------------------------------------------
 // block-level tree sum of one XYZZ per lane through LDS (RED_TPB lanes -> lane 0): log2 depth
 static constexpr int RED_TPB = 64;
-__device__ inline XY block_tree_sum(XY v, uint32_t* lds /* RED_TPB/2 * XYW words */) {
+template <class F> __device__ inline Xyzz<F> block_tree_sum(Xyzz<F> v, uint32_t* lds /* RED_TPB/2 * XYW words */) {
+  constexpr int XYW = 4 * Coord<F>::CW;
   const int lane = threadIdx.x;
   for (int d = RED_TPB / 2; d >= 1; d >>= 1) {
-    if (lane >= d && lane < 2 * d) st_xy(lds + (lane - d) * XYW, v);
+    if (lane >= d && lane < 2 * d) st_xy<F>(lds + (lane - d) * XYW, v);
     __syncthreads();
-    if (lane < d) v = xyzz_add<FqOps>(v, ld_xy(lds + lane * XYW));
+    if (lane < d) v = xyzz_add<F>(v, ld_xy<F>(lds + lane * XYW));
     __syncthreads();
   }
   return v;
 }
 // hot buckets (more than one task): sums[b] = sum of the bucket's partials.  Blocks stride over the buckets; the test is
 // block-uniform, so the barrier inside the tree is safe.
+template <class F>
 __global__ void __launch_bounds__(RED_TPB) k_merge_partials(const uint32_t* __restrict__ task_off, size_t nbuckets, const uint32_t* __restrict__ partial,
                                                             uint32_t* __restrict__ sums) {
+  constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
   __shared__ uint32_t lds[RED_TPB / 2 * XYW];
   for (size_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
     const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
     if (nt == 1) continue;
-    XY acc = xyzz_inf<FqOps>();
-    for (uint32_t k = threadIdx.x; k < nt; k += RED_TPB) acc = xyzz_add<FqOps>(acc, ld_xy(partial + (size_t)(t0 + k) * XYW));
-    acc = block_tree_sum(acc, lds);
-    if (threadIdx.x == 0) st_xy(sums + b * XYW, acc);
+    XY acc = xyzz_inf<F>();
+    for (uint32_t k = threadIdx.x; k < nt; k += RED_TPB) acc = xyzz_add<F>(acc, ld_xy<F>(partial + (size_t)(t0 + k) * XYW));
+    acc = block_tree_sum<F>(acc, lds);
+    if (threadIdx.x == 0) st_xy<F>(sums + b * XYW, acc);
   }
 }
 
 // Both marginals of the NHI x NLO bucket matrix in ONE launch: blocks [0,NLO) produce the column sums
 // C_lo = sum_hi S[hi][lo]; blocks [NLO, NLO+NHI) the row sums R_hi = sum_lo S[hi][lo].
+template <class F>
 __global__ void __launch_bounds__(RED_TPB) k_marginals(const uint32_t* __restrict__ in, size_t NLO, size_t NHI,
                                                        uint32_t* __restrict__ colsum, uint32_t* __restrict__ rowsum) {
+  constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
   __shared__ uint32_t lds[RED_TPB / 2 * XYW];
   const int lane = threadIdx.x;
   const bool is_col = blockIdx.x < NLO;
   const size_t o = is_col ? blockIdx.x : blockIdx.x - NLO;
   const size_t count = is_col ? NHI : NLO, stride_o = is_col ? 1 : NLO, stride_j = is_col ? NLO : 1;
-  XY acc = xyzz_inf<FqOps>();
-  for (size_t j = lane; j < count; j += RED_TPB) acc = xyzz_add<FqOps>(acc, ld_xy(in + (o * stride_o + j * stride_j) * XYW));
-  acc = block_tree_sum(acc, lds);
-  if (lane == 0) st_xy((is_col ? colsum : rowsum) + o * XYW, acc);
+  XY acc = xyzz_inf<F>();
+  for (size_t j = lane; j < count; j += RED_TPB) acc = xyzz_add<F>(acc, ld_xy<F>(in + (o * stride_o + j * stride_j) * XYW));
+  acc = block_tree_sum<F>(acc, lds);
+  if (lane == 0) st_xy<F>((is_col ? colsum : rowsum) + o * XYW, acc);
 }
 // Bit classes of both weighted sums in one launch: blocks [0,nbA) slice colsum by the bits of (lo+1),
 // blocks [nbA, nbA+nbB) slice rowsum by the bits of hi.  D[t] for the final combine: t = bit (A) or lo_bits + bit (B).
+template <class F>
 __global__ void __launch_bounds__(RED_TPB) k_weight_bits(const uint32_t* __restrict__ colsum, size_t NLO, int nbA,
                                                          const uint32_t* __restrict__ rowsum, size_t NHI, uint32_t* __restrict__ clsA, uint32_t* __restrict__ clsB) {
+  constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
   __shared__ uint32_t lds[RED_TPB / 2 * XYW];
   const int lane = threadIdx.x;
   const bool isA = (int)blockIdx.x < nbA;
   const int bit = isA ? blockIdx.x : blockIdx.x - nbA;
   const uint32_t* in = isA ? colsum : rowsum; const size_t m = isA ? NLO : NHI; const uint32_t woff = isA ? 1u : 0u;
-  XY acc = xyzz_inf<FqOps>();
+  XY acc = xyzz_inf<F>();
   for (size_t i = lane; i < m; i += RED_TPB)
-    if (((uint32_t)i + woff) >> bit & 1) acc = xyzz_add<FqOps>(acc, ld_xy(in + i * XYW));
-  acc = block_tree_sum(acc, lds);
-  if (lane == 0) st_xy((isA ? clsA : clsB) + bit * XYW, acc);
+    if (((uint32_t)i + woff) >> bit & 1) acc = xyzz_add<F>(acc, ld_xy<F>(in + i * XYW));
+  acc = block_tree_sum<F>(acc, lds);
+  if (lane == 0) st_xy<F>((isA ? clsA : clsB) + bit * XYW, acc);
 }
 // total = sum_{b<=shift} 2^b A_b + 2^shift sum_b 2^b B_b = sum_t 2^t D_t with D_t = A_t (t<=shift) (+) B_{t-shift} (t>=shift).
 // One wave: lane t doubles D_t t times (<= 19 doublings instead of a 40-step serial Horner), then an LDS tree;
 // lane 0 writes the Jacobian sum and its affine normalisation.
+template <class F>
 __global__ void __launch_bounds__(64) k_combine(const uint32_t* __restrict__ clsA, int nbA, const uint32_t* __restrict__ clsB, int nbB, int shift,
                                                 uint32_t* __restrict__ out_jac, uint32_t* __restrict__ out_abi) {
+  constexpr int CW = Coord<F>::CW, XYW = 4 * CW; typedef Xyzz<F> XY;
   __shared__ uint32_t lds[32 * XYW];
   const int t = threadIdx.x;
-  XY v = xyzz_inf<FqOps>();
-  if (t < nbA) v = ld_xy(clsA + t * XYW);
-  if (t >= shift && t - shift < nbB) v = xyzz_add<FqOps>(v, ld_xy(clsB + (t - shift) * XYW));
-  for (int d = 0; d < t && t < 32; ++d) v = xyzz_dbl<FqOps>(v);
+  XY v = xyzz_inf<F>();
+  if (t < nbA) v = ld_xy<F>(clsA + t * XYW);
+  if (t >= shift && t - shift < nbB) v = xyzz_add<F>(v, ld_xy<F>(clsB + (t - shift) * XYW));
+  for (int d = 0; d < t && t < 32; ++d) v = xyzz_dbl<F>(v);
   for (int d = 16; d >= 1; d >>= 1) {
-    if (t >= d && t < 2 * d) st_xy(lds + (t - d) * XYW, v);
+    if (t >= d && t < 2 * d) st_xy<F>(lds + (t - d) * XYW, v);
     __syncthreads();
-    if (t < d) v = xyzz_add<FqOps>(v, ld_xy(lds + t * XYW));
+    if (t < d) v = xyzz_add<F>(v, ld_xy<F>(lds + t * XYW));
     __syncthreads();
   }
   if (t == 0) {
-    Jac<FqOps> j = xyzz_to_jac<FqOps>(v);
-    st_raw<FqC>(out_jac, j.X); st_raw<FqC>(out_jac + 12, j.Y); st_raw<FqC>(out_jac + 24, j.Z);
-    if (out_abi) PtIO<FqOps>::st(out_abi, xyzz_to_aff<FqOps>(v));
+    Jac<F> j = xyzz_to_jac<F>(v);
+    Coord<F>::st(out_jac, j.X); Coord<F>::st(out_jac + CW, j.Y); Coord<F>::st(out_jac + 2 * CW, j.Z);
+    if (out_abi) PtIO<F>::st(out_abi, xyzz_to_aff<F>(v));
   }
 }
 
@@ -357,7 +404,7 @@ struct MsmWs {   // workspace carve-up (one per in-flight MSM)
   uint2* order; size_t max_tasks;
 };
 MsmWs carve(const MsmPlan& P, void* workspace) {
-  const size_t B = P.nbuckets;
+  const size_t B = P.nbuckets, XYW = 4 * (size_t)coord_words(P.grp);
   uint8_t* ws = (uint8_t*)workspace;
   MsmWs w;
   w.zero_begin = (uint32_t*)ws;
@@ -388,7 +435,7 @@ MsmWs carve(const MsmPlan& P, void* workspace) {
 }  // namespace
 
 // stage 1 (atomic/memory bound): signed digits, counting sort by bucket, bucket order by population
-hipError_t launch_g1_msm_sort(const MsmPlan& P, const uint8_t* inf, const uint32_t* scalars, void* workspace, hipStream_t s) {
+hipError_t PART(launch_msm_sort)(const MsmPlan& P, const uint8_t* inf, const uint32_t* scalars, void* workspace, hipStream_t s) {
   const size_t B = P.nbuckets, n = P.n;
   MsmWs w = carve(P, workspace);
   hipError_t e;
@@ -408,48 +455,73 @@ hipError_t launch_g1_msm_sort(const MsmPlan& P, const uint8_t* inf, const uint32
   return hipGetLastError();
 }
 // stage 2 (VALU bound, the dominant kernel): one bucket per lane
-hipError_t launch_g1_msm_accumulate(const MsmPlan& P, const uint32_t* table, void* workspace, hipStream_t s) {
+hipError_t PART(launch_msm_accumulate)(const MsmPlan& P, const uint32_t* table, void* workspace, hipStream_t s) {
   MsmWs w = carve(P, workspace);
-  static const int acc_lds = getenv("ZKT_ACC_LDS") ? atoi(getenv("ZKT_ACC_LDS")) : 0;   // experiment: cap occupancy through dynamic LDS
-  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((w.max_tasks + 63) / 64)), dim3(64), acc_lds, s, table, (const uint32_t*)w.entries,
-                     (const uint32_t*)w.offsets, (const uint2*)w.order, (const uint32_t*)w.task_off, P.nbuckets, w.sums, w.partial);
+  MSM_DISPATCH(P.grp, hipLaunchKernelGGL(k_accumulate<F>, dim3((unsigned)((w.max_tasks + 63) / 64)), dim3(64), 0, s, table, (const uint32_t*)w.entries,
+                                         (const uint32_t*)w.offsets, (const uint2*)w.order, (const uint32_t*)w.task_off, P.nbuckets, w.sums, w.partial));
   return hipGetLastError();
 }
 // stage 3 (latency bound): sum_b (b+1) S_b, b = hi*NLO + lo  ->  Jacobian partial (+ affine point if out_abi)
-hipError_t launch_g1_msm_reduce(const MsmPlan& P, void* workspace, uint32_t* dev_result_jac, uint32_t* dev_out_abi, hipStream_t s) {
+hipError_t PART(launch_msm_reduce)(const MsmPlan& P, void* workspace, uint32_t* dev_result_jac, uint32_t* dev_out_abi, hipStream_t s) {
   const size_t B = P.nbuckets;
   MsmWs w = carve(P, workspace);
   const size_t NLO = B < 1024 ? B : 1024, NHI = B / NLO;
   int lo_bits = 0; while ((size_t(1) << lo_bits) < NLO) ++lo_bits;
   int hi_bits = 0; while ((size_t(1) << hi_bits) < NHI) ++hi_bits;
   const int nbA = lo_bits + 1, nbB = NHI > 1 ? hi_bits : 0;     // weights lo+1 in [1,NLO]; hi in [0,NHI)
-  hipLaunchKernelGGL(k_merge_partials, dim3((unsigned)(B < 2048 ? B : 2048)), dim3(RED_TPB), 0, s, (const uint32_t*)w.task_off, B, (const uint32_t*)w.partial, w.sums);
-  hipLaunchKernelGGL(k_marginals, dim3((unsigned)(NLO + (NHI > 1 ? NHI : 0))), dim3(RED_TPB), 0, s, (const uint32_t*)w.sums, NLO, NHI, w.colsum, w.rowsum);
-  hipLaunchKernelGGL(k_weight_bits, dim3((unsigned)(nbA + nbB)), dim3(RED_TPB), 0, s, (const uint32_t*)w.colsum, NLO, nbA, (const uint32_t*)w.rowsum, NHI, w.clsA, w.clsB);
-  hipLaunchKernelGGL(k_combine, dim3(1), dim3(64), 0, s, (const uint32_t*)w.clsA, nbA, (const uint32_t*)w.clsB, nbB, lo_bits, dev_result_jac, dev_out_abi);
+  MSM_DISPATCH(P.grp,
+    hipLaunchKernelGGL(k_merge_partials<F>, dim3((unsigned)(B < 2048 ? B : 2048)), dim3(RED_TPB), 0, s, (const uint32_t*)w.task_off, B, (const uint32_t*)w.partial, w.sums);
+    hipLaunchKernelGGL(k_marginals<F>, dim3((unsigned)(NLO + (NHI > 1 ? NHI : 0))), dim3(RED_TPB), 0, s, (const uint32_t*)w.sums, NLO, NHI, w.colsum, w.rowsum);
+    hipLaunchKernelGGL(k_weight_bits<F>, dim3((unsigned)(nbA + nbB)), dim3(RED_TPB), 0, s, (const uint32_t*)w.colsum, NLO, nbA, (const uint32_t*)w.rowsum, NHI, w.clsA, w.clsB);
+    hipLaunchKernelGGL(k_combine<F>, dim3(1), dim3(64), 0, s, (const uint32_t*)w.clsA, nbA, (const uint32_t*)w.clsB, nbB, lo_bits, dev_result_jac, dev_out_abi));
   return hipGetLastError();
 }
 
-// precompute launcher (declared here to keep the MSM layout private to this file)
-hipError_t launch_g1_precompute(uint32_t* table, uint8_t* inf, size_t n, int c, int nwin, hipStream_t s) {
+// window-multiple table build
+hipError_t PART(launch_msm_precompute)(int grp, uint32_t* table, uint8_t* inf, size_t n, int c, int nwin, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_precompute, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, table, inf, n, c, nwin);
+  MSM_DISPATCH(grp, hipLaunchKernelGGL(k_precompute<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, table, inf, n, c, nwin));
   return hipGetLastError();
 }
 
-// combine step of a sharded MSM + affine normalisation
+// combine step of a sharded MSM + affine normalisation: sum of `count` Jacobian partials (3*CW words each)
+template <class F>
 __global__ void k_jac_sum_to_affine(const uint32_t* __restrict__ parts, size_t count, uint32_t* __restrict__ out_abi) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Jac<FqOps> acc = jac_inf<FqOps>();
+  constexpr int CW = Coord<F>::CW;
+  Jac<F> acc = jac_inf<F>();
   for (size_t i = 0; i < count; ++i) {
-    Jac<FqOps> p; p.X = ld_raw<FqC>(parts + i * 36); p.Y = ld_raw<FqC>(parts + i * 36 + 12); p.Z = ld_raw<FqC>(parts + i * 36 + 24);
-    acc = jac_add<FqOps>(acc, p);
+    Jac<F> p; p.X = Coord<F>::ld(parts + i * 3 * CW); p.Y = Coord<F>::ld(parts + i * 3 * CW + CW); p.Z = Coord<F>::ld(parts + i * 3 * CW + 2 * CW);
+    acc = jac_add<F>(acc, p);
   }
-  PtIO<FqOps>::st(out_abi, jac_to_aff(acc));
+  PtIO<F>::st(out_abi, jac_to_aff(acc));
 }
-hipError_t launch_g1_jac_sum_to_affine(const uint32_t* parts, size_t count, uint32_t* out_abi, hipStream_t s) {
-  hipLaunchKernelGGL(k_jac_sum_to_affine, dim3(1), dim3(64), 0, s, parts, count, out_abi);
+hipError_t PART(launch_msm_jac_sum_to_affine)(int grp, const uint32_t* parts, size_t count, uint32_t* out_abi, hipStream_t s) {
+  MSM_DISPATCH(grp, hipLaunchKernelGGL(k_jac_sum_to_affine<F>, dim3(1), dim3(64), 0, s, parts, count, out_abi));
   return hipGetLastError();
 }
+
+
+#if defined(ZKT_MSM_PART_G1)
+// public entry points: G1 lives in this object, G2 / secp256k1 in the PART_OTHER object
+hipError_t launch_msm_to_kernel_layout_other(int, const uint32_t*, uint32_t*, uint8_t*, size_t, hipStream_t);
+hipError_t launch_msm_precompute_other(int, uint32_t*, uint8_t*, size_t, int, int, hipStream_t);
+hipError_t launch_msm_sort_other(const MsmPlan&, const uint8_t*, const uint32_t*, void*, hipStream_t);
+hipError_t launch_msm_accumulate_other(const MsmPlan&, const uint32_t*, void*, hipStream_t);
+hipError_t launch_msm_reduce_other(const MsmPlan&, void*, uint32_t*, uint32_t*, hipStream_t);
+hipError_t launch_msm_jac_sum_to_affine_other(int, const uint32_t*, size_t, uint32_t*, hipStream_t);
+hipError_t launch_msm_to_kernel_layout(int grp, const uint32_t* a, uint32_t* t, uint8_t* i, size_t n, hipStream_t s) {
+  return grp == G_G1 ? launch_msm_to_kernel_layout_g1(grp, a, t, i, n, s) : launch_msm_to_kernel_layout_other(grp, a, t, i, n, s); }
+hipError_t launch_msm_precompute(int grp, uint32_t* t, uint8_t* i, size_t n, int c, int nw, hipStream_t s) {
+  return grp == G_G1 ? launch_msm_precompute_g1(grp, t, i, n, c, nw, s) : launch_msm_precompute_other(grp, t, i, n, c, nw, s); }
+hipError_t launch_msm_sort(const MsmPlan& P, const uint8_t* i, const uint32_t* k, void* w, hipStream_t s) {
+  return P.grp == G_G1 ? launch_msm_sort_g1(P, i, k, w, s) : launch_msm_sort_other(P, i, k, w, s); }
+hipError_t launch_msm_accumulate(const MsmPlan& P, const uint32_t* t, void* w, hipStream_t s) {
+  return P.grp == G_G1 ? launch_msm_accumulate_g1(P, t, w, s) : launch_msm_accumulate_other(P, t, w, s); }
+hipError_t launch_msm_reduce(const MsmPlan& P, void* w, uint32_t* j, uint32_t* o, hipStream_t s) {
+  return P.grp == G_G1 ? launch_msm_reduce_g1(P, w, j, o, s) : launch_msm_reduce_other(P, w, j, o, s); }
+hipError_t launch_msm_jac_sum_to_affine(int grp, const uint32_t* p, size_t c, uint32_t* o, hipStream_t s) {
+  return grp == G_G1 ? launch_msm_jac_sum_to_affine_g1(grp, p, c, o, s) : launch_msm_jac_sum_to_affine_other(grp, p, c, o, s); }
+#endif
 
 }  // namespace zkt

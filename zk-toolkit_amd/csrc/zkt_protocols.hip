@@ -140,26 +140,6 @@ extern void zkt_internal_set_error_index(size_t i);
 
 extern "C" {
 
-// eval_with_g2_hidings (polynomial.rs:283-293) and the secp256k1 vector form (affine_points.rs:25-31,123-144):
-// n scalar multiplications then a pairwise-tree sum.  (G1 has the Pippenger path in zkt_msm.hip.)
-static int msm_simple(int grp, const void* bases, const uint64_t* scalars, size_t n, void* out) {
-  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
-  const size_t PB = grp == G_G2 ? G2B : SPB;
-  if (!out || (n && (!bases || !scalars))) return ZKT_ERR_SHAPE;
-  if (n == 0) { memset(out, 0, PB); ((uint32_t*)out)[PB / 4 - 2] = 1; return ZKT_OK; }
-  hipStream_t s = nullptr;
-  Dev db(n * PB), dk(n * FRB), dt(n * PB);
-  int rc; if ((rc = up(db, bases, n * PB, s)) || (rc = up(dk, scalars, n * FRB, s))) return rc;
-  if (!dt.p) return ZKT_ERR_DEVICE;
-  PCHK(launch_group_mul(grp, db.w(), dk.w(), 8, dt.w(), n, s));
-  PCHK(launch_group_sum_inplace(grp, dt.w(), n, s));
-  if ((rc = down(out, dt.p, PB, s))) return rc;
-  PCHK(hipStreamSynchronize(s));
-  return ZKT_OK;
-}
-int zkt_g2_msm(const zkt_g2_affine* bases, const uint64_t* scalars, size_t n, zkt_g2_affine* out) { return msm_simple(G_G2, bases, scalars, n, out); }
-int zkt_secp_msm(const zkt_secp_affine* bases, const uint64_t* scalars, size_t n, zkt_secp_affine* out) { return msm_simple(G_SECP, bases, scalars, n, out); }
-
 // CRS::new (crs.rs:49-146), trapdoors injected.  ui/vi/wi: (m+1) x n Fr coefficients, low degree first.
 int zkt_groth16_setup(zkt_groth16_crs* c, const uint64_t* ui, const uint64_t* vi, const uint64_t* wi,
                       const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma, const uint64_t* delta, const uint64_t* x) {
