@@ -6,7 +6,7 @@ Tate-pairing rate, on MI355X.  Contract: python bench.py --gpus N --steps K --wa
 step  = one MSM over 2^20 device-resident bases (a CRS) and 2^20 device-resident 255-bit
         scalars, result normalised to an affine point on the host.
 N>1   = each rank owns a 2^20-term shard of one N*2^20-term MSM (weak scaling); the only
-        exchange is an all_gather of the 144-byte Jacobian partial sums + a local add.
+        exchange is an all_gather of the 168-byte Jacobian partial sums + a local add.
 value = total scalar-muls per second over all ranks (terms / wall time, max over ranks)."""
 import argparse, ctypes, importlib, json, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the MSM pipeline wants its three stage streams on distinct hardware queues
@@ -94,7 +94,7 @@ def main():
     elif args.scalar_dist == "bits":
         h_scalars[:, 1:] = 0; h_scalars[:, 0] &= np.uint64(1)
     d_scalars = torch.from_numpy(h_scalars.view(np.int64)).to(dev)
-    d_partial = torch.zeros(36, dtype=torch.int32, device=dev)
+    d_partial = torch.zeros(zk.G1_PARTIAL_WORDS, dtype=torch.int32, device=dev)
     out = np.zeros((1, 13), dtype=np.uint64)
     outp = out.ctypes.data_as(ctypes.c_void_p)
 
@@ -102,13 +102,13 @@ def main():
     NSLOT = 8          # ZKT_MSM_SLOTS
 
     def finish(slot):
-        """collect one MSM; for N>1 also the exchange step: all_gather of the 144-B partials + local add."""
+        """collect one MSM; for N>1 also the exchange step: all_gather of the 168-B partials + local add."""
         if world == 1:
             zk.check(L.zkt_g1_msm_collect(h, slot, outp, None))
         else:
             zk.check(L.zkt_g1_msm_collect(h, slot, None, vp(d_partial)))
             if backend == "nccl":
-                g = sharded.sharded_sum(d_partial, lambda stack: stack.contiguous())      # RCCL all_gather of the 144-B partials
+                g = sharded.sharded_sum(d_partial, lambda stack: stack.contiguous())      # RCCL all_gather of the 168-B partials
             else:
                 g = sharded.sharded_sum(d_partial.cpu(), lambda stack: stack.contiguous()).to(dev)
             torch.cuda.current_stream().synchronize()
@@ -158,7 +158,7 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32 limbs (384-bit Montgomery integer)", "data": "synthetic",
         "config": {"workload": "Batched G1 Pippenger MSM, 2^%d random bases/scalars per GPU, bases device-resident with window multiples" % args.log2n,
-                   "terms_per_gpu": n, "scalar_bits": 255, "scalar_dist": args.scalar_dist, "sharding": "index range per rank; all_gather of 144-B partial sums" if world > 1 else "none",
+                   "terms_per_gpu": n, "scalar_bits": 255, "scalar_dist": args.scalar_dist, "sharding": "index range per rank; all_gather of 168-B partial sums" if world > 1 else "none",
                    "bases_setup_s": round(setup_s, 3), "msms_in_flight": DEPTH,
                    "single_msm_latency_ms": round(latency_ms, 3) if world == 1 else None},
         "roofline": {"bound": "hbm", "kernel": L.zkt_last_kernel_name().decode(),

@@ -170,7 +170,8 @@ size_t zkt_g1_bases_len(const zkt_g1_bases* b);
 void zkt_g1_bases_free(zkt_g1_bases* b);
 /* MSM over resident bases and DEVICE scalars (4 limbs each).  Writes the affine sum to
  * host `out` (blocking) — and, if `dev_partial_jac` is non-NULL, the un-normalised
- * Jacobian partial sum (36 u32 words X,Y,Z Montgomery) to that DEVICE buffer for a
+ * Jacobian partial sum (ZKT_G1_PARTIAL_WORDS u32 words: X,Y,Z in the engine's internal
+ * limb form, opaque to the caller) to that DEVICE buffer for a
  * multi-GPU combine (see zkt_g1_jac_sum_dev). */
 int zkt_g1_msm_dev(const zkt_g1_bases* bases, const uint64_t* dev_scalars, size_t n, void* stream,
                    zkt_g1_affine* out, uint32_t* dev_partial_jac);
@@ -180,15 +181,19 @@ int zkt_g1_msm_dev(const zkt_g1_bases* bases, const uint64_t* dev_scalars, size_
  * everything already enqueued on `stream` (where the scalars are produced) and returns at once;
  * collect() blocks until that slot's affine result (and optional Jacobian partial) is available. */
 #define ZKT_MSM_SLOTS 8
+/* u32 words of one opaque Jacobian partial sum (3 internal coordinates) per group */
+#define ZKT_G1_PARTIAL_WORDS 42
+#define ZKT_G2_PARTIAL_WORDS 84
+#define ZKT_SECP_PARTIAL_WORDS 24
 int zkt_g1_msm_submit(zkt_g1_bases* bases, const uint64_t* dev_scalars, size_t n, void* stream, int slot);
 int zkt_g1_msm_collect(zkt_g1_bases* bases, int slot, zkt_g1_affine* out, uint32_t* dev_partial_jac);
-/* combine step of a sharded MSM: sum `count` Jacobian partials (36 u32 words each, device)
+/* combine step of a sharded MSM: sum `count` Jacobian partials (ZKT_G1_PARTIAL_WORDS u32 words each, device)
  * and normalise to affine on the host */
 int zkt_g1_jac_sum_dev(const uint32_t* dev_partials, size_t count, void* stream, zkt_g1_affine* out);
 /* bytes of device workspace a zkt_g1_msm_dev of n terms allocates once and keeps */
 size_t zkt_g1_msm_workspace_bytes(size_t n);
 
-/* the same resident-bases / pipelined MSM interface for G2 and secp256k1 (Jacobian partial = 72 / 24 u32 words) */
+/* the same resident-bases / pipelined MSM interface for G2 and secp256k1 (Jacobian partial = ZKT_G2_PARTIAL_WORDS / ZKT_SECP_PARTIAL_WORDS u32 words) */
 typedef struct zkt_g2_bases zkt_g2_bases;
 typedef struct zkt_secp_bases zkt_secp_bases;
 int zkt_g2_bases_upload(const zkt_g2_affine* host_bases, size_t n, zkt_g2_bases** out);

@@ -44,6 +44,54 @@ def test_field_ops(H, field, mod, w, pre):
         assert arr_to_ints(o) == [pow(x, -1, mod) for x in arr_to_ints(nz)], op
 
 
+def _fq_program_model(seed, steps, regs):
+    st = seed
+    r = list(regs)
+    for _ in range(steps):
+        st = (st * 6364136223846793005 + 1442695040888963407) & (2**64 - 1)
+        op, d, a, b = (st >> 33) % 10, (st >> 40) & 3, (st >> 42) & 3, (st >> 44) & 3
+        if op in (0, 1): r[d] = (r[a] + r[b]) % Q
+        elif op in (2, 3): r[d] = (r[a] - r[b]) % Q
+        elif op == 4: r[d] = -r[a] % Q
+        elif op == 5: r[d] = 2 * r[a] % Q
+        elif op == 6: r[d] = r[a] * r[b] % Q
+        elif op == 7: r[d] = r[a] * r[a] % Q
+        elif op == 8: r[d] = r[a]
+        else: r[d] = 1 if r[a] == r[b] else (r[a] + 1) % Q
+    return r
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fq_lazy_limb_programs(H, seed):
+    """Fq is held in 14 lazily-reduced 28-bit limbs (< 4p): long random op chains, non-canonical representatives and
+    boundary operands must keep the limb/size invariants and give the residues plain mod-p arithmetic gives."""
+    rng = SplitMix64(900 + seed)
+    edge = [0, 1, Q - 1, Q - 2, 2, (Q + 1) // 2, (1 << 380), (1 << 364) - 1, Q - (1 << 364), (1 << 28) - 1, Q >> 1]
+    regs = [edge[(seed + i) % len(edge)] if (seed + i) % 3 == 0 else rng.below(Q) for i in range(4)]
+    if seed == 1: regs = [0, 0, Q - 1, 1]
+    if seed == 2: regs = [Q - 1, Q - 1, Q - 1, Q - 1]
+    a = ints_to_arr(regs, 6); o = np.zeros_like(a)
+    H.zkt_hostcheck_fq_program.argtypes = [ctypes.c_uint64, ctypes.c_int, _u32p, _u32p]
+    steps = 4000
+    assert H.zkt_hostcheck_fq_program(seed * 7919 + 1, steps, p32(a), p32(o)) == 0        # no invariant violation
+    assert arr_to_ints(o) == _fq_program_model(seed * 7919 + 1, steps, regs)
+
+
+def test_fq_lazy_reduce_quotient_estimate():
+    """fp_lazy_reduce's q = floor(top * QEST_M / 2^32) from the top limb alone: never above floor(v/p) and at most 3
+    below it for every v < 12p (so a reduced value is < 4p).  Checked at the extremes of every reachable top limb."""
+    top_p = Q >> 364
+    M = (1 << 32) // (top_p + 1)
+    for top in range(0, (12 * Q >> 364) + 1):
+        q = (top * M) >> 32
+        # un-normalised input: the limbs below the top may each hold up to 3*2^28, i.e. spill < 4 units into the top
+        lo, hi = top << 364, min(((top + 4) << 364) - 1, 12 * Q - 1)
+        assert q * Q <= lo                                 # never overshoots: v - q*p >= 0
+        assert hi - q * Q < 4 * Q                          # result < 4p
+    # add: operands < 4p -> v < 8p; sub: a + 8p - b < 12p, limbs stay below 2^31 (fp.h bounds)
+    assert (12 * Q >> 364) * M < 2**63
+
+
 @pytest.mark.parametrize("field,mod", [(2, SECP_P), (3, SECP_N)])
 def test_field_ops_256bit_moduli(H, field, mod):
     rng = SplitMix64(41 + field)

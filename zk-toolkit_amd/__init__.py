@@ -13,6 +13,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "zkt.h")
 
 ZKT_OK, ZKT_ERR_INV_ZERO, ZKT_ERR_INFINITY, ZKT_ERR_SHAPE, ZKT_ERR_DEVICE = 0, 1, 2, 3, 4
 G1_WORDS64, G2_WORDS64, FQ12_WORDS64 = 13, 25, 72
+G1_PARTIAL_WORDS, G2_PARTIAL_WORDS, SECP_PARTIAL_WORDS = 42, 84, 24   # ZKT_*_PARTIAL_WORDS: u32 words of one opaque Jacobian partial
 
 _lib = None
 

@@ -18,9 +18,9 @@ template <class C> ZKT_HD Fp<C> ld_raw(const uint32_t* p) { Fp<C> r;
 template <class C> ZKT_HD void st_raw(uint32_t* p, const Fp<C>& a) {
 #pragma unroll
   for (int i = 0; i < C::N; ++i) p[i] = a.v[i]; }
-// canonical in memory <-> Montgomery in registers
-template <class C> ZKT_HD Fp<C> ld_fp(const uint32_t* p) { return fp_to_mont(ld_raw<C>(p)); }
-template <class C> ZKT_HD void st_fp(uint32_t* p, const Fp<C>& a) { st_raw<C>(p, fp_from_mont(a)); }
+// canonical in memory (C::ABI_N words) <-> Montgomery in registers (C::N limbs)
+template <class C> ZKT_HD Fp<C> ld_fp(const uint32_t* p) { return fp_from_words<C>(p); }
+template <class C> ZKT_HD void st_fp(uint32_t* p, const Fp<C>& a) { fp_to_words(a, p); }
 
 ZKT_HD Fq2 ld_fq2(const uint32_t* p) { Fq2 r; r.c1 = ld_fp<FqC>(p); r.c0 = ld_fp<FqC>(p + 12); return r; }
 ZKT_HD void st_fq2(uint32_t* p, const Fq2& a) { st_fp<FqC>(p, a.c1); st_fp<FqC>(p + 12, a.c0); }
@@ -32,23 +32,23 @@ ZKT_HD void st_fq12(uint32_t* p, const Fq12& a) { st_fq6(p, a.c1); st_fq6(p + 72
 // point loaders per coordinate field
 template <class F> struct PtIO;
 template <class C> struct PtIO<PrimeOps<C>> {
-  static constexpr int COORD = C::N, WORDS = 2 * C::N + 2;
+  static constexpr int A = C::ABI_N, WORDS = 2 * A + 2;
   ZKT_HD static Aff<PrimeOps<C>> ld(const uint32_t* p) {
-    Aff<PrimeOps<C>> a; a.inf = p[2 * C::N] != 0;
-    a.x = ld_fp<C>(p); a.y = ld_fp<C>(p + C::N);
+    Aff<PrimeOps<C>> a; a.inf = p[2 * A] != 0;
+    a.x = ld_fp<C>(p); a.y = ld_fp<C>(p + A);
     return a;
   }
   ZKT_HD static void st(uint32_t* p, const Aff<PrimeOps<C>>& a) {
     if (a.inf) {
 #pragma unroll
-      for (int i = 0; i < 2 * C::N; ++i) p[i] = 0;
-      p[2 * C::N] = 1; p[2 * C::N + 1] = 0; return;
+      for (int i = 0; i < 2 * A; ++i) p[i] = 0;
+      p[2 * A] = 1; p[2 * A + 1] = 0; return;
     }
-    st_fp<C>(p, a.x); st_fp<C>(p + C::N, a.y); p[2 * C::N] = 0; p[2 * C::N + 1] = 0;
+    st_fp<C>(p, a.x); st_fp<C>(p + A, a.y); p[2 * A] = 0; p[2 * A + 1] = 0;
   }
 };
 template <> struct PtIO<Fq2Ops> {
-  static constexpr int COORD = 24, WORDS = 50;
+  static constexpr int WORDS = 50;
   ZKT_HD static Aff<Fq2Ops> ld(const uint32_t* p) {
     Aff<Fq2Ops> a; a.inf = p[48] != 0; a.x = ld_fq2(p); a.y = ld_fq2(p + 24); return a;
   }

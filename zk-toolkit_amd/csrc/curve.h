@@ -27,8 +27,6 @@ template <class C> struct PrimeOps {
   ZKT_HD static E inv(const E& a) { return fp_inv(a); }
   ZKT_HD static bool is_zero(const E& a) { return fp_is_zero(a); }
   ZKT_HD static bool eq(const E& a, const E& b) { return fp_eq(a, b); }
-  ZKT_HD static E to_mont(const E& a) { return fp_to_mont(a); }
-  ZKT_HD static E from_mont(const E& a) { return fp_from_mont(a); }
 };
 typedef PrimeOps<FqC> FqOps;
 typedef PrimeOps<SpC> SpOps;
@@ -45,8 +43,6 @@ struct Fq2Ops {
   ZKT_HD static E inv(const E& a) { return fq2_inv(a); }
   ZKT_HD static bool is_zero(const E& a) { return fq2_is_zero(a); }
   ZKT_HD static bool eq(const E& a, const E& b) { return fq2_eq(a, b); }
-  ZKT_HD static E to_mont(const E& a) { return fq2_to_mont(a); }
-  ZKT_HD static E from_mont(const E& a) { return fq2_from_mont(a); }
 };
 
 // ---- point types (coordinates in the Montgomery domain) -----------------------

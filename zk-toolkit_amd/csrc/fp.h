@@ -1,5 +1,12 @@
-// Prime-field arithmetic for gfx950 (CDNA4): N x 32-bit limbs, Montgomery form
-// internally, canonical residues in [0,p) at every function boundary.
+// Prime-field arithmetic for gfx950 (CDNA4), Montgomery form internally, canonical
+// residues in [0,p) at every ABI boundary.  Two limb layouts, chosen per field by C::W:
+//   W = 32  N x 32-bit limbs, values always canonical (< p): Fr and the secp256k1 fields.
+//   W = 28  N x 28-bit limbs, R = 2^(28N), values lazily reduced (< 4p, limbs < 2^28):
+//           BLS12-381 Fq, the field under every hot kernel.  A column of the product
+//           scan sums 2N products < 2^56 and fits one 64-bit accumulator, so the
+//           multiply is pure v_mad_u64_u32 (no v_addc per product), squaring can share
+//           cross products, and add/sub are carry-free limb adds plus one fused
+//           "subtract floor-estimate * p and propagate" pass (fp_lazy_reduce).
 //
 // Replaces the reference's PrimeFieldElem (BigUint residue, `*` then `%`):
 //   src/building_block/field/prime_field_elem.rs:263-457   (reference paths are
@@ -56,12 +63,23 @@ template <class C> ZKT_HD Fp<C> fp_zero() { Fp<C> r;
 template <class C> ZKT_HD Fp<C> fp_one() { Fp<C> r;   // Montgomery 1 = R mod p
 #pragma unroll
   for (int i = 0; i < C::N; ++i) r.v[i] = C::one(i); return r; }
-template <class C> ZKT_HD bool fp_is_zero(const Fp<C>& a) { uint32_t o = 0;
+// W = 28: a lazily reduced value is zero iff it is one of 0, p, 2p, 3p.  The first limbs of
+// those four differ from a random limb with probability 1 - 2^-26, so test limb 0 first.
+template <class C> ZKT_HD bool fp_is_zero(const Fp<C>& a) {
+  if constexpr (C::W == 28) {
+    const uint32_t a0 = a.v[0];
+    if (!((a0 == C::kp(0, 0)) | (a0 == C::kp(1, 0)) | (a0 == C::kp(2, 0)) | (a0 == C::kp(3, 0)))) return false;
+    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
 #pragma unroll
-  for (int i = 0; i < C::N; ++i) o |= a.v[i]; return o == 0; }
-template <class C> ZKT_HD bool fp_eq(const Fp<C>& a, const Fp<C>& b) { uint32_t o = 0;
+    for (int i = 0; i < C::N; ++i) { o0 |= a.v[i]; o1 |= a.v[i] ^ C::kp(1, i); o2 |= a.v[i] ^ C::kp(2, i); o3 |= a.v[i] ^ C::kp(3, i); }
+    return (o0 == 0) | (o1 == 0) | (o2 == 0) | (o3 == 0);
+  } else {
+    uint32_t o = 0;
 #pragma unroll
-  for (int i = 0; i < C::N; ++i) o |= a.v[i] ^ b.v[i]; return o == 0; }
+    for (int i = 0; i < C::N; ++i) o |= a.v[i];
+    return o == 0;
+  }
+}
 
 // t (N limbs + carry word `top`) -> t - p if t >= p.  Requires t < 2p.
 template <class C> ZKT_HD void fp_cond_sub(Fp<C>& r, uint32_t top) {
@@ -73,62 +91,164 @@ template <class C> ZKT_HD void fp_cond_sub(Fp<C>& r, uint32_t top) {
   for (int i = 0; i < C::N; ++i) r.v[i] = keep ? r.v[i] : s[i];
 }
 
-// plus (prime_field_elem.rs:278-286)
-template <class C> ZKT_HD Fp<C> fp_add(const Fp<C>& a, const Fp<C>& b) {
-  Fp<C> r; uint32_t c = 0;
+// W = 28.  v: limbs < 2^31, value < 12p.  Returns the same residue with limbs < 2^28 and value < 4p.
+// q = floor(v_top * QEST_M / 2^32) never exceeds floor(v/p) and is at most 3 below it for v < 12p
+// (checked exhaustively over the reachable top limbs in tests/test_hostcheck.py); the pass adds
+// q*(2^(WN) - p) limb by limb while propagating carries, and the 2^(WN) bit falls off the top.
+template <class C> ZKT_HD Fp<C> fp_lazy_reduce(const uint32_t* v) {
+  constexpr uint32_t M = (1u << C::W) - 1;
+  Fp<C> r; const uint32_t q = (uint32_t)(((uint64_t)v[C::N - 1] * C::QEST_M) >> 32);
+  uint32_t carry = 0;
 #pragma unroll
-  for (int i = 0; i < C::N; ++i) r.v[i] = addc(a.v[i], b.v[i], c);
-  fp_cond_sub(r, c);
+  for (int i = 0; i < C::N; ++i) {
+    uint64_t t = (uint64_t)q * C::comp(i) + (uint64_t)(v[i] + carry);
+    r.v[i] = (uint32_t)t & M; carry = (uint32_t)(t >> C::W);
+  }
   return r;
 }
-// minus (prime_field_elem.rs:288-300): a<b -> p-(b-a)
+
+// plus (prime_field_elem.rs:278-286)
+template <class C> ZKT_HD Fp<C> fp_add(const Fp<C>& a, const Fp<C>& b) {
+  if constexpr (C::W == 28) {
+    uint32_t v[C::N];
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) v[i] = a.v[i] + b.v[i];
+    return fp_lazy_reduce<C>(v);
+  } else {
+    Fp<C> r; uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) r.v[i] = addc(a.v[i], b.v[i], c);
+    fp_cond_sub(r, c);
+    return r;
+  }
+}
+// minus (prime_field_elem.rs:288-300): a<b -> p-(b-a).  W = 28: a + 8p - b with 8p spread so no limb borrows.
 template <class C> ZKT_HD Fp<C> fp_sub(const Fp<C>& a, const Fp<C>& b) {
-  Fp<C> r; uint32_t bw = 0;
+  if constexpr (C::W == 28) {
+    uint32_t v[C::N];
 #pragma unroll
-  for (int i = 0; i < C::N; ++i) r.v[i] = subb(a.v[i], b.v[i], bw);
-  uint32_t mask = 0u - bw, c = 0;
+    for (int i = 0; i < C::N; ++i) v[i] = a.v[i] + C::subk(i) - b.v[i];
+    return fp_lazy_reduce<C>(v);
+  } else {
+    Fp<C> r; uint32_t bw = 0;
 #pragma unroll
-  for (int i = 0; i < C::N; ++i) r.v[i] = addc(r.v[i], C::mod(i) & mask, c);
-  return r;
+    for (int i = 0; i < C::N; ++i) r.v[i] = subb(a.v[i], b.v[i], bw);
+    uint32_t mask = 0u - bw, c = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) r.v[i] = addc(r.v[i], C::mod(i) & mask, c);
+    return r;
+  }
 }
 // negate (prime_field_elem.rs:448-457): 0 stays 0
 template <class C> ZKT_HD Fp<C> fp_neg(const Fp<C>& a) {
-  Fp<C> r; uint32_t bw = 0;
+  if constexpr (C::W == 28) {
+    return fp_sub(fp_zero<C>(), a);
+  } else {
+    Fp<C> r; uint32_t bw = 0;
 #pragma unroll
-  for (int i = 0; i < C::N; ++i) r.v[i] = subb(C::mod(i), a.v[i], bw);
-  uint32_t mask = fp_is_zero(a) ? 0u : 0xffffffffu;
+    for (int i = 0; i < C::N; ++i) r.v[i] = subb(C::mod(i), a.v[i], bw);
+    uint32_t mask = fp_is_zero(a) ? 0u : 0xffffffffu;
 #pragma unroll
-  for (int i = 0; i < C::N; ++i) r.v[i] &= mask;
-  return r;
+    for (int i = 0; i < C::N; ++i) r.v[i] &= mask;
+    return r;
+  }
+}
+template <class C> ZKT_HD bool fp_eq(const Fp<C>& a, const Fp<C>& b) {
+  if constexpr (C::W == 28) {
+    return fp_is_zero(fp_sub(a, b));
+  } else {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+  }
 }
 template <class C> ZKT_HD Fp<C> fp_dbl(const Fp<C>& a) { return fp_add(a, a); }
 
-// Montgomery product a*b*R^-1 mod p, inputs and output in [0,p).
-// times (prime_field_elem.rs:302-308) in the Montgomery domain.
+// acc += a*b on one 64-bit column accumulator (W = 28 path): a single v_mad_u64_u32
+ZKT_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+
+// Montgomery product a*b*R^-1 mod p.  times (prime_field_elem.rs:302-308) in the Montgomery domain.
+// W = 32: inputs and output in [0,p).
+// W = 28: inputs < 4p with limbs < 2^28; output (ab + mp)/R < p(1 + 16p/R) < 1.01p, limbs < 2^28.
+//         Column sums: 28 products < 2^56 plus a carry < 2^36 stay below 2^61.
 template <class C> ZKT_HD Fp<C> fp_mul_impl(const Fp<C>& a, const Fp<C>& b) {
   constexpr int N = C::N;
   Fp<C> r; uint32_t m[N];
-  uint64_t lo = 0; uint32_t hi = 0;
+  if constexpr (C::W == 28) {
+    constexpr uint32_t M = (1u << 28) - 1;
+    uint64_t acc = 0;
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
+    for (int k = 0; k < N; ++k) {
 #pragma unroll
-    for (int i = 0; i <= k; ++i) mac(lo, hi, a.v[i], b.v[k - i]);
+      for (int i = 0; i <= k; ++i) acc = mad64(a.v[i], b.v[k - i], acc);
 #pragma unroll
-    for (int j = 0; j < k; ++j) mac_k(lo, hi, m[j], C::mod(k - j));
-    m[k] = (uint32_t)lo * C::INV;
-    mac_k(lo, hi, m[k], C::mod(0));
-    lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
+      for (int j = 0; j < k; ++j) acc = mad64(m[j], C::mod(k - j), acc);
+      m[k] = ((uint32_t)acc * C::INV) & M;
+      acc = mad64(m[k], C::mod(0), acc);
+      acc >>= 28;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N; ++k) {
+#pragma unroll
+      for (int i = k - N + 1; i < N; ++i) acc = mad64(a.v[i], b.v[k - i], acc);
+#pragma unroll
+      for (int j = k - N + 1; j < N; ++j) acc = mad64(m[j], C::mod(k - j), acc);
+      r.v[k - N] = (uint32_t)acc & M;
+      acc >>= 28;
+    }
+    return r;
+  } else {
+    uint64_t lo = 0; uint32_t hi = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+      for (int i = 0; i <= k; ++i) mac(lo, hi, a.v[i], b.v[k - i]);
+#pragma unroll
+      for (int j = 0; j < k; ++j) mac_k(lo, hi, m[j], C::mod(k - j));
+      m[k] = (uint32_t)lo * C::INV;
+      mac_k(lo, hi, m[k], C::mod(0));
+      lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N; ++k) {
+#pragma unroll
+      for (int i = k - N + 1; i < N; ++i) mac(lo, hi, a.v[i], b.v[k - i]);
+#pragma unroll
+      for (int j = k - N + 1; j < N; ++j) mac_k(lo, hi, m[j], C::mod(k - j));
+      r.v[k - N] = (uint32_t)lo;
+      lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
+    }
+    fp_cond_sub(r, (uint32_t)lo);
+    return r;
   }
+}
+
+// W = 28 squaring: each cross product once against the pre-doubled operand (limbs < 2^29, so the
+// doubled products stay < 2^57 and a column still fits 64 bits): 105 + 196 MADs instead of 392.
+template <class C> ZKT_HD Fp<C> fp_sqr_impl(const Fp<C>& a) {
+  static_assert(C::W == 28, "lazy-limb fields only");
+  constexpr int N = C::N; constexpr uint32_t M = (1u << 28) - 1;
+  Fp<C> r; uint32_t m[N], d[N]; uint64_t acc = 0;
 #pragma unroll
-  for (int k = N; k < 2 * N; ++k) {
+  for (int i = 0; i < N; ++i) d[i] = a.v[i] << 1;
 #pragma unroll
-    for (int i = k - N + 1; i < N; ++i) mac(lo, hi, a.v[i], b.v[k - i]);
+  for (int k = 0; k < 2 * N; ++k) {
 #pragma unroll
-    for (int j = k - N + 1; j < N; ++j) mac_k(lo, hi, m[j], C::mod(k - j));
-    r.v[k - N] = (uint32_t)lo;
-    lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0;
+    for (int i = (k < N ? 0 : k - N + 1); 2 * i < k; ++i) acc = mad64(d[i], a.v[k - i], acc);
+    if ((k & 1) == 0) acc = mad64(a.v[k / 2], a.v[k / 2], acc);
+    if (k < N) {
+#pragma unroll
+      for (int j = 0; j < k; ++j) acc = mad64(m[j], C::mod(k - j), acc);
+      m[k] = ((uint32_t)acc * C::INV) & M;
+      acc = mad64(m[k], C::mod(0), acc);
+    } else {
+#pragma unroll
+      for (int j = k - N + 1; j < N; ++j) acc = mad64(m[j], C::mod(k - j), acc);
+      r.v[k - N] = (uint32_t)acc & M;
+    }
+    acc >>= 28;
   }
-  fp_cond_sub(r, (uint32_t)lo);
   return r;
 }
 
@@ -140,32 +260,68 @@ template <class C> ZKT_HD Fp<C> fp_mul_impl(const Fp<C>& a, const Fp<C>& b) {
 // kernels define ZKT_INLINE_MUL before including this header.
 #if !defined(ZKT_INLINE_MUL)
 template <class C> ZKT_FN Fp<C> fp_mul(Fp<C> a, Fp<C> b) { return fp_mul_impl(a, b); }
+template <class C> ZKT_FN Fp<C> fp_sqr_fn(Fp<C> a) { return fp_sqr_impl(a); }
 #else
 template <class C> ZKT_HD Fp<C> fp_mul(const Fp<C>& a, const Fp<C>& b) { return fp_mul_impl(a, b); }
+template <class C> ZKT_HD Fp<C> fp_sqr_fn(const Fp<C>& a) { return fp_sqr_impl(a); }
 #endif
 
-// Montgomery square.  sq (prime_field_elem.rs:330-335).  A dedicated squaring
-// (cross products once, doubled per column) saves 66 of the 300 MAD pairs but
-// pays ~6 shift/add ops per column for the 96-bit doubling — no net win while
-// v_mad_u64_u32 issues at the plain VALU rate, so it is the product.
-template <class C> ZKT_HD Fp<C> fp_sqr(const Fp<C>& a) { return fp_mul(a, a); }
+// Montgomery square.  sq (prime_field_elem.rs:330-335).  With 32-bit limbs a dedicated squaring
+// pays ~6 shift/add ops per column for the 96-bit doubling and does not win, so it is the product;
+// with 28-bit limbs the doubling is free (see fp_sqr_impl).
+template <class C> ZKT_HD Fp<C> fp_sqr(const Fp<C>& a) {
+  if constexpr (C::W == 28) return fp_sqr_fn(a); else return fp_mul(a, a);
+}
 
-// canonical <-> Montgomery
-template <class C> ZKT_HD Fp<C> fp_to_mont(const Fp<C>& a) {
-  Fp<C> r2;
+// canonical words (ABI_N x 32 bit, < p) <-> internal Montgomery form
+template <class C> ZKT_HD Fp<C> fp_from_words(const uint32_t* w) {
+  Fp<C> x, r2;
 #pragma unroll
   for (int i = 0; i < C::N; ++i) r2.v[i] = C::r2(i);
-  return fp_mul(a, r2);
+  if constexpr (C::W == 28) {
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) {
+      const int lo = (28 * i) >> 5, sh = (28 * i) & 31;
+      uint32_t t = w[lo] >> sh;
+      if (sh > 4 && lo + 1 < C::ABI_N) t |= w[lo + 1] << (32 - sh);
+      x.v[i] = t & 0x0fffffffu;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) x.v[i] = w[i];
+  }
+  return fp_mul(x, r2);
 }
-template <class C> ZKT_HD Fp<C> fp_from_mont(const Fp<C>& a) {
+template <class C> ZKT_HD void fp_to_words(const Fp<C>& a, uint32_t* w) {
   Fp<C> one = fp_zero<C>(); one.v[0] = 1;
-  return fp_mul(a, one);
+  Fp<C> x = fp_mul(a, one);
+  if constexpr (C::W == 28) {
+    // x < 1.01p: one conditional subtraction makes it canonical
+    uint32_t s[C::N], bw = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) { uint32_t t = x.v[i] - C::mod(i) - bw; bw = t >> 31; s[i] = t & 0x0fffffffu; }
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) s[i] = bw ? x.v[i] : s[i];
+#pragma unroll
+    for (int j = 0; j < C::ABI_N; ++j) {
+      uint32_t t = 0;
+#pragma unroll
+      for (int i = 0; i < C::N; ++i) {
+        const int sft = 28 * i - 32 * j;
+        if (sft > -28 && sft < 32) t |= sft >= 0 ? (s[i] << (sft & 31)) : (s[i] >> ((-sft) & 31));
+      }
+      w[j] = t;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) w[i] = x.v[i];
+  }
 }
 // is a canonical input really < p ?  (ABI contract check)
-template <class C> ZKT_HD bool fp_is_canonical(const Fp<C>& a) {
+template <class C> ZKT_HD bool fp_words_canonical(const uint32_t* w) {
   uint32_t bw = 0;
 #pragma unroll
-  for (int i = 0; i < C::N; ++i) (void)subb(a.v[i], C::mod(i), bw);
+  for (int i = 0; i < C::ABI_N; ++i) (void)subb(w[i], C::mod32(i), bw);
   return bw != 0;
 }
 
@@ -176,11 +332,11 @@ template <class C> ZKT_HD bool fp_is_canonical(const Fp<C>& a) {
 template <class C> ZKT_FN Fp<C> fp_inv_fermat(Fp<C> a) {
   Fp<C> r = fp_one<C>();
   bool started = false;
-  for (int i = C::N * 32 - 1; i >= 0; --i) {
+  for (int i = C::ABI_N * 32 - 1; i >= 0; --i) {
     uint32_t w = 0;
     // constant table lookup with a run-time index: select via unrolled compare
 #pragma unroll
-    for (int j = 0; j < C::N; ++j) w = (j == (i >> 5)) ? C::pm2(j) : w;
+    for (int j = 0; j < C::ABI_N; ++j) w = (j == (i >> 5)) ? C::pm2(j) : w;
     bool bit = (w >> (i & 31)) & 1;
     if (started) r = fp_sqr(r);
     if (bit) { r = started ? fp_mul(r, a) : a; started = true; }
@@ -191,13 +347,12 @@ template <class C> ZKT_FN Fp<C> fp_inv_fermat(Fp<C> a) {
 // Inverse by the binary extended Euclid on the plain integers (odd p): ~2*bits iterations of
 // shifts and carry-chain adds instead of ~1.5*bits Montgomery products — about 4x cheaper than
 // fp_inv_fermat on this machine, and it is the tail of every affine normalisation.
-// In: a*R (Montgomery), non-zero.  Out: a^-1*R.  The integer inverse of a*R is a^-1*R^-1;
-// one Montgomery product with R^3 lifts it back.
-template <class C> ZKT_FN Fp<C> fp_inv(Fp<C> a) {
-  constexpr int N = C::N;
+// u: non-zero residue < p as ABI_N 32-bit words; overwritten with u^-1 mod p.
+template <class C> ZKT_HD void bgcd_inverse(uint32_t* io) {
+  constexpr int N = C::ABI_N;
   uint32_t u[N + 1], v[N + 1], x1[N + 1], x2[N + 1];
 #pragma unroll
-  for (int i = 0; i < N; ++i) { u[i] = a.v[i]; v[i] = C::mod(i); x1[i] = 0; x2[i] = 0; }
+  for (int i = 0; i < N; ++i) { u[i] = io[i]; v[i] = C::mod32(i); x1[i] = 0; x2[i] = 0; }
   u[N] = v[N] = x1[N] = x2[N] = 0; x1[0] = 1;
   auto is_one = [&](const uint32_t* t) { uint32_t o = t[0] ^ 1u;
 #pragma unroll
@@ -207,7 +362,7 @@ template <class C> ZKT_FN Fp<C> fp_inv(Fp<C> a) {
     for (int i = 0; i < N; ++i) t[i] = (t[i] >> 1) | (t[i + 1] << 31); t[N] >>= 1; };
   auto add_p = [&](uint32_t* t) { uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < N; ++i) t[i] = addc(t[i], C::mod(i), c); t[N] += c; };
+    for (int i = 0; i < N; ++i) t[i] = addc(t[i], C::mod32(i), c); t[N] += c; };
   auto sub = [&](uint32_t* t, const uint32_t* s) { uint32_t b = 0;
 #pragma unroll
     for (int i = 0; i <= N; ++i) t[i] = subb(t[i], s[i], b); return b; };
@@ -223,10 +378,28 @@ template <class C> ZKT_FN Fp<C> fp_inv(Fp<C> a) {
     if (geq(u, v)) { sub(u, v); sub_mod(x1, x2); } else { sub(v, u); sub_mod(x2, x1); }
   }
   const bool use1 = is_one(u);
-  Fp<C> r, r3;
 #pragma unroll
-  for (int i = 0; i < N; ++i) { r.v[i] = use1 ? x1[i] : x2[i]; r3.v[i] = C::r3(i); }
-  return fp_mul(r, r3);
+  for (int i = 0; i < N; ++i) io[i] = use1 ? x1[i] : x2[i];
+}
+
+// In: a*R (Montgomery), non-zero.  Out: a^-1*R.
+// W = 32: the integer inverse of a*R is a^-1*R^-1; one Montgomery product with R^3 lifts it back.
+// W = 28: leave the Montgomery domain (canonical words), invert, re-enter.
+template <class C> ZKT_FN Fp<C> fp_inv(Fp<C> a) {
+  uint32_t w[C::ABI_N];
+  if constexpr (C::W == 28) {
+    fp_to_words(a, w);
+    bgcd_inverse<C>(w);
+    return fp_from_words<C>(w);
+  } else {
+    Fp<C> r, r3;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) w[i] = a.v[i];
+    bgcd_inverse<C>(w);
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) { r.v[i] = w[i]; r3.v[i] = C::r3(i); }
+    return fp_mul(r, r3);
+  }
 }
 
 // generic power with a run-time exponent of `nlimbs` 32-bit limbs (MSB-first

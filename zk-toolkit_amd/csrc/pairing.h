@@ -27,7 +27,7 @@ namespace zkt {
 ZKT_HD Fq2 xi_inv_const() {
   Fq2 g;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) { g.c0.v[i] = xi_inv_limb(0, i); g.c1.v[i] = xi_inv_limb(1, i); }
+  for (int i = 0; i < FqC::N; ++i) { g.c0.v[i] = xi_inv_limb(0, i); g.c1.v[i] = xi_inv_limb(1, i); }
   return g;
 }
 

@@ -50,8 +50,6 @@ ZKT_FN Fq2 fq2_inv(const Fq2& a) {                                      // fq2.r
   Fq t = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
   return Fq2{fp_mul(a.c0, t), fp_neg(fp_mul(a.c1, t))};
 }
-ZKT_HD Fq2 fq2_to_mont(const Fq2& a) { return Fq2{fp_to_mont(a.c0), fp_to_mont(a.c1)}; }
-ZKT_HD Fq2 fq2_from_mont(const Fq2& a) { return Fq2{fp_from_mont(a.c0), fp_from_mont(a.c1)}; }
 
 // ---- Fq6 --------------------------------------------------------------------
 ZKT_HD Fq6 fq6_zero() { return Fq6{fq2_zero(), fq2_zero(), fq2_zero()}; }
@@ -135,7 +133,7 @@ ZKT_FN Fq12 fq12_cyclotomic_sqr(const Fq12& f) {
 template <int K> ZKT_HD Fq2 frob_const(int idx) {
   Fq2 g;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) {
+  for (int i = 0; i < FqC::N; ++i) {
     g.c0.v[i] = K == 1 ? frob1_limb(idx, 0, i) : frob2_limb(idx, 0, i);
     g.c1.v[i] = K == 1 ? frob1_limb(idx, 1, i) : frob2_limb(idx, 1, i);
   }

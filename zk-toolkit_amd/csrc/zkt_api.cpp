@@ -8,6 +8,9 @@
 #include <cstdio>
 #include "../../include/zkt.h"
 #include "zkt_internal.h"
+#include "zkt_constants.h"
+static_assert(ZKT_G1_PARTIAL_WORDS == 3 * zkt::FqC::N && ZKT_G2_PARTIAL_WORDS == 6 * zkt::FqC::N && ZKT_SECP_PARTIAL_WORDS == 3 * zkt::SpC::N,
+              "include/zkt.h partial sizes follow the internal limb layout");
 
 using namespace zkt;
 
@@ -110,7 +113,7 @@ struct zkt_bases_impl {               // one resident base set of any group; zkt
   size_t n = 0;
   int grp = G_G1;
   MsmPlan plan{};
-  uint32_t* table = nullptr;     // nwin*n x 24 words
+  uint32_t* table = nullptr;     // nwin*n affine points, 2 internal coordinates each
   uint8_t* inf = nullptr;        // nwin*n flags
   // software pipeline: the three stages of consecutive MSMs run on three streams (sort | accumulate | reduce),
   // chained by events, so the atomic-bound sort and the latency-bound reduce of neighbours hide under the
@@ -123,7 +126,7 @@ struct zkt_g1_bases : zkt_bases_impl {};
 struct zkt_g2_bases : zkt_bases_impl {};
 struct zkt_secp_bases : zkt_bases_impl {};
 static size_t grp_pt_bytes(int grp) { return grp == G_G1 ? sizeof(zkt_g1_affine) : grp == G_G2 ? sizeof(zkt_g2_affine) : sizeof(zkt_secp_affine); }
-static size_t grp_coord_bytes(int grp) { return grp == G_G1 ? 48 : grp == G_G2 ? 96 : 32; }
+static size_t grp_coord_bytes(int grp) { return 4 * (grp == G_G1 ? zkt::FqC::N : grp == G_G2 ? 2 * zkt::FqC::N : zkt::SpC::N); }   // internal (Montgomery) coordinate
 static int streams_ready(zkt_bases_impl* h) {
   if (h->s_acc) return ZKT_OK;
   int lo = 0, hi = 0;

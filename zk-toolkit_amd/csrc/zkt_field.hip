@@ -14,6 +14,19 @@ __global__ void __launch_bounds__(TPB) k_fp_op(const uint32_t* __restrict__ a, c
                                                uint32_t* __restrict__ out, size_t n, unsigned long long* err) {
   size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
+  if constexpr (C::W == 28) {                                          // lazy-limb field: enter and leave the Montgomery domain
+    constexpr int A = C::ABI_N;
+    Fp<C> x = ld_fp<C>(a + i * A), r;
+    if (OP == OP_ADD) r = fp_add(x, ld_fp<C>(b + i * A));
+    else if (OP == OP_SUB) r = fp_sub(x, ld_fp<C>(b + i * A));
+    else if (OP == OP_NEG) r = fp_neg(x);
+    else if (OP == OP_MUL) r = fp_mul(x, ld_fp<C>(b + i * A));
+    else if (OP == OP_SQR) r = fp_sqr(x);
+    else if (fp_is_zero(x)) { atomicMin(err, (unsigned long long)i); r = x; }
+    else r = fp_inv(x);
+    st_fp<C>(out + i * A, r);
+    return;
+  }
   Fp<C> x = ld_raw<C>(a + i * C::N), r;
   if (OP == OP_ADD) r = fp_add(x, ld_raw<C>(b + i * C::N));          // canonical in, canonical out
   else if (OP == OP_SUB) r = fp_sub(x, ld_raw<C>(b + i * C::N));
@@ -26,7 +39,11 @@ __global__ void __launch_bounds__(TPB) k_fp_op(const uint32_t* __restrict__ a, c
     r = fp_mul(fp_mul(x, x), r2);
   } else {                                                             // safe_inv: Err on zero (prime_field_elem.rs:379-382)
     if (fp_is_zero(x)) { atomicMin(err, (unsigned long long)i); r = x; }
-    else r = fp_from_mont(fp_inv(fp_to_mont(x)));
+    else {
+      Fp<C> r2, one = fp_zero<C>(); one.v[0] = 1;
+      for (int j = 0; j < C::N; ++j) r2.v[j] = C::r2(j);
+      r = fp_mul(fp_inv(fp_mul(x, r2)), one);
+    }
   }
   st_raw<C>(out + i * C::N, r);
 }

@@ -24,6 +24,11 @@ namespace zkt {
 // The pipeline is generic over the group: G1 over Fq (FqOps), G2 over Fq2 (Fq2Ops, row f-1: eval_with_g2_hidings,
 // polynomial.rs:283-293) and secp256k1 (SpOps: (AffinePoints * PrimeFieldElems).sum(), secp256k1/affine_points.rs:25-31,123-144).
 // Coordinates are stored raw (Montgomery) with CW words each: affine point = 2*CW, XYZZ = 4*CW, Jacobian partial = 3*CW.
+// Kernels of the sort and reduce stages run beside the VALU-saturating accumulate waves of a neighbouring MSM; raise
+// their wave priority so their (few, latency-bound) instructions are not queued behind them.
+#ifndef ZKT_SIDE_PRIO
+#define ZKT_SIDE_PRIO __builtin_amdgcn_s_setprio(3)
+#endif
 template <class F> struct Coord;
 template <class C> struct Coord<PrimeOps<C>> {
   static constexpr int CW = C::N;
@@ -31,9 +36,9 @@ template <class C> struct Coord<PrimeOps<C>> {
   __device__ static void st(uint32_t* p, const Fp<C>& a) { st_raw<C>(p, a); }
 };
 template <> struct Coord<Fq2Ops> {
-  static constexpr int CW = 24;
-  __device__ static Fq2 ld(const uint32_t* p) { Fq2 r; r.c0 = ld_raw<FqC>(p); r.c1 = ld_raw<FqC>(p + 12); return r; }
-  __device__ static void st(uint32_t* p, const Fq2& a) { st_raw<FqC>(p, a.c0); st_raw<FqC>(p + 12, a.c1); }
+  static constexpr int CW = 2 * FqC::N;
+  __device__ static Fq2 ld(const uint32_t* p) { Fq2 r; r.c0 = ld_raw<FqC>(p); r.c1 = ld_raw<FqC>(p + FqC::N); return r; }
+  __device__ static void st(uint32_t* p, const Fq2& a) { st_raw<FqC>(p, a.c0); st_raw<FqC>(p + FqC::N, a.c1); }
 };
 template <class F> __device__ inline Xyzz<F> ld_xy(const uint32_t* p) {
   constexpr int CW = Coord<F>::CW; Xyzz<F> r;
@@ -43,7 +48,7 @@ template <class F> __device__ inline void st_xy(uint32_t* p, const Xyzz<F>& a) {
   constexpr int CW = Coord<F>::CW;
   Coord<F>::st(p, a.X); Coord<F>::st(p + CW, a.Y); Coord<F>::st(p + 2 * CW, a.ZZ); Coord<F>::st(p + 3 * CW, a.ZZZ);
 }
-static int coord_words(int grp) { return grp == G_G1 ? 12 : grp == G_G2 ? 24 : 8; }
+static int coord_words(int grp) { return grp == G_G1 ? FqC::N : grp == G_G2 ? 2 * FqC::N : SpC::N; }
 
 // ---------------------------------------------------------------------------------
 // plan
@@ -138,6 +143,7 @@ template <bool SCATTER>
 static __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t n, int c, int nwin,
                                                 uint32_t* __restrict__ counts_or_cursor, const uint32_t* __restrict__ offsets,
                                                 uint32_t* __restrict__ entries) {
+  ZKT_SIDE_PRIO;
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = i < n;
   uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -194,6 +200,7 @@ __device__ inline uint32_t block_excl_scan_256(uint32_t v, uint32_t* lds /*256*/
   return excl;
 }
 static __global__ void __launch_bounds__(256) k_scan_sums(const uint32_t* __restrict__ in, size_t m, uint32_t* __restrict__ blocksum) {
+  ZKT_SIDE_PRIO;
   __shared__ uint32_t lds[256];
   size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
   uint32_t s = 0;
@@ -203,6 +210,7 @@ static __global__ void __launch_bounds__(256) k_scan_sums(const uint32_t* __rest
   if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
 }
 static __global__ void __launch_bounds__(256) k_scan_top(uint32_t* __restrict__ blocksum, int nblk, uint32_t* __restrict__ grand_total) {
+  ZKT_SIDE_PRIO;
   __shared__ uint32_t lds[256];
   uint32_t run = 0;
   for (int base = 0; base < nblk; base += 256) {          // nblk <= 2^19/2048 = 256 in practice
@@ -216,6 +224,7 @@ static __global__ void __launch_bounds__(256) k_scan_top(uint32_t* __restrict__ 
 }
 static __global__ void __launch_bounds__(256) k_scan_final(const uint32_t* __restrict__ in, size_t m, const uint32_t* __restrict__ blocksum,
                                                     uint32_t* __restrict__ out) {
+  ZKT_SIDE_PRIO;
   __shared__ uint32_t lds[256];
   size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
   uint32_t v[SCAN_ITEMS], s = 0;
@@ -242,6 +251,7 @@ static constexpr uint32_t CHUNK = 128;
 static constexpr int SIZE_BINS = CHUNK + 1;      // bin k holds tasks of size CHUNK - k
 __device__ inline uint32_t ntasks_of(uint32_t c) { return c <= CHUNK ? 1u : (c + CHUNK - 1) / CHUNK; }
 static __global__ void __launch_bounds__(256) k_task_count(const uint32_t* __restrict__ counts, size_t m, uint32_t* __restrict__ ntask, uint32_t* __restrict__ hist) {
+  ZKT_SIDE_PRIO;
   __shared__ uint32_t h[SIZE_BINS];
   for (int i = threadIdx.x; i < SIZE_BINS; i += 256) h[i] = 0;
   __syncthreads();
@@ -257,6 +267,7 @@ static __global__ void __launch_bounds__(256) k_task_count(const uint32_t* __res
 }
 static __global__ void __launch_bounds__(256) k_task_scatter(const uint32_t* __restrict__ counts, size_t m, const uint32_t* __restrict__ binoff,
                                                       uint32_t* __restrict__ bincur, uint2* __restrict__ order) {
+  ZKT_SIDE_PRIO;
   // rank inside the block with LDS atomics, then ONE global atomic per (block, non-empty bin): ~50 distinct sizes
   // are shared by 2^19 buckets, so per-element global atomics would serialise.
   __shared__ uint32_t h[SIZE_BINS], base[SIZE_BINS];
@@ -280,8 +291,11 @@ static __global__ void __launch_bounds__(256) k_task_scatter(const uint32_t* __r
 // ---------------------------------------------------------------------------------
 // bucket accumulation: one task (bucket chunk) per lane — the dominant kernel
 // ---------------------------------------------------------------------------------
+#ifndef ZKT_ACC_ATTR
+#define ZKT_ACC_ATTR
+#endif
 template <class F>
-__global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ table, const uint32_t* __restrict__ entries,
+__global__ void __launch_bounds__(64) ZKT_ACC_ATTR k_accumulate(const uint32_t* __restrict__ table, const uint32_t* __restrict__ entries,
                                                    const uint32_t* __restrict__ offsets, const uint2* __restrict__ order,
                                                    const uint32_t* __restrict__ task_off, size_t nbuckets,
                                                    uint32_t* __restrict__ sums, uint32_t* __restrict__ partial) {
@@ -293,11 +307,22 @@ __global__ void __launch_bounds__(64) k_accumulate(const uint32_t* __restrict__ 
   if (end - beg > CHUNK) end = beg + CHUNK;
   constexpr int CW = Coord<F>::CW, XYW = 4 * CW;
   Xyzz<F> acc = xyzz_inf<F>();
+  // software-pipelined gather: the next point (and the entry after it) are in flight while this one is added, so the
+  // random-access latency of the table hides under ~6000 VALU instructions instead of stalling the two waves of a SIMD
+  typedef typename F::E E;
+  uint32_t ent = beg < end ? entries[beg] : 0, ent_next = beg + 1 < end ? entries[beg + 1] : 0;      // empty bucket: harmless load of entry 0
+  const uint32_t* p = table + (size_t)(ent & 0x7fffffffu) * (2 * CW);
+  E nx = Coord<F>::ld(p), ny = Coord<F>::ld(p + CW);
   for (uint32_t e = beg; e < end; ++e) {
-    uint32_t ent = entries[e];
-    const uint32_t* p = table + (size_t)(ent & 0x7fffffffu) * (2 * CW);
-    typename F::E x = Coord<F>::ld(p), y = Coord<F>::ld(p + CW);
-    if (ent >> 31) y = F::neg(y);
+    E x = nx, y = ny;
+    const bool negate = ent >> 31;
+    if (e + 1 < end) {
+      ent = ent_next;
+      ent_next = e + 2 < end ? entries[e + 2] : 0;
+      p = table + (size_t)(ent & 0x7fffffffu) * (2 * CW);
+      nx = Coord<F>::ld(p); ny = Coord<F>::ld(p + CW);
+    }
+    if (negate) y = F::neg(y);
     acc = xyzz_add_aff<F>(acc, x, y);
   }
   const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
@@ -326,6 +351,7 @@ template <class F> __device__ inline Xyzz<F> block_tree_sum(Xyzz<F> v, uint32_t*
 template <class F>
 __global__ void __launch_bounds__(RED_TPB) k_merge_partials(const uint32_t* __restrict__ task_off, size_t nbuckets, const uint32_t* __restrict__ partial,
                                                             uint32_t* __restrict__ sums) {
+  ZKT_SIDE_PRIO;
   constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
   __shared__ uint32_t lds[RED_TPB / 2 * XYW];
   for (size_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
@@ -343,6 +369,7 @@ __global__ void __launch_bounds__(RED_TPB) k_merge_partials(const uint32_t* __re
 template <class F>
 __global__ void __launch_bounds__(RED_TPB) k_marginals(const uint32_t* __restrict__ in, size_t NLO, size_t NHI,
                                                        uint32_t* __restrict__ colsum, uint32_t* __restrict__ rowsum) {
+  ZKT_SIDE_PRIO;
   constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
   __shared__ uint32_t lds[RED_TPB / 2 * XYW];
   const int lane = threadIdx.x;
@@ -359,6 +386,7 @@ __global__ void __launch_bounds__(RED_TPB) k_marginals(const uint32_t* __restric
 template <class F>
 __global__ void __launch_bounds__(RED_TPB) k_weight_bits(const uint32_t* __restrict__ colsum, size_t NLO, int nbA,
                                                          const uint32_t* __restrict__ rowsum, size_t NHI, uint32_t* __restrict__ clsA, uint32_t* __restrict__ clsB) {
+  ZKT_SIDE_PRIO;
   constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
   __shared__ uint32_t lds[RED_TPB / 2 * XYW];
   const int lane = threadIdx.x;
@@ -377,6 +405,7 @@ __global__ void __launch_bounds__(RED_TPB) k_weight_bits(const uint32_t* __restr
 template <class F>
 __global__ void __launch_bounds__(64) k_combine(const uint32_t* __restrict__ clsA, int nbA, const uint32_t* __restrict__ clsB, int nbB, int shift,
                                                 uint32_t* __restrict__ out_jac, uint32_t* __restrict__ out_abi) {
+  ZKT_SIDE_PRIO;
   constexpr int CW = Coord<F>::CW, XYW = 4 * CW; typedef Xyzz<F> XY;
   __shared__ uint32_t lds[32 * XYW];
   const int t = threadIdx.x;
