@@ -185,3 +185,38 @@ def test_g2_secp_msm_large_by_linearity(L, name, W, order, gen_fn, n):
     assert getattr(O, f"zkto_{name}_mul_batch")(ptr(g), ptr(ints_to_arr([tot], 4)), 4, ptr(want), 1, 1) == 0
     assert (got == want).all()
     print(f"{name} one-shot MSM n={n}: {dt*1e3:.1f} ms (incl. upload + window-multiple table build)")
+
+
+@pytest.mark.parametrize("name,W,order,gen_fn,pw", [("g1", G1W, R, "zkto_g1_generator", zk.G1_PARTIAL_WORDS), ("g2", G2W, R, "zkto_g2_generator", zk.G2_PARTIAL_WORDS),
+                                                    ("secp", 9, SECP_N, "zkto_secp_generator", zk.SECP_PARTIAL_WORDS)])
+def test_sharded_msm_partials_combine(L, name, W, order, gen_fn, pw):
+    """The multi-GPU combine step on one card: split an MSM into index-range shards with resident bases, take each
+    shard's opaque Jacobian partial, sum the partials with zkt_*_jac_sum_dev -> identical to the unsharded MSM (and the oracle)."""
+    import torch
+    n, shards = 3000, 3
+    rng = np.random.Generator(np.random.PCG64(77))
+    ks = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64); ks[:, 3] >>= np.uint64(2)
+    ss = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64); ss[:, 3] >>= np.uint64(2)
+    g = np.zeros((1, W), np.uint64); getattr(O, gen_fn)(ptr(g))
+    bases = np.zeros((n, W), np.uint64)
+    zk.check(getattr(L, f"zkt_{name}_mul_batch")(ptr(np.repeat(g, n, axis=0)), ptr(ks), 4, ptr(bases), n))
+    whole = np.zeros((1, W), np.uint64); zk.check(getattr(L, f"zkt_{name}_msm")(ptr(bases), ptr(ss), n, ptr(whole)))
+    parts = torch.zeros((shards, pw), dtype=torch.int32, device="cuda")
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    from importlib import import_module
+    shard_range = import_module("zk-toolkit_amd.sharded").shard_range
+    for k in range(shards):
+        lo, hi = shard_range(n, k, shards)
+        h = ctypes.c_void_p(); zk.check(getattr(L, f"zkt_{name}_bases_upload")(ptr(bases[lo:hi].copy()), hi - lo, ctypes.byref(h)))
+        d_s = torch.from_numpy(ss[lo:hi].copy().view(np.int64)).cuda()
+        out = np.zeros((1, W), np.uint64)
+        zk.check(getattr(L, f"zkt_{name}_msm_dev")(h, vp(d_s), hi - lo, None, ptr(out), vp(parts[k])))
+        getattr(L, f"zkt_{name}_bases_free")(h)
+    torch.cuda.synchronize()
+    got = np.zeros((1, W), np.uint64)
+    zk.check(getattr(L, f"zkt_{name}_jac_sum_dev")(vp(parts), shards, None, ptr(got)))
+    assert (got == whole).all()
+    tot = sum(limbs_to_int(a) * limbs_to_int(b) for a, b in zip(ks, ss)) % order
+    want = np.zeros((1, W), np.uint64)
+    assert getattr(O, f"zkto_{name}_mul_batch")(ptr(g), ptr(ints_to_arr([tot], 4)), 4, ptr(want), 1, 1) == 0
+    assert (got == want).all()
