@@ -213,6 +213,27 @@ int zkt_secp_msm_submit(zkt_secp_bases* bases, const uint64_t* dev_scalars, size
 int zkt_secp_msm_collect(zkt_secp_bases* bases, int slot, zkt_secp_affine* out, uint32_t* dev_partial_jac);
 int zkt_secp_jac_sum_dev(const uint32_t* dev_partials, size_t count, void* stream, zkt_secp_affine* out);
 
+/* f-3: Groth16 at scale on the reference's evaluation domain {1..n}.  The reference keeps (m+1) dense interpolated
+ * polynomials per matrix (QAP::build, qap/qap.rs:137-226; Prover.ui/vi/wi prover.rs:44-46) and the prover works in
+ * coefficient form (prover.rs:64-71,103-131) — O(m n) group operations, infeasible at 2^20 constraints.  These entry
+ * points take the R1CS itself, one sparse row per constraint (R1CS.constraints, r1cs.rs; Constraint{a,b,c},
+ * constraint.rs:5-9; SparseVec), and produce the SAME proof points: setup derives device-resident Lagrange-basis
+ * bases from the trapdoor, prove is 3 sparse mat-vecs + Fr NTTs + 4 G1 MSMs + 1 G2 MSM.
+ * rowptr: n+1 offsets into col/val; col: wire index 0..m; val: 4-limb canonical Fr. */
+typedef struct { const uint64_t* rowptr; const uint32_t* col; const uint64_t* val; } zkt_sparse_rows;
+typedef struct zkt_groth16_pk zkt_groth16_pk;
+/* CRS::new (crs.rs:49-146) with injected trapdoors.  Fills the verifying part of `vk` (g1_alpha, g1_beta, g1_delta,
+ * g1_uvw_stmt[l+1], g2_beta, g2_gamma, g2_delta, gt_alpha_beta — and g1_uvw_wit[m-l] if that pointer is non-NULL;
+ * g1_xi, g1_xt_by_delta, g2_xi are not produced) and returns the proving key, resident on the device.
+ * ZKT_ERR_INV_ZERO if x lies in {1..2n-1} (the reference would still build a CRS for x in n+1..2n-1; a uniform x never does). */
+int zkt_groth16_setup_r1cs(size_t n, size_t l, size_t m, const zkt_sparse_rows* A, const zkt_sparse_rows* B, const zkt_sparse_rows* C,
+                           const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma, const uint64_t* delta, const uint64_t* x,
+                           zkt_groth16_crs* vk, zkt_groth16_pk** out);
+/* Prover::prove (prover.rs:96-147), r and s injected; wires = a_0..a_m, 4-limb canonical Fr on the host. */
+int zkt_groth16_prove_r1cs(zkt_groth16_pk* pk, const uint64_t* wires, const uint64_t* r, const uint64_t* s,
+                           zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* C);
+void zkt_groth16_pk_free(zkt_groth16_pk* pk);
+
 int zkt_g1_mul_batch_dev(const zkt_g1_affine* dev_points, const uint64_t* dev_scalars, int scalar_limbs,
                          zkt_g1_affine* dev_out, size_t n, void* stream);
 int zkt_g2_mul_batch_dev(const zkt_g2_affine* dev_points, const uint64_t* dev_scalars, int scalar_limbs,

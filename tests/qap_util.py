@@ -108,3 +108,83 @@ def alloc_crs(n, l, m):
 
 def dense(polys, n):
     return ints_to_arr([c for p in polys for c in (p + [0] * (n - len(p)))], 4)
+
+
+# ---- evaluation-domain form of the same QAP: what zkt_groth16_setup_r1cs / prove_r1cs compute ----
+def sparse_rows(M):
+    """dense n x cols matrix -> CSR (rowptr u64[n+1], col u32[nnz], val (nnz,4) u64)"""
+    rowptr, col, val = [0], [], []
+    for row in M:
+        for i, v in enumerate(row):
+            if v % R: col.append(i); val.append(v % R)
+        rowptr.append(len(col))
+    return np.array(rowptr, np.uint64), np.array(col if col else [0], np.uint32), ints_to_arr(val if val else [0], 4)
+
+
+def domain_model(Amat, Bmat, Cmat, witness, x):
+    """Python-int model of the scalable prover's Fr stage on the reference's domain {1..n}:
+       returns (a(x), b(x), h(x)*t(x)) computed WITHOUT any coefficient-form polynomial:
+       a(x) = sum_j (A w)_j L_j(x);  h on E = {n+1..2n-1} through the arithmetic-progression shift (one convolution
+       with 1/d), h(x) t(x) = t(x) * sum_s h(n+s) Lambda_s(x)."""
+    n = len(Amat)
+    fact = [1] * (2 * n + 1)
+    for k in range(1, 2 * n + 1): fact[k] = fact[k - 1] * k % R
+    inv = lambda v: pow(v, -1, R)
+    tx = 1
+    for j in range(1, n + 1): tx = tx * (x - j) % R
+    tprime_inv = lambda j: (-1) ** (n - j) * inv(fact[j - 1] * fact[n - j]) % R
+    L = [tx * inv((x - j) % R) * tprime_inv(j) % R for j in range(1, n + 1)]
+    dot = lambda M: [sum(M[j][i] * witness[i] for i in range(len(witness))) % R for j in range(n)]
+    Az, Bz, Cz = dot(Amat), dot(Bmat), dot(Cmat)
+    ax = sum(v * l for v, l in zip(Az, L)) % R
+    bx = sum(v * l for v, l in zip(Bz, L)) % R
+    if n == 1: return ax, bx, 0
+    def shift(vals):                    # values at 1..n -> values at n+1..2n-1
+        f = [vals[j - 1] * tprime_inv(j) % R for j in range(1, n + 1)]
+        out = []
+        for s in range(1, n):
+            S = sum(f[j - 1] * inv(n + s - j) for j in range(1, n + 1)) % R
+            P = fact[n + s - 1] * inv(fact[s - 1]) % R
+            out.append((S, P))
+        return out
+    sa, sb, sc = shift(Az), shift(Bz), shift(Cz)
+    hE = [(P * Sa % R * Sb - Sc) % R for (Sa, P), (Sb, _), (Sc, _) in zip(sa, sb, sc)]     # (P Sa * P Sb - P Sc) / t(n+s), t(n+s) = P
+    TE = 1
+    for e in range(n + 1, 2 * n): TE = TE * (x - e) % R
+    ht = 0
+    for s in range(1, n):
+        lam = TE * inv((x - (n + s)) % R) % R * ((-1) ** (n - 1 - s) * inv(fact[s - 1] * fact[n - 1 - s]) % R) % R
+        ht = (ht + hE[s - 1] * lam) % R
+    return ax, bx, ht * tx % R
+
+
+class SparseRows(ctypes.Structure):
+    """zkt_sparse_rows (include/zkt.h): one sparse row per constraint, as R1CS.constraints holds them (r1cs.rs, constraint.rs:5-9)"""
+    _fields_ = [("rowptr", ctypes.POINTER(ctypes.c_uint64)), ("col", ctypes.POINTER(ctypes.c_uint32)), ("val", ctypes.POINTER(ctypes.c_uint64))]
+
+
+def sparse_struct(rowptr, col, val):
+    s = SparseRows(rowptr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), col.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), ptr(val))
+    s._keep = (rowptr, col, val)
+    return s
+
+
+def chain_circuit_sparse(n, seed=7):
+    """chain_circuit(n) built directly in CSR form — usable at n = 2^20.  Returns (A, B, C) as
+    (rowptr, col, val) triples, the witness as an (m+1, 4) u64 array, l = 1, m = n + 1."""
+    from zkt_testlib import SplitMix64
+    rng = SplitMix64(seed)
+    cs = [rng.below(1 << 32) for _ in range(n)]
+    ws = [rng.below(R)]
+    for j in range(n): ws.append((ws[j] * ws[j] + cs[j]) % R)
+    wit = [1, ws[n]] + ws[:n]
+    one = np.array([1, 0, 0, 0], np.uint64)
+    idx = np.arange(n, dtype=np.uint32) + 2                        # wire of w_j
+    nxt = np.concatenate([idx[1:], np.array([1], np.uint32)])      # wire of w_{j+1} (the last one is `out`)
+    rp1 = np.arange(n + 1, dtype=np.uint64)
+    vA = np.tile(one, (n, 1))
+    # C row j: (-c_j) * one + 1 * w_{j+1}; wire 0 first
+    colC = np.empty(2 * n, np.uint32); colC[0::2] = 0; colC[1::2] = nxt
+    valC = np.zeros((2 * n, 4), np.uint64)
+    valC[0::2] = ints_to_arr([(-c) % R for c in cs], 4); valC[1::2] = one
+    return ((rp1, idx.copy(), vA.copy()), (rp1.copy(), idx.copy(), vA.copy()), (np.arange(0, 2 * n + 1, 2, dtype=np.uint64), colC, valC)), ints_to_arr(wit, 4), 1, n + 1

@@ -1,0 +1,76 @@
+"""the scalable Groth16 path (sparse R1CS on the reference's domain {1..n}, no coefficient-form
+polynomials) must produce the verifying key and the proof points of the reference algorithm bit for bit.  The checker is the
+oracle's restatement of CRS::new / Prover::prove (crs.rs:49-146, prover.rs:96-147) on the dense QAP of tests/qap_util.py."""
+import ctypes, importlib
+import numpy as np
+import pytest
+from zkt_testlib import *
+from qap_util import *
+
+pytestmark = pytest.mark.gpu
+zk = importlib.import_module("zk-toolkit_amd")
+O = oracle()
+fr = lambda v: ints_to_arr([v], 4)
+
+
+@pytest.fixture(scope="module")
+def L():
+    zk.init()
+    return zk.lib()
+
+
+def _r1cs_setup(L, mats, n, l, m, trap):
+    structs = [sparse_struct(*sparse_rows(M)) if isinstance(M, list) else sparse_struct(*M) for M in mats]
+    vk, vbuf = alloc_crs(1, l, m)                      # xi / xt_by_delta arrays are not produced by this path
+    pk = ctypes.c_void_p()
+    zk.check(L.zkt_groth16_setup_r1cs(n, l, m, *[ctypes.addressof(s) for s in structs], *[t.ctypes.data for t in trap], ctypes.addressof(vk), ctypes.addressof(pk)))
+    return vk, vbuf, pk
+
+
+@pytest.mark.parametrize("case", ["cubic", "chain1", "chain2", "chain3", "chain16", "chain61"])
+def test_r1cs_path_matches_reference_algorithm(L, case):
+    A, B, C, wit, l = example_cubic() if case == "cubic" else chain_circuit(int(case[5:]))
+    n, m = len(A), len(wit) - 1
+    ui, vi, wi, h, _ = qap_from_r1cs(A, B, C, wit)
+    U, V, W = dense(ui, n), dense(vi, n), dense(wi, n)
+    rng = SplitMix64(4242 + n)
+    trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+    r, s = fr(rng.below(R - 1) + 1), fr(rng.below(R - 1) + 1)
+    wires, H = ints_to_arr(wit, 4), ints_to_arr(h, 4)
+    ocrs, obuf = alloc_crs(n, l, m)
+    assert O.zkto_groth16_setup(ctypes.byref(ocrs), ptr(U), ptr(V), ptr(W), *[ptr(t) for t in trap]) == 0
+    op = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+    assert O.zkto_groth16_prove(ctypes.byref(ocrs), ptr(U), ptr(V), ptr(wires), ptr(H), len(h), ptr(r), ptr(s), 1 if n <= 5 else 0, *[ptr(x) for x in op]) == 0
+    vk, vbuf, pk = _r1cs_setup(L, (A, B, C), n, l, m, trap)
+    for k in ("g1_alpha", "g1_beta", "g1_delta", "g1_uvw_stmt", "g2_beta", "g2_gamma", "g2_delta", "gt_alpha_beta"):
+        assert (obuf[k] == vbuf[k]).all(), f"verifying-key field {k} differs"
+    if m > l: assert (obuf["g1_uvw_wit"] == vbuf["g1_uvw_wit"]).all()
+    gp = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+    for _ in range(2):                                 # the proving key is reusable
+        zk.check(L.zkt_groth16_prove_r1cs(pk, wires.ctypes.data, r.ctypes.data, s.ctypes.data, *[x.ctypes.data for x in gp]))
+        for a, b, name in zip(op, gp, "ABC"):
+            assert (a == b).all(), f"proof element {name} differs"
+    stmt = ints_to_arr(wit[:l + 1], 4)
+    assert L.zkt_groth16_verify(ctypes.byref(vk), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(stmt), l + 1) == 1
+    L.zkt_groth16_pk_free(pk)
+
+
+@pytest.mark.parametrize("n", [1000, 4096])
+def test_r1cs_path_larger_sizes_verify(L, n):
+    """beyond the sizes the quadratic oracle can follow: the proof must verify (verifier.rs:30-54), and must stop
+    verifying when the statement or the witness is wrong."""
+    mats, wires, l, m = chain_circuit_sparse(n, seed=11)
+    rng = SplitMix64(777 + n)
+    trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+    r, s = fr(rng.below(R - 1) + 1), fr(rng.below(R - 1) + 1)
+    vk, vbuf, pk = _r1cs_setup(L, mats, n, l, m, trap)
+    gp = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+    zk.check(L.zkt_groth16_prove_r1cs(pk, wires.ctypes.data, r.ctypes.data, s.ctypes.data, *[x.ctypes.data for x in gp]))
+    stmt = wires[:l + 1].copy()
+    assert L.zkt_groth16_verify(ctypes.byref(vk), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(stmt), l + 1) == 1
+    bad = stmt.copy(); bad[1, 0] ^= np.uint64(1)
+    assert L.zkt_groth16_verify(ctypes.byref(vk), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(bad), l + 1) == 0
+    w2 = wires.copy(); w2[5, 0] ^= np.uint64(2)       # a witness that no longer satisfies the constraints
+    zk.check(L.zkt_groth16_prove_r1cs(pk, w2.ctypes.data, r.ctypes.data, s.ctypes.data, *[x.ctypes.data for x in gp]))
+    assert L.zkt_groth16_verify(ctypes.byref(vk), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(stmt), l + 1) == 0
+    L.zkt_groth16_pk_free(pk)

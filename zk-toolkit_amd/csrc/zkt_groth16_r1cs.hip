@@ -1,0 +1,453 @@
+// Groth16 at scale on the reference's own evaluation domain {1..n}  (SURVEY §8 row f-3).
+//
+// The reference interpolates every wire's column of the R1CS over x = 1..n (QAP::build_polynomial, qap/qap.rs:33-97),
+// keeps (m+1) dense polynomials, and the prover evaluates each "in the exponent" (prover.rs:103-117) and divides
+// a*b - c by t in coefficient form (prover.rs:64-71): O(m n) group operations and O(n^2) field work, with (m+1) n
+// coefficients resident — 2^40 of them at the 2^20-constraint configuration.  The proof points only depend on the
+// polynomials as functions, so the same group elements are produced here without ever forming a coefficient:
+//
+//   sum_i a_i u_i(x)        = sum_j (A w)_j L_j(x)                   L_j = Lagrange basis of {1..n}
+//   sum_k h_k x^k t(x)/delta = sum_s h(n+s) Lambda_s(x) t(x)/delta    Lambda_s = Lagrange basis of E = {n+1..2n-1}
+//   p(n+s) for p in {a,b,c} from p(1..n):  p(n+s) = t(n+s) * sum_j [p(j)/t'(j)] / (n+s-j)    — one cyclic convolution
+//                                                                       with the kernel 1/d (Fr NTT, size >= 2n)
+//   h(n+s) = (a b - c)(n+s) / t(n+s)
+//
+// so a proof is 3 sparse mat-vecs, 3+3 NTTs, 4 G1 MSMs and 1 G2 MSM over device-resident bases [L_j(x)]_1, [L_j(x)]_2,
+// [uvw_wit]_1 and [Lambda_s(x) t(x)/delta]_1 that setup derives from the trapdoor.  tests/test_r1cs_domain_math.py checks
+// the identity in python integers; tests/test_gpu_groth16_r1cs.py checks the proof points bit-for-bit against the oracle's
+// restatement of the reference prover on the dense QAP.
+#include <vector>
+#include <memory>
+#include <cstring>
+#include <cstdio>
+#include "abi.h"
+#include "zkt_internal.h"
+#include "../../include/zkt.h"
+
+namespace zkt {
+typedef FrC C;
+typedef Fp<FrC> Fr;
+static constexpr int FW = 8;          // u32 words of an Fr element (canonical and Montgomery alike)
+
+__device__ inline Fr ldm(const uint32_t* p) { return ld_raw<C>(p); }       // Montgomery in memory
+__device__ inline void stm(uint32_t* p, const Fr& a) { st_raw<C>(p, a); }
+__device__ inline Fr fr_small(uint32_t k) { uint32_t w[8] = {k, 0, 0, 0, 0, 0, 0, 0}; return fp_from_words<C>(w); }
+
+// ---- elementwise helpers ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_to_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  stm(out + i * FW, ld_fp<C>(in + i * FW));
+}
+__global__ void __launch_bounds__(256) k_from_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  st_fp<C>(out + i * FW, ldm(in + i * FW));
+}
+__global__ void __launch_bounds__(256) k_inv(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n, unsigned long long* err) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  Fr v = ldm(in + i * FW);
+  if (fp_is_zero(v)) { atomicMin(err, (unsigned long long)i); stm(out + i * FW, v); return; }
+  stm(out + i * FW, fp_inv(v));
+}
+// out[0] = 1, out[k] = k  (prefix product = k!)
+__global__ void __launch_bounds__(256) k_iota(uint32_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  stm(out + i * FW, fr_small(i ? (uint32_t)i : 1u));
+}
+// out[j-1] = x - j, j = 1..cnt
+__global__ void __launch_bounds__(256) k_x_minus(const uint32_t* __restrict__ consts, uint32_t* __restrict__ out, size_t cnt) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= cnt) return;
+  stm(out + i * FW, fp_sub(ldm(consts), fr_small((uint32_t)(i + 1))));
+}
+// out[0] = 1, out[k>0] = w   (prefix product = w^k)
+__global__ void __launch_bounds__(256) k_fill_pow(const uint32_t* __restrict__ w, uint32_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  stm(out + i * FW, i ? ldm(w) : fp_one<C>());
+}
+
+// ---- inclusive prefix product (factorials, prod (x - j), twiddle tables) ------------------------------------------
+static constexpr int SC_TPB = 256, SC_ITEMS = 8, SC_TILE = SC_TPB * SC_ITEMS;
+__global__ void __launch_bounds__(SC_TPB) k_scanmul_tile(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n, uint32_t* __restrict__ tile_total) {
+  __shared__ uint32_t lds[SC_TPB * FW];
+  const int t = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * SC_TILE + (size_t)t * SC_ITEMS;
+  Fr loc[SC_ITEMS]; Fr run = fp_one<C>();
+#pragma unroll
+  for (int k = 0; k < SC_ITEMS; ++k) { if (base + k < n) run = fp_mul(run, ldm(in + (base + k) * FW)); loc[k] = run; }
+  stm(lds + t * FW, run); __syncthreads();
+  for (int d = 1; d < SC_TPB; d <<= 1) {                 // Hillis-Steele over the 256 thread totals
+    Fr o = t >= d ? ldm(lds + (t - d) * FW) : fp_one<C>(); __syncthreads();
+    if (t >= d) { run = fp_mul(o, run); stm(lds + t * FW, run); } __syncthreads();
+  }
+  Fr excl = t ? ldm(lds + (t - 1) * FW) : fp_one<C>();
+#pragma unroll
+  for (int k = 0; k < SC_ITEMS; ++k) if (base + k < n) stm(out + (base + k) * FW, fp_mul(excl, loc[k]));
+  if (t == SC_TPB - 1) stm(tile_total + (size_t)blockIdx.x * FW, run);
+}
+__global__ void __launch_bounds__(256) k_scanmul_apply(uint32_t* __restrict__ data, size_t n, const uint32_t* __restrict__ tile_prefix) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  size_t tile = i / SC_TILE; if (tile == 0) return;
+  stm(data + i * FW, fp_mul(ldm(tile_prefix + (tile - 1) * FW), ldm(data + i * FW)));
+}
+
+// ---- CSR mat-vec in Fr (Montgomery): out[r] = sum_k val[k] * vec[idx[k]] ---------------------------------------------
+__global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val,
+                                              const uint32_t* __restrict__ vec, uint32_t* __restrict__ out, size_t rows) {
+  size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; if (r >= rows) return;
+  Fr acc = fp_zero<C>();
+  for (uint32_t k = ptr[r]; k < ptr[r + 1]; ++k) acc = fp_add(acc, fp_mul(ldm(val + (size_t)k * FW), ldm(vec + (size_t)idx[k] * FW)));
+  stm(out + r * FW, acc);
+}
+
+// ---- setup scalars ----------------------------------------------------------------------------------------
+// consts layout (Montgomery, 8 words each)
+enum { K_X = 0, K_ALPHA, K_BETA, K_GINV, K_DINV, K_TX, K_TE, K_HB, K_OMEGA, K_OMEGA_INV, K_NINV, K_COUNT };
+__global__ void k_setup_consts(const uint32_t* __restrict__ trap /*alpha,beta,gamma,delta,x canonical*/, uint32_t* __restrict__ consts, int logN) {
+  if (threadIdx.x || blockIdx.x) return;
+  stm(consts + K_ALPHA * FW, ld_fp<C>(trap)); stm(consts + K_BETA * FW, ld_fp<C>(trap + 8));
+  stm(consts + K_GINV * FW, fp_inv(ld_fp<C>(trap + 16))); stm(consts + K_DINV * FW, fp_inv(ld_fp<C>(trap + 24)));
+  stm(consts + K_X * FW, ld_fp<C>(trap + 32));
+  uint32_t rw[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rw[i] = fr_root_word(i);
+  Fr w = fp_from_words<C>(rw);
+  for (int k = FR_TWO_ADICITY; k > logN; --k) w = fp_sqr(w);                      // order 2^logN
+  stm(consts + K_OMEGA * FW, w); stm(consts + K_OMEGA_INV * FW, fp_inv(w));
+  Fr two = fr_small(2), nn = fp_one<C>();
+  for (int k = 0; k < logN; ++k) nn = fp_mul(nn, two);
+  stm(consts + K_NINV * FW, fp_inv(nn));
+}
+// after the prefix product of (x - j): t(x) = pre[n-1], T_E(x) = pre[2n-2] / pre[n-1], hb = t(x) T_E(x) / delta
+__global__ void k_setup_consts2(const uint32_t* __restrict__ pre, size_t n, uint32_t* __restrict__ consts) {
+  if (threadIdx.x || blockIdx.x) return;
+  Fr tx = ldm(pre + (n - 1) * FW);
+  Fr te = n >= 2 ? fp_mul(ldm(pre + (2 * n - 2) * FW), fp_inv(tx)) : fp_one<C>();
+  stm(consts + K_TX * FW, tx); stm(consts + K_TE * FW, te);
+  stm(consts + K_HB * FW, fp_mul(fp_mul(tx, te), ldm(consts + K_DINV * FW)));
+}
+// j = 1..n: cinv[j-1] = 1/t'(j) = (-1)^(n-j) / ((j-1)! (n-j)!);  L[j-1] = t(x) / (x - j) * cinv[j-1]
+__global__ void __launch_bounds__(256) k_lagrange(const uint32_t* __restrict__ consts, const uint32_t* __restrict__ invfact, const uint32_t* __restrict__ xinv,
+                                                  size_t n, uint32_t* __restrict__ cinv, uint32_t* __restrict__ L_mont, uint32_t* __restrict__ L_canon) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= n) return;     // j = i + 1
+  Fr c = fp_mul(ldm(invfact + i * FW), ldm(invfact + (n - 1 - i) * FW));
+  if ((n - 1 - i) & 1) c = fp_neg(c);
+  stm(cinv + i * FW, c);
+  Fr l = fp_mul(fp_mul(ldm(consts + K_TX * FW), ldm(xinv + i * FW)), c);
+  stm(L_mont + i * FW, l); st_fp<C>(L_canon + i * FW, l);
+}
+// s = 1..n-1: hb[s-1] = t(x)/delta * T_E(x) / (x - (n+s)) * (-1)^(n-1-s) / ((s-1)! (n-1-s)!)   (canonical: fixed-base scalars)
+//             P[s-1] = t(n+s) = (n+s-1)! / (s-1)!                                               (Montgomery)
+__global__ void __launch_bounds__(256) k_hbasis(const uint32_t* __restrict__ consts, const uint32_t* __restrict__ fact, const uint32_t* __restrict__ invfact,
+                                                const uint32_t* __restrict__ xinv, size_t n, uint32_t* __restrict__ hb_canon, uint32_t* __restrict__ P) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i + 1 >= n) return;   // s = i + 1
+  Fr c = fp_mul(ldm(invfact + i * FW), ldm(invfact + (n - 2 - i) * FW));
+  if ((n - 2 - i) & 1) c = fp_neg(c);
+  st_fp<C>(hb_canon + i * FW, fp_mul(fp_mul(ldm(consts + K_HB * FW), ldm(xinv + (n + i) * FW)), c));
+  stm(P + i * FW, fp_mul(ldm(fact + (n + i) * FW), ldm(invfact + i * FW)));
+}
+// convolution kernel g[d] = 1/d = (d-1)!/d!, d = 1..2n-1; g[0] = 0 and zero padding up to N
+__global__ void __launch_bounds__(256) k_recip(const uint32_t* __restrict__ fact, const uint32_t* __restrict__ invfact, size_t n, size_t N, uint32_t* __restrict__ g) {
+  size_t d = (size_t)blockIdx.x * 256 + threadIdx.x; if (d >= N) return;
+  stm(g + d * FW, (d >= 1 && d <= 2 * n - 1) ? fp_mul(ldm(fact + (d - 1) * FW), ldm(invfact + d * FW)) : fp_zero<C>());
+}
+// y_i = (beta u_i(x) + alpha v_i(x) + w_i(x)) / (gamma | delta), canonical  (crs.rs:66-84)
+__global__ void __launch_bounds__(256) k_uvw(const uint32_t* __restrict__ consts, const uint32_t* __restrict__ ue, const uint32_t* __restrict__ ve, const uint32_t* __restrict__ we,
+                                             size_t l, size_t rows, uint32_t* __restrict__ y_canon) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= rows) return;
+  Fr s = fp_add(fp_add(fp_mul(ldm(consts + K_BETA * FW), ldm(ue + i * FW)), fp_mul(ldm(consts + K_ALPHA * FW), ldm(ve + i * FW))), ldm(we + i * FW));
+  st_fp<C>(y_canon + i * FW, fp_mul(s, ldm(consts + (i <= l ? K_GINV : K_DINV) * FW)));
+}
+
+// ---- Fr NTT of size N = 2^logN: radix-2, one launch per stage, table twiddles ------------------------------------
+// forward = decimation in frequency (natural order in, bit-reversed out); inverse = decimation in time on the
+// bit-reversed spectrum (natural order out), so no reordering pass exists; the 1/N lives in the precomputed kernel spectrum.
+__global__ void __launch_bounds__(256) k_ntt_dif_stage(uint32_t* __restrict__ a, size_t N, size_t half, const uint32_t* __restrict__ tw) {
+  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; if (t >= N / 2) return;
+  size_t j = t & (half - 1), i0 = ((t - j) << 1) + j, i1 = i0 + half;
+  Fr u = ldm(a + i0 * FW), v = ldm(a + i1 * FW);
+  stm(a + i0 * FW, fp_add(u, v));
+  stm(a + i1 * FW, fp_mul(fp_sub(u, v), ldm(tw + j * (N / (2 * half)) * FW)));
+}
+__global__ void __launch_bounds__(256) k_ntt_dit_stage(uint32_t* __restrict__ a, size_t N, size_t half, const uint32_t* __restrict__ twinv) {
+  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; if (t >= N / 2) return;
+  size_t j = t & (half - 1), i0 = ((t - j) << 1) + j, i1 = i0 + half;
+  Fr u = ldm(a + i0 * FW), v = fp_mul(ldm(a + i1 * FW), ldm(twinv + j * (N / (2 * half)) * FW));
+  stm(a + i0 * FW, fp_add(u, v));
+  stm(a + i1 * FW, fp_sub(u, v));
+}
+__global__ void __launch_bounds__(256) k_pointwise(uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  stm(a + i * FW, fp_mul(ldm(a + i * FW), ldm(b + i * FW)));
+}
+__global__ void __launch_bounds__(256) k_scale_all(uint32_t* __restrict__ a, const uint32_t* __restrict__ s, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  stm(a + i * FW, fp_mul(ldm(a + i * FW), ldm(s)));
+}
+
+// ---- prover Fr stage -----------------------------------------------------------------------------------------
+// f[0] = 0, f[j] = p(j) / t'(j) for j = 1..n, zero up to N
+__global__ void __launch_bounds__(256) k_prep_f(const uint32_t* __restrict__ pz, const uint32_t* __restrict__ cinv, size_t n, size_t N, uint32_t* __restrict__ f) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= N) return;
+  stm(f + i * FW, (i >= 1 && i <= n) ? fp_mul(ldm(pz + (i - 1) * FW), ldm(cinv + (i - 1) * FW)) : fp_zero<C>());
+}
+// h(n+s) = (P Sa * P Sb - P Sc) / t(n+s) with t(n+s) = P  =>  P Sa Sb - Sc,  s = 1..n-1, canonical for the MSM
+__global__ void __launch_bounds__(256) k_hvals(const uint32_t* __restrict__ Sa, const uint32_t* __restrict__ Sb, const uint32_t* __restrict__ Sc,
+                                               const uint32_t* __restrict__ P, size_t n, uint32_t* __restrict__ h_canon) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i + 1 >= n) return;
+  size_t k = n + 1 + i;
+  Fr h = fp_sub(fp_mul(fp_mul(ldm(P + i * FW), ldm(Sa + k * FW)), ldm(Sb + k * FW)), ldm(Sc + k * FW));
+  st_fp<C>(h_canon + i * FW, h);
+}
+}  // namespace zkt
+
+using namespace zkt;
+
+namespace {
+#define RCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[zkt] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return ZKT_ERR_DEVICE; } } while (0)
+#define ZCHK(x) do { int _rc = (x); if (_rc != ZKT_OK) return _rc; } while (0)
+inline unsigned nb(size_t n) { return (unsigned)((n + 255) / 256); }
+const size_t G1B = sizeof(zkt_g1_affine), G2B = sizeof(zkt_g2_affine), FRB = 32;
+const uint64_t G1_GEN[13] = {0xfb3af00adb22c6bbull, 0x6c55e83ff97a1aefull, 0xa14e3a3f171bac58ull, 0xc3688c4f9774b905ull, 0x2695638c4fa9ac0full, 0x17f1d3a73197d794ull,
+                             0x0caa232946c5e7e1ull, 0xd03cc744a2888ae4ull, 0x00db18cb2c04b3edull, 0xfcf5e095d5d00af6ull, 0xa09e30ed741d8ae4ull, 0x08b3f481e3aaa0f1ull, 0};   // g1_point.rs:38-47
+const uint64_t G2_GEN[25] = {0xe5ac7d055d042b7eull, 0x334cf11213945d57ull, 0xb5da61bbdc7f5049ull, 0x596bd0d09920b61aull, 0x7dacd3a088274f65ull, 0x13e02b6052719f60ull,
+                             0xd48056c8c121bdb8ull, 0x0bac0326a805bbefull, 0xb4510b647ae3d177ull, 0xc6e47ad4fa403b02ull, 0x260805272dc51051ull, 0x024aa2b2f08f0a91ull,
+                             0xaaa9075ff05f79beull, 0x3f370d275cec1da1ull, 0x267492ab572e99abull, 0xcb3e287e85a763afull, 0x32acd2b02bc28b99ull, 0x0606c4a02ea734ccull,
+                             0xe193548608b82801ull, 0x923ac9cc3baca289ull, 0x6d429a695160d12cull, 0xadfd9baa8cbdd3a7ull, 0x8cc9cdc6da2e351aull, 0x0ce5d527727d6e11ull, 0};   // g2_point.rs:36-46
+
+struct DBuf {                       // owning device buffer
+  void* p = nullptr; size_t bytes = 0;
+  int alloc(size_t b) { bytes = b ? b : 32; return hipMalloc(&p, bytes) == hipSuccess ? ZKT_OK : ZKT_ERR_DEVICE; }
+  void release() { if (p) hipFree(p); p = nullptr; }
+  ~DBuf() { release(); }
+  uint32_t* w() const { return (uint32_t*)p; }
+  DBuf() = default; DBuf(const DBuf&) = delete; DBuf& operator=(const DBuf&) = delete;
+};
+struct Csr { DBuf ptr, idx, val; size_t rows = 0, nnz = 0; };
+
+// inclusive prefix product, in place allowed (in == out); two levels of tiles cover 2048^2 elements
+int scan_mul(const uint32_t* in, uint32_t* out, size_t n, hipStream_t s) {
+  if (n == 0) return ZKT_OK;
+  const size_t tiles = (n + SC_TILE - 1) / SC_TILE;
+  if (tiles > (size_t)SC_TILE) return ZKT_ERR_SHAPE;
+  DBuf tot, tot2; ZCHK(tot.alloc(tiles * FRB)); ZCHK(tot2.alloc(FRB));
+  hipLaunchKernelGGL(k_scanmul_tile, dim3((unsigned)tiles), dim3(SC_TPB), 0, s, in, out, n, tot.w());
+  if (tiles > 1) {
+    hipLaunchKernelGGL(k_scanmul_tile, dim3(1), dim3(SC_TPB), 0, s, (const uint32_t*)tot.w(), tot.w(), tiles, tot2.w());
+    hipLaunchKernelGGL(k_scanmul_apply, dim3(nb(n)), dim3(256), 0, s, out, n, (const uint32_t*)tot.w());
+  }
+  RCHK(hipStreamSynchronize(s));     // the tile totals die with this frame
+  return ZKT_OK;
+}
+int ntt_forward(uint32_t* a, size_t N, const uint32_t* tw, hipStream_t s) {
+  for (size_t half = N / 2; half >= 1; half >>= 1) hipLaunchKernelGGL(k_ntt_dif_stage, dim3(nb(N / 2)), dim3(256), 0, s, a, N, half, tw);
+  RCHK(hipGetLastError()); return ZKT_OK;
+}
+int ntt_inverse(uint32_t* a, size_t N, const uint32_t* twinv, hipStream_t s) {
+  for (size_t half = 1; half <= N / 2; half <<= 1) hipLaunchKernelGGL(k_ntt_dit_stage, dim3(nb(N / 2)), dim3(256), 0, s, a, N, half, twinv);
+  RCHK(hipGetLastError()); return ZKT_OK;
+}
+// host CSR (reference order: one sparse row per constraint, r1cs.rs / constraint.rs:5-9) -> device CSR and its transpose
+int upload_csr(const zkt_sparse_rows* M, size_t n, size_t cols, Csr& rowwise, Csr& colwise, hipStream_t s) {
+  const size_t nnz = (size_t)M->rowptr[n];
+  if (nnz >= 0xffffffffull || M->rowptr[0] != 0) return ZKT_ERR_SHAPE;
+  std::vector<uint32_t> rp(n + 1), cp(cols + 1, 0), ridx(nnz ? nnz : 1), order(nnz ? nnz : 1);
+  for (size_t j = 0; j <= n; ++j) { if (j && M->rowptr[j] < M->rowptr[j - 1]) return ZKT_ERR_SHAPE; rp[j] = (uint32_t)M->rowptr[j]; }
+  for (size_t k = 0; k < nnz; ++k) { if (M->col[k] >= cols) return ZKT_ERR_SHAPE; cp[M->col[k] + 1]++; }
+  for (size_t i = 0; i < cols; ++i) cp[i + 1] += cp[i];
+  std::vector<uint32_t> cur(cp.begin(), cp.end() - 1);
+  std::vector<uint64_t> tval((nnz ? nnz : 1) * 4);
+  for (size_t j = 0; j < n; ++j)
+    for (uint32_t k = rp[j]; k < rp[j + 1]; ++k) { uint32_t d = cur[M->col[k]]++; ridx[d] = (uint32_t)j; memcpy(&tval[(size_t)d * 4], &M->val[(size_t)k * 4], 32); }
+  auto put = [&](Csr& c, const std::vector<uint32_t>& p, const uint32_t* idx, const uint64_t* val, size_t rows) -> int {
+    c.rows = rows; c.nnz = nnz;
+    ZCHK(c.ptr.alloc(p.size() * 4)); ZCHK(c.idx.alloc(nnz * 4)); ZCHK(c.val.alloc(nnz * FRB));
+    RCHK(hipMemcpyAsync(c.ptr.p, p.data(), p.size() * 4, hipMemcpyHostToDevice, s));
+    if (nnz) {
+      DBuf tmp; ZCHK(tmp.alloc(nnz * FRB));
+      RCHK(hipMemcpyAsync(c.idx.p, idx, nnz * 4, hipMemcpyHostToDevice, s));
+      RCHK(hipMemcpyAsync(tmp.p, val, nnz * FRB, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(k_to_mont, dim3(nb(nnz)), dim3(256), 0, s, (const uint32_t*)tmp.w(), c.val.w(), nnz);
+      RCHK(hipStreamSynchronize(s));
+    }
+    return ZKT_OK;
+  };
+  ZCHK(put(rowwise, rp, M->col, M->val, n));
+  ZCHK(put(colwise, cp, ridx.data(), tval.data(), cols));
+  return ZKT_OK;
+}
+}  // namespace
+
+struct zkt_groth16_pk {
+  size_t n = 0, l = 0, m = 0, N = 0; int logN = 0;
+  Csr A, B, Cm;                                  // constraint rows (device), values in Montgomery form
+  DBuf cinv, P, ghat, tw, twinv;                  // Fr tables
+  zkt_g1_bases *L1 = nullptr, *W = nullptr, *H = nullptr; zkt_g2_bases* L2 = nullptr;
+  zkt_g1_affine alpha1, beta1, delta1; zkt_g2_affine beta2, delta2;
+  DBuf wires_c, wires_m, z_m[3], z_c[2], f[3], h_c;   // per-proof work buffers
+  hipStream_t s = nullptr;
+  ~zkt_groth16_pk() {
+    if (L1) zkt_g1_bases_free(L1); if (W) zkt_g1_bases_free(W); if (H) zkt_g1_bases_free(H); if (L2) zkt_g2_bases_free(L2);
+    if (s) hipStreamDestroy(s);
+  }
+};
+
+extern int zkt_internal_ready();   // zkt_api.cpp
+extern void zkt_internal_set_error_index(size_t i);
+
+extern "C" {
+
+int zkt_groth16_setup_r1cs(size_t n, size_t l, size_t m, const zkt_sparse_rows* A, const zkt_sparse_rows* B, const zkt_sparse_rows* Cmat,
+                           const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma, const uint64_t* delta, const uint64_t* x,
+                           zkt_groth16_crs* vk, zkt_groth16_pk** out) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!A || !B || !Cmat || !alpha || !beta || !gamma || !delta || !x || !vk || !out || n == 0 || l > m || n >= (1ull << 30)) return ZKT_ERR_SHAPE;
+  if (!A->rowptr || !B->rowptr || !Cmat->rowptr) return ZKT_ERR_SHAPE;
+  uint64_t trap[20]; memcpy(trap, alpha, 32); memcpy(trap + 4, beta, 32); memcpy(trap + 8, gamma, 32); memcpy(trap + 12, delta, 32); memcpy(trap + 16, x, 32);
+  for (int k = 0; k < 5; ++k) { bool z = true; for (int j = 0; j < 4; ++j) z = z && trap[4 * k + j] == 0; if (z) return ZKT_ERR_INV_ZERO; }   // rand_elem(true): non-zero (crs.rs:59-63)
+  std::unique_ptr<zkt_groth16_pk> pk(new zkt_groth16_pk);
+  pk->n = n; pk->l = l; pk->m = m;
+  const size_t rows = m + 1;
+  int logN = 1; while (((size_t)1 << logN) < 2 * n) ++logN;
+  const size_t N = (size_t)1 << logN; pk->N = N; pk->logN = logN;
+  RCHK(hipStreamCreateWithFlags(&pk->s, hipStreamNonBlocking));
+  hipStream_t s = pk->s;
+  Csr At, Bt, Ct;
+  ZCHK(upload_csr(A, n, rows, pk->A, At, s)); ZCHK(upload_csr(B, n, rows, pk->B, Bt, s)); ZCHK(upload_csr(Cmat, n, rows, pk->Cm, Ct, s));
+
+  // ---- Fr tables ----
+  DBuf dtrap, consts, fact, invfact, xm, pre, xinv, Lm, Lc, hbc, g, derr;
+  ZCHK(dtrap.alloc(160)); ZCHK(consts.alloc(K_COUNT * FRB)); ZCHK(fact.alloc((2 * n + 1) * FRB)); ZCHK(invfact.alloc((2 * n + 1) * FRB));
+  ZCHK(xm.alloc((2 * n) * FRB)); ZCHK(pre.alloc((2 * n) * FRB)); ZCHK(xinv.alloc((2 * n) * FRB)); ZCHK(Lm.alloc(n * FRB)); ZCHK(Lc.alloc(n * FRB));
+  ZCHK(hbc.alloc(n * FRB)); ZCHK(g.alloc(N * FRB)); ZCHK(derr.alloc(8));
+  ZCHK(pk->cinv.alloc(n * FRB)); ZCHK(pk->P.alloc(n * FRB)); ZCHK(pk->ghat.alloc(N * FRB)); ZCHK(pk->tw.alloc(N / 2 * FRB)); ZCHK(pk->twinv.alloc(N / 2 * FRB));
+  unsigned long long noerr = NO_ERR;
+  RCHK(hipMemcpyAsync(derr.p, &noerr, 8, hipMemcpyHostToDevice, s));
+  RCHK(hipMemcpyAsync(dtrap.p, trap, 160, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_setup_consts, dim3(1), dim3(64), 0, s, (const uint32_t*)dtrap.w(), consts.w(), logN);
+  hipLaunchKernelGGL(k_iota, dim3(nb(2 * n + 1)), dim3(256), 0, s, fact.w(), 2 * n + 1);
+  ZCHK(scan_mul(fact.w(), fact.w(), 2 * n + 1, s));
+  hipLaunchKernelGGL(k_inv, dim3(nb(2 * n + 1)), dim3(256), 0, s, (const uint32_t*)fact.w(), invfact.w(), 2 * n + 1, (unsigned long long*)derr.p);
+  const size_t nx = 2 * n - 1;
+  hipLaunchKernelGGL(k_x_minus, dim3(nb(nx)), dim3(256), 0, s, (const uint32_t*)(consts.w() + K_X * FW), xm.w(), nx);
+  ZCHK(scan_mul(xm.w(), pre.w(), nx, s));
+  hipLaunchKernelGGL(k_inv, dim3(nb(nx)), dim3(256), 0, s, (const uint32_t*)xm.w(), xinv.w(), nx, (unsigned long long*)derr.p);
+  unsigned long long e = NO_ERR;
+  RCHK(hipMemcpyAsync(&e, derr.p, 8, hipMemcpyDeviceToHost, s)); RCHK(hipStreamSynchronize(s));
+  if (e != NO_ERR) { zkt_internal_set_error_index((size_t)e); return ZKT_ERR_INV_ZERO; }      // x fell on the domain {1..2n-1}: t(x) = 0, no CRS
+  hipLaunchKernelGGL(k_setup_consts2, dim3(1), dim3(64), 0, s, (const uint32_t*)pre.w(), n, consts.w());
+  hipLaunchKernelGGL(k_lagrange, dim3(nb(n)), dim3(256), 0, s, (const uint32_t*)consts.w(), (const uint32_t*)invfact.w(), (const uint32_t*)xinv.w(), n, pk->cinv.w(), Lm.w(), Lc.w());
+  if (n >= 2) hipLaunchKernelGGL(k_hbasis, dim3(nb(n - 1)), dim3(256), 0, s, (const uint32_t*)consts.w(), (const uint32_t*)fact.w(), (const uint32_t*)invfact.w(), (const uint32_t*)xinv.w(), n, hbc.w(), pk->P.w());
+  hipLaunchKernelGGL(k_recip, dim3(nb(N)), dim3(256), 0, s, (const uint32_t*)fact.w(), (const uint32_t*)invfact.w(), n, N, g.w());
+  // twiddles: w^k and w^-k, k < N/2, as prefix products
+  hipLaunchKernelGGL(k_fill_pow, dim3(nb(N / 2)), dim3(256), 0, s, (const uint32_t*)(consts.w() + K_OMEGA * FW), pk->tw.w(), N / 2);
+  ZCHK(scan_mul(pk->tw.w(), pk->tw.w(), N / 2, s));
+  hipLaunchKernelGGL(k_fill_pow, dim3(nb(N / 2)), dim3(256), 0, s, (const uint32_t*)(consts.w() + K_OMEGA_INV * FW), pk->twinv.w(), N / 2);
+  ZCHK(scan_mul(pk->twinv.w(), pk->twinv.w(), N / 2, s));
+  RCHK(hipMemcpyAsync(pk->ghat.p, g.p, N * FRB, hipMemcpyDeviceToDevice, s));
+  ZCHK(ntt_forward(pk->ghat.w(), N, pk->tw.w(), s));
+  hipLaunchKernelGGL(k_scale_all, dim3(nb(N)), dim3(256), 0, s, pk->ghat.w(), (const uint32_t*)(consts.w() + K_NINV * FW), N);
+
+  // ---- per-wire evaluations u_i(x) = sum_j A[j][i] L_j(x)  and the scalars of crs.rs:66-84 ----
+  DBuf ue, ve, we, y; ZCHK(ue.alloc(rows * FRB)); ZCHK(ve.alloc(rows * FRB)); ZCHK(we.alloc(rows * FRB)); ZCHK(y.alloc(rows * FRB));
+  Csr* T[3] = {&At, &Bt, &Ct}; DBuf* ev[3] = {&ue, &ve, &we};
+  for (int k = 0; k < 3; ++k)
+    hipLaunchKernelGGL(k_spmv, dim3(nb(rows)), dim3(256), 0, s, (const uint32_t*)T[k]->ptr.w(), (const uint32_t*)T[k]->idx.w(), (const uint32_t*)T[k]->val.w(), (const uint32_t*)Lm.w(), ev[k]->w(), rows);
+  hipLaunchKernelGGL(k_uvw, dim3(nb(rows)), dim3(256), 0, s, (const uint32_t*)consts.w(), (const uint32_t*)ue.w(), (const uint32_t*)ve.w(), (const uint32_t*)we.w(), l, rows, y.w());
+  RCHK(hipGetLastError());
+
+  // ---- group side: fixed-base multiplications of the generators (crs.rs:85-135) ----
+  DBuf gen1, gen2, p1, p2, small1, small2, gt;
+  const size_t big = (rows > n ? rows : n);
+  ZCHK(gen1.alloc(G1B)); ZCHK(gen2.alloc(G2B)); ZCHK(p1.alloc(big * G1B)); ZCHK(p2.alloc(n * G2B)); ZCHK(small1.alloc(3 * G1B)); ZCHK(small2.alloc(3 * G2B)); ZCHK(gt.alloc(576));
+  RCHK(hipMemcpyAsync(gen1.p, G1_GEN, G1B, hipMemcpyHostToDevice, s)); RCHK(hipMemcpyAsync(gen2.p, G2_GEN, G2B, hipMemcpyHostToDevice, s));
+  // uvw: statement part to the verifying key, witness part stays on the device as MSM bases
+  RCHK(launch_group_mul(G_G1, gen1.w(), y.w(), 8, p1.w(), rows, s, true));
+  RCHK(hipMemcpyAsync(vk->g1_uvw_stmt, p1.p, (l + 1) * G1B, hipMemcpyDeviceToHost, s));
+  if (vk->g1_uvw_wit && m > l) RCHK(hipMemcpyAsync(vk->g1_uvw_wit, p1.w() + (l + 1) * 26, (m - l) * G1B, hipMemcpyDeviceToHost, s));
+  RCHK(hipStreamSynchronize(s));
+  if (m > l) ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)(p1.w() + (l + 1) * 26), m - l, s, &pk->W));
+  RCHK(launch_group_mul(G_G1, gen1.w(), Lc.w(), 8, p1.w(), n, s, true));
+  RCHK(hipStreamSynchronize(s));
+  ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)p1.p, n, s, &pk->L1));
+  if (n >= 2) {
+    RCHK(launch_group_mul(G_G1, gen1.w(), hbc.w(), 8, p1.w(), n - 1, s, true));
+    RCHK(hipStreamSynchronize(s));
+    ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)p1.p, n - 1, s, &pk->H));
+  }
+  RCHK(launch_group_mul(G_G2, gen2.w(), Lc.w(), 8, p2.w(), n, s, true));
+  RCHK(hipStreamSynchronize(s));
+  ZCHK(zkt_g2_bases_from_device((const zkt_g2_affine*)p2.p, n, s, &pk->L2));
+  RCHK(launch_group_mul(G_G1, gen1.w(), dtrap.w(), 8, small1.w(), 1, s, true));               // alpha
+  RCHK(launch_group_mul(G_G1, gen1.w(), dtrap.w() + 8, 8, small1.w() + 26, 1, s, true));      // beta
+  RCHK(launch_group_mul(G_G1, gen1.w(), dtrap.w() + 24, 8, small1.w() + 52, 1, s, true));     // delta
+  RCHK(launch_group_mul(G_G2, gen2.w(), dtrap.w() + 8, 8, small2.w(), 1, s, true));           // beta
+  RCHK(launch_group_mul(G_G2, gen2.w(), dtrap.w() + 16, 8, small2.w() + 50, 1, s, true));     // gamma
+  RCHK(launch_group_mul(G_G2, gen2.w(), dtrap.w() + 24, 8, small2.w() + 100, 1, s, true));    // delta
+  RCHK(hipMemcpyAsync(derr.p, &noerr, 8, hipMemcpyHostToDevice, s));
+  RCHK(launch_tate(small1.w(), small2.w(), gt.w(), 1, (unsigned long long*)derr.p, s));        // crs.rs:137-139
+  RCHK(hipMemcpyAsync(vk->g1_alpha, small1.p, G1B, hipMemcpyDeviceToHost, s)); RCHK(hipMemcpyAsync(vk->g1_beta, small1.w() + 26, G1B, hipMemcpyDeviceToHost, s));
+  RCHK(hipMemcpyAsync(vk->g1_delta, small1.w() + 52, G1B, hipMemcpyDeviceToHost, s)); RCHK(hipMemcpyAsync(vk->g2_beta, small2.p, G2B, hipMemcpyDeviceToHost, s));
+  RCHK(hipMemcpyAsync(vk->g2_gamma, small2.w() + 50, G2B, hipMemcpyDeviceToHost, s)); RCHK(hipMemcpyAsync(vk->g2_delta, small2.w() + 100, G2B, hipMemcpyDeviceToHost, s));
+  RCHK(hipMemcpyAsync(vk->gt_alpha_beta, gt.p, 576, hipMemcpyDeviceToHost, s));
+  RCHK(hipStreamSynchronize(s));
+  vk->n = n; vk->l = l; vk->m = m;
+  pk->alpha1 = *vk->g1_alpha; pk->beta1 = *vk->g1_beta; pk->delta1 = *vk->g1_delta; pk->beta2 = *vk->g2_beta; pk->delta2 = *vk->g2_delta;
+
+  // ---- per-proof work buffers ----
+  ZCHK(pk->wires_c.alloc(rows * FRB)); ZCHK(pk->wires_m.alloc(rows * FRB)); ZCHK(pk->h_c.alloc(n * FRB));
+  for (int k = 0; k < 3; ++k) { ZCHK(pk->z_m[k].alloc(n * FRB)); ZCHK(pk->f[k].alloc(N * FRB)); }
+  for (int k = 0; k < 2; ++k) ZCHK(pk->z_c[k].alloc(n * FRB));
+  *out = pk.release();
+  return ZKT_OK;
+}
+
+void zkt_groth16_pk_free(zkt_groth16_pk* pk) { delete pk; }
+
+// Prover::prove (prover.rs:96-147) with r, s injected; wires = a_0..a_m canonical (host).
+int zkt_groth16_prove_r1cs(zkt_groth16_pk* pk, const uint64_t* wires, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!pk || !wires || !r || !s_ || !A || !B || !Cp) return ZKT_ERR_SHAPE;
+  const size_t n = pk->n, l = pk->l, m = pk->m, rows = m + 1, N = pk->N;
+  hipStream_t s = pk->s;
+  RCHK(hipMemcpyAsync(pk->wires_c.p, wires, rows * FRB, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_to_mont, dim3(nb(rows)), dim3(256), 0, s, (const uint32_t*)pk->wires_c.w(), pk->wires_m.w(), rows);
+  Csr* M[3] = {&pk->A, &pk->B, &pk->Cm};
+  for (int k = 0; k < 3; ++k)
+    hipLaunchKernelGGL(k_spmv, dim3(nb(n)), dim3(256), 0, s, (const uint32_t*)M[k]->ptr.w(), (const uint32_t*)M[k]->idx.w(), (const uint32_t*)M[k]->val.w(), (const uint32_t*)pk->wires_m.w(), pk->z_m[k].w(), n);
+  for (int k = 0; k < 2; ++k) hipLaunchKernelGGL(k_from_mont, dim3(nb(n)), dim3(256), 0, s, (const uint32_t*)pk->z_m[k].w(), pk->z_c[k].w(), n);
+  RCHK(hipGetLastError());
+  // the three MSMs that only need (A w) and (B w), and the witness MSM, start now and overlap the quotient stage
+  ZCHK(zkt_g1_msm_submit(pk->L1, (const uint64_t*)pk->z_c[0].p, n, s, 0));          // sum_i a_i u_i(x)   in G1
+  ZCHK(zkt_g1_msm_submit(pk->L1, (const uint64_t*)pk->z_c[1].p, n, s, 1));          // sum_i a_i v_i(x)   in G1
+  ZCHK(zkt_g2_msm_submit(pk->L2, (const uint64_t*)pk->z_c[1].p, n, s, 0));          // sum_i a_i v_i(x)   in G2
+  if (m > l) ZCHK(zkt_g1_msm_submit(pk->W, (const uint64_t*)(pk->wires_c.w() + (l + 1) * FW), m - l, s, 0));
+  if (n >= 2) {
+    for (int k = 0; k < 3; ++k) {
+      hipLaunchKernelGGL(k_prep_f, dim3(nb(N)), dim3(256), 0, s, (const uint32_t*)pk->z_m[k].w(), (const uint32_t*)pk->cinv.w(), n, N, pk->f[k].w());
+      ZCHK(ntt_forward(pk->f[k].w(), N, pk->tw.w(), s));
+      hipLaunchKernelGGL(k_pointwise, dim3(nb(N)), dim3(256), 0, s, pk->f[k].w(), (const uint32_t*)pk->ghat.w(), N);
+      ZCHK(ntt_inverse(pk->f[k].w(), N, pk->twinv.w(), s));
+    }
+    hipLaunchKernelGGL(k_hvals, dim3(nb(n - 1)), dim3(256), 0, s, (const uint32_t*)pk->f[0].w(), (const uint32_t*)pk->f[1].w(), (const uint32_t*)pk->f[2].w(), (const uint32_t*)pk->P.w(), n, pk->h_c.w());
+    RCHK(hipGetLastError());
+    ZCHK(zkt_g1_msm_submit(pk->H, (const uint64_t*)pk->h_c.p, n - 1, s, 0));        // h(x) t(x) / delta
+  }
+  zkt_g1_affine sumA, sumB1, sumW, ht; zkt_g2_affine sumB;
+  memset(&sumW, 0, sizeof sumW); sumW.is_infinity = 1; memset(&ht, 0, sizeof ht); ht.is_infinity = 1;
+  ZCHK(zkt_g1_msm_collect(pk->L1, 0, &sumA, nullptr)); ZCHK(zkt_g1_msm_collect(pk->L1, 1, &sumB1, nullptr)); ZCHK(zkt_g2_msm_collect(pk->L2, 0, &sumB, nullptr));
+  if (m > l) ZCHK(zkt_g1_msm_collect(pk->W, 0, &sumW, nullptr));
+  if (n >= 2) ZCHK(zkt_g1_msm_collect(pk->H, 0, &ht, nullptr));
+  // the seven single scalar multiplications and the final sums (prover.rs:118-140)
+  int rc;
+  zkt_g1_affine dr, ds, As, Br, drs, t1, t2, B1, ndrs; zkt_g2_affine d2s, t3;
+  if ((rc = zkt_g1_mul_batch(&pk->delta1, r, 4, &dr, 1)) || (rc = zkt_g1_mul_batch(&pk->delta1, s_, 4, &ds, 1)) || (rc = zkt_g2_mul_batch(&pk->delta2, s_, 4, &d2s, 1))) return rc;
+  if ((rc = zkt_g1_add_batch(&pk->alpha1, &sumA, &t1, 1)) || (rc = zkt_g1_add_batch(&t1, &dr, A, 1))) return rc;               // A
+  if ((rc = zkt_g2_add_batch(&pk->beta2, &sumB, &t3, 1)) || (rc = zkt_g2_add_batch(&t3, &d2s, B, 1))) return rc;             // B
+  if ((rc = zkt_g1_add_batch(&pk->beta1, &sumB1, &t1, 1)) || (rc = zkt_g1_add_batch(&t1, &ds, &B1, 1))) return rc;           // B_g1
+  if ((rc = zkt_g1_mul_batch(A, s_, 4, &As, 1)) || (rc = zkt_g1_mul_batch(&B1, r, 4, &Br, 1)) || (rc = zkt_g1_mul_batch(&dr, s_, 4, &drs, 1))) return rc;
+  if ((rc = zkt_g1_neg_batch(&drs, &ndrs, 1))) return rc;
+  if ((rc = zkt_g1_add_batch(&sumW, &ht, &t1, 1)) || (rc = zkt_g1_add_batch(&t1, &As, &t2, 1)) || (rc = zkt_g1_add_batch(&t2, &Br, &t1, 1)) ||
+      (rc = zkt_g1_add_batch(&t1, &ndrs, Cp, 1))) return rc;                                                                 // C
+  return ZKT_OK;
+}
+
+}  // extern "C"
