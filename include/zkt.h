@@ -218,7 +218,7 @@ int zkt_secp_jac_sum_dev(const uint32_t* dev_partials, size_t count, void* strea
  * coefficient form (prover.rs:64-71,103-131) — O(m n) group operations, infeasible at 2^20 constraints.  These entry
  * points take the R1CS itself, one sparse row per constraint (R1CS.constraints, r1cs.rs; Constraint{a,b,c},
  * constraint.rs:5-9; SparseVec), and produce the SAME proof points: setup derives device-resident Lagrange-basis
- * bases from the trapdoor, prove is 3 sparse mat-vecs + Fr NTTs + 4 G1 MSMs + 1 G2 MSM.
+ * bases from the trapdoor, prove is 3 sparse mat-vecs + Fr NTTs + three MSMs whose outputs are A, B, C.
  * rowptr: n+1 offsets into col/val; col: wire index 0..m; val: 4-limb canonical Fr. */
 typedef struct { const uint64_t* rowptr; const uint32_t* col; const uint64_t* val; } zkt_sparse_rows;
 typedef struct zkt_groth16_pk zkt_groth16_pk;
@@ -232,6 +232,9 @@ int zkt_groth16_setup_r1cs(size_t n, size_t l, size_t m, const zkt_sparse_rows* 
 /* Prover::prove (prover.rs:96-147), r and s injected; wires = a_0..a_m, 4-limb canonical Fr on the host. */
 int zkt_groth16_prove_r1cs(zkt_groth16_pk* pk, const uint64_t* wires, const uint64_t* r, const uint64_t* s,
                            zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* C);
+/* the same with the wires already in HBM (device pointer) */
+int zkt_groth16_prove_r1cs_dev(zkt_groth16_pk* pk, const uint64_t* dev_wires, const uint64_t* r, const uint64_t* s,
+                               zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* C);
 void zkt_groth16_pk_free(zkt_groth16_pk* pk);
 
 int zkt_g1_mul_batch_dev(const zkt_g1_affine* dev_points, const uint64_t* dev_scalars, int scalar_limbs,

@@ -53,6 +53,7 @@ def lib():
         L.zkt_groth16_prove.argtypes = [vp, vp, vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp, vp]
         L.zkt_groth16_setup_r1cs.argtypes = [ctypes.c_size_t] * 3 + [vp] * 10
         L.zkt_groth16_prove_r1cs.argtypes = [vp] * 7
+        L.zkt_groth16_prove_r1cs_dev.argtypes = [vp] * 7
         L.zkt_groth16_pk_free.argtypes = [vp]; L.zkt_groth16_pk_free.restype = None
         _lib = L
     return _lib

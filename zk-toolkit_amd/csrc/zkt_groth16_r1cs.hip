@@ -12,8 +12,14 @@
 //                                                                       with the kernel 1/d (Fr NTT, size >= 2n)
 //   h(n+s) = (a b - c)(n+s) / t(n+s)
 //
-// so a proof is 3 sparse mat-vecs, 3+3 NTTs, 4 G1 MSMs and 1 G2 MSM over device-resident bases [L_j(x)]_1, [L_j(x)]_2,
-// [uvw_wit]_1 and [Lambda_s(x) t(x)/delta]_1 that setup derives from the trapdoor.  tests/test_r1cs_domain_math.py checks
+// and the single scalar multiplications of prover.rs:118-140 fold into the sums: with A = alpha + sum_A + r delta and
+// B_g1 = beta + sum_B + s delta,  s A + r B_g1 - r s delta = s alpha + r beta + r s delta + sum_j (s (A w)_j + r (B w)_j) L_j(x).
+// A proof is therefore 3 sparse mat-vecs, 3+3 NTTs and exactly three MSMs over device-resident bases derived from the trapdoor:
+//   A:  [L_j(x)]_1 | alpha, delta                                      scalars (A w)_j | 1, r
+//   B:  [L_j(x)]_2 | beta, delta                                       scalars (B w)_j | 1, s
+//   C:  [L_j(x)]_1 | uvw_wit | [Lambda_s(x) t(x)/delta]_1 | alpha, beta, delta
+//                                                                      scalars s (A w)_j + r (B w)_j | a_i | h(n+s) | s, r, r s
+// whose affine outputs ARE the proof points — no per-proof single-lane scalar multiplication remains.  tests/test_r1cs_domain_math.py checks
 // the identity in python integers; tests/test_gpu_groth16_r1cs.py checks the proof points bit-for-bit against the oracle's
 // restatement of the reference prover on the dense QAP.
 #include <vector>
@@ -157,26 +163,52 @@ __global__ void __launch_bounds__(256) k_uvw(const uint32_t* __restrict__ consts
   st_fp<C>(y_canon + i * FW, fp_mul(s, ldm(consts + (i <= l ? K_GINV : K_DINV) * FW)));
 }
 
-// ---- Fr NTT of size N = 2^logN: radix-2, one launch per stage, table twiddles ------------------------------------
+// ---- Fr NTT of size N = 2^logN ------------------------------------------------------------------------------------
 // forward = decimation in frequency (natural order in, bit-reversed out); inverse = decimation in time on the
 // bit-reversed spectrum (natural order out), so no reordering pass exists; the 1/N lives in the precomputed kernel spectrum.
-__global__ void __launch_bounds__(256) k_ntt_dif_stage(uint32_t* __restrict__ a, size_t N, size_t half, const uint32_t* __restrict__ tw) {
-  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; if (t >= N / 2) return;
-  size_t j = t & (half - 1), i0 = ((t - j) << 1) + j, i1 = i0 + half;
-  Fr u = ldm(a + i0 * FW), v = ldm(a + i1 * FW);
-  stm(a + i0 * FW, fp_add(u, v));
-  stm(a + i1 * FW, fp_mul(fp_sub(u, v), ldm(tw + j * (N / (2 * half)) * FW)));
-}
-__global__ void __launch_bounds__(256) k_ntt_dit_stage(uint32_t* __restrict__ a, size_t N, size_t half, const uint32_t* __restrict__ twinv) {
-  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; if (t >= N / 2) return;
-  size_t j = t & (half - 1), i0 = ((t - j) << 1) + j, i1 = i0 + half;
-  Fr u = ldm(a + i0 * FW), v = fp_mul(ldm(a + i1 * FW), ldm(twinv + j * (N / (2 * half)) * FW));
-  stm(a + i0 * FW, fp_add(u, v));
-  stm(a + i1 * FW, fp_sub(u, v));
-}
-__global__ void __launch_bounds__(256) k_pointwise(uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
-  stm(a + i * FW, fp_mul(ldm(a + i * FW), ldm(b + i * FW)));
+// HBM-bound (one butterfly = one Fr multiply per 64 B moved), so stages are fused through LDS: a launch runs `cnt`
+// consecutive radix-2 stages (butterfly distances 2^lo .. 2^(lo+cnt-1)) on a tile of 2^cnt strided rows x 2^cbits
+// adjacent columns (<= 1024 elements, 32 KB), every element read and written once per launch, rows of >= 128 B contiguous.
+// logN = 21 is three launches per transform (10 + 8 + 3 stages) instead of 21.
+static constexpr int NTT_TILE_LOG = 10, NTT_TPB = 256;
+template <bool DIF>
+__global__ void __launch_bounds__(NTT_TPB) k_ntt_group(uint32_t* __restrict__ a, int logN, int lo, int cnt, int cbits, const uint32_t* __restrict__ tw,
+                                                       const uint32_t* __restrict__ mulvec) {
+  __shared__ uint32_t lds[(1 << NTT_TILE_LOG) * FW];
+  const int tile = 1 << (cnt + cbits), cmask = (1 << cbits) - 1;
+  const size_t tiles_per_hi = (size_t)1 << (lo - cbits);
+  const size_t hi = blockIdx.x / tiles_per_hi, c0 = (blockIdx.x % tiles_per_hi) << cbits;
+  const size_t gbase = (hi << (lo + cnt)) | c0;
+  for (int e = threadIdx.x; e < tile; e += NTT_TPB) {
+    const size_t g = gbase | ((size_t)(e >> cbits) << lo) | (size_t)(e & cmask);
+    const uint4* src = reinterpret_cast<const uint4*>(a + g * FW);
+    uint4* dst = reinterpret_cast<uint4*>(lds + e * FW);
+    dst[0] = src[0]; dst[1] = src[1];
+  }
+  __syncthreads();
+  for (int st = 0; st < cnt; ++st) {
+    const int t = DIF ? cnt - 1 - st : st;                       // local butterfly distance 2^t rows
+    for (int b = threadIdx.x; b < tile / 2; b += NTT_TPB) {
+      const int cc = b & cmask, kb = b >> cbits;
+      const int k0 = ((kb >> t) << (t + 1)) | (kb & ((1 << t) - 1));
+      const int e0 = (k0 << cbits) | cc, e1 = e0 + (1 << (t + cbits));
+      const size_t j = ((size_t)(k0 & ((1 << t) - 1)) << lo) | c0 | (size_t)cc;      // position inside the butterfly group
+      const Fr w = ldm(tw + (j << (logN - 1 - lo - t)) * FW);
+      Fr u = ldm(lds + e0 * FW), v = ldm(lds + e1 * FW);
+      if (DIF) { stm(lds + e0 * FW, fp_add(u, v)); stm(lds + e1 * FW, fp_mul(fp_sub(u, v), w)); }
+      else { v = fp_mul(v, w); stm(lds + e0 * FW, fp_add(u, v)); stm(lds + e1 * FW, fp_sub(u, v)); }
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < tile; e += NTT_TPB) {
+    const size_t g = gbase | ((size_t)(e >> cbits) << lo) | (size_t)(e & cmask);
+    if (mulvec) stm(a + g * FW, fp_mul(ldm(lds + e * FW), ldm(mulvec + g * FW)));      // fused pointwise product with a spectrum
+    else {
+      const uint4* src = reinterpret_cast<const uint4*>(lds + e * FW);
+      uint4* dst = reinterpret_cast<uint4*>(a + g * FW);
+      dst[0] = src[0]; dst[1] = src[1];
+    }
+  }
 }
 __global__ void __launch_bounds__(256) k_scale_all(uint32_t* __restrict__ a, const uint32_t* __restrict__ s, size_t n) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
@@ -196,6 +228,29 @@ __global__ void __launch_bounds__(256) k_hvals(const uint32_t* __restrict__ Sa, 
   size_t k = n + 1 + i;
   Fr h = fp_sub(fp_mul(fp_mul(ldm(P + i * FW), ldm(Sa + k * FW)), ldm(Sb + k * FW)), ldm(Sc + k * FW));
   st_fp<C>(h_canon + i * FW, h);
+}
+// scalar vectors of the three MSMs (canonical).  rs = {r, s} canonical.
+//   sA = [Az | 1 | r]   sB = [Bz | 1 | s]   sC = [s Az + r Bz | wires[l+1..m] | h | s | r | r s]  (h is written in place by k_hvals)
+__global__ void __launch_bounds__(256) k_prove_scalars(const uint32_t* __restrict__ Az, const uint32_t* __restrict__ Bz, const uint32_t* __restrict__ wires_c,
+                                                       const uint32_t* __restrict__ rs, size_t n, size_t l, size_t m,
+                                                       uint32_t* __restrict__ sA, uint32_t* __restrict__ sB, uint32_t* __restrict__ sC) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t nw = m - l, nh = n >= 2 ? n - 1 : 0;
+  if (i < n) {
+    Fr a = ldm(Az + i * FW), b = ldm(Bz + i * FW), r = ld_fp<C>(rs), s = ld_fp<C>(rs + FW);
+    st_fp<C>(sA + i * FW, a); st_fp<C>(sB + i * FW, b);
+    st_fp<C>(sC + i * FW, fp_add(fp_mul(s, a), fp_mul(r, b)));
+  } else if (i < n + nw) {
+    const uint32_t* src = wires_c + (l + 1 + (i - n)) * FW;
+#pragma unroll
+    for (int k = 0; k < FW; ++k) sC[i * FW + k] = src[k];
+  } else if (i == n + nw) {                                   // the constant tails
+    Fr r = ld_fp<C>(rs), s = ld_fp<C>(rs + FW);
+    uint32_t* tA = sA + n * FW; uint32_t* tB = sB + n * FW; uint32_t* tC = sC + (n + nw + nh) * FW;
+    st_fp<C>(tA, fp_one<C>()); st_fp<C>(tA + FW, r);
+    st_fp<C>(tB, fp_one<C>()); st_fp<C>(tB + FW, s);
+    st_fp<C>(tC, s); st_fp<C>(tC + FW, r); st_fp<C>(tC + 2 * FW, fp_mul(r, s));
+  }
 }
 }  // namespace zkt
 
@@ -237,12 +292,29 @@ int scan_mul(const uint32_t* in, uint32_t* out, size_t n, hipStream_t s) {
   RCHK(hipStreamSynchronize(s));     // the tile totals die with this frame
   return ZKT_OK;
 }
-int ntt_forward(uint32_t* a, size_t N, const uint32_t* tw, hipStream_t s) {
-  for (size_t half = N / 2; half >= 1; half >>= 1) hipLaunchKernelGGL(k_ntt_dif_stage, dim3(nb(N / 2)), dim3(256), 0, s, a, N, half, tw);
+// stage groups: the contiguous one first (distances 1..2^(c0-1)), then strided groups of <= 8 stages with >= 4 adjacent columns
+struct NttGroup { int lo, cnt, cbits; };
+int ntt_groups(int logN, NttGroup* g) {
+  int k = 0, c0 = logN < NTT_TILE_LOG ? logN : NTT_TILE_LOG;
+  g[k++] = {0, c0, 0};
+  for (int lo = c0, rem = logN - c0; rem > 0;) {
+    int cnt = rem < 8 ? rem : 8, cb = NTT_TILE_LOG - cnt; if (cb > lo) cb = lo;
+    g[k++] = {lo, cnt, cb}; lo += cnt; rem -= cnt;
+  }
+  return k;
+}
+// forward: natural -> bit-reversed; if `mulvec`, the spectrum is multiplied by it on the way out
+int ntt_forward(uint32_t* a, int logN, const uint32_t* tw, const uint32_t* mulvec, hipStream_t s) {
+  NttGroup g[8]; const int k = ntt_groups(logN, g);
+  for (int i = k - 1; i >= 0; --i)
+    hipLaunchKernelGGL(k_ntt_group<true>, dim3((unsigned)(((size_t)1 << logN) >> (g[i].cnt + g[i].cbits))), dim3(NTT_TPB), 0, s, a, logN, g[i].lo, g[i].cnt, g[i].cbits, tw,
+                       i == 0 ? mulvec : (const uint32_t*)nullptr);
   RCHK(hipGetLastError()); return ZKT_OK;
 }
-int ntt_inverse(uint32_t* a, size_t N, const uint32_t* twinv, hipStream_t s) {
-  for (size_t half = 1; half <= N / 2; half <<= 1) hipLaunchKernelGGL(k_ntt_dit_stage, dim3(nb(N / 2)), dim3(256), 0, s, a, N, half, twinv);
+int ntt_inverse(uint32_t* a, int logN, const uint32_t* twinv, hipStream_t s) {
+  NttGroup g[8]; const int k = ntt_groups(logN, g);
+  for (int i = 0; i < k; ++i)
+    hipLaunchKernelGGL(k_ntt_group<false>, dim3((unsigned)(((size_t)1 << logN) >> (g[i].cnt + g[i].cbits))), dim3(NTT_TPB), 0, s, a, logN, g[i].lo, g[i].cnt, g[i].cbits, twinv, (const uint32_t*)nullptr);
   RCHK(hipGetLastError()); return ZKT_OK;
 }
 // host CSR (reference order: one sparse row per constraint, r1cs.rs / constraint.rs:5-9) -> device CSR and its transpose
@@ -280,12 +352,12 @@ struct zkt_groth16_pk {
   size_t n = 0, l = 0, m = 0, N = 0; int logN = 0;
   Csr A, B, Cm;                                  // constraint rows (device), values in Montgomery form
   DBuf cinv, P, ghat, tw, twinv;                  // Fr tables
-  zkt_g1_bases *L1 = nullptr, *W = nullptr, *H = nullptr; zkt_g2_bases* L2 = nullptr;
-  zkt_g1_affine alpha1, beta1, delta1; zkt_g2_affine beta2, delta2;
-  DBuf wires_c, wires_m, z_m[3], z_c[2], f[3], h_c;   // per-proof work buffers
+  zkt_g1_bases *setA = nullptr, *setC = nullptr; zkt_g2_bases* setB = nullptr;   // the three resident base sets (see the file header)
+  size_t nA = 0, nC = 0;
+  DBuf wires_c, wires_m, z_m[3], f[3], sA, sB, sC, rs;   // per-proof work buffers
   hipStream_t s = nullptr;
   ~zkt_groth16_pk() {
-    if (L1) zkt_g1_bases_free(L1); if (W) zkt_g1_bases_free(W); if (H) zkt_g1_bases_free(H); if (L2) zkt_g2_bases_free(L2);
+    if (setA) zkt_g1_bases_free(setA); if (setC) zkt_g1_bases_free(setC); if (setB) zkt_g2_bases_free(setB);
     if (s) hipStreamDestroy(s);
   }
 };
@@ -343,7 +415,7 @@ int zkt_groth16_setup_r1cs(size_t n, size_t l, size_t m, const zkt_sparse_rows* 
   hipLaunchKernelGGL(k_fill_pow, dim3(nb(N / 2)), dim3(256), 0, s, (const uint32_t*)(consts.w() + K_OMEGA_INV * FW), pk->twinv.w(), N / 2);
   ZCHK(scan_mul(pk->twinv.w(), pk->twinv.w(), N / 2, s));
   RCHK(hipMemcpyAsync(pk->ghat.p, g.p, N * FRB, hipMemcpyDeviceToDevice, s));
-  ZCHK(ntt_forward(pk->ghat.w(), N, pk->tw.w(), s));
+  ZCHK(ntt_forward(pk->ghat.w(), logN, pk->tw.w(), nullptr, s));
   hipLaunchKernelGGL(k_scale_all, dim3(nb(N)), dim3(256), 0, s, pk->ghat.w(), (const uint32_t*)(consts.w() + K_NINV * FW), N);
 
   // ---- per-wire evaluations u_i(x) = sum_j A[j][i] L_j(x)  and the scalars of crs.rs:66-84 ----
@@ -354,34 +426,38 @@ int zkt_groth16_setup_r1cs(size_t n, size_t l, size_t m, const zkt_sparse_rows* 
   hipLaunchKernelGGL(k_uvw, dim3(nb(rows)), dim3(256), 0, s, (const uint32_t*)consts.w(), (const uint32_t*)ue.w(), (const uint32_t*)ve.w(), (const uint32_t*)we.w(), l, rows, y.w());
   RCHK(hipGetLastError());
 
-  // ---- group side: fixed-base multiplications of the generators (crs.rs:85-135) ----
-  DBuf gen1, gen2, p1, p2, small1, small2, gt;
-  const size_t big = (rows > n ? rows : n);
-  ZCHK(gen1.alloc(G1B)); ZCHK(gen2.alloc(G2B)); ZCHK(p1.alloc(big * G1B)); ZCHK(p2.alloc(n * G2B)); ZCHK(small1.alloc(3 * G1B)); ZCHK(small2.alloc(3 * G2B)); ZCHK(gt.alloc(576));
+  // ---- group side: fixed-base multiplications of the generators (crs.rs:85-135), written straight into the three base sets ----
+  const size_t nw = m - l, nh = n >= 2 ? n - 1 : 0, nA = n + 2, nC = n + nw + nh + 3;
+  pk->nA = nA; pk->nC = nC;
+  DBuf gen1, gen2, pU, pA, pB, pC, small1, small2, gt;
+  ZCHK(gen1.alloc(G1B)); ZCHK(gen2.alloc(G2B)); ZCHK(pU.alloc(rows * G1B)); ZCHK(pA.alloc(nA * G1B)); ZCHK(pB.alloc(nA * G2B)); ZCHK(pC.alloc(nC * G1B));
+  ZCHK(small1.alloc(3 * G1B)); ZCHK(small2.alloc(3 * G2B)); ZCHK(gt.alloc(576));
   RCHK(hipMemcpyAsync(gen1.p, G1_GEN, G1B, hipMemcpyHostToDevice, s)); RCHK(hipMemcpyAsync(gen2.p, G2_GEN, G2B, hipMemcpyHostToDevice, s));
-  // uvw: statement part to the verifying key, witness part stays on the device as MSM bases
-  RCHK(launch_group_mul(G_G1, gen1.w(), y.w(), 8, p1.w(), rows, s, true));
-  RCHK(hipMemcpyAsync(vk->g1_uvw_stmt, p1.p, (l + 1) * G1B, hipMemcpyDeviceToHost, s));
-  if (vk->g1_uvw_wit && m > l) RCHK(hipMemcpyAsync(vk->g1_uvw_wit, p1.w() + (l + 1) * 26, (m - l) * G1B, hipMemcpyDeviceToHost, s));
-  RCHK(hipStreamSynchronize(s));
-  if (m > l) ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)(p1.w() + (l + 1) * 26), m - l, s, &pk->W));
-  RCHK(launch_group_mul(G_G1, gen1.w(), Lc.w(), 8, p1.w(), n, s, true));
-  RCHK(hipStreamSynchronize(s));
-  ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)p1.p, n, s, &pk->L1));
-  if (n >= 2) {
-    RCHK(launch_group_mul(G_G1, gen1.w(), hbc.w(), 8, p1.w(), n - 1, s, true));
-    RCHK(hipStreamSynchronize(s));
-    ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)p1.p, n - 1, s, &pk->H));
-  }
-  RCHK(launch_group_mul(G_G2, gen2.w(), Lc.w(), 8, p2.w(), n, s, true));
-  RCHK(hipStreamSynchronize(s));
-  ZCHK(zkt_g2_bases_from_device((const zkt_g2_affine*)p2.p, n, s, &pk->L2));
   RCHK(launch_group_mul(G_G1, gen1.w(), dtrap.w(), 8, small1.w(), 1, s, true));               // alpha
   RCHK(launch_group_mul(G_G1, gen1.w(), dtrap.w() + 8, 8, small1.w() + 26, 1, s, true));      // beta
   RCHK(launch_group_mul(G_G1, gen1.w(), dtrap.w() + 24, 8, small1.w() + 52, 1, s, true));     // delta
   RCHK(launch_group_mul(G_G2, gen2.w(), dtrap.w() + 8, 8, small2.w(), 1, s, true));           // beta
   RCHK(launch_group_mul(G_G2, gen2.w(), dtrap.w() + 16, 8, small2.w() + 50, 1, s, true));     // gamma
   RCHK(launch_group_mul(G_G2, gen2.w(), dtrap.w() + 24, 8, small2.w() + 100, 1, s, true));    // delta
+  // uvw: statement part to the verifying key, witness part into the C set
+  RCHK(launch_group_mul(G_G1, gen1.w(), y.w(), 8, pU.w(), rows, s, true));
+  RCHK(hipMemcpyAsync(vk->g1_uvw_stmt, pU.p, (l + 1) * G1B, hipMemcpyDeviceToHost, s));
+  if (vk->g1_uvw_wit && nw) RCHK(hipMemcpyAsync(vk->g1_uvw_wit, pU.w() + (l + 1) * 26, nw * G1B, hipMemcpyDeviceToHost, s));
+  if (nw) RCHK(hipMemcpyAsync(pC.w() + n * 26, pU.w() + (l + 1) * 26, nw * G1B, hipMemcpyDeviceToDevice, s));
+  RCHK(launch_group_mul(G_G1, gen1.w(), Lc.w(), 8, pC.w(), n, s, true));                       // [L_j(x)]_1
+  RCHK(hipMemcpyAsync(pA.p, pC.p, n * G1B, hipMemcpyDeviceToDevice, s));
+  if (nh) RCHK(launch_group_mul(G_G1, gen1.w(), hbc.w(), 8, pC.w() + (n + nw) * 26, nh, s, true));   // [Lambda_s(x) t(x)/delta]_1
+  RCHK(launch_group_mul(G_G2, gen2.w(), Lc.w(), 8, pB.w(), n, s, true));                       // [L_j(x)]_2
+  RCHK(hipMemcpyAsync(pA.w() + n * 26, small1.p, G1B, hipMemcpyDeviceToDevice, s));            // A tail: alpha, delta
+  RCHK(hipMemcpyAsync(pA.w() + (n + 1) * 26, small1.w() + 52, G1B, hipMemcpyDeviceToDevice, s));
+  RCHK(hipMemcpyAsync(pB.w() + n * 50, small2.p, G2B, hipMemcpyDeviceToDevice, s));            // B tail: beta, delta
+  RCHK(hipMemcpyAsync(pB.w() + (n + 1) * 50, small2.w() + 100, G2B, hipMemcpyDeviceToDevice, s));
+  RCHK(hipMemcpyAsync(pC.w() + (n + nw + nh) * 26, small1.p, 3 * G1B, hipMemcpyDeviceToDevice, s));   // C tail: alpha, beta, delta
+  RCHK(hipStreamSynchronize(s));
+  pU.release();
+  ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)pA.p, nA, s, &pk->setA)); pA.release();
+  ZCHK(zkt_g2_bases_from_device((const zkt_g2_affine*)pB.p, nA, s, &pk->setB)); pB.release();
+  ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)pC.p, nC, s, &pk->setC)); pC.release();
   RCHK(hipMemcpyAsync(derr.p, &noerr, 8, hipMemcpyHostToDevice, s));
   RCHK(launch_tate(small1.w(), small2.w(), gt.w(), 1, (unsigned long long*)derr.p, s));        // crs.rs:137-139
   RCHK(hipMemcpyAsync(vk->g1_alpha, small1.p, G1B, hipMemcpyDeviceToHost, s)); RCHK(hipMemcpyAsync(vk->g1_beta, small1.w() + 26, G1B, hipMemcpyDeviceToHost, s));
@@ -390,64 +466,55 @@ int zkt_groth16_setup_r1cs(size_t n, size_t l, size_t m, const zkt_sparse_rows* 
   RCHK(hipMemcpyAsync(vk->gt_alpha_beta, gt.p, 576, hipMemcpyDeviceToHost, s));
   RCHK(hipStreamSynchronize(s));
   vk->n = n; vk->l = l; vk->m = m;
-  pk->alpha1 = *vk->g1_alpha; pk->beta1 = *vk->g1_beta; pk->delta1 = *vk->g1_delta; pk->beta2 = *vk->g2_beta; pk->delta2 = *vk->g2_delta;
 
   // ---- per-proof work buffers ----
-  ZCHK(pk->wires_c.alloc(rows * FRB)); ZCHK(pk->wires_m.alloc(rows * FRB)); ZCHK(pk->h_c.alloc(n * FRB));
+  ZCHK(pk->wires_c.alloc(rows * FRB)); ZCHK(pk->wires_m.alloc(rows * FRB)); ZCHK(pk->rs.alloc(2 * FRB));
+  ZCHK(pk->sA.alloc(nA * FRB)); ZCHK(pk->sB.alloc(nA * FRB)); ZCHK(pk->sC.alloc(nC * FRB));
   for (int k = 0; k < 3; ++k) { ZCHK(pk->z_m[k].alloc(n * FRB)); ZCHK(pk->f[k].alloc(N * FRB)); }
-  for (int k = 0; k < 2; ++k) ZCHK(pk->z_c[k].alloc(n * FRB));
   *out = pk.release();
   return ZKT_OK;
 }
 
 void zkt_groth16_pk_free(zkt_groth16_pk* pk) { delete pk; }
 
-// Prover::prove (prover.rs:96-147) with r, s injected; wires = a_0..a_m canonical (host).
-int zkt_groth16_prove_r1cs(zkt_groth16_pk* pk, const uint64_t* wires, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp) {
+// Prover::prove (prover.rs:96-147) with r, s injected; wires = a_0..a_m canonical, on the host or (…_dev) already in HBM.
+static int prove_impl(zkt_groth16_pk* pk, const uint64_t* wires, bool wires_on_device, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp) {
   if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
   if (!pk || !wires || !r || !s_ || !A || !B || !Cp) return ZKT_ERR_SHAPE;
-  const size_t n = pk->n, l = pk->l, m = pk->m, rows = m + 1, N = pk->N;
+  const size_t n = pk->n, l = pk->l, m = pk->m, rows = m + 1, N = pk->N, nw = m - l;
   hipStream_t s = pk->s;
-  RCHK(hipMemcpyAsync(pk->wires_c.p, wires, rows * FRB, hipMemcpyHostToDevice, s));
+  uint64_t rs[8]; memcpy(rs, r, 32); memcpy(rs + 4, s_, 32);
+  RCHK(hipMemcpyAsync(pk->rs.p, rs, 64, hipMemcpyHostToDevice, s));
+  RCHK(hipMemcpyAsync(pk->wires_c.p, wires, rows * FRB, wires_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_to_mont, dim3(nb(rows)), dim3(256), 0, s, (const uint32_t*)pk->wires_c.w(), pk->wires_m.w(), rows);
   Csr* M[3] = {&pk->A, &pk->B, &pk->Cm};
   for (int k = 0; k < 3; ++k)
     hipLaunchKernelGGL(k_spmv, dim3(nb(n)), dim3(256), 0, s, (const uint32_t*)M[k]->ptr.w(), (const uint32_t*)M[k]->idx.w(), (const uint32_t*)M[k]->val.w(), (const uint32_t*)pk->wires_m.w(), pk->z_m[k].w(), n);
-  for (int k = 0; k < 2; ++k) hipLaunchKernelGGL(k_from_mont, dim3(nb(n)), dim3(256), 0, s, (const uint32_t*)pk->z_m[k].w(), pk->z_c[k].w(), n);
+  hipLaunchKernelGGL(k_prove_scalars, dim3(nb(n + nw + 1)), dim3(256), 0, s, (const uint32_t*)pk->z_m[0].w(), (const uint32_t*)pk->z_m[1].w(), (const uint32_t*)pk->wires_c.w(),
+                     (const uint32_t*)pk->rs.w(), n, l, m, pk->sA.w(), pk->sB.w(), pk->sC.w());
   RCHK(hipGetLastError());
-  // the three MSMs that only need (A w) and (B w), and the witness MSM, start now and overlap the quotient stage
-  ZCHK(zkt_g1_msm_submit(pk->L1, (const uint64_t*)pk->z_c[0].p, n, s, 0));          // sum_i a_i u_i(x)   in G1
-  ZCHK(zkt_g1_msm_submit(pk->L1, (const uint64_t*)pk->z_c[1].p, n, s, 1));          // sum_i a_i v_i(x)   in G1
-  ZCHK(zkt_g2_msm_submit(pk->L2, (const uint64_t*)pk->z_c[1].p, n, s, 0));          // sum_i a_i v_i(x)   in G2
-  if (m > l) ZCHK(zkt_g1_msm_submit(pk->W, (const uint64_t*)(pk->wires_c.w() + (l + 1) * FW), m - l, s, 0));
+  // A and B only need (A w) and (B w): they start now and run under the quotient stage
+  ZCHK(zkt_g2_msm_submit(pk->setB, (const uint64_t*)pk->sB.p, pk->nA, s, 0));
+  ZCHK(zkt_g1_msm_submit(pk->setA, (const uint64_t*)pk->sA.p, pk->nA, s, 0));
   if (n >= 2) {
     for (int k = 0; k < 3; ++k) {
       hipLaunchKernelGGL(k_prep_f, dim3(nb(N)), dim3(256), 0, s, (const uint32_t*)pk->z_m[k].w(), (const uint32_t*)pk->cinv.w(), n, N, pk->f[k].w());
-      ZCHK(ntt_forward(pk->f[k].w(), N, pk->tw.w(), s));
-      hipLaunchKernelGGL(k_pointwise, dim3(nb(N)), dim3(256), 0, s, pk->f[k].w(), (const uint32_t*)pk->ghat.w(), N);
-      ZCHK(ntt_inverse(pk->f[k].w(), N, pk->twinv.w(), s));
+      ZCHK(ntt_forward(pk->f[k].w(), pk->logN, pk->tw.w(), pk->ghat.w(), s));          // spectrum * spectrum of 1/d (and 1/N)
+      ZCHK(ntt_inverse(pk->f[k].w(), pk->logN, pk->twinv.w(), s));
     }
-    hipLaunchKernelGGL(k_hvals, dim3(nb(n - 1)), dim3(256), 0, s, (const uint32_t*)pk->f[0].w(), (const uint32_t*)pk->f[1].w(), (const uint32_t*)pk->f[2].w(), (const uint32_t*)pk->P.w(), n, pk->h_c.w());
+    hipLaunchKernelGGL(k_hvals, dim3(nb(n - 1)), dim3(256), 0, s, (const uint32_t*)pk->f[0].w(), (const uint32_t*)pk->f[1].w(), (const uint32_t*)pk->f[2].w(), (const uint32_t*)pk->P.w(), n,
+                       pk->sC.w() + (n + nw) * FW);
     RCHK(hipGetLastError());
-    ZCHK(zkt_g1_msm_submit(pk->H, (const uint64_t*)pk->h_c.p, n - 1, s, 0));        // h(x) t(x) / delta
   }
-  zkt_g1_affine sumA, sumB1, sumW, ht; zkt_g2_affine sumB;
-  memset(&sumW, 0, sizeof sumW); sumW.is_infinity = 1; memset(&ht, 0, sizeof ht); ht.is_infinity = 1;
-  ZCHK(zkt_g1_msm_collect(pk->L1, 0, &sumA, nullptr)); ZCHK(zkt_g1_msm_collect(pk->L1, 1, &sumB1, nullptr)); ZCHK(zkt_g2_msm_collect(pk->L2, 0, &sumB, nullptr));
-  if (m > l) ZCHK(zkt_g1_msm_collect(pk->W, 0, &sumW, nullptr));
-  if (n >= 2) ZCHK(zkt_g1_msm_collect(pk->H, 0, &ht, nullptr));
-  // the seven single scalar multiplications and the final sums (prover.rs:118-140)
-  int rc;
-  zkt_g1_affine dr, ds, As, Br, drs, t1, t2, B1, ndrs; zkt_g2_affine d2s, t3;
-  if ((rc = zkt_g1_mul_batch(&pk->delta1, r, 4, &dr, 1)) || (rc = zkt_g1_mul_batch(&pk->delta1, s_, 4, &ds, 1)) || (rc = zkt_g2_mul_batch(&pk->delta2, s_, 4, &d2s, 1))) return rc;
-  if ((rc = zkt_g1_add_batch(&pk->alpha1, &sumA, &t1, 1)) || (rc = zkt_g1_add_batch(&t1, &dr, A, 1))) return rc;               // A
-  if ((rc = zkt_g2_add_batch(&pk->beta2, &sumB, &t3, 1)) || (rc = zkt_g2_add_batch(&t3, &d2s, B, 1))) return rc;             // B
-  if ((rc = zkt_g1_add_batch(&pk->beta1, &sumB1, &t1, 1)) || (rc = zkt_g1_add_batch(&t1, &ds, &B1, 1))) return rc;           // B_g1
-  if ((rc = zkt_g1_mul_batch(A, s_, 4, &As, 1)) || (rc = zkt_g1_mul_batch(&B1, r, 4, &Br, 1)) || (rc = zkt_g1_mul_batch(&dr, s_, 4, &drs, 1))) return rc;
-  if ((rc = zkt_g1_neg_batch(&drs, &ndrs, 1))) return rc;
-  if ((rc = zkt_g1_add_batch(&sumW, &ht, &t1, 1)) || (rc = zkt_g1_add_batch(&t1, &As, &t2, 1)) || (rc = zkt_g1_add_batch(&t2, &Br, &t1, 1)) ||
-      (rc = zkt_g1_add_batch(&t1, &ndrs, Cp, 1))) return rc;                                                                 // C
+  ZCHK(zkt_g1_msm_submit(pk->setC, (const uint64_t*)pk->sC.p, pk->nC, s, 0));
+  ZCHK(zkt_g1_msm_collect(pk->setA, 0, A, nullptr)); ZCHK(zkt_g2_msm_collect(pk->setB, 0, B, nullptr)); ZCHK(zkt_g1_msm_collect(pk->setC, 0, Cp, nullptr));
   return ZKT_OK;
+}
+int zkt_groth16_prove_r1cs(zkt_groth16_pk* pk, const uint64_t* wires, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp) {
+  return prove_impl(pk, wires, false, r, s_, A, B, Cp);
+}
+int zkt_groth16_prove_r1cs_dev(zkt_groth16_pk* pk, const uint64_t* dev_wires, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp) {
+  return prove_impl(pk, dev_wires, true, r, s_, A, B, Cp);
 }
 
 }  // extern "C"
