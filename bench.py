@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--pairings", type=int, default=1 << 16, help="pairings in the secondary measurement (0 = skip)")
+    ap.add_argument("--groth16-log2n", type=int, default=20, help="constraints (log2) of the Groth16 prove+verify leg at N=1 (0 = skip)")
+    ap.add_argument("--groth16-proofs", type=int, default=8)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--scalar-dist", default="uniform", choices=["uniform", "ones", "bits"],
                     help="uniform in [0,r) (the metric) | all ones | random 0/1 (skew stress: one hot bucket)")
@@ -207,6 +209,37 @@ def main():
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             result["pairing"] = {"metric": "Tate pairings/sec", "value": m / dt, "batch": m, "kernel_ms": L.zkt_last_kernel_ms(),
                                  "hbm_achieved_GBs": PAIRING_BYTES * m / dt / 1e9, "hbm_frac": PAIRING_BYTES * m / dt / 1e9 / HBM_PEAK_GBS}
+
+        # BASELINE config 4: Groth16 prove + verify on the synthetic chain R1CS, sparse-R1CS path (row f-3)
+        if world == 1 and args.groth16_log2n > 0:
+            from qap_util import chain_circuit_sparse, sparse_struct, alloc_crs
+            from zkt_testlib import SplitMix64, ints_to_arr, ptr
+            gn = 1 << args.groth16_log2n
+            mats, wires, gl, gm = chain_circuit_sparse(gn, seed=7)
+            rng = SplitMix64(7)
+            trap = [ints_to_arr([rng.below(R_MOD - 1) + 1], 4) for _ in range(5)]
+            pr, ps = ints_to_arr([rng.below(R_MOD - 1) + 1], 4), ints_to_arr([rng.below(R_MOD - 1) + 1], 4)
+            structs = [sparse_struct(*M) for M in mats]
+            vk, vbuf = alloc_crs(1, gl, gm); vk.g1_uvw_wit = None
+            pk = ctypes.c_void_p()
+            t0 = time.perf_counter()
+            zk.check(L.zkt_groth16_setup_r1cs(gn, gl, gm, *[ctypes.addressof(x) for x in structs], *[t.ctypes.data for t in trap], ctypes.addressof(vk), ctypes.addressof(pk)))
+            g_setup = time.perf_counter() - t0
+            gp = (np.zeros((1, 13), np.uint64), np.zeros((1, 25), np.uint64), np.zeros((1, 13), np.uint64))
+            d_w = torch.from_numpy(wires.view(np.int64)).to(dev)
+            prove = lambda: zk.check(L.zkt_groth16_prove_r1cs_dev(pk, d_w.data_ptr(), pr.ctypes.data, ps.ctypes.data, *[x.ctypes.data for x in gp]))
+            prove(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.groth16_proofs): prove()
+            dt = (time.perf_counter() - t0) / args.groth16_proofs
+            stmt = wires[:gl + 1].copy()
+            t0 = time.perf_counter()
+            ok = L.zkt_groth16_verify(ctypes.byref(vk), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(stmt), gl + 1)
+            tv = time.perf_counter() - t0
+            L.zkt_groth16_pk_free(pk)
+            result["groth16"] = {"metric": "Groth16 proofs/sec", "value": 1.0 / dt, "constraints": gn, "wires": gm + 1, "ms_per_proof": dt * 1e3,
+                                 "setup_s": round(g_setup, 2), "verify_ms": tv * 1e3, "verifies": bool(ok == 1), "proofs_timed": args.groth16_proofs,
+                                 "workload": "chain R1CS w_{j+1} = w_j^2 + c_j, witness resident in HBM, trapdoors and r,s injected"}
 
         # CPU baseline: the oracle (faithful restatement of the reference algorithm) on a bounded sample
         if world == 1 and not args.no_cpu:

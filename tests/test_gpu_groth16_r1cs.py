@@ -55,7 +55,7 @@ def test_r1cs_path_matches_reference_algorithm(L, case):
     L.zkt_groth16_pk_free(pk)
 
 
-@pytest.mark.parametrize("n", [1000, 4096])
+@pytest.mark.parametrize("n", [1000, 5000])
 def test_r1cs_path_larger_sizes_verify(L, n):
     """beyond the sizes the quadratic oracle can follow: the proof must verify (verifier.rs:30-54), and must stop
     verifying when the statement or the witness is wrong."""

@@ -96,12 +96,30 @@ __global__ void __launch_bounds__(256) k_scanmul_apply(uint32_t* __restrict__ da
 }
 
 // ---- CSR mat-vec in Fr (Montgomery): out[r] = sum_k val[k] * vec[idx[k]] ---------------------------------------------
+// One lane per row; rows longer than SPMV_LONG (the transposed "one" wire of setup has a term in every constraint)
+// are left to k_spmv_long: one block per listed row, strided partial sums and an LDS tree.
+static constexpr uint32_t SPMV_LONG = 4096;
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val,
                                               const uint32_t* __restrict__ vec, uint32_t* __restrict__ out, size_t rows) {
   size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; if (r >= rows) return;
+  const uint32_t beg = ptr[r], end = ptr[r + 1];
+  if (end - beg > SPMV_LONG) return;
   Fr acc = fp_zero<C>();
-  for (uint32_t k = ptr[r]; k < ptr[r + 1]; ++k) acc = fp_add(acc, fp_mul(ldm(val + (size_t)k * FW), ldm(vec + (size_t)idx[k] * FW)));
+  for (uint32_t k = beg; k < end; ++k) acc = fp_add(acc, fp_mul(ldm(val + (size_t)k * FW), ldm(vec + (size_t)idx[k] * FW)));
   stm(out + r * FW, acc);
+}
+__global__ void __launch_bounds__(256) k_spmv_long(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val,
+                                                   const uint32_t* __restrict__ vec, uint32_t* __restrict__ out, const uint32_t* __restrict__ long_rows) {
+  __shared__ uint32_t lds[256 * FW];
+  const uint32_t r = long_rows[blockIdx.x], t = threadIdx.x;
+  Fr acc = fp_zero<C>();
+  for (uint32_t k = ptr[r] + t; k < ptr[r + 1]; k += 256) acc = fp_add(acc, fp_mul(ldm(val + (size_t)k * FW), ldm(vec + (size_t)idx[k] * FW)));
+  stm(lds + t * FW, acc); __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if ((int)t < d) { acc = fp_add(acc, ldm(lds + (t + d) * FW)); stm(lds + t * FW, acc); }
+    __syncthreads();
+  }
+  if (t == 0) stm(out + (size_t)r * FW, acc);
 }
 
 // ---- setup scalars ----------------------------------------------------------------------------------------
@@ -276,7 +294,7 @@ struct DBuf {                       // owning device buffer
   uint32_t* w() const { return (uint32_t*)p; }
   DBuf() = default; DBuf(const DBuf&) = delete; DBuf& operator=(const DBuf&) = delete;
 };
-struct Csr { DBuf ptr, idx, val; size_t rows = 0, nnz = 0; };
+struct Csr { DBuf ptr, idx, val, long_rows; size_t rows = 0, nnz = 0, n_long = 0; };
 
 // inclusive prefix product, in place allowed (in == out); two levels of tiles cover 2048^2 elements
 int scan_mul(const uint32_t* in, uint32_t* out, size_t n, hipStream_t s) {
@@ -317,6 +335,10 @@ int ntt_inverse(uint32_t* a, int logN, const uint32_t* twinv, hipStream_t s) {
     hipLaunchKernelGGL(k_ntt_group<false>, dim3((unsigned)(((size_t)1 << logN) >> (g[i].cnt + g[i].cbits))), dim3(NTT_TPB), 0, s, a, logN, g[i].lo, g[i].cnt, g[i].cbits, twinv, (const uint32_t*)nullptr);
   RCHK(hipGetLastError()); return ZKT_OK;
 }
+void spmv(const Csr& M, const uint32_t* vec, uint32_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_spmv, dim3(nb(M.rows)), dim3(256), 0, s, (const uint32_t*)M.ptr.w(), (const uint32_t*)M.idx.w(), (const uint32_t*)M.val.w(), vec, out, M.rows);
+  if (M.n_long) hipLaunchKernelGGL(k_spmv_long, dim3((unsigned)M.n_long), dim3(256), 0, s, (const uint32_t*)M.ptr.w(), (const uint32_t*)M.idx.w(), (const uint32_t*)M.val.w(), vec, out, (const uint32_t*)M.long_rows.w());
+}
 // host CSR (reference order: one sparse row per constraint, r1cs.rs / constraint.rs:5-9) -> device CSR and its transpose
 int upload_csr(const zkt_sparse_rows* M, size_t n, size_t cols, Csr& rowwise, Csr& colwise, hipStream_t s) {
   const size_t nnz = (size_t)M->rowptr[n];
@@ -331,6 +353,10 @@ int upload_csr(const zkt_sparse_rows* M, size_t n, size_t cols, Csr& rowwise, Cs
     for (uint32_t k = rp[j]; k < rp[j + 1]; ++k) { uint32_t d = cur[M->col[k]]++; ridx[d] = (uint32_t)j; memcpy(&tval[(size_t)d * 4], &M->val[(size_t)k * 4], 32); }
   auto put = [&](Csr& c, const std::vector<uint32_t>& p, const uint32_t* idx, const uint64_t* val, size_t rows) -> int {
     c.rows = rows; c.nnz = nnz;
+    std::vector<uint32_t> lr;
+    for (size_t i = 0; i < rows; ++i) if (p[i + 1] - p[i] > SPMV_LONG) lr.push_back((uint32_t)i);
+    c.n_long = lr.size();
+    if (c.n_long) { ZCHK(c.long_rows.alloc(lr.size() * 4)); RCHK(hipMemcpy(c.long_rows.p, lr.data(), lr.size() * 4, hipMemcpyHostToDevice)); }
     ZCHK(c.ptr.alloc(p.size() * 4)); ZCHK(c.idx.alloc(nnz * 4)); ZCHK(c.val.alloc(nnz * FRB));
     RCHK(hipMemcpyAsync(c.ptr.p, p.data(), p.size() * 4, hipMemcpyHostToDevice, s));
     if (nnz) {
@@ -421,8 +447,7 @@ int zkt_groth16_setup_r1cs(size_t n, size_t l, size_t m, const zkt_sparse_rows* 
   // ---- per-wire evaluations u_i(x) = sum_j A[j][i] L_j(x)  and the scalars of crs.rs:66-84 ----
   DBuf ue, ve, we, y; ZCHK(ue.alloc(rows * FRB)); ZCHK(ve.alloc(rows * FRB)); ZCHK(we.alloc(rows * FRB)); ZCHK(y.alloc(rows * FRB));
   Csr* T[3] = {&At, &Bt, &Ct}; DBuf* ev[3] = {&ue, &ve, &we};
-  for (int k = 0; k < 3; ++k)
-    hipLaunchKernelGGL(k_spmv, dim3(nb(rows)), dim3(256), 0, s, (const uint32_t*)T[k]->ptr.w(), (const uint32_t*)T[k]->idx.w(), (const uint32_t*)T[k]->val.w(), (const uint32_t*)Lm.w(), ev[k]->w(), rows);
+  for (int k = 0; k < 3; ++k) spmv(*T[k], Lm.w(), ev[k]->w(), s);
   hipLaunchKernelGGL(k_uvw, dim3(nb(rows)), dim3(256), 0, s, (const uint32_t*)consts.w(), (const uint32_t*)ue.w(), (const uint32_t*)ve.w(), (const uint32_t*)we.w(), l, rows, y.w());
   RCHK(hipGetLastError());
 
@@ -488,8 +513,7 @@ static int prove_impl(zkt_groth16_pk* pk, const uint64_t* wires, bool wires_on_d
   RCHK(hipMemcpyAsync(pk->wires_c.p, wires, rows * FRB, wires_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_to_mont, dim3(nb(rows)), dim3(256), 0, s, (const uint32_t*)pk->wires_c.w(), pk->wires_m.w(), rows);
   Csr* M[3] = {&pk->A, &pk->B, &pk->Cm};
-  for (int k = 0; k < 3; ++k)
-    hipLaunchKernelGGL(k_spmv, dim3(nb(n)), dim3(256), 0, s, (const uint32_t*)M[k]->ptr.w(), (const uint32_t*)M[k]->idx.w(), (const uint32_t*)M[k]->val.w(), (const uint32_t*)pk->wires_m.w(), pk->z_m[k].w(), n);
+  for (int k = 0; k < 3; ++k) spmv(*M[k], pk->wires_m.w(), pk->z_m[k].w(), s);
   hipLaunchKernelGGL(k_prove_scalars, dim3(nb(n + nw + 1)), dim3(256), 0, s, (const uint32_t*)pk->z_m[0].w(), (const uint32_t*)pk->z_m[1].w(), (const uint32_t*)pk->wires_c.w(),
                      (const uint32_t*)pk->rs.w(), n, l, m, pk->sA.w(), pk->sB.w(), pk->sC.w());
   RCHK(hipGetLastError());

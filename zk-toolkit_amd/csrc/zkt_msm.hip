@@ -312,18 +312,33 @@ __global__ void __launch_bounds__(64) ZKT_ACC_ATTR k_accumulate(const uint32_t* 
   typedef typename F::E E;
   uint32_t ent = beg < end ? entries[beg] : 0, ent_next = beg + 1 < end ? entries[beg + 1] : 0;      // empty bucket: harmless load of entry 0
   const uint32_t* p = table + (size_t)(ent & 0x7fffffffu) * (2 * CW);
-  E nx = Coord<F>::ld(p), ny = Coord<F>::ld(p + CW);
-  for (uint32_t e = beg; e < end; ++e) {
-    E x = nx, y = ny;
-    const bool negate = ent >> 31;
-    if (e + 1 < end) {
+#ifndef ZKT_ACC_PREFETCH_MAX_CW
+#define ZKT_ACC_PREFETCH_MAX_CW 16
+#endif
+  if constexpr (CW <= ZKT_ACC_PREFETCH_MAX_CW) {
+    E nx = Coord<F>::ld(p), ny = Coord<F>::ld(p + CW);
+    for (uint32_t e = beg; e < end; ++e) {
+      E x = nx, y = ny;
+      const bool negate = ent >> 31;
+      if (e + 1 < end) {
+        ent = ent_next;
+        ent_next = e + 2 < end ? entries[e + 2] : 0;
+        p = table + (size_t)(ent & 0x7fffffffu) * (2 * CW);
+        nx = Coord<F>::ld(p); ny = Coord<F>::ld(p + CW);
+      }
+      if (negate) y = F::neg(y);
+      acc = xyzz_add_aff<F>(acc, x, y);
+    }
+  } else {                                        // wide coordinates (Fq2): the add is long enough to cover the gather; keep the registers
+    for (uint32_t e = beg; e < end; ++e) {
+      E x = Coord<F>::ld(p), y = Coord<F>::ld(p + CW);
+      const bool negate = ent >> 31;
       ent = ent_next;
       ent_next = e + 2 < end ? entries[e + 2] : 0;
       p = table + (size_t)(ent & 0x7fffffffu) * (2 * CW);
-      nx = Coord<F>::ld(p); ny = Coord<F>::ld(p + CW);
+      if (negate) y = F::neg(y);
+      acc = xyzz_add_aff<F>(acc, x, y);
     }
-    if (negate) y = F::neg(y);
-    acc = xyzz_add_aff<F>(acc, x, y);
   }
   const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
   st_xy<F>(nt == 1 ? sums + b * XYW : partial + (size_t)(t0 + tk.y) * XYW, acc);
