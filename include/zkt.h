@@ -146,6 +146,20 @@ int zkt_groth16_verify_batch(const zkt_groth16_crs* crs, const zkt_g1_affine* A,
 int zkt_groth16_verify(const zkt_groth16_crs* crs, const zkt_g1_affine* A, const zkt_g2_affine* B, const zkt_g1_affine* C,
                        const uint64_t* stmt_wires, size_t n_stmt);
 
+/* f-4: equalities of pairing products as the reference's callers test them (lhs == rhs on GTPoints: signature.rs:34-39,
+ * pinocchio/verifier.rs:43-84).  For each of n elements: prod_{j<k} tate(+-g1[i*k+j], g2[i*k+j]) == 1, k <= 4; negate[j] != 0
+ * negates slot j's G1 point (e(-P,Q) = e(P,Q)^-1), so e(P1,Q1) == e(P2,Q2) e(P3,Q3) is k = 3, negate = {0,1,1}.  The k Miller
+ * loops share one squaring chain and one final exponentiation (the decision is a bool, so this is parity-safe).  ok[i] = 1/0;
+ * ZKT_ERR_INFINITY (+index) if an argument is the point at infinity (the reference's tate() panics). */
+int zkt_pairing_product_check_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, const uint8_t* negate, size_t k, size_t n, uint32_t* ok);
+/* f-4: BLS signatures, Signer signature.rs:8-40.  Messages are n byte strings, concatenated, offsets[n+1].
+ * G2Point::hash_to_g2point g2_point.rs:84-88 (the bytes as a big-endian integer, reduced mod r, times the G2 generator);
+ * sign = hash * sk (signature.rs:28-31; sk = 4-limb PrivateKey.value, private_key.rs:10-27; gen_public_key is
+ * zkt_g1_mul_batch of the generator); verify = tate(g1, sig) == tate(pk, hash) (signature.rs:34-39), one signature per lane. */
+int zkt_bls_hash_to_g2_batch(const uint8_t* msgs, const uint64_t* offsets, size_t n, zkt_g2_affine* out);
+int zkt_bls_sign_batch(const uint8_t* msgs, const uint64_t* offsets, const uint64_t* sks, size_t n, zkt_g2_affine* sigs);
+int zkt_bls_verify_batch(const uint8_t* msgs, const uint64_t* offsets, const zkt_g2_affine* sigs, const zkt_g1_affine* pks, size_t n, uint32_t* ok);
+
 /* a18: Bulletproofs::inner_product_argument bulletproofs.rs:19-55 over secp256k1; n a power of two; a, b are 4-limb
  * residues mod the group order; xs = one challenge per level (the reference draws them at bulletproofs.rs:42).
  * out_trace (optional): per level {L, R, P'}.  Returns 1/0 like the reference's bool, negative = -status. */

@@ -1,0 +1,126 @@
+"""BLS signatures (Signer, signature.rs:8-40; hash_to_g2point g2_point.rs:84-88) and the batched
+pairing-product equality the reference's verifiers are made of.  Checker: the oracle's scalar multiplications and Tate
+pairings composed exactly as signature.rs:28-39 composes them."""
+import ctypes, importlib
+import numpy as np
+import pytest
+from zkt_testlib import *
+from test_oracle_pairing import pair
+
+pytestmark = pytest.mark.gpu
+zk = importlib.import_module("zk-toolkit_amd")
+O = oracle()
+
+
+@pytest.fixture(scope="module")
+def L():
+    zk.init()
+    return zk.lib()
+
+
+def _gens():
+    g1 = np.zeros((1, G1W), np.uint64); O.zkto_g1_generator(ptr(g1))
+    g2 = np.zeros((1, G2W), np.uint64); O.zkto_g2_generator(ptr(g2))
+    return g1, g2
+
+
+def _g2_mul(p, ks):
+    out = np.zeros((len(ks), G2W), np.uint64)
+    assert O.zkto_g2_mul_batch(ptr(np.ascontiguousarray(p)), ptr(ints_to_arr(ks, 4)), 4, ptr(out), len(ks), 8) == 0
+    return out
+
+
+def _g1_mul(p, ks):
+    out = np.zeros((len(ks), G1W), np.uint64)
+    assert O.zkto_g1_mul_batch(ptr(np.ascontiguousarray(p)), ptr(ints_to_arr(ks, 4)), 4, ptr(out), len(ks), 8) == 0
+    return out
+
+
+def _pack(msgs):
+    off = np.zeros(len(msgs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(m) for m in msgs])
+    buf = np.frombuffer(b"".join(msgs) or b"\0", dtype=np.uint8).copy()
+    return buf, off
+
+
+MSGS = [b"chili crab", b"robert kiyosaki", b"\x00\x01", b"\xff" * 40, bytes(range(1, 100)), b"a"]      # signature.rs:52, g2_point.rs:174; > 32 bytes wraps mod r
+
+
+def test_hash_to_g2_and_sign_vs_oracle(L):
+    g1, g2 = _gens()
+    buf, off = _pack(MSGS)
+    n = len(MSGS)
+    H = np.zeros((n, G2W), np.uint64)
+    zk.check(L.zkt_bls_hash_to_g2_batch(buf.ctypes.data, off.ctypes.data, n, H.ctypes.data))
+    want = _g2_mul(np.repeat(g2, n, axis=0), [int.from_bytes(m, "big") % R for m in MSGS])              # g2_point.rs:85-87
+    assert (H == want).all()
+    rng = SplitMix64(321)
+    sks = [rng.below(R - 1) + 1 for _ in range(n)]                                                       # private_key.rs:18-24
+    sig = np.zeros((n, G2W), np.uint64)
+    zk.check(L.zkt_bls_sign_batch(buf.ctypes.data, off.ctypes.data, ptr(ints_to_arr(sks, 4)), n, ptr(sig)))
+    assert (sig == _g2_mul(want, sks)).all()                                                             # signature.rs:28-31
+    # the empty message hashes to scalar 0 -> the point at infinity (BigUint::from_bytes_be(&[]) = 0)
+    b0, o0 = _pack([b""])
+    H0 = np.zeros((1, G2W), np.uint64)
+    zk.check(L.zkt_bls_hash_to_g2_batch(b0.ctypes.data, o0.ctypes.data, 1, ptr(H0)))
+    assert int(H0[0, 24]) & 0xFFFFFFFF == 1
+
+
+def test_verify_batch_matches_reference_decision(L):
+    g1, g2 = _gens()
+    n = len(MSGS)
+    buf, off = _pack(MSGS)
+    rng = SplitMix64(654)
+    sks = [rng.below(R - 1) + 1 for _ in range(n)]
+    pks = _g1_mul(np.repeat(g1, n, axis=0), sks)                                                         # signature.rs:23-25
+    sig = np.zeros((n, G2W), np.uint64)
+    zk.check(L.zkt_bls_sign_batch(buf.ctypes.data, off.ctypes.data, ptr(ints_to_arr(sks, 4)), n, ptr(sig)))
+    # tamper: wrong key for #1, signature of another message for #2, a signature scaled by 2 for #4
+    pks_t = pks.copy(); pks_t[1] = pks[0]
+    sig_t = sig.copy(); sig_t[2] = sig[3]; sig_t[4] = _g2_mul(sig[4:5], [2])[0]
+    ok = np.zeros(n, np.uint32)
+    zk.check(L.zkt_bls_verify_batch(buf.ctypes.data, off.ctypes.data, ptr(sig_t), ptr(pks_t), n, ok.ctypes.data))
+    # the reference's decision: tate(g1, sig) == tate(pk, H) (signature.rs:34-39), by the oracle
+    H = _g2_mul(np.repeat(g2, n, axis=0), [int.from_bytes(m, "big") % R for m in MSGS])
+    rc, lhs, _ = pair(3, np.repeat(g1, n, axis=0), sig_t); assert rc == 0
+    rc, rhs, _ = pair(3, pks_t, H); assert rc == 0
+    want = [(lhs[i] == rhs[i]).all() for i in range(n)]
+    assert want == [True, False, False, True, False, True]
+    assert [bool(v) for v in ok] == want
+    # a signature at infinity: the reference's tate() panics -> error with the index
+    sig_inf = sig.copy(); sig_inf[3] = 0; sig_inf[3, 24] = 1
+    rc = L.zkt_bls_verify_batch(buf.ctypes.data, off.ctypes.data, ptr(sig_inf), ptr(pks), n, ok.ctypes.data)
+    assert rc == ZKT_ERR_INFINITY and L.zkt_last_error_index() == 3
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
+def test_pairing_product_check(L, k):
+    """e((a1+..+a_{k-1}) P, Q) == prod_j e(a_j P, Q): k pairs with the right-hand ones negated multiply to one."""
+    g1, g2 = _gens()
+    rng = SplitMix64(900 + k)
+    n = 5
+    P1 = np.zeros((n, k, G1W), np.uint64); Q2 = np.zeros((n, k, G2W), np.uint64)
+    expect = []
+    for i in range(n):
+        q = _g2_mul(g2, [rng.below(R - 1) + 1])[0]
+        a = [rng.below(R - 1) + 1 for _ in range(max(k - 1, 1))]
+        good = i % 2 == 0 and k > 1
+        lhs = (sum(a) if good else sum(a) + 1) % R
+        P1[i, 0] = _g1_mul(g1, [lhs])[0]; Q2[i, 0] = q
+        for j in range(1, k):
+            P1[i, j] = _g1_mul(g1, [a[j - 1]])[0]; Q2[i, j] = q
+        expect.append(good)
+    neg = np.array([0] + [1] * (k - 1), np.uint8)
+    ok = np.zeros(n, np.uint32)
+    zk.check(L.zkt_pairing_product_check_batch(ptr(P1), ptr(Q2), neg.ctypes.data, k, n, ok.ctypes.data))
+    assert [bool(v) for v in ok] == expect
+    # cross-check one element against the oracle's pairings multiplied out
+    rc, e, _ = pair(3, np.ascontiguousarray(P1[0]), np.ascontiguousarray(Q2[0])); assert rc == 0
+    if k > 1:
+        prod = e[1:2].copy()
+        for j in range(2, k):
+            o = np.zeros((1, FQ12), np.uint64); assert O.zkto_fq12_op(2, ptr(prod), ptr(e[j:j + 1].copy()), ptr(o), 1) == 0; prod = o
+        assert (prod[0] == e[0]).all() == expect[0]
+    P1[2, 0] = 0; P1[2, 0, 12] = 1
+    assert L.zkt_pairing_product_check_batch(ptr(P1), ptr(Q2), neg.ctypes.data, k, n, ok.ctypes.data) == ZKT_ERR_INFINITY
+    assert L.zkt_last_error_index() == 2

@@ -74,6 +74,41 @@ hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uin
   return hipGetLastError();
 }
 
+// Equality of pairing products as the reference's callers test it (lhs == rhs on GTPoints: signature.rs:34-39,
+// pinocchio/verifier.rs:43-84): e(P1,Q1) == e(P2,Q2) e(P3,Q3)  <=>  tate-product(P1,Q1; -P2,Q2; -P3,Q3) == 1, since
+// e(-P,Q) = e(P,Q)^-1 exactly.  One element per lane; an argument at infinity is the reference's panic (rational_function.rs:36,59).
+template <int K>
+__global__ void __launch_bounds__(64) k_pairing_product_check(PairArgs a, uint32_t* __restrict__ ok, size_t n, unsigned long long* err) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Fq xp[K], yp[K]; Fq2 xq[K], yq[K];
+  bool inf = false;
+  for (int k = 0; k < K; ++k) {
+    Aff<FqOps> p = PtIO<FqOps>::ld(a.g1[k] + i * a.s1[k]);
+    Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(a.g2[k] + i * a.s2[k]);
+    inf = inf || p.inf || q.inf;
+    xp[k] = p.x; yp[k] = a.neg[k] ? fp_neg(p.y) : p.y; xq[k] = q.x; yq[k] = q.y;
+  }
+  if (inf) { atomicMin(err, (unsigned long long)i); ok[i] = 0; return; }
+  Fq12 e = final_exponentiation(miller_g1_g2_multi<K>(xp, yp, xq, yq));
+  uint32_t got[144]; st_fq12(got, e);
+  uint32_t diff = got[132] ^ 1u;                       // canonical one: w0.v0.u0 = 1 (the last Fq of the {w1,w0} layout), all else 0
+  for (int k = 0; k < 144; ++k) if (k != 132) diff |= got[k];
+  ok[i] = diff == 0;
+}
+hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  dim3 g((unsigned)((n + 63) / 64)), t(64);
+  switch (K) {
+    case 1: hipLaunchKernelGGL(k_pairing_product_check<1>, g, t, 0, s, a, ok, n, err); break;
+    case 2: hipLaunchKernelGGL(k_pairing_product_check<2>, g, t, 0, s, a, ok, n, err); break;
+    case 3: hipLaunchKernelGGL(k_pairing_product_check<3>, g, t, 0, s, a, ok, n, err); break;
+    case 4: hipLaunchKernelGGL(k_pairing_product_check<4>, g, t, 0, s, a, ok, n, err); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_tate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);

@@ -111,6 +111,17 @@ __global__ void __launch_bounds__(256) k_sum(const uint32_t* __restrict__ a, siz
   if (t == 0) st_raw<C>(out, acc);
 }
 
+// G2Point::hash_to_g2point scalar stage (g2_point.rs:84-88): BigUint::from_bytes_be(buf) reduced into the subgroup field, canonical
+__global__ void __launch_bounds__(256) k_bytes_mod_r(const uint8_t* __restrict__ msgs, const unsigned long long* __restrict__ off, size_t n, uint32_t* __restrict__ out) {
+  typedef FrC C;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8] = {256, 0, 0, 0, 0, 0, 0, 0};
+  const Fp<C> radix = fp_from_words<C>(w);
+  Fp<C> acc = fp_zero<C>();
+  for (unsigned long long k = off[i]; k < off[i + 1]; ++k) { w[0] = msgs[k]; acc = fp_add(fp_mul(acc, radix), fp_from_words<C>(w)); }
+  st_fp<C>(out + i * 8, acc);
+}
 }  // namespace zkt
 
 using namespace zkt;
@@ -432,6 +443,84 @@ int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, c
   if (hipStreamSynchronize(s) != hipSuccess || si > NS) return -ZKT_ERR_DEVICE;
   if (memcmp(&hP, &hrhs, SPB) != 0) return 0;
   return memcmp(hth, hlr, FRB) == 0 ? 1 : 0;                                          // :147-149
+}
+
+// ---- f-4: pairing-product equalities and BLS signatures ----------------------------------------------------------------
+// prod_k tate(+-P[i][k], Q[i][k]) == 1 for n elements of k <= 4 pairs each; negate[k] != 0 negates slot k's G1 point.
+int zkt_pairing_product_check_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, const uint8_t* negate, size_t k, size_t n, uint32_t* ok) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!g1 || !g2 || !ok || k == 0 || k > 4) return ZKT_ERR_SHAPE;
+  if (n == 0) return ZKT_OK;
+  hipStream_t s = nullptr;
+  Dev d1(n * k * G1B), d2(n * k * G2B), dok(n * 4), derr(8);
+  int rc;
+  if ((rc = up(d1, g1, n * k * G1B, s)) || (rc = up(d2, g2, n * k * G2B, s))) return rc;
+  unsigned long long noerr = NO_ERR, e = NO_ERR; if ((rc = up(derr, &noerr, 8, s))) return rc;
+  if (!dok.p) return ZKT_ERR_DEVICE;
+  PairArgs a{};
+  for (size_t j = 0; j < k; ++j) { a.g1[j] = d1.w() + j * 26; a.g2[j] = d2.w() + j * 50; a.s1[j] = (uint32_t)(k * 26); a.s2[j] = (uint32_t)(k * 50); a.neg[j] = negate && negate[j]; }
+  PCHK(launch_pairing_product_check(a, (int)k, dok.w(), n, (unsigned long long*)derr.p, s));
+  if ((rc = down(ok, dok.p, n * 4, s)) || (rc = down(&e, derr.p, 8, s))) return rc;
+  PCHK(hipStreamSynchronize(s));
+  if (e != NO_ERR) { zkt_internal_set_error_index((size_t)e); return ZKT_ERR_INFINITY; }
+  return ZKT_OK;
+}
+
+// G2Point::hash_to_g2point (g2_point.rs:84-88) for n messages: msgs = the concatenated bytes, offsets[n+1]
+static int bls_hash_dev(const uint8_t* msgs, const uint64_t* offsets, size_t n, Dev& dH, hipStream_t s) {
+  const size_t total = (size_t)offsets[n];
+  Dev dm(total), doff((n + 1) * 8), dsc(n * FRB), dgen2(G2B);
+  int rc;
+  if ((rc = up(dm, msgs, total, s)) || (rc = up(doff, offsets, (n + 1) * 8, s)) || (rc = up(dgen2, G2_GEN, G2B, s))) return rc;
+  if (!dsc.p || !dH.p) return ZKT_ERR_DEVICE;
+  hipLaunchKernelGGL(k_bytes_mod_r, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t*)dm.p, (const unsigned long long*)doff.p, n, dsc.w());
+  PCHK(launch_group_mul(G_G2, dgen2.w(), dsc.w(), 8, dH.w(), n, s, true));
+  PCHK(hipStreamSynchronize(s));
+  return ZKT_OK;
+}
+int zkt_bls_hash_to_g2_batch(const uint8_t* msgs, const uint64_t* offsets, size_t n, zkt_g2_affine* out) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!offsets || !out || (offsets[n] && !msgs)) return ZKT_ERR_SHAPE;
+  if (n == 0) return ZKT_OK;
+  hipStream_t s = nullptr; Dev dH(n * G2B);
+  int rc = bls_hash_dev(msgs, offsets, n, dH, s); if (rc) return rc;
+  if ((rc = down(out, dH.p, n * G2B, s))) return rc;
+  PCHK(hipStreamSynchronize(s));
+  return ZKT_OK;
+}
+// Signer::sign (signature.rs:28-31): hash_to_g2point(m) * sk
+int zkt_bls_sign_batch(const uint8_t* msgs, const uint64_t* offsets, const uint64_t* sks, size_t n, zkt_g2_affine* sigs) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!offsets || !sks || !sigs || (offsets[n] && !msgs)) return ZKT_ERR_SHAPE;
+  if (n == 0) return ZKT_OK;
+  hipStream_t s = nullptr; Dev dH(n * G2B), dsk(n * FRB), dsig(n * G2B);
+  int rc = bls_hash_dev(msgs, offsets, n, dH, s); if (rc) return rc;
+  if ((rc = up(dsk, sks, n * FRB, s))) return rc;
+  if (!dsig.p) return ZKT_ERR_DEVICE;
+  PCHK(launch_group_mul(G_G2, dH.w(), dsk.w(), 8, dsig.w(), n, s));
+  if ((rc = down(sigs, dsig.p, n * G2B, s))) return rc;
+  PCHK(hipStreamSynchronize(s));
+  return ZKT_OK;
+}
+// Signer::verify (signature.rs:34-39): tate(g1, sig) == tate(pk, hash_to_g2point(m)), one signature per lane as the
+// two-pair product tate(g1, sig) * tate(-pk, H) == 1.  ok[i] = 1/0; ZKT_ERR_INFINITY (+index) where the reference's tate() would panic.
+int zkt_bls_verify_batch(const uint8_t* msgs, const uint64_t* offsets, const zkt_g2_affine* sigs, const zkt_g1_affine* pks, size_t n, uint32_t* ok) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!offsets || !sigs || !pks || !ok || (offsets[n] && !msgs)) return ZKT_ERR_SHAPE;
+  if (n == 0) return ZKT_OK;
+  hipStream_t s = nullptr; Dev dH(n * G2B), dsig(n * G2B), dpk(n * G1B), dgen1(G1B), dok(n * 4), derr(8);
+  int rc = bls_hash_dev(msgs, offsets, n, dH, s); if (rc) return rc;
+  if ((rc = up(dsig, sigs, n * G2B, s)) || (rc = up(dpk, pks, n * G1B, s)) || (rc = up(dgen1, G1_GEN, G1B, s))) return rc;
+  unsigned long long noerr = NO_ERR, e = NO_ERR; if ((rc = up(derr, &noerr, 8, s))) return rc;
+  if (!dok.p) return ZKT_ERR_DEVICE;
+  PairArgs a{};
+  a.g1[0] = dgen1.w(); a.s1[0] = 0; a.g2[0] = dsig.w(); a.s2[0] = 50; a.neg[0] = 0;
+  a.g1[1] = dpk.w(); a.s1[1] = 26; a.g2[1] = dH.w(); a.s2[1] = 50; a.neg[1] = 1;
+  PCHK(launch_pairing_product_check(a, 2, dok.w(), n, (unsigned long long*)derr.p, s));
+  if ((rc = down(ok, dok.p, n * 4, s)) || (rc = down(&e, derr.p, 8, s))) return rc;
+  PCHK(hipStreamSynchronize(s));
+  if (e != NO_ERR) { zkt_internal_set_error_index((size_t)e); return ZKT_ERR_INFINITY; }
+  return ZKT_OK;
 }
 
 }  // extern "C"
