@@ -160,6 +160,30 @@ int zkt_bls_hash_to_g2_batch(const uint8_t* msgs, const uint64_t* offsets, size_
 int zkt_bls_sign_batch(const uint8_t* msgs, const uint64_t* offsets, const uint64_t* sks, size_t n, zkt_g2_affine* sigs);
 int zkt_bls_verify_batch(const uint8_t* msgs, const uint64_t* offsets, const zkt_g2_affine* sigs, const zkt_g1_affine* pks, size_t n, uint32_t* ok);
 
+/* f-4: Pinocchio (protocol 2 of eprint 2013/279) — CRS (EvaluationKeys crs.rs:12-22, VerificationKeys crs.rs:24-39), CRS::new crs.rs:49-161,
+ * Prover::prove pinocchio/prover.rs:98-170, Verifier::verify pinocchio/verifier.rs:31-85, Proof proof.rs:6-17.  vi/wi/yi are the
+ * (n_io + n_mid) x n dense Fr coefficient arrays of Prover.vi/wi/yi (prover.rs:43-45), low degree first; wires 0..n_io-1 are
+ * Witness::io() (witness.rs:20-23, the constant one included), the rest Witness::mid() (witness.rs:25-27); max_degree as
+ * prover.rs:68-78.  rnd = r_v, r_w, alpha_v, alpha_w, alpha_y, beta, gamma, s (crs.rs:58-64,82), 4 limbs each, non-zero;
+ * delta_v, delta_y = prover.rs:104-105; h = coefficients of p / t (prover.rs:143-146), h_len <= max_degree. */
+typedef struct {
+  size_t n, n_io, n_mid, max_degree;
+  zkt_g1_affine *vk_mid /*n_mid*/, *g1_wk_mid; zkt_g2_affine* g2_wk_mid; zkt_g1_affine *yk_mid, *alpha_vk_mid, *alpha_wk_mid, *alpha_yk_mid;
+  zkt_g2_affine* si /*max_degree*/; zkt_g1_affine* beta_vwy_k_mid;
+  zkt_g1_affine* one_g1; zkt_g2_affine *one_g2, *alpha_v; zkt_g1_affine* alpha_w; zkt_g2_affine *alpha_y, *gamma, *beta_gamma; zkt_g1_affine* t;
+  zkt_g1_affine* vk_io /*n_io*/; zkt_g2_affine* wk_io; zkt_g1_affine *yk_io, *alpha_v_t, *alpha_y_t, *beta_t;
+} zkt_pinocchio_crs;
+typedef struct {
+  zkt_g1_affine *v_mid_s, *g1_w_mid_s; zkt_g2_affine* g2_w_mid_s; zkt_g1_affine* y_mid_s; zkt_g2_affine* h_s;
+  zkt_g1_affine *alpha_v_mid_s, *alpha_w_mid_s, *alpha_y_mid_s, *beta_vwy_mid_s;
+} zkt_pinocchio_proof;
+int zkt_pinocchio_setup(zkt_pinocchio_crs* crs, const uint64_t* vi, const uint64_t* wi, const uint64_t* yi, const uint64_t* rnd);
+int zkt_pinocchio_prove(const zkt_pinocchio_crs* crs, const uint64_t* wires, const uint64_t* h, size_t h_len,
+                        const uint64_t* delta_v, const uint64_t* delta_y, zkt_pinocchio_proof* proof);
+/* 1 accept, 0 reject, negative = -status (a pairing argument at infinity panics in the reference); the five equalities are
+ * evaluated in the reference's order */
+int zkt_pinocchio_verify(const zkt_pinocchio_crs* crs, const zkt_pinocchio_proof* proof, const uint64_t* io_wires);
+
 /* a18: Bulletproofs::inner_product_argument bulletproofs.rs:19-55 over secp256k1; n a power of two; a, b are 4-limb
  * residues mod the group order; xs = one challenge per level (the reference draws them at bulletproofs.rs:42).
  * out_trace (optional): per level {L, R, P'}.  Returns 1/0 like the reference's bool, negative = -status. */

@@ -138,6 +138,109 @@ int zkto_groth16_verify(const zkto_groth16_crs* c, const uint64_t* A_, const uin
   } catch (const std::domain_error&) { return -2; }
 }
 
+// ---- Pinocchio (protocol 2 of eprint 2013/279): src/zk/w_trusted_setup/pinocchio/{crs.rs:49-161, prover.rs:98-170, verifier.rs:31-85}
+// Random values injected: rnd = r_v, r_w, alpha_v, alpha_w, alpha_y, beta, gamma, s (crs.rs:58-64,82); prover: delta_v, delta_y (prover.rs:104-105).
+// vi/wi/yi: (n_io + n_mid) dense polynomials of n coefficients (Prover.vi/wi/yi, prover.rs:43-45); wires 0..n_io-1 are the io part
+// (witness.rs:20-23), the rest the mid part (witness.rs:25-27).
+struct zkto_pinocchio_crs {    // same field order as zkt_pinocchio_crs in include/zkt.h
+  size_t n, n_io, n_mid, max_degree;
+  uint64_t *vk_mid, *g1_wk_mid, *g2_wk_mid, *yk_mid, *alpha_vk_mid, *alpha_wk_mid, *alpha_yk_mid, *si, *beta_vwy_k_mid;       // EvaluationKeys crs.rs:12-22
+  uint64_t *one_g1, *one_g2, *alpha_v, *alpha_w, *alpha_y, *gamma, *beta_gamma, *t, *vk_io, *wk_io, *yk_io, *alpha_v_t, *alpha_y_t, *beta_t;   // VerificationKeys crs.rs:24-39
+};
+struct zkto_pinocchio_proof { uint64_t *v_mid_s, *g1_w_mid_s, *g2_w_mid_s, *y_mid_s, *h_s, *alpha_v_mid_s, *alpha_w_mid_s, *alpha_y_mid_s, *beta_vwy_mid_s; };   // proof.rs:6-17
+
+int zkto_pinocchio_setup(zkto_pinocchio_crs* c, const uint64_t* vi, const uint64_t* wi, const uint64_t* yi, const uint64_t* rnd) {
+  init_fields();
+  const size_t n = c->n, nio = c->n_io, nmid = c->n_mid;
+  G1Point g1 = g1_generator(); G2Point g2 = g2_generator();
+  Fr r_v = ldr(rnd), r_w = ldr(rnd + 4), alpha_v = ldr(rnd + 8), alpha_w = ldr(rnd + 12), alpha_y = ldr(rnd + 16), beta = ldr(rnd + 20), gamma = ldr(rnd + 24), s = ldr(rnd + 28);
+  Fr r_y = r_v * r_w;                                                                        // crs.rs:67
+  G1Point g1_v = mul_fr(g1, r_v), g1_w = mul_fr(g1, r_w), g1_y = mul_fr(g1, r_y); G2Point g2_w = mul_fr(g2, r_w);   // :68-71
+  for (size_t k = 0; k < nmid; ++k) {                                                        // :86-108, mid = mid_beg..=end
+    const size_t i = nio + k;
+    Fr v = poly_eval(vi + i * n * FR, n, s), w = poly_eval(wi + i * n * FR, n, s), y = poly_eval(yi + i * n * FR, n, s);
+    stg1(c->vk_mid + k * G1W, mul_fr(g1_v, v)); stg1(c->g1_wk_mid + k * G1W, mul_fr(g1_w, w)); stg2(c->g2_wk_mid + k * G2W, mul_fr(g2_w, w));
+    stg1(c->yk_mid + k * G1W, mul_fr(g1_y, y));
+    stg1(c->alpha_vk_mid + k * G1W, mul_fr(mul_fr(g1_v, alpha_v), v)); stg1(c->alpha_wk_mid + k * G1W, mul_fr(mul_fr(g1_w, alpha_w), w));
+    stg1(c->alpha_yk_mid + k * G1W, mul_fr(mul_fr(g1_y, alpha_y), y));
+    stg1(c->beta_vwy_k_mid + k * G1W, affine_add(affine_add(mul_fr(mul_fr(g1_v, beta), v), mul_fr(mul_fr(g1_w, beta), w)), mul_fr(mul_fr(g1_y, beta), y)));
+  }
+  Fr sp(1);
+  for (size_t k = 0; k < c->max_degree; ++k) { stg2(c->si + k * G2W, mul_fr(g2, sp)); sp = sp * s; }   // :98-99 (pow_seq)
+  stg1(c->one_g1, mul_fr(g1, Fr(1))); stg2(c->one_g2, mul_fr(g2, Fr(1)));                    // :112-113
+  stg2(c->alpha_v, mul_fr(g2, alpha_v)); stg1(c->alpha_w, mul_fr(g1, alpha_w)); stg2(c->alpha_y, mul_fr(g2, alpha_y));
+  stg2(c->gamma, mul_fr(g2, gamma)); stg2(c->beta_gamma, mul_fr(mul_fr(g2, gamma), beta));
+  G1Point t = mul_fr(g1_y, t_eval(n, s));                                                    // :120
+  stg1(c->t, t);
+  for (size_t i = 0; i < nio; ++i) {                                                         // :122-124
+    stg1(c->vk_io + i * G1W, mul_fr(g1_v, poly_eval(vi + i * n * FR, n, s)));
+    stg2(c->wk_io + i * G2W, mul_fr(g2_w, poly_eval(wi + i * n * FR, n, s)));
+    stg1(c->yk_io + i * G1W, mul_fr(g1_y, poly_eval(yi + i * n * FR, n, s)));
+  }
+  stg1(c->alpha_v_t, mul_fr(t, alpha_v)); stg1(c->alpha_y_t, mul_fr(t, alpha_y)); stg1(c->beta_t, mul_fr(t, beta));   // :138-140
+  return 0;
+}
+
+// Prover::prove (prover.rs:98-170); h = p / t coefficients (prover.rs:143-146), delta_v / delta_y injected
+int zkto_pinocchio_prove(const zkto_pinocchio_crs* c, const uint64_t* wires, const uint64_t* hcoef, size_t h_len,
+                         const uint64_t* delta_v_, const uint64_t* delta_y_, zkto_pinocchio_proof* pf) {
+  init_fields();
+  const size_t nio = c->n_io, nmid = c->n_mid;
+  Fr dv = ldr(delta_v_), dy = ldr(delta_y_);
+  G1Point t = ldg1(c->t), bt = ldg1(c->beta_t);
+  G1Point v_mid = mul_fr(t, dv), g1_w_mid = G1Point::infinity(), y_mid = mul_fr(t, dy);      // :124-128
+  G2Point g2_w_mid = G2Point::infinity();
+  G1Point a_v = mul_fr(ldg1(c->alpha_v_t), dv), a_w = G1Point::infinity(), a_y = mul_fr(ldg1(c->alpha_y_t), dy);
+  G1Point b_vwy = affine_add(mul_fr(bt, dv), mul_fr(bt, dy));                                // :131
+  for (size_t k = 0; k < nmid; ++k) {                                                        // :133-146
+    Fr w = ldr(wires + (nio + k) * FR);
+    v_mid = affine_add(v_mid, mul_fr(ldg1(c->vk_mid + k * G1W), w));
+    g1_w_mid = affine_add(g1_w_mid, mul_fr(ldg1(c->g1_wk_mid + k * G1W), w));
+    g2_w_mid = affine_add(g2_w_mid, mul_fr(ldg2(c->g2_wk_mid + k * G2W), w));
+    y_mid = affine_add(y_mid, mul_fr(ldg1(c->yk_mid + k * G1W), w));
+    a_v = affine_add(a_v, mul_fr(ldg1(c->alpha_vk_mid + k * G1W), w));
+    a_w = affine_add(a_w, mul_fr(ldg1(c->alpha_wk_mid + k * G1W), w));
+    a_y = affine_add(a_y, mul_fr(ldg1(c->alpha_yk_mid + k * G1W), w));
+    b_vwy = affine_add(b_vwy, mul_fr(ldg1(c->beta_vwy_k_mid + k * G1W), w));
+  }
+  std::vector<G2Point> si(h_len);
+  for (size_t k = 0; k < h_len; ++k) si[k] = ldg2(c->si + k * G2W);
+  G2Point h_s = msm_naive(si.data(), hcoef, FR, h_len);                                      // :153 eval_with_g2_hidings
+  G2Point w_s = g2_w_mid;
+  for (size_t i = 0; i < nio; ++i) w_s = affine_add(w_s, mul_fr(ldg2(c->wk_io + i * G2W), ldr(wires + i * FR)));   // :155-159
+  G2Point adj = affine_add(affine_add(h_s, mul_fr(w_s, dv)), mul_fr(ldg2(c->one_g2), dy).neg());    // :160
+  stg1(pf->v_mid_s, v_mid); stg1(pf->g1_w_mid_s, g1_w_mid); stg2(pf->g2_w_mid_s, g2_w_mid); stg1(pf->y_mid_s, y_mid); stg2(pf->h_s, adj);
+  stg1(pf->alpha_v_mid_s, a_v); stg1(pf->alpha_w_mid_s, a_w); stg1(pf->alpha_y_mid_s, a_y); stg1(pf->beta_vwy_mid_s, b_vwy);
+  return 0;
+}
+
+// Verifier::verify (verifier.rs:31-85): 1 accept, 0 reject, -2 if a tate() argument is the point at infinity (panic)
+int zkto_pinocchio_verify(const zkto_pinocchio_crs* c, const zkto_pinocchio_proof* pf, const uint64_t* io_wires) {
+  init_fields();
+  static Pairing pr;
+  auto e = [&](const G1Point& a, const G2Point& b) { return pr.tate(a, b); };
+  try {
+    G1Point v_mid = ldg1(pf->v_mid_s), g1_w = ldg1(pf->g1_w_mid_s), y_mid = ldg1(pf->y_mid_s);
+    G2Point g2_w = ldg2(pf->g2_w_mid_s), one2 = ldg2(c->one_g2);
+    {                                                                                        // :43-49
+      G1Point vwy = affine_add(affine_add(v_mid, g1_w), y_mid);
+      if (!(e(ldg1(pf->beta_vwy_mid_s), ldg2(c->gamma)) == e(vwy, ldg2(c->beta_gamma)))) return 0;
+    }
+    if (!(e(ldg1(pf->alpha_v_mid_s), one2) == e(v_mid, ldg2(c->alpha_v)))) return 0;         // :52-56
+    if (!(e(ldg1(pf->alpha_w_mid_s), one2) == e(ldg1(c->alpha_w), g2_w))) return 0;          // :57-61
+    if (!(e(ldg1(pf->alpha_y_mid_s), one2) == e(y_mid, ldg2(c->alpha_y)))) return 0;         // :62-66
+    G1Point v_s = v_mid, y_s = y_mid; G2Point w_s = g2_w;                                    // :69-79
+    for (size_t i = 0; i < c->n_io; ++i) {
+      Fr w = ldr(io_wires + i * FR);
+      v_s = affine_add(v_s, mul_fr(ldg1(c->vk_io + i * G1W), w));
+      w_s = affine_add(w_s, mul_fr(ldg2(c->wk_io + i * G2W), w));
+      y_s = affine_add(y_s, mul_fr(ldg1(c->yk_io + i * G1W), w));
+    }
+    Fq12 lhs = e(v_s, w_s), rhs = e(ldg1(c->t), ldg2(pf->h_s)) * e(y_s, one2);               // :81-84
+    return lhs == rhs ? 1 : 0;
+  } catch (const std::domain_error&) { return -2; }
+}
+
 // ---- Bulletproofs::inner_product_argument (bulletproofs.rs:19-55), challenges injected (xs[level]) -----------
 typedef Fp<SpTag> Sp; typedef Fp<SnTag> Sn;
 static SecpPoint ldsp(const uint64_t* p) { if (p[8] & 0xffffffffu) return SecpPoint::infinity(); return SecpPoint(Sp::from_limbs(p, 4), Sp::from_limbs(p + 4, 4)); }

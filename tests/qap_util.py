@@ -68,8 +68,9 @@ def qap_from_r1cs(Amat, Bmat, Cmat, witness):
 def example_cubic():
     """(x*x*x) + x + 5 == 35 with x = 3 — the reference's own Groth16 test (prover.rs:159-192): 7 wires, l = 2."""
     w = [1, 3, 35, 9, 27, 8, 35]           # one, x, out | t1=x*x, t2=t1*x, t3=x+5, t4=t2+t3   (wires.rs:47-54)
-    A = [[0, 1, 0, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0, 0], [5, 1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 1, 1, 0], [0, 0, 0, 0, 0, 0, 1]]
-    B = [[0, 1, 0, 0, 0, 0, 0], [0, 1, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0]]
+    # gates as Gate::build emits them (gate.rs:206-235): t1 = x*x, t2 = x*t1, t3 = (x+5)*1, t4 = (t2+t3)*1, out = t4*1
+    A = [[0, 1, 0, 0, 0, 0, 0], [0, 1, 0, 0, 0, 0, 0], [5, 1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 1, 1, 0], [0, 0, 0, 0, 0, 0, 1]]
+    B = [[0, 1, 0, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0]]
     C = [[0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 1, 0], [0, 0, 0, 0, 0, 0, 1], [0, 0, 1, 0, 0, 0, 0]]
     return A, B, C, w, 2
 
@@ -188,3 +189,47 @@ def chain_circuit_sparse(n, seed=7):
     valC = np.zeros((2 * n, 4), np.uint64)
     valC[0::2] = ints_to_arr([(-c) % R for c in cs], 4); valC[1::2] = one
     return ((rp1, idx.copy(), vA.copy()), (rp1.copy(), idx.copy(), vA.copy()), (np.arange(0, 2 * n + 1, 2, dtype=np.uint64), colC, valC)), ints_to_arr(wit, 4), 1, n + 1
+
+
+# ---- Pinocchio (pinocchio/{crs,prover,verifier}.rs): ctypes mirrors of zkt_pinocchio_crs / zkt_pinocchio_proof -------------
+_PIN_EK = [("vk_mid", G1W, "mid"), ("g1_wk_mid", G1W, "mid"), ("g2_wk_mid", G2W, "mid"), ("yk_mid", G1W, "mid"), ("alpha_vk_mid", G1W, "mid"),
+           ("alpha_wk_mid", G1W, "mid"), ("alpha_yk_mid", G1W, "mid"), ("si", G2W, "deg"), ("beta_vwy_k_mid", G1W, "mid")]
+_PIN_VK = [("one_g1", G1W, 1), ("one_g2", G2W, 1), ("alpha_v", G2W, 1), ("alpha_w", G1W, 1), ("alpha_y", G2W, 1), ("gamma", G2W, 1), ("beta_gamma", G2W, 1),
+           ("t", G1W, 1), ("vk_io", G1W, "io"), ("wk_io", G2W, "io"), ("yk_io", G1W, "io"), ("alpha_v_t", G1W, 1), ("alpha_y_t", G1W, 1), ("beta_t", G1W, 1)]
+_PIN_PROOF = [("v_mid_s", G1W), ("g1_w_mid_s", G1W), ("g2_w_mid_s", G2W), ("y_mid_s", G1W), ("h_s", G2W), ("alpha_v_mid_s", G1W), ("alpha_w_mid_s", G1W),
+              ("alpha_y_mid_s", G1W), ("beta_vwy_mid_s", G1W)]
+
+
+class PinCrs(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_size_t) for k in ("n", "n_io", "n_mid", "max_degree")] + [(k, ctypes.POINTER(ctypes.c_uint64)) for k, _, _ in _PIN_EK + _PIN_VK]
+
+
+class PinProof(ctypes.Structure):
+    _fields_ = [(k, ctypes.POINTER(ctypes.c_uint64)) for k, _ in _PIN_PROOF]
+
+
+def alloc_pinocchio(n, n_io, n_mid, max_degree):
+    cnt = {"mid": max(n_mid, 1), "io": max(n_io, 1), "deg": max_degree, 1: 1}
+    bufs = {k: np.zeros((cnt[c], w), np.uint64) for k, w, c in _PIN_EK + _PIN_VK}
+    crs = PinCrs(n=n, n_io=n_io, n_mid=n_mid, max_degree=max_degree)
+    for k, v in bufs.items(): setattr(crs, k, ptr(v))
+    return crs, bufs
+
+
+def alloc_pinocchio_proof():
+    bufs = {k: np.zeros((1, w), np.uint64) for k, w in _PIN_PROOF}
+    pf = PinProof()
+    for k, v in bufs.items(): setattr(pf, k, ptr(v))
+    return pf, bufs
+
+
+def pinocchio_instance(Amat, Bmat, Cmat, wit):
+    """dense vi/wi/yi, quotient h and max_degree as Prover::new computes them (pinocchio/prover.rs:50-96)"""
+    n = len(Amat)
+    vi, wi, yi, h, t = qap_from_r1cs(Amat, Bmat, Cmat, wit)
+    comb = lambda P: [sum(wit[i] * P[i][k] for i in range(len(wit))) % R for k in range(n)]
+    p = poly_mul(comb(vi), comb(wi))
+    for k, c in enumerate(comb(yi)): p[k] = (p[k] - c) % R
+    deg = lambda q: max([k for k, c in enumerate(q) if c % R] + [0])
+    max_degree = max([deg(q) for P in (vi, wi, yi) for q in P] + [deg(p), deg(t)]) + 1      # prover.rs:68-78
+    return dense(vi, n), dense(wi, n), dense(yi, n), h, max_degree

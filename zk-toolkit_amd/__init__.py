@@ -57,6 +57,7 @@ def lib():
         L.zkt_groth16_pk_free.argtypes = [vp]; L.zkt_groth16_pk_free.restype = None
         sz = ctypes.c_size_t
         L.zkt_pairing_product_check_batch.argtypes = [vp, vp, vp, sz, sz, vp]
+        L.zkt_pinocchio_prove.argtypes = [vp, vp, vp, sz, vp, vp, vp]
         L.zkt_bls_hash_to_g2_batch.argtypes = [vp, vp, sz, vp]
         L.zkt_bls_sign_batch.argtypes = [vp, vp, vp, sz, vp]
         L.zkt_bls_verify_batch.argtypes = [vp, vp, vp, vp, sz, vp]
