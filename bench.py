@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+VALU_INSTR_PER_ADD, NWIN_2P20 = 5450, 13     # k_accumulate: instructions per XYZZ mixed add on the hot path (ISA count, 3.6 k of them v_mad_u64_u32); windows at n = 2^20 (c = 20)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MSM_BYTES_PER_TERM = 128       # 96 B affine base + 32 B scalar
 PAIRING_BYTES = 864            # 96 + 192 in, 576 out
@@ -168,7 +169,12 @@ def main():
                      "frac": MSM_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_note": "FETCH_SIZE+WRITE_SIZE per launch from profiles/r01_hbm_traffic_pmc.json; 13x the algorithmic bytes by design: every term is gathered once per window from the resident window-multiple table (DESIGN.md §4)",
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": MSM_BYTES_PER_TERM * n,
-                     "note": "integer-VALU bound by construction (SURVEY §8d); see DESIGN.md for the VALU roofline"},
+                     "note": "integer-VALU bound by construction (SURVEY §8d); see DESIGN.md for the VALU roofline",
+                     # the roof that actually bounds the kernel: VALU instruction issue.  5.45 k instructions per bucket add (ISA count of the
+                     # k_accumulate hot loop), nwin*n adds per launch; peak = 256 CU x 4 SIMD x 64 lanes / 4 clk at 2.4 GHz.
+                     "valu": {"achieved": VALU_INSTR_PER_ADD * NWIN_2P20 * n / (k_ms * 1e-3) / 1e12 if args.log2n == 20 else None, "peak": 39.3, "unit": "T lane-instr/s",
+                              "frac": VALU_INSTR_PER_ADD * NWIN_2P20 * n / (k_ms * 1e-3) / 1e12 / 39.3 if args.log2n == 20 else None,
+                              "note": "v_mad_u64_u32 (66 % of the mix) issues every ~5 clk, not 4 (profiles/r01_mad_issue_latency.txt): the reachable roof for this mix is ~31-33 T/s"}},
     }
 
     # parity check of the timed configuration at full size, by linearity: bases are k_i*G, so the MSM over all ranks

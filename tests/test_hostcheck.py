@@ -49,7 +49,7 @@ def _fq_program_model(seed, steps, regs):
     r = list(regs)
     for _ in range(steps):
         st = (st * 6364136223846793005 + 1442695040888963407) & (2**64 - 1)
-        op, d, a, b = (st >> 33) % 10, (st >> 40) & 3, (st >> 42) & 3, (st >> 44) & 3
+        op, d, a, b = (st >> 33) % 12, (st >> 40) & 3, (st >> 42) & 3, (st >> 44) & 3
         if op in (0, 1): r[d] = (r[a] + r[b]) % Q
         elif op in (2, 3): r[d] = (r[a] - r[b]) % Q
         elif op == 4: r[d] = -r[a] % Q
@@ -57,6 +57,8 @@ def _fq_program_model(seed, steps, regs):
         elif op == 6: r[d] = r[a] * r[b] % Q
         elif op == 7: r[d] = r[a] * r[a] % Q
         elif op == 8: r[d] = r[a]
+        elif op == 10: r[d] = (r[a] - r[b] - 2 * r[(b + 1) & 3]) % Q
+        elif op == 11: r[d] = (r[a] * r[b] - r[(a + 1) & 3] * r[(b + 2) & 3]) % Q
         else: r[d] = 1 if r[a] == r[b] else (r[a] + 1) % Q
     return r
 
@@ -82,14 +84,14 @@ def test_fq_lazy_reduce_quotient_estimate():
     below it for every v < 12p (so a reduced value is < 4p).  Checked at the extremes of every reachable top limb."""
     top_p = Q >> 364
     M = (1 << 32) // (top_p + 1)
-    for top in range(0, (12 * Q >> 364) + 1):
+    for top in range(0, (20 * Q >> 364) + 1):                 # fp_sub2 reduces values up to a + 16p < 20p
         q = (top * M) >> 32
-        # un-normalised input: the limbs below the top may each hold up to 3*2^28, i.e. spill < 4 units into the top
-        lo, hi = top << 364, min(((top + 4) << 364) - 1, 12 * Q - 1)
+        # un-normalised input: the limbs below the top may each hold up to 6*2^28 (fp_sub2), i.e. spill < 7 units into the top
+        lo, hi = top << 364, min(((top + 7) << 364) - 1, 20 * Q - 1)
         assert q * Q <= lo                                 # never overshoots: v - q*p >= 0
         assert hi - q * Q < 4 * Q                          # result < 4p
     # add: operands < 4p -> v < 8p; sub: a + 8p - b < 12p, limbs stay below 2^31 (fp.h bounds)
-    assert (12 * Q >> 364) * M < 2**63
+    assert (20 * Q >> 364) * M < 2**63
 
 
 @pytest.mark.parametrize("field,mod", [(2, SECP_P), (3, SECP_N)])

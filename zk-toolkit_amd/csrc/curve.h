@@ -23,6 +23,8 @@ template <class C> struct PrimeOps {
   ZKT_HD static E mul(const E& a, const E& b) { return fp_mul(a, b); }
   ZKT_HD static E sqr(const E& a) { return fp_sqr(a); }
   ZKT_HD static E dbl(const E& a) { return fp_dbl(a); }
+  ZKT_HD static E sub2(const E& a, const E& b, const E& c) { return fp_sub2(a, b, c); }                    // a - b - 2c
+  ZKT_HD static E mulsub(const E& a, const E& b, const E& c, const E& d) { return fp_mulsub(a, b, c, d); }   // a b - c d
   ZKT_HD static E neg(const E& a) { return fp_neg(a); }
   ZKT_HD static E inv(const E& a) { return fp_inv(a); }
   ZKT_HD static bool is_zero(const E& a) { return fp_is_zero(a); }
@@ -39,6 +41,8 @@ struct Fq2Ops {
   ZKT_HD static E mul(const E& a, const E& b) { return fq2_mul(a, b); }
   ZKT_HD static E sqr(const E& a) { return fq2_sqr(a); }
   ZKT_HD static E dbl(const E& a) { return fq2_dbl(a); }
+  ZKT_HD static E sub2(const E& a, const E& b, const E& c) { return Fq2{fp_sub2(a.c0, b.c0, c.c0), fp_sub2(a.c1, b.c1, c.c1)}; }
+  ZKT_HD static E mulsub(const E& a, const E& b, const E& c, const E& d) { return fq2_sub(fq2_mul(a, b), fq2_mul(c, d)); }
   ZKT_HD static E neg(const E& a) { return fq2_neg(a); }
   ZKT_HD static E inv(const E& a) { return fq2_inv(a); }
   ZKT_HD static bool is_zero(const E& a) { return fq2_is_zero(a); }
@@ -139,8 +143,8 @@ template <class F> ZKT_HD Xyzz<F> xyzz_dbl_aff(const typename F::E& x, const typ
   E U = F::dbl(y), V = F::sqr(U), W = F::mul(U, V), S = F::mul(x, V);
   E xx = F::sqr(x), M = F::add(F::dbl(xx), xx);
   Xyzz<F> r;
-  r.X = F::sub(F::sqr(M), F::dbl(S));
-  r.Y = F::sub(F::mul(M, F::sub(S, r.X)), F::mul(W, y));
+  r.X = F::sub2(F::sqr(M), F::zero(), S);
+  r.Y = F::mulsub(M, F::sub(S, r.X), W, y);
   r.ZZ = V; r.ZZZ = W;
   return r;
 }
@@ -150,8 +154,8 @@ template <class F> ZKT_HD Xyzz<F> xyzz_dbl(const Xyzz<F>& p) {
   E U = F::dbl(p.Y), V = F::sqr(U), W = F::mul(U, V), S = F::mul(p.X, V);
   E xx = F::sqr(p.X), M = F::add(F::dbl(xx), xx);
   Xyzz<F> r;
-  r.X = F::sub(F::sqr(M), F::dbl(S));
-  r.Y = F::sub(F::mul(M, F::sub(S, r.X)), F::mul(W, p.Y));
+  r.X = F::sub2(F::sqr(M), F::zero(), S);
+  r.Y = F::mulsub(M, F::sub(S, r.X), W, p.Y);
   r.ZZ = F::mul(V, p.ZZ); r.ZZZ = F::mul(W, p.ZZZ);
   return r;
 }
@@ -167,8 +171,8 @@ template <class F> ZKT_HD Xyzz<F> xyzz_add_aff(const Xyzz<F>& p, const typename 
   }
   E PP = F::sqr(Pp), PPP = F::mul(Pp, PP), Qq = F::mul(p.X, PP);
   Xyzz<F> r;
-  r.X = F::sub(F::sub(F::sqr(Rr), PPP), F::dbl(Qq));
-  r.Y = F::sub(F::mul(Rr, F::sub(Qq, r.X)), F::mul(p.Y, PPP));
+  r.X = F::sub2(F::sqr(Rr), PPP, Qq);
+  r.Y = F::mulsub(Rr, F::sub(Qq, r.X), p.Y, PPP);
   r.ZZ = F::mul(p.ZZ, PP); r.ZZZ = F::mul(p.ZZZ, PPP);
   return r;
 }
@@ -186,8 +190,8 @@ template <class F> ZKT_HD Xyzz<F> xyzz_add(const Xyzz<F>& p, const Xyzz<F>& q) {
   }
   E PP = F::sqr(Pp), PPP = F::mul(Pp, PP), Qq = F::mul(U1, PP);
   Xyzz<F> r;
-  r.X = F::sub(F::sub(F::sqr(Rr), PPP), F::dbl(Qq));
-  r.Y = F::sub(F::mul(Rr, F::sub(Qq, r.X)), F::mul(S1, PPP));
+  r.X = F::sub2(F::sqr(Rr), PPP, Qq);
+  r.Y = F::mulsub(Rr, F::sub(Qq, r.X), S1, PPP);
   r.ZZ = F::mul(F::mul(p.ZZ, q.ZZ), PP); r.ZZZ = F::mul(F::mul(p.ZZZ, q.ZZZ), PPP);
   return r;
 }

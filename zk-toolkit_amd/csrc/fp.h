@@ -164,6 +164,18 @@ template <class C> ZKT_HD bool fp_eq(const Fp<C>& a, const Fp<C>& b) {
   }
 }
 template <class C> ZKT_HD Fp<C> fp_dbl(const Fp<C>& a) { return fp_add(a, a); }
+// a - b - 2c in one reduction pass (the x-coordinate of every addition formula).  W = 28: a + 16p - b - 2c with 16p spread so that
+// no limb borrows (limbs < 2^31, value < 20p: the quotient estimate of fp_lazy_reduce still leaves < 4p, tests/test_hostcheck.py).
+template <class C> ZKT_HD Fp<C> fp_sub2(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c) {
+  if constexpr (C::W == 28) {
+    uint32_t v[C::N];
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) v[i] = a.v[i] + C::subk3(i) - b.v[i] - 2 * c.v[i];
+    return fp_lazy_reduce<C>(v);
+  } else {
+    return fp_sub(fp_sub(a, b), fp_dbl(c));
+  }
+}
 
 // acc += a*b on one 64-bit column accumulator (W = 28 path): a single v_mad_u64_u32
 ZKT_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
@@ -252,6 +264,34 @@ template <class C> ZKT_HD Fp<C> fp_sqr_impl(const Fp<C>& a) {
   return r;
 }
 
+// a*b - c*d with ONE Montgomery reduction (y = m(x1 - x3) - y1 style terms): the subtrahend enters as c * (8p - d) with the
+// borrow-safe spread of 8p, limbs < 2^29, so a column sums 14 products < 2^56, 14 < 2^57 and 14 reduction products < 2^56:
+// below 2^62.  Output (ab + c(8p-d) + mp)/R < p (1 + 48 p/R) < 1.04p.
+template <class C> ZKT_HD Fp<C> fp_mulsub_impl(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d) {
+  static_assert(C::W == 28, "lazy-limb fields only");
+  constexpr int N = C::N; constexpr uint32_t M = (1u << 28) - 1;
+  Fp<C> r; uint32_t m[N], nd[N]; uint64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) nd[i] = C::subk(i) - d.v[i];
+#pragma unroll
+  for (int k = 0; k < 2 * N; ++k) {
+#pragma unroll
+    for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); ++i) { acc = mad64(a.v[i], b.v[k - i], acc); acc = mad64(c.v[i], nd[k - i], acc); }
+    if (k < N) {
+#pragma unroll
+      for (int j = 0; j < k; ++j) acc = mad64(m[j], C::mod(k - j), acc);
+      m[k] = ((uint32_t)acc * C::INV) & M;
+      acc = mad64(m[k], C::mod(0), acc);
+    } else {
+#pragma unroll
+      for (int j = k - N + 1; j < N; ++j) acc = mad64(m[j], C::mod(k - j), acc);
+      r.v[k - N] = (uint32_t)acc & M;
+    }
+    acc >>= 28;
+  }
+  return r;
+}
+
 // Call policy.  One inlined multiply is ~1000 instructions (8 KB); curve and
 // pairing kernels contain hundreds of them, far beyond the 64 KB instruction
 // cache, so by default the multiply is ONE function per field and kernel image,
@@ -261,10 +301,15 @@ template <class C> ZKT_HD Fp<C> fp_sqr_impl(const Fp<C>& a) {
 #if !defined(ZKT_INLINE_MUL)
 template <class C> ZKT_FN Fp<C> fp_mul(Fp<C> a, Fp<C> b) { return fp_mul_impl(a, b); }
 template <class C> ZKT_FN Fp<C> fp_sqr_fn(Fp<C> a) { return fp_sqr_impl(a); }
+template <class C> ZKT_FN Fp<C> fp_mulsub_fn(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d) { return fp_mulsub_impl(a, b, c, d); }
 #else
 template <class C> ZKT_HD Fp<C> fp_mul(const Fp<C>& a, const Fp<C>& b) { return fp_mul_impl(a, b); }
 template <class C> ZKT_HD Fp<C> fp_sqr_fn(const Fp<C>& a) { return fp_sqr_impl(a); }
+template <class C> ZKT_HD Fp<C> fp_mulsub_fn(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d) { return fp_mulsub_impl(a, b, c, d); }
 #endif
+template <class C> ZKT_HD Fp<C> fp_mulsub(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d) {
+  if constexpr (C::W == 28) return fp_mulsub_fn(a, b, c, d); else return fp_sub(fp_mul(a, b), fp_mul(c, d));
+}
 
 // Montgomery square.  sq (prime_field_elem.rs:330-335).  With 32-bit limbs a dedicated squaring
 // pays ~6 shift/add ops per column for the 96-bit doubling and does not win, so it is the product;
