@@ -49,7 +49,7 @@ def _fq_program_model(seed, steps, regs):
     r = list(regs)
     for _ in range(steps):
         st = (st * 6364136223846793005 + 1442695040888963407) & (2**64 - 1)
-        op, d, a, b = (st >> 33) % 12, (st >> 40) & 3, (st >> 42) & 3, (st >> 44) & 3
+        op, d, a, b = (st >> 33) % 13, (st >> 40) & 3, (st >> 42) & 3, (st >> 44) & 3
         if op in (0, 1): r[d] = (r[a] + r[b]) % Q
         elif op in (2, 3): r[d] = (r[a] - r[b]) % Q
         elif op == 4: r[d] = -r[a] % Q
@@ -59,6 +59,7 @@ def _fq_program_model(seed, steps, regs):
         elif op == 8: r[d] = r[a]
         elif op == 10: r[d] = (r[a] - r[b] - 2 * r[(b + 1) & 3]) % Q
         elif op == 11: r[d] = (r[a] * r[b] - r[(a + 1) & 3] * r[(b + 2) & 3]) % Q
+        elif op == 12: r[d] = (r[a] * r[b] + r[(a + 1) & 3] * r[(b + 2) & 3]) % Q
         else: r[d] = 1 if r[a] == r[b] else (r[a] + 1) % Q
     return r
 

@@ -267,12 +267,13 @@ template <class C> ZKT_HD Fp<C> fp_sqr_impl(const Fp<C>& a) {
 // a*b - c*d with ONE Montgomery reduction (y = m(x1 - x3) - y1 style terms): the subtrahend enters as c * (8p - d) with the
 // borrow-safe spread of 8p, limbs < 2^29, so a column sums 14 products < 2^56, 14 < 2^57 and 14 reduction products < 2^56:
 // below 2^62.  Output (ab + c(8p-d) + mp)/R < p (1 + 48 p/R) < 1.04p.
-template <class C> ZKT_HD Fp<C> fp_mulsub_impl(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d) {
+// SUB = false: a*b + c*d the same way (no spread needed).
+template <class C, bool SUB> ZKT_HD Fp<C> fp_mul2_impl(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d) {
   static_assert(C::W == 28, "lazy-limb fields only");
   constexpr int N = C::N; constexpr uint32_t M = (1u << 28) - 1;
   Fp<C> r; uint32_t m[N], nd[N]; uint64_t acc = 0;
 #pragma unroll
-  for (int i = 0; i < N; ++i) nd[i] = C::subk(i) - d.v[i];
+  for (int i = 0; i < N; ++i) nd[i] = SUB ? C::subk(i) - d.v[i] : d.v[i];
 #pragma unroll
   for (int k = 0; k < 2 * N; ++k) {
 #pragma unroll
@@ -301,14 +302,19 @@ template <class C> ZKT_HD Fp<C> fp_mulsub_impl(const Fp<C>& a, const Fp<C>& b, c
 #if !defined(ZKT_INLINE_MUL)
 template <class C> ZKT_FN Fp<C> fp_mul(Fp<C> a, Fp<C> b) { return fp_mul_impl(a, b); }
 template <class C> ZKT_FN Fp<C> fp_sqr_fn(Fp<C> a) { return fp_sqr_impl(a); }
-template <class C> ZKT_FN Fp<C> fp_mulsub_fn(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d) { return fp_mulsub_impl(a, b, c, d); }
+template <class C> ZKT_FN Fp<C> fp_mulsub_fn(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d) { return fp_mul2_impl<C, true>(a, b, c, d); }
+template <class C> ZKT_FN Fp<C> fp_muladd_fn(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d) { return fp_mul2_impl<C, false>(a, b, c, d); }
 #else
 template <class C> ZKT_HD Fp<C> fp_mul(const Fp<C>& a, const Fp<C>& b) { return fp_mul_impl(a, b); }
 template <class C> ZKT_HD Fp<C> fp_sqr_fn(const Fp<C>& a) { return fp_sqr_impl(a); }
-template <class C> ZKT_HD Fp<C> fp_mulsub_fn(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d) { return fp_mulsub_impl(a, b, c, d); }
+template <class C> ZKT_HD Fp<C> fp_mulsub_fn(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d) { return fp_mul2_impl<C, true>(a, b, c, d); }
+template <class C> ZKT_HD Fp<C> fp_muladd_fn(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d) { return fp_mul2_impl<C, false>(a, b, c, d); }
 #endif
 template <class C> ZKT_HD Fp<C> fp_mulsub(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d) {
   if constexpr (C::W == 28) return fp_mulsub_fn(a, b, c, d); else return fp_sub(fp_mul(a, b), fp_mul(c, d));
+}
+template <class C> ZKT_HD Fp<C> fp_muladd(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d) {
+  if constexpr (C::W == 28) return fp_muladd_fn(a, b, c, d); else return fp_add(fp_mul(a, b), fp_mul(c, d));
 }
 
 // Montgomery square.  sq (prime_field_elem.rs:330-335).  With 32-bit limbs a dedicated squaring

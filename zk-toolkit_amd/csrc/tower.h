@@ -34,11 +34,11 @@ ZKT_HD Fq2 fq2_sub(const Fq2& a, const Fq2& b) { return Fq2{fp_sub(a.c0, b.c0), 
 ZKT_HD Fq2 fq2_neg(const Fq2& a) { return Fq2{fp_neg(a.c0), fp_neg(a.c1)}; }                               // fq2.rs:82-94
 ZKT_HD Fq2 fq2_dbl(const Fq2& a) { return Fq2{fp_dbl(a.c0), fp_dbl(a.c1)}; }
 ZKT_HD Fq2 fq2_conj(const Fq2& a) { return Fq2{a.c0, fp_neg(a.c1)}; }
-// fq2.rs:134-146 computes the 4-product schoolbook; Karatsuba gives the same element
+// fq2.rs:134-146: the 4-product schoolbook, here with lazy reduction — each coordinate is a sum of two products under ONE
+// Montgomery reduction (fp_mulsub / fp_muladd): 784 + 392 MADs like Karatsuba's three multiplications, but none of its five
+// additions and subtractions.
 ZKT_FQ2 Fq2 fq2_mul(const Fq2& a, const Fq2& b) {
-  Fq v0 = fp_mul(a.c0, b.c0), v1 = fp_mul(a.c1, b.c1);
-  Fq s = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
-  return Fq2{fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
+  return Fq2{fp_mulsub(a.c0, b.c0, a.c1, b.c1), fp_muladd(a.c0, b.c1, a.c1, b.c0)};
 }
 ZKT_FQ2 Fq2 fq2_sqr(const Fq2& a) {                                      // fq2.rs:34-36
   Fq t = fp_mul(a.c0, a.c1);
