@@ -1,0 +1,38 @@
+// Batched Tate pairing kernel: one pairing per lane (rows a10–a13 of SURVEY §8).
+//   Pairing::tate   bls12_381/pairing.rs:86-100
+// The algorithm and why it is bit-identical to the reference are in pairing.h.
+// This kernel has its own translation unit: the register budget of a kernel is propagated to the (non-inlined) field and tower
+// functions it calls only when no other kernel shares them.  v_mad_u64_u32 issues at half rate with one wave per SIMD
+// (profiles/r01_mad_issue_latency.txt), so two waves per SIMD (256 registers, no AGPRs) is the goal — but measured on MI355X with
+// -DZKT_TATE_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))' the extra spills (9.5 instead of 7.9 KB of scratch per lane) cost more
+// than the issue rate gains: 426 k instead of 667 k pairings/s.  The default therefore stays at one wave per SIMD until the Fq12
+// working set is cut (or spread over several lanes).
+#include "abi.h"
+#include "zkt_internal.h"
+
+namespace zkt {
+
+#ifndef ZKT_TATE_ATTR
+#define ZKT_TATE_ATTR
+#endif
+__global__ void __launch_bounds__(64) ZKT_TATE_ATTR k_tate(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
+                                             uint32_t* __restrict__ out, size_t n, unsigned long long* err) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Aff<FqOps> p = PtIO<FqOps>::ld(g1 + i * ABI_G1_WORDS);
+  Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2 + i * ABI_G2_WORDS);
+  if (p.inf || q.inf) {   // RationalFunction::new_* / eval_with_* panic on infinity (rational_function.rs:36,59)
+    atomicMin(err, (unsigned long long)i);
+    return;
+  }
+  Fq12 f = miller_g1_g2(p.x, p.y, q.x, q.y);
+  st_fq12(out + i * 144, final_exponentiation(f));
+}
+
+hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
+  return hipGetLastError();
+}
+
+}  // namespace zkt
