@@ -273,6 +273,15 @@ int zkt_groth16_prove_r1cs(zkt_groth16_pk* pk, const uint64_t* wires, const uint
 /* the same with the wires already in HBM (device pointer) */
 int zkt_groth16_prove_r1cs_dev(zkt_groth16_pk* pk, const uint64_t* dev_wires, const uint64_t* r, const uint64_t* s,
                                zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* C);
+/* Multi-GPU form (BASELINE config 4): rank `shard` of `nshards` keeps a contiguous index range of each resident base set.  A proof is
+ * then zkt_groth16_prove_r1cs_partials on every rank (dev_partials: ZKT_GROTH16_PARTIAL_WORDS u32 = the Jacobian partials of A, B, C),
+ * an all_gather of those, and zkt_g1_jac_sum_dev / zkt_g2_jac_sum_dev / zkt_g1_jac_sum_dev over the gathered A, B, C columns
+ * (each made contiguous: count x PARTIAL_WORDS). */
+#define ZKT_GROTH16_PARTIAL_WORDS (2 * ZKT_G1_PARTIAL_WORDS + ZKT_G2_PARTIAL_WORDS)
+int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_sparse_rows* A, const zkt_sparse_rows* B, const zkt_sparse_rows* C,
+                                   const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma, const uint64_t* delta, const uint64_t* x,
+                                   size_t shard, size_t nshards, zkt_groth16_crs* vk, zkt_groth16_pk** out);
+int zkt_groth16_prove_r1cs_partials(zkt_groth16_pk* pk, const uint64_t* dev_wires, const uint64_t* r, const uint64_t* s, uint32_t* dev_partials);
 void zkt_groth16_pk_free(zkt_groth16_pk* pk);
 
 int zkt_g1_mul_batch_dev(const zkt_g1_affine* dev_points, const uint64_t* dev_scalars, int scalar_limbs,

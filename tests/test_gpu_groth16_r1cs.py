@@ -74,3 +74,39 @@ def test_r1cs_path_larger_sizes_verify(L, n):
     zk.check(L.zkt_groth16_prove_r1cs(pk, w2.ctypes.data, r.ctypes.data, s.ctypes.data, *[x.ctypes.data for x in gp]))
     assert L.zkt_groth16_verify(ctypes.byref(vk), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(stmt), l + 1) == 0
     L.zkt_groth16_pk_free(pk)
+
+
+def test_r1cs_sharded_proof_equals_unsharded(L):
+    """BASELINE config 4 on one card: three shards of the resident base sets, each produces its three Jacobian partials; summing
+    them (the all_gather + combine step of the multi-GPU run) gives the unsharded proof bit for bit."""
+    import torch
+    n, shards = 200, 3
+    mats, wires, l, m = chain_circuit_sparse(n, seed=5)
+    rng = SplitMix64(999)
+    trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+    r, s = fr(rng.below(R - 1) + 1), fr(rng.below(R - 1) + 1)
+    vk, vbuf, pk = _r1cs_setup(L, mats, n, l, m, trap)
+    want = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+    zk.check(L.zkt_groth16_prove_r1cs(pk, wires.ctypes.data, r.ctypes.data, s.ctypes.data, *[x.ctypes.data for x in want]))
+    L.zkt_groth16_pk_free(pk)
+    d_w = torch.from_numpy(wires.view(np.int64)).cuda()
+    parts = torch.zeros((shards, zk.GROTH16_PARTIAL_WORDS), dtype=torch.int32, device="cuda")
+    structs = [sparse_struct(*M) for M in mats]
+    for k in range(shards):
+        vk2, vbuf2 = alloc_crs(1, l, m); pk2 = ctypes.c_void_p()
+        zk.check(L.zkt_groth16_setup_r1cs_sharded(n, l, m, *[ctypes.addressof(x) for x in structs], *[t.ctypes.data for t in trap], k, shards,
+                                                   ctypes.addressof(vk2), ctypes.addressof(pk2)))
+        zk.check(L.zkt_groth16_prove_r1cs_partials(pk2, d_w.data_ptr(), r.ctypes.data, s.ctypes.data, parts[k].data_ptr()))
+        # a shard cannot produce affine points on its own
+        assert L.zkt_groth16_prove_r1cs_dev(pk2, d_w.data_ptr(), r.ctypes.data, s.ctypes.data, *[x.ctypes.data for x in want]) == ZKT_ERR_SHAPE
+        L.zkt_groth16_pk_free(pk2)
+    torch.cuda.synchronize()
+    a, b = zk.G1_PARTIAL_WORDS, zk.G1_PARTIAL_WORDS + zk.G2_PARTIAL_WORDS
+    got = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    pa, pb, pc = parts[:, :a].contiguous(), parts[:, a:b].contiguous(), parts[:, b:].contiguous()
+    zk.check(L.zkt_g1_jac_sum_dev(vp(pa), shards, None, ptr(got[0])))
+    zk.check(L.zkt_g2_jac_sum_dev(vp(pb), shards, None, ptr(got[1])))
+    zk.check(L.zkt_g1_jac_sum_dev(vp(pc), shards, None, ptr(got[2])))
+    for x, y, name in zip(want, got, "ABC"):
+        assert (x == y).all(), f"sharded proof element {name} differs"

@@ -13,7 +13,8 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "zkt.h")
 
 ZKT_OK, ZKT_ERR_INV_ZERO, ZKT_ERR_INFINITY, ZKT_ERR_SHAPE, ZKT_ERR_DEVICE = 0, 1, 2, 3, 4
 G1_WORDS64, G2_WORDS64, FQ12_WORDS64 = 13, 25, 72
-G1_PARTIAL_WORDS, G2_PARTIAL_WORDS, SECP_PARTIAL_WORDS = 42, 84, 24   # ZKT_*_PARTIAL_WORDS: u32 words of one opaque Jacobian partial
+G1_PARTIAL_WORDS, G2_PARTIAL_WORDS, SECP_PARTIAL_WORDS = 42, 84, 24
+GROTH16_PARTIAL_WORDS = 2 * G1_PARTIAL_WORDS + G2_PARTIAL_WORDS   # ZKT_*_PARTIAL_WORDS: u32 words of one opaque Jacobian partial
 
 _lib = None
 
@@ -54,6 +55,8 @@ def lib():
         L.zkt_groth16_setup_r1cs.argtypes = [ctypes.c_size_t] * 3 + [vp] * 10
         L.zkt_groth16_prove_r1cs.argtypes = [vp] * 7
         L.zkt_groth16_prove_r1cs_dev.argtypes = [vp] * 7
+        L.zkt_groth16_setup_r1cs_sharded.argtypes = [ctypes.c_size_t] * 3 + [vp] * 8 + [ctypes.c_size_t] * 2 + [vp] * 2
+        L.zkt_groth16_prove_r1cs_partials.argtypes = [vp] * 5
         L.zkt_groth16_pk_free.argtypes = [vp]; L.zkt_groth16_pk_free.restype = None
         sz = ctypes.c_size_t
         L.zkt_pairing_product_check_batch.argtypes = [vp, vp, vp, sz, sz, vp]

@@ -380,6 +380,8 @@ struct zkt_groth16_pk {
   DBuf cinv, P, ghat, tw, twinv;                  // Fr tables
   zkt_g1_bases *setA = nullptr, *setC = nullptr; zkt_g2_bases* setB = nullptr;   // the three resident base sets (see the file header)
   size_t nA = 0, nC = 0;
+  size_t loA = 0, hiA = 0, loC = 0, hiC = 0;     // this shard's index range of the A/B sets and of the C set (whole sets when unsharded)
+  size_t shard = 0, nshards = 1;
   DBuf wires_c, wires_m, z_m[3], f[3], sA, sB, sC, rs;   // per-proof work buffers
   hipStream_t s = nullptr;
   ~zkt_groth16_pk() {
@@ -393,10 +395,14 @@ extern void zkt_internal_set_error_index(size_t i);
 
 extern "C" {
 
-int zkt_groth16_setup_r1cs(size_t n, size_t l, size_t m, const zkt_sparse_rows* A, const zkt_sparse_rows* B, const zkt_sparse_rows* Cmat,
-                           const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma, const uint64_t* delta, const uint64_t* x,
-                           zkt_groth16_crs* vk, zkt_groth16_pk** out) {
+// Multi-GPU form (BASELINE config 4): rank `shard` of `nshards` keeps a contiguous index range of each of the three base
+// sets resident; the Fr stage of a proof is replicated (it is ~10 % of the work), the three MSMs run on the shard, and the only
+// exchange is an all_gather of the three Jacobian partials followed by zkt_g{1,2}_jac_sum_dev.
+int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_sparse_rows* A, const zkt_sparse_rows* B, const zkt_sparse_rows* Cmat,
+                                   const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma, const uint64_t* delta, const uint64_t* x,
+                                   size_t shard, size_t nshards, zkt_groth16_crs* vk, zkt_groth16_pk** out) {
   if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (nshards == 0 || shard >= nshards || nshards > n) return ZKT_ERR_SHAPE;
   if (!A || !B || !Cmat || !alpha || !beta || !gamma || !delta || !x || !vk || !out || n == 0 || l > m || n >= (1ull << 30)) return ZKT_ERR_SHAPE;
   if (!A->rowptr || !B->rowptr || !Cmat->rowptr) return ZKT_ERR_SHAPE;
   uint64_t trap[20]; memcpy(trap, alpha, 32); memcpy(trap + 4, beta, 32); memcpy(trap + 8, gamma, 32); memcpy(trap + 12, delta, 32); memcpy(trap + 16, x, 32);
@@ -453,7 +459,9 @@ int zkt_groth16_setup_r1cs(size_t n, size_t l, size_t m, const zkt_sparse_rows* 
 
   // ---- group side: fixed-base multiplications of the generators (crs.rs:85-135), written straight into the three base sets ----
   const size_t nw = m - l, nh = n >= 2 ? n - 1 : 0, nA = n + 2, nC = n + nw + nh + 3;
-  pk->nA = nA; pk->nC = nC;
+  pk->nA = nA; pk->nC = nC; pk->shard = shard; pk->nshards = nshards;
+  auto range = [&](size_t tot, size_t& lo, size_t& hi) { size_t base = tot / nshards, extra = tot % nshards; lo = shard * base + (shard < extra ? shard : extra); hi = lo + base + (shard < extra ? 1 : 0); };
+  range(nA, pk->loA, pk->hiA); range(nC, pk->loC, pk->hiC);
   DBuf gen1, gen2, pU, pA, pB, pC, small1, small2, gt;
   ZCHK(gen1.alloc(G1B)); ZCHK(gen2.alloc(G2B)); ZCHK(pU.alloc(rows * G1B)); ZCHK(pA.alloc(nA * G1B)); ZCHK(pB.alloc(nA * G2B)); ZCHK(pC.alloc(nC * G1B));
   ZCHK(small1.alloc(3 * G1B)); ZCHK(small2.alloc(3 * G2B)); ZCHK(gt.alloc(576));
@@ -480,9 +488,9 @@ int zkt_groth16_setup_r1cs(size_t n, size_t l, size_t m, const zkt_sparse_rows* 
   RCHK(hipMemcpyAsync(pC.w() + (n + nw + nh) * 26, small1.p, 3 * G1B, hipMemcpyDeviceToDevice, s));   // C tail: alpha, beta, delta
   RCHK(hipStreamSynchronize(s));
   pU.release();
-  ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)pA.p, nA, s, &pk->setA)); pA.release();
-  ZCHK(zkt_g2_bases_from_device((const zkt_g2_affine*)pB.p, nA, s, &pk->setB)); pB.release();
-  ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)pC.p, nC, s, &pk->setC)); pC.release();
+  ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)(pA.w() + pk->loA * 26), pk->hiA - pk->loA, s, &pk->setA)); pA.release();
+  ZCHK(zkt_g2_bases_from_device((const zkt_g2_affine*)(pB.w() + pk->loA * 50), pk->hiA - pk->loA, s, &pk->setB)); pB.release();
+  ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)(pC.w() + pk->loC * 26), pk->hiC - pk->loC, s, &pk->setC)); pC.release();
   RCHK(hipMemcpyAsync(derr.p, &noerr, 8, hipMemcpyHostToDevice, s));
   RCHK(launch_tate(small1.w(), small2.w(), gt.w(), 1, (unsigned long long*)derr.p, s));        // crs.rs:137-139
   RCHK(hipMemcpyAsync(vk->g1_alpha, small1.p, G1B, hipMemcpyDeviceToHost, s)); RCHK(hipMemcpyAsync(vk->g1_beta, small1.w() + 26, G1B, hipMemcpyDeviceToHost, s));
@@ -500,12 +508,19 @@ int zkt_groth16_setup_r1cs(size_t n, size_t l, size_t m, const zkt_sparse_rows* 
   return ZKT_OK;
 }
 
+int zkt_groth16_setup_r1cs(size_t n, size_t l, size_t m, const zkt_sparse_rows* A, const zkt_sparse_rows* B, const zkt_sparse_rows* Cmat,
+                           const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma, const uint64_t* delta, const uint64_t* x,
+                           zkt_groth16_crs* vk, zkt_groth16_pk** out) {
+  return zkt_groth16_setup_r1cs_sharded(n, l, m, A, B, Cmat, alpha, beta, gamma, delta, x, 0, 1, vk, out);
+}
 void zkt_groth16_pk_free(zkt_groth16_pk* pk) { delete pk; }
 
 // Prover::prove (prover.rs:96-147) with r, s injected; wires = a_0..a_m canonical, on the host or (…_dev) already in HBM.
-static int prove_impl(zkt_groth16_pk* pk, const uint64_t* wires, bool wires_on_device, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp) {
+static int prove_impl(zkt_groth16_pk* pk, const uint64_t* wires, bool wires_on_device, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp,
+                      uint32_t* dev_partials = nullptr) {
   if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
-  if (!pk || !wires || !r || !s_ || !A || !B || !Cp) return ZKT_ERR_SHAPE;
+  if (!pk || !wires || !r || !s_) return ZKT_ERR_SHAPE;
+  if (dev_partials ? false : (!A || !B || !Cp || pk->nshards != 1)) return ZKT_ERR_SHAPE;      // a shard can only produce partials
   const size_t n = pk->n, l = pk->l, m = pk->m, rows = m + 1, N = pk->N, nw = m - l;
   hipStream_t s = pk->s;
   uint64_t rs[8]; memcpy(rs, r, 32); memcpy(rs + 4, s_, 32);
@@ -518,8 +533,8 @@ static int prove_impl(zkt_groth16_pk* pk, const uint64_t* wires, bool wires_on_d
                      (const uint32_t*)pk->rs.w(), n, l, m, pk->sA.w(), pk->sB.w(), pk->sC.w());
   RCHK(hipGetLastError());
   // A and B only need (A w) and (B w): they start now and run under the quotient stage
-  ZCHK(zkt_g2_msm_submit(pk->setB, (const uint64_t*)pk->sB.p, pk->nA, s, 0));
-  ZCHK(zkt_g1_msm_submit(pk->setA, (const uint64_t*)pk->sA.p, pk->nA, s, 0));
+  ZCHK(zkt_g2_msm_submit(pk->setB, (const uint64_t*)(pk->sB.w() + pk->loA * FW), pk->hiA - pk->loA, s, 0));
+  ZCHK(zkt_g1_msm_submit(pk->setA, (const uint64_t*)(pk->sA.w() + pk->loA * FW), pk->hiA - pk->loA, s, 0));
   if (n >= 2) {
     for (int k = 0; k < 3; ++k) {
       hipLaunchKernelGGL(k_prep_f, dim3(nb(N)), dim3(256), 0, s, (const uint32_t*)pk->z_m[k].w(), (const uint32_t*)pk->cinv.w(), n, N, pk->f[k].w());
@@ -530,12 +545,22 @@ static int prove_impl(zkt_groth16_pk* pk, const uint64_t* wires, bool wires_on_d
                        pk->sC.w() + (n + nw) * FW);
     RCHK(hipGetLastError());
   }
-  ZCHK(zkt_g1_msm_submit(pk->setC, (const uint64_t*)pk->sC.p, pk->nC, s, 0));
+  ZCHK(zkt_g1_msm_submit(pk->setC, (const uint64_t*)(pk->sC.w() + pk->loC * FW), pk->hiC - pk->loC, s, 0));
+  if (dev_partials) {            // [A: ZKT_G1_PARTIAL_WORDS | B: ZKT_G2_PARTIAL_WORDS | C: ZKT_G1_PARTIAL_WORDS]
+    ZCHK(zkt_g1_msm_collect(pk->setA, 0, nullptr, dev_partials)); ZCHK(zkt_g2_msm_collect(pk->setB, 0, nullptr, dev_partials + ZKT_G1_PARTIAL_WORDS));
+    ZCHK(zkt_g1_msm_collect(pk->setC, 0, nullptr, dev_partials + ZKT_G1_PARTIAL_WORDS + ZKT_G2_PARTIAL_WORDS));
+    return ZKT_OK;
+  }
   ZCHK(zkt_g1_msm_collect(pk->setA, 0, A, nullptr)); ZCHK(zkt_g2_msm_collect(pk->setB, 0, B, nullptr)); ZCHK(zkt_g1_msm_collect(pk->setC, 0, Cp, nullptr));
   return ZKT_OK;
 }
 int zkt_groth16_prove_r1cs(zkt_groth16_pk* pk, const uint64_t* wires, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp) {
   return prove_impl(pk, wires, false, r, s_, A, B, Cp);
+}
+// one shard's share of a proof: the three un-normalised Jacobian partial sums, on the device
+int zkt_groth16_prove_r1cs_partials(zkt_groth16_pk* pk, const uint64_t* dev_wires, const uint64_t* r, const uint64_t* s_, uint32_t* dev_partials) {
+  if (!dev_partials) return ZKT_ERR_SHAPE;
+  return prove_impl(pk, dev_wires, true, r, s_, nullptr, nullptr, nullptr, dev_partials);
 }
 int zkt_groth16_prove_r1cs_dev(zkt_groth16_pk* pk, const uint64_t* dev_wires, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp) {
   return prove_impl(pk, dev_wires, true, r, s_, A, B, Cp);
