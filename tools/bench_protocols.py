@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Throughput of the protocol-level entry points on one MI355X, host-pointer API (PCIe included).
+Prints one JSON object; kept as profiles/r01_protocols.json."""
+import ctypes, importlib, json, os, sys, time
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from zkt_testlib import *
+from qap_util import *
+zk = importlib.import_module("zk-toolkit_amd"); zk.init(); L = zk.lib()
+fr = lambda v: ints_to_arr([v], 4)
+res = {}
+
+
+def g1_gen():
+    g = np.zeros((1, G1W), np.uint64); g[0, :6] = int_to_limbs(G1_GEN[0], 6); g[0, 6:12] = int_to_limbs(G1_GEN[1], 6); return g
+
+
+# ---- BLS signature verification (signature.rs:34-39), 2^16 signatures, 32-byte messages -------------------------------------
+n = 1 << 16
+rng = np.random.Generator(np.random.PCG64(5))
+msgs = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+off = (np.arange(n + 1, dtype=np.uint64) * 32)
+sks = rand_scalars(9, n)
+pks = np.zeros((n, G1W), np.uint64); zk.check(L.zkt_g1_mul_batch(ptr(np.repeat(g1_gen(), n, axis=0)), ptr(sks), 4, ptr(pks), n))
+sigs = np.zeros((n, G2W), np.uint64)
+t0 = time.perf_counter(); zk.check(L.zkt_bls_sign_batch(msgs.ctypes.data, off.ctypes.data, ptr(sks), n, ptr(sigs))); t_sign = time.perf_counter() - t0
+ok = np.zeros(n, np.uint32)
+zk.check(L.zkt_bls_verify_batch(msgs.ctypes.data, off.ctypes.data, ptr(sigs), ptr(pks), n, ok.ctypes.data))
+t0 = time.perf_counter(); zk.check(L.zkt_bls_verify_batch(msgs.ctypes.data, off.ctypes.data, ptr(sigs), ptr(pks), n, ok.ctypes.data)); t_ver = time.perf_counter() - t0
+assert ok.all()
+res["bls"] = {"signatures": n, "sign_per_s": n / t_sign, "verify_per_s": n / t_ver, "all_valid": True}
+
+# ---- Groth16 batch verification (f-2): 2^16 proofs of the reference's example circuit against one CRS ----------------------------
+A_, B_, C_, wit, l = example_cubic()
+nn, m = len(A_), len(wit) - 1
+ui, vi, wi, h, _ = qap_from_r1cs(A_, B_, C_, wit)
+U, V, W = dense(ui, nn), dense(vi, nn), dense(wi, nn)
+sm = SplitMix64(71); trap = [fr(sm.below(R - 1) + 1) for _ in range(5)]
+crs, buf = alloc_crs(nn, l, m)
+zk.check(L.zkt_groth16_setup(ctypes.byref(crs), ptr(U), ptr(V), ptr(W), *[ptr(t) for t in trap]))
+wires = ints_to_arr(wit, 4); H = ints_to_arr(h, 4)
+pa, pb, pc = np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64)
+zk.check(L.zkt_groth16_prove(ctypes.byref(crs), ptr(U), ptr(V), ptr(wires), ptr(H), len(h), ptr(fr(12345)), ptr(fr(6789)), ptr(pa), ptr(pb), ptr(pc)))
+k = 1 << 16
+As, Bs, Cs = np.repeat(pa, k, axis=0), np.repeat(pb, k, axis=0), np.repeat(pc, k, axis=0)
+stmts = np.repeat(ints_to_arr(wit[:l + 1], 4).reshape(1, -1), k, axis=0).copy()
+okv = np.zeros(k, np.uint32)
+zk.check(L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(stmts), l + 1, k, okv.ctypes.data))
+t0 = time.perf_counter(); zk.check(L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(stmts), l + 1, k, okv.ctypes.data)); t_v = time.perf_counter() - t0
+assert okv.all()
+res["groth16_verify_batch"] = {"proofs": k, "statement_wires": l + 1, "verifications_per_s": k / t_v}
+
+# ---- Bulletproofs inner-product argument, n = 64*1024 generators, 16 levels (BASELINE config 5 shape) ---------------------------
+n = 1 << 16
+sm = SplitMix64(77)
+O_g = np.zeros((1, 9), np.uint64)
+SG = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798, 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)      # secp256k1/affine_point.rs:40-47
+O_g[0, :4] = int_to_limbs(SG[0], 4); O_g[0, 4:8] = int_to_limbs(SG[1], 4)
+ks = rand_scalars(11, 2 * n + 1, SECP_N)
+pts = np.zeros((2 * n + 1, 9), np.uint64)
+zk.check(L.zkt_secp_mul_batch(ptr(np.repeat(O_g, 2 * n + 1, axis=0)), ptr(ks), 4, ptr(pts), 2 * n + 1))
+gg, hh, u = pts[:n].copy(), pts[n:2 * n].copy(), pts[2 * n:].copy()
+a, b = rand_scalars(12, n, SECP_N), rand_scalars(13, n, SECP_N)
+c = sum(limbs_to_int(x) * limbs_to_int(y) for x, y in zip(a, b)) % SECP_N
+P = np.zeros((1, 9), np.uint64)
+zk.check(L.zkt_secp_msm(ptr(np.concatenate([gg, hh, u])), ptr(np.concatenate([a, b, ints_to_arr([c], 4)])), 2 * n + 1, ptr(P)))
+xs = rand_scalars(14, 16, SECP_N); xs[:, 0] |= np.uint64(1)
+assert L.zkt_bp_inner_product_argument(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b), ptr(xs), None) == 1
+t0 = time.perf_counter(); r = L.zkt_bp_inner_product_argument(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b), ptr(xs), None); t_ipa = time.perf_counter() - t0
+assert r == 1
+res["bulletproofs_ipa"] = {"generators": n, "levels": 16, "seconds": t_ipa, "accepts": True}
+
+# ---- Pinocchio (f-4): chain circuit with 32 constraints ---------------------------------------------------------------------
+A_, B_, C_, wit, l = chain_circuit(32)
+nn, n_io = len(A_), l + 1
+Vp, Wp, Yp, hq, max_degree = pinocchio_instance(A_, B_, C_, wit)
+sm = SplitMix64(5)
+rnd = ints_to_arr([sm.below(R - 1) + 1 for _ in range(8)], 4)
+crs, cbuf = alloc_pinocchio(nn, n_io, len(wit) - n_io, max_degree)
+t0 = time.perf_counter(); zk.check(L.zkt_pinocchio_setup(ctypes.byref(crs), ptr(Vp), ptr(Wp), ptr(Yp), ptr(rnd))); t_s = time.perf_counter() - t0
+pf, pbuf = alloc_pinocchio_proof()
+wires, Hq = ints_to_arr(wit, 4), ints_to_arr(hq, 4)
+t0 = time.perf_counter(); zk.check(L.zkt_pinocchio_prove(ctypes.byref(crs), ptr(wires), ptr(Hq), len(hq), ptr(fr(777)), ptr(fr(888)), ctypes.byref(pf))); t_p = time.perf_counter() - t0
+t0 = time.perf_counter(); okp = L.zkt_pinocchio_verify(ctypes.byref(crs), ctypes.byref(pf), ptr(wires[:n_io].copy())); t_v = time.perf_counter() - t0
+assert okp == 1
+res["pinocchio"] = {"constraints": nn, "setup_s": t_s, "prove_s": t_p, "verify_s": t_v, "accepts": True,
+                    "note": "host-pointer MSM entry points (window tables rebuilt per call); latency of a single small proof, not a throughput figure"}
+print(json.dumps(res, indent=1))
