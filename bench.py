@@ -289,7 +289,7 @@ def main():
             from zkt_testlib import oracle, ptr
             O = oracle()
             cores = min(os.cpu_count() or 1, 16)      # the GPU box's CPU share for one GPU is 16 cores
-            m = 128 * cores
+            m = 2048 * cores                           # ~10 s of CPU work on 16 threads
             pts = d_bases[:m].cpu().numpy().view(np.uint64).copy(); sc = h_scalars[:m].copy()
             tmp = np.zeros_like(pts); acc = np.zeros((1, 13), dtype=np.uint64); acc[0, 12] = 1
             t0 = time.perf_counter()
@@ -299,6 +299,17 @@ def main():
             dt = time.perf_counter() - t0
             result["cpu_baseline"] = {"value": m / dt, "unit": "scalar-muls/s", "cores": cores, "kind": "port",
                                       "sample": "%d-term MSM by the oracle's reference algorithm (per-term double-and-add on %d threads + sequential affine adds), %.1f s" % (m, cores, dt)}
+            if "pairing" in result:                    # the reference's tate(): textbook Miller loop + 4314-bit exponentiation, eight pairings per thread
+                mp = 8 * cores
+                pp = d_bases[:mp].cpu().numpy().view(np.uint64).copy(); qq = d_q[:mp].cpu().numpy().view(np.uint64).copy()
+                oo = np.zeros((mp, 72), dtype=np.uint64); idx = ctypes.c_size_t(0)
+                t0 = time.perf_counter()
+                assert O.zkto_pairing_batch(3, ptr(pp), ptr(qq), ptr(oo), mp, cores, ctypes.byref(idx)) == 0
+                dtp = time.perf_counter() - t0
+                same = bool((oo == d_e[:mp].cpu().numpy().view(np.uint64)).all())
+                result["pairing"]["cpu_baseline"] = {"value": mp / dtp, "unit": "pairings/s", "cores": cores, "kind": "port",
+                                                     "sample": "%d Tate pairings by the oracle's reference algorithm on %d threads, %.1f s" % (mp, cores, dtp),
+                                                     "matches_gpu_bits": same}
         print(json.dumps(result))
     L.zkt_g1_bases_free(h)
     if world > 1:
