@@ -220,3 +220,28 @@ def test_sharded_msm_partials_combine(L, name, W, order, gen_fn, pw):
     want = np.zeros((1, W), np.uint64)
     assert getattr(O, f"zkto_{name}_mul_batch")(ptr(g), ptr(ints_to_arr([tot], 4)), 4, ptr(want), 1, 1) == 0
     assert (got == want).all()
+
+
+@pytest.mark.parametrize("name,W,order,gen_fn", [("g1", G1W, R, "zkto_g1_generator"), ("g2", G2W, R, "zkto_g2_generator"), ("secp", 9, SECP_N, "zkto_secp_generator")])
+def test_msm_adversarial_pool(L, name, W, order, gen_fn):
+    """Bases drawn from a tiny pool {P1..P3, -P1, -P2, infinity} with scalars from {0, 1, 2, order-1, a few random values}: almost every
+    bucket then sees equal points (the doubling branch of the mixed add, macros.rs:57-108), opposite points (P + (-P) = infinity,
+    macros.rs:53-56) and infinity operands, in the accumulate, merge and reduce kernels alike.  Checked against the oracle's sequential sum."""
+    n = 600
+    rng = SplitMix64(4100)
+    g = np.zeros((1, W), np.uint64); getattr(O, gen_fn)(ptr(g))
+    pool = np.zeros((6, W), np.uint64)
+    assert getattr(O, f"zkto_{name}_mul_batch")(ptr(np.repeat(g, 3, axis=0)), ptr(ints_to_arr([rng.below(order - 1) + 1 for _ in range(3)], 4)), 4, ptr(pool[:3]), 3, 3) == 0
+    assert getattr(O, f"zkto_{name}_mul_batch")(ptr(pool[:2].copy()), ptr(ints_to_arr([order - 1] * 2, 4)), 4, ptr(pool[3:5]), 2, 2) == 0     # -P = (order-1) P
+    pool[5] = 0; pool[5, W - 1] = 1
+    few = [rng.below(order) for _ in range(3)]
+    choices = [0, 1, 2, order - 1, 1, 2] + few
+    bases = np.stack([pool[rng.below(6)] for _ in range(n)])
+    ss = [choices[rng.below(len(choices))] for _ in range(n)]
+    sc = ints_to_arr(ss, 4)
+    got = np.zeros((1, W), np.uint64); zk.check(getattr(L, f"zkt_{name}_msm")(ptr(bases), ptr(sc), n, ptr(got)))
+    tmp = np.zeros_like(bases); assert getattr(O, f"zkto_{name}_mul_batch")(ptr(bases), ptr(sc), 4, ptr(tmp), n, 8) == 0
+    acc = np.zeros((1, W), np.uint64); acc[0, W - 1] = 1
+    for i in range(n):
+        nxt = np.zeros_like(acc); assert getattr(O, f"zkto_{name}_add_batch")(ptr(acc), ptr(tmp[i:i + 1].copy()), ptr(nxt), 1) == 0; acc = nxt
+    assert (got == acc).all()
