@@ -40,3 +40,11 @@ def test_gt_eq_is_plain_memory_equality():
     assert L.zkt_gt_eq(ptr(a), ptr(b)) == 1
     b[5] ^= 1
     assert L.zkt_gt_eq(ptr(a), ptr(b)) == 0
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/zkt.h is the drop-in boundary a cgo / Rust-FFI binding consumes: it must compile as C (no C++, no torch types),
+    and so must the plain-C consumer that the GPU suite runs (tests/c/abi_consumer.c)."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "c", "abi_consumer.c")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", src])

@@ -288,3 +288,14 @@ def test_g1_msm_skewed_scalars(L, kind):
     else:
         want = _msm_oracle(bases, sc, n)
     assert (got == want).all(), kind
+
+
+def test_plain_c_consumer_of_the_abi(L, tmp_path):
+    """tests/c/abi_consumer.c: a C99 program linked against libzkt_hip.so only — no Python or torch in the calling process."""
+    import subprocess
+    exe = str(tmp_path / "abi_consumer")
+    libdir = os.path.join(ROOT, "zk-toolkit_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "abi_consumer.c"),
+                           "-L", libdir, "-lzkt_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "abi_consumer ok" in out.stdout, out.stdout + out.stderr
