@@ -41,8 +41,8 @@ struct Fq2Ops {
   ZKT_HD static E mul(const E& a, const E& b) { return fq2_mul(a, b); }
   ZKT_HD static E sqr(const E& a) { return fq2_sqr(a); }
   ZKT_HD static E dbl(const E& a) { return fq2_dbl(a); }
-  ZKT_HD static E sub2(const E& a, const E& b, const E& c) { return Fq2{fp_sub2(a.c0, b.c0, c.c0), fp_sub2(a.c1, b.c1, c.c1)}; }
-  ZKT_HD static E mulsub(const E& a, const E& b, const E& c, const E& d) { return fq2_sub(fq2_mul(a, b), fq2_mul(c, d)); }
+  ZKT_HD static E sub2(const E& a, const E& b, const E& c) { return fq2_sub2(a, b, c); }
+  ZKT_HD static E mulsub(const E& a, const E& b, const E& c, const E& d) { return fq2_mulsub(a, b, c, d); }
   ZKT_HD static E neg(const E& a) { return fq2_neg(a); }
   ZKT_HD static E inv(const E& a) { return fq2_inv(a); }
   ZKT_HD static bool is_zero(const E& a) { return fq2_is_zero(a); }

@@ -24,12 +24,7 @@
 
 namespace zkt {
 
-ZKT_HD Fq2 xi_inv_const() {
-  Fq2 g;
-#pragma unroll
-  for (int i = 0; i < FqC::N; ++i) { g.c0.v[i] = xi_inv_limb(0, i); g.c1.v[i] = xi_inv_limb(1, i); }
-  return g;
-}
+ZKT_HD Fq2 xi_inv_const() { return fq2_const([](int i) { return xi_inv_limb(0, i); }, [](int i) { return xi_inv_limb(1, i); }); }
 
 // One Miller step on the G1 side as its own function: its Fq temporaries live in a transient frame instead of the
 // Miller loop's, which must stay small (<4 KB per lane keeps the whole grid's Fq12 working set inside the 256 MB MALL).
@@ -177,7 +172,6 @@ ZKT_HD bool miller_bit(int i) {
   for (int j = 0; j < 8; ++j) w = (j == (i >> 5)) ? miller_bits_word(j) : w;
   return (w >> (i & 31)) & 1;
 }
-ZKT_HD Fq2 fq2_from_fq(const Fq& a) { return Fq2{a, fp_zero<FqC>()}; }
 
 // calc_g1_g2(P, Q): Miller loop on P in G1 (Fq Jacobian), evaluated at the untwisted Q
 ZKT_FN Fq12 miller_g1_g2_exact(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq) {

@@ -20,6 +20,7 @@ namespace zkt {
 #else
 #define ZKT_FQ2 ZKT_HD
 #endif
+#if !defined(ZKT_FQ2_SPLIT)
 struct Fq2 { Fq c0, c1; };
 struct Fq6 { Fq2 c0, c1, c2; };
 struct Fq12 { Fq6 c0, c1; };
@@ -45,11 +46,90 @@ ZKT_FQ2 Fq2 fq2_sqr(const Fq2& a) {                                      // fq2.
   return Fq2{fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_dbl(t)};
 }
 ZKT_HD Fq2 fq2_mul_fq(const Fq2& a, const Fq& s) { return Fq2{fp_mul(a.c0, s), fp_mul(a.c1, s)}; }
+ZKT_HD Fq2 fq2_sub2(const Fq2& a, const Fq2& b, const Fq2& c) { return Fq2{fp_sub2(a.c0, b.c0, c.c0), fp_sub2(a.c1, b.c1, c.c1)}; }   // a - b - 2c
+ZKT_HD Fq2 fq2_mulsub(const Fq2& a, const Fq2& b, const Fq2& c, const Fq2& d) { return fq2_sub(fq2_mul(a, b), fq2_mul(c, d)); }          // a b - c d
+ZKT_HD Fq2 fq2_from_fq(const Fq& a) { return Fq2{a, fp_zero<FqC>()}; }
+// an Fq2 constant from its two limb tables
+template <class F0, class F1> ZKT_HD Fq2 fq2_const(F0 c0_limb, F1 c1_limb) {
+  Fq2 g;
+#pragma unroll
+  for (int i = 0; i < FqC::N; ++i) { g.c0.v[i] = c0_limb(i); g.c1.v[i] = c1_limb(i); }
+  return g;
+}
 ZKT_HD Fq2 fq2_mul_xi(const Fq2& a) { return Fq2{fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1)}; }   // Fq2::reduce, fq2.rs:52-58
 ZKT_FN Fq2 fq2_inv(const Fq2& a) {                                      // fq2.rs:26-32
   Fq t = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
   return Fq2{fp_mul(a.c0, t), fp_neg(fp_mul(a.c1, t))};
 }
+
+#else
+// ---- Fq2 spread over a pair of adjacent lanes (device only; used by the G2 bucket accumulation, zkt_msm_g2pair.hip) -------------
+// The even lane of a pair holds c0, the odd lane c1 of every Fq2 value; code written against the fq2_* functions does not change.
+// Additions are lane-local; a product exchanges the operands with the partner lane (DPP quad_perm [1,0,3,2], one v_mov_dpp per limb)
+// and is ONE two-product multiply per lane — even: a0 b0 - a1 b1, odd: a1 b0 + a0 b1.  Per-lane state halves (no spilling in the
+// G2 bucket accumulation); the multiply count per Fq2 product is the same as on one lane.
+struct Fq2 { Fq h; };
+struct Fq6 { Fq2 c0, c1, c2; };
+struct Fq12 { Fq6 c0, c1; };
+__device__ inline bool fq2_odd() { return threadIdx.x & 1; }
+__device__ inline Fq fq_partner(const Fq& a) { Fq r;
+#pragma unroll
+  for (int i = 0; i < FqC::N; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], 0xB1, 0xF, 0xF, true);
+  return r; }
+__device__ inline Fq fq_sel(bool c, const Fq& a, const Fq& b) { Fq r;      // c ? a : b
+#pragma unroll
+  for (int i = 0; i < FqC::N; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+  return r; }
+__device__ inline Fq2 fq2_zero() { return Fq2{fp_zero<FqC>()}; }
+__device__ inline Fq2 fq2_one() { return Fq2{fq_sel(fq2_odd(), fp_zero<FqC>(), fp_one<FqC>())}; }
+__device__ inline bool fq2_is_zero(const Fq2& a) { int z = fp_is_zero(a.h); return z && __builtin_amdgcn_mov_dpp(z, 0xB1, 0xF, 0xF, true); }
+__device__ inline Fq2 fq2_add(const Fq2& a, const Fq2& b) { return Fq2{fp_add(a.h, b.h)}; }
+__device__ inline Fq2 fq2_sub(const Fq2& a, const Fq2& b) { return Fq2{fp_sub(a.h, b.h)}; }
+__device__ inline bool fq2_eq(const Fq2& a, const Fq2& b) { return fq2_is_zero(fq2_sub(a, b)); }
+__device__ inline Fq2 fq2_neg(const Fq2& a) { return Fq2{fp_neg(a.h)}; }
+__device__ inline Fq2 fq2_dbl(const Fq2& a) { return Fq2{fp_dbl(a.h)}; }
+__device__ inline Fq2 fq2_sub2(const Fq2& a, const Fq2& b, const Fq2& c) { return Fq2{fp_sub2(a.h, b.h, c.h)}; }
+__device__ inline Fq2 fq2_conj(const Fq2& a) { return Fq2{fq_sel(fq2_odd(), fp_neg(a.h), a.h)}; }
+__device__ inline Fq2 fq2_from_fq(const Fq& a) { return Fq2{fq_sel(fq2_odd(), fp_zero<FqC>(), a)}; }
+template <class F0, class F1> __device__ inline Fq2 fq2_const(F0 c0_limb, F1 c1_limb) {
+  Fq2 g; const bool odd = fq2_odd();
+#pragma unroll
+  for (int i = 0; i < FqC::N; ++i) g.h.v[i] = odd ? c1_limb(i) : c0_limb(i);
+  return g;
+}
+// even: a0 b0 + a1 (8p - b1)      odd: a1 b0 + a0 b1      (own half = a.h, oa = the partner's)
+__device__ inline Fq2 fq2_mul(const Fq2& a, const Fq2& b) {
+  const bool odd = fq2_odd();
+  const Fq oa = fq_partner(a.h), ob = fq_partner(b.h);
+  Fq y1, nd;
+#pragma unroll
+  for (int i = 0; i < FqC::N; ++i) { y1.v[i] = odd ? ob.v[i] : b.h.v[i]; nd.v[i] = odd ? b.h.v[i] : FqC::subk(i) - ob.v[i]; }
+  return Fq2{fp_muladd(a.h, y1, oa, nd)};                 // nd may carry 30-bit limbs: the second factor of fp_mul2 need not be normalised
+}
+__device__ inline Fq2 fq2_mulsub(const Fq2& a, const Fq2& b, const Fq2& c, const Fq2& d) { return fq2_sub(fq2_mul(a, b), fq2_mul(c, d)); }
+// even: (a0 + a1)(a0 - a1)        odd: (a1 + a1) a0
+__device__ inline Fq2 fq2_sqr(const Fq2& a) {
+  const bool odd = fq2_odd();
+  const Fq oa = fq_partner(a.h);
+  return Fq2{fp_mul(fp_add(a.h, fq_sel(odd, a.h, oa)), fq_sel(odd, oa, fp_sub(a.h, oa)))};
+}
+__device__ inline Fq2 fq2_mul_fq(const Fq2& a, const Fq& s) { return Fq2{fp_mul(a.h, s)}; }
+// (c0 - c1, c0 + c1): even a0 - a1, odd a1 + a0 — one reduction pass either way
+__device__ inline Fq2 fq2_mul_xi(const Fq2& a) {
+  const bool odd = fq2_odd();
+  const Fq oa = fq_partner(a.h);
+  uint32_t v[FqC::N];
+#pragma unroll
+  for (int i = 0; i < FqC::N; ++i) v[i] = a.h.v[i] + (odd ? oa.v[i] : FqC::subk(i) - oa.v[i]);
+  return Fq2{fp_lazy_reduce<FqC>(v)};
+}
+__device__ inline __attribute__((noinline)) Fq2 fq2_inv(const Fq2& a) {   // fq2.rs:26-32: conj / norm; both lanes invert the same norm
+  const Fq sq = fp_sqr(a.h);
+  const Fq t = fp_inv(fp_add(sq, fq_partner(sq)));
+  const Fq m = fp_mul(a.h, t);
+  return Fq2{fq_sel(fq2_odd(), fp_neg(m), m)};
+}
+#endif
 
 // ---- Fq6 --------------------------------------------------------------------
 ZKT_HD Fq6 fq6_zero() { return Fq6{fq2_zero(), fq2_zero(), fq2_zero()}; }
@@ -131,18 +211,17 @@ ZKT_FN Fq12 fq12_cyclotomic_sqr(const Fq12& f) {
 
 // Frobenius pi^K, K in {1,2}: conj^K on every Fq2 coefficient of w^i times gamma_i^(K)
 template <int K> ZKT_HD Fq2 frob_const(int idx) {
-  Fq2 g;
-#pragma unroll
-  for (int i = 0; i < FqC::N; ++i) {
-    g.c0.v[i] = K == 1 ? frob1_limb(idx, 0, i) : frob2_limb(idx, 0, i);
-    g.c1.v[i] = K == 1 ? frob1_limb(idx, 1, i) : frob2_limb(idx, 1, i);
-  }
-  return g;
+  return fq2_const([&](int i) { return K == 1 ? frob1_limb(idx, 0, i) : frob2_limb(idx, 0, i); },
+                   [&](int i) { return K == 1 ? frob1_limb(idx, 1, i) : frob2_limb(idx, 1, i); });
 }
+ZKT_HD Fq frob2_fq(int idx) { Fq g;      // gamma^(2) lies in Fq
+#pragma unroll
+  for (int i = 0; i < FqC::N; ++i) g.v[i] = frob2_limb(idx, 0, i);
+  return g; }
 template <int K> ZKT_HD Fq2 frob_coeff(const Fq2& a, int idx) {
   Fq2 c = (K & 1) ? fq2_conj(a) : a;
   if (idx == 0) return c;
-  if (K == 2) return fq2_mul_fq(c, frob_const<2>(idx).c0);   // gamma^(2) lies in Fq
+  if (K == 2) return fq2_mul_fq(c, frob2_fq(idx));
   return fq2_mul(c, frob_const<1>(idx));
 }
 template <int K> ZKT_FN Fq12 fq12_frob(const Fq12& a) {

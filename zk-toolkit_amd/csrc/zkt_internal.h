@@ -55,3 +55,7 @@ hipError_t launch_msm_reduce(const MsmPlan& plan, void* workspace, uint32_t* dev
 hipError_t launch_msm_jac_sum_to_affine(int grp, const uint32_t* jac_partials, size_t count, uint32_t* out_abi_pt, hipStream_t s);
 
 }  // namespace zkt
+
+// G2 bucket accumulation with two lanes per task (zkt_msm_g2pair.hip, a translation unit with its own namespace): global scope
+hipError_t zkt_launch_accumulate_g2_pair(const uint32_t* table, const uint32_t* entries, const uint32_t* offsets, const void* order, const uint32_t* task_off,
+                                         size_t nbuckets, uint32_t chunk, uint32_t* sums, uint32_t* partial, size_t max_tasks, hipStream_t s);

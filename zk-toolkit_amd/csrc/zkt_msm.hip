@@ -501,6 +501,11 @@ hipError_t PART(launch_msm_sort)(const MsmPlan& P, const uint8_t* inf, const uin
 // stage 2 (VALU bound, the dominant kernel): one bucket per lane
 hipError_t PART(launch_msm_accumulate)(const MsmPlan& P, const uint32_t* table, void* workspace, hipStream_t s) {
   MsmWs w = carve(P, workspace);
+#if defined(ZKT_MSM_PART_OTHER) && !defined(ZKT_G2_ONE_LANE)
+  if (P.grp == G_G2)        // two lanes per task: zkt_msm_g2pair.hip
+    return ::zkt_launch_accumulate_g2_pair(table, (const uint32_t*)w.entries, (const uint32_t*)w.offsets, (const void*)w.order, (const uint32_t*)w.task_off, P.nbuckets, CHUNK,
+                                           w.sums, w.partial, w.max_tasks, s);
+#endif
   MSM_DISPATCH(P.grp, hipLaunchKernelGGL(k_accumulate<F>, dim3((unsigned)((w.max_tasks + 63) / 64)), dim3(64), 0, s, table, (const uint32_t*)w.entries,
                                          (const uint32_t*)w.offsets, (const uint2*)w.order, (const uint32_t*)w.task_off, P.nbuckets, w.sums, w.partial));
   return hipGetLastError();
