@@ -7,7 +7,10 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from zkt_testlib import *
 from qap_util import *
+from concurrent.futures import ThreadPoolExecutor
 zk = importlib.import_module("zk-toolkit_amd"); zk.init(); L = zk.lib()
+O = oracle()                      # CPU baselines only: the oracle restates the reference algorithm (checker / baseline, never the product path)
+CORES = min(os.cpu_count() or 1, 16)
 fr = lambda v: ints_to_arr([v], 4)
 res = {}
 
@@ -29,7 +32,20 @@ ok = np.zeros(n, np.uint32)
 zk.check(L.zkt_bls_verify_batch(msgs.ctypes.data, off.ctypes.data, ptr(sigs), ptr(pks), n, ok.ctypes.data))
 t0 = time.perf_counter(); zk.check(L.zkt_bls_verify_batch(msgs.ctypes.data, off.ctypes.data, ptr(sigs), ptr(pks), n, ok.ctypes.data)); t_ver = time.perf_counter() - t0
 assert ok.all()
-res["bls"] = {"signatures": n, "sign_per_s": n / t_sign, "verify_per_s": n / t_ver, "all_valid": True}
+# CPU baseline: signature.rs:34-39 is two tate() calls (+ one G2 scalar multiplication for the hash); 2*CORES pairings on CORES threads
+mc = CORES
+g1r = np.repeat(g1_gen(), mc, axis=0)
+Hc = np.zeros((mc, G2W), np.uint64)
+g2g = np.zeros((1, G2W), np.uint64); O.zkto_g2_generator(ptr(g2g))
+t0 = time.perf_counter()
+assert O.zkto_g2_mul_batch(ptr(np.repeat(g2g, mc, axis=0)), ptr(ints_to_arr([int.from_bytes(bytes(m_), "big") % R for m_ in msgs[:mc]], 4)), 4, ptr(Hc), mc, CORES) == 0
+e1, e2 = np.zeros((mc, FQ12), np.uint64), np.zeros((mc, FQ12), np.uint64)
+assert O.zkto_pairing_batch(3, ptr(g1r), ptr(sigs[:mc].copy()), ptr(e1), mc, CORES, None) == 0
+assert O.zkto_pairing_batch(3, ptr(pks[:mc].copy()), ptr(Hc), ptr(e2), mc, CORES, None) == 0
+t_cpu = time.perf_counter() - t0
+assert (e1 == e2).all()
+res["bls"] = {"signatures": n, "sign_per_s": n / t_sign, "verify_per_s": n / t_ver, "all_valid": True,
+              "cpu_baseline": {"verify_per_s": mc / t_cpu, "cores": CORES, "kind": "port", "sample": "%d verifications by the oracle's reference algorithm, %.1f s" % (mc, t_cpu)}}
 
 # ---- Groth16 batch verification (f-2): 2^16 proofs of the reference's example circuit against one CRS ----------------------------
 A_, B_, C_, wit, l = example_cubic()
@@ -49,7 +65,18 @@ okv = np.zeros(k, np.uint32)
 zk.check(L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(stmts), l + 1, k, okv.ctypes.data))
 t0 = time.perf_counter(); zk.check(L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(stmts), l + 1, k, okv.ctypes.data)); t_v = time.perf_counter() - t0
 assert okv.all()
-res["groth16_verify_batch"] = {"proofs": k, "statement_wires": l + 1, "verifications_per_s": k / t_v}
+ocrs = Crs(n=nn, l=l, m=m)
+for kf in buf: setattr(ocrs, kf, ptr(buf[kf]))
+stmt1 = ints_to_arr(wit[:l + 1], 4)
+def _one(_):
+    return O.zkto_groth16_verify(ctypes.byref(ocrs), ptr(pa), ptr(pb), ptr(pc), ptr(stmt1), l + 1)
+t0 = time.perf_counter()
+with ThreadPoolExecutor(CORES) as ex: outs = list(ex.map(_one, range(CORES)))
+t_cpu = time.perf_counter() - t0
+assert all(o == 1 for o in outs)
+res["groth16_verify_batch"] = {"proofs": k, "statement_wires": l + 1, "verifications_per_s": k / t_v,
+                               "cpu_baseline": {"verifications_per_s": CORES / t_cpu, "cores": CORES, "kind": "port",
+                                                "sample": "%d verifications (3 tate() each, verifier.rs:30-54) by the oracle, one per thread, %.1f s" % (CORES, t_cpu)}}
 
 # ---- Bulletproofs inner-product argument, n = 64*1024 generators, 16 levels (BASELINE config 5 shape) ---------------------------
 n = 1 << 16
@@ -69,7 +96,15 @@ xs = rand_scalars(14, 16, SECP_N); xs[:, 0] |= np.uint64(1)
 assert L.zkt_bp_inner_product_argument(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b), ptr(xs), None) == 1
 t0 = time.perf_counter(); r = L.zkt_bp_inner_product_argument(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b), ptr(xs), None); t_ipa = time.perf_counter() - t0
 assert r == 1
-res["bulletproofs_ipa"] = {"generators": n, "levels": 16, "seconds": t_ipa, "accepts": True}
+nc = 256                           # CPU baseline at 256 generators (8 levels); the reference's cost is linear in the number of generators
+ot = np.zeros((8 * 3, 9), np.uint64)
+Pc = np.zeros((1, 9), np.uint64); assert O.zkto_bp_commit(nc, ptr(gg[:nc].copy()), ptr(hh[:nc].copy()), ptr(u), ptr(a[:nc].copy()), ptr(b[:nc].copy()), ptr(Pc)) == 0
+t0 = time.perf_counter()
+assert O.zkto_bp_ipa(nc, ptr(gg[:nc].copy()), ptr(hh[:nc].copy()), ptr(u), ptr(Pc), ptr(a[:nc].copy()), ptr(b[:nc].copy()), ptr(xs[:8].copy()), ptr(ot)) == 1
+t_cpu = time.perf_counter() - t0
+res["bulletproofs_ipa"] = {"generators": n, "levels": 16, "seconds": t_ipa, "accepts": True,
+                           "cpu_baseline": {"generators": nc, "seconds": t_cpu, "cores": 1, "kind": "port",
+                                            "sample": "oracle's reference algorithm at %d generators; x%d for %d generators = %.0f s" % (nc, n // nc, n, t_cpu * n / nc)}}
 
 # ---- Pinocchio (f-4): chain circuit with 32 constraints ---------------------------------------------------------------------
 A_, B_, C_, wit, l = chain_circuit(32)
