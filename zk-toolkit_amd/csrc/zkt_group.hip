@@ -73,19 +73,95 @@ hipError_t launch_group_mul(int grp, const uint32_t* p, const uint32_t* k, int k
   switch (grp) { case G_G1: return mul_t<FqOps>(p, fixed_base, k, kw, fixed_scalar, o, n, s); case G_G2: return mul_t<Fq2Ops>(p, fixed_base, k, kw, fixed_scalar, o, n, s); case G_SECP: return mul_t<SpOps>(p, fixed_base, k, kw, fixed_scalar, o, n, s); }
   return hipErrorInvalidValue;
 }
-// sum of n affine points by rounds of pairwise additions (in place, `pts` is clobbered; result in pts[0]).
-// Straightforward O(n) adds, log2(n) launches — the G2 / secp256k1 sums behind eval_with_g2_hidings
-// (polynomial.rs:283-293) and (AffinePoints * PrimeFieldElems).sum() (secp256k1/affine_points.rs:25-31,123-144).
-hipError_t launch_group_sum_inplace(int grp, uint32_t* pts, size_t n, hipStream_t s) {
-  const size_t W = grp == G_G1 ? ABI_G1_WORDS : grp == G_G2 ? ABI_G2_WORDS : ABI_SECP_WORDS;
-  while (n > 1) {
-    size_t half = n / 2, odd = n & 1;
-    // pts[i] += pts[half + odd + i] for i < half; the middle element (if odd) stays in place
-    hipError_t e = launch_group_add(grp, pts, pts + (half + odd) * W, pts, half, s);
-    if (e != hipSuccess) return e;
-    n = half + odd;
+// Several independent batched scalar multiplications in ONE launch.  A 255-step double-and-add costs ~4 ms of latency however few
+// points it covers, so callers that issue many small independent ones per step (every level of the inner-product argument,
+// bulletproofs.rs:36-47) pay that latency once instead of six times.
+template <class F>
+__global__ void __launch_bounds__(64) k_group_mul_segs(MulSegs segs, int kw, size_t total) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= total) return;
+  int sidx = 0;
+  while (sidx + 1 < segs.n && i >= segs.s[sidx].count) { i -= segs.s[sidx].count; ++sidx; }
+  const MulSeg g = segs.s[sidx];
+  constexpr int W = PtIO<F>::WORDS;
+  Aff<F> p = PtIO<F>::ld(g.pts + i * (size_t)g.pt_stride);
+  PtIO<F>::st(g.out + i * W, jac_to_aff(scalar_mul_aff<F>(p, g.k + i * (size_t)g.k_stride, kw)));
+}
+hipError_t launch_group_mul_segs(int grp, const MulSegs& segs, int kw, hipStream_t s) {
+  size_t total = 0;
+  for (int k = 0; k < segs.n; ++k) total += segs.s[k].count;
+  if (total == 0) return hipSuccess;
+  switch (grp) {
+    case G_G1: hipLaunchKernelGGL(k_group_mul_segs<FqOps>, dim3(nblk(total, 64)), dim3(64), 0, s, segs, kw, total); break;
+    case G_G2: hipLaunchKernelGGL(k_group_mul_segs<Fq2Ops>, dim3(nblk(total, 64)), dim3(64), 0, s, segs, kw, total); break;
+    case G_SECP: hipLaunchKernelGGL(k_group_mul_segs<SpOps>, dim3(nblk(total, 64)), dim3(64), 0, s, segs, kw, total); break;
+    default: return hipErrorInvalidValue;
   }
-  return hipSuccess;
+  return hipGetLastError();
+}
+
+// ---- sum of n affine points ------------------------------------------------------------------------------------------------
+// the G2 / secp256k1 sums behind eval_with_g2_hidings (polynomial.rs:283-293) and (AffinePoints * PrimeFieldElems).sum()
+// (secp256k1/affine_points.rs:25-31,123-144).  Two launches: every lane adds a strided share into a Jacobian accumulator (mixed
+// additions, no inversion), a block folds its 64 accumulators through LDS, and one block folds the <= 64 block results and
+// normalises.  (The earlier log2(n) rounds of affine pairwise additions cost one inversion latency per round.)
+template <class F> struct JacRaw;
+template <class C> struct JacRaw<PrimeOps<C>> {
+  static constexpr int EW = C::N;
+  __device__ static void st(uint32_t* p, const Fp<C>& a) { st_raw<C>(p, a); }
+  __device__ static Fp<C> ld(const uint32_t* p) { return ld_raw<C>(p); }
+};
+template <> struct JacRaw<Fq2Ops> {
+  static constexpr int EW = 2 * FqC::N;
+  __device__ static void st(uint32_t* p, const Fq2& a) { st_raw<FqC>(p, a.c0); st_raw<FqC>(p + FqC::N, a.c1); }
+  __device__ static Fq2 ld(const uint32_t* p) { Fq2 r; r.c0 = ld_raw<FqC>(p); r.c1 = ld_raw<FqC>(p + FqC::N); return r; }
+};
+template <class F> __device__ inline void st_jac(uint32_t* p, const Jac<F>& a) { constexpr int E = JacRaw<F>::EW; JacRaw<F>::st(p, a.X); JacRaw<F>::st(p + E, a.Y); JacRaw<F>::st(p + 2 * E, a.Z); }
+template <class F> __device__ inline Jac<F> ld_jac(const uint32_t* p) { constexpr int E = JacRaw<F>::EW; return Jac<F>{JacRaw<F>::ld(p), JacRaw<F>::ld(p + E), JacRaw<F>::ld(p + 2 * E)}; }
+template <class F> __device__ inline Jac<F> block_jac_sum(Jac<F> v, uint32_t* lds) {      // 64 lanes -> lane 0
+  constexpr int JW = 3 * JacRaw<F>::EW;
+  const int lane = threadIdx.x;
+  for (int d = 32; d >= 1; d >>= 1) {
+    if (lane >= d && lane < 2 * d) st_jac<F>(lds + (lane - d) * JW, v);
+    __syncthreads();
+    if (lane < d) v = jac_add(v, ld_jac<F>(lds + lane * JW));
+    __syncthreads();
+  }
+  return v;
+}
+static constexpr int SUM_BLOCKS = 64;
+template <class F>
+__global__ void __launch_bounds__(64) k_group_sum_partials(const uint32_t* __restrict__ pts, size_t n, uint32_t* __restrict__ partials) {
+  constexpr int W = PtIO<F>::WORDS, JW = 3 * JacRaw<F>::EW;
+  __shared__ uint32_t lds[32 * JW];
+  Jac<F> acc = jac_inf<F>();
+  for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < n; i += (size_t)gridDim.x * 64) acc = jac_add_aff(acc, PtIO<F>::ld(pts + i * W));
+  acc = block_jac_sum<F>(acc, lds);
+  if (threadIdx.x == 0) st_jac<F>(partials + (size_t)blockIdx.x * JW, acc);
+}
+template <class F>
+__global__ void __launch_bounds__(64) k_group_sum_finish(const uint32_t* __restrict__ partials, int count, uint32_t* __restrict__ out) {
+  constexpr int JW = 3 * JacRaw<F>::EW;
+  __shared__ uint32_t lds[32 * JW];
+  Jac<F> acc = (int)threadIdx.x < count ? ld_jac<F>(partials + (size_t)threadIdx.x * JW) : jac_inf<F>();
+  acc = block_jac_sum<F>(acc, lds);
+  if (threadIdx.x == 0) PtIO<F>::st(out, jac_to_aff(acc));
+}
+template <class F> static hipError_t sum_t(uint32_t* pts, size_t n, uint32_t* scratch, hipStream_t s) {
+  const int nb = (int)(n < (size_t)SUM_BLOCKS * 64 ? (n + 63) / 64 : SUM_BLOCKS);
+  hipLaunchKernelGGL(k_group_sum_partials<F>, dim3(nb), dim3(64), 0, s, (const uint32_t*)pts, n, scratch);
+  hipLaunchKernelGGL(k_group_sum_finish<F>, dim3(1), dim3(64), 0, s, (const uint32_t*)scratch, nb, pts);     // result in pts[0]
+  return hipGetLastError();
+}
+// `pts` is clobbered (result in pts[0]); `scratch` holds SUM_BLOCKS Jacobian partials (zkt_group_sum_scratch_words()).
+size_t group_sum_scratch_words(int grp) { return (size_t)SUM_BLOCKS * 3 * (grp == G_G1 ? FqC::N : grp == G_G2 ? 2 * FqC::N : SpC::N); }
+hipError_t launch_group_sum_inplace(int grp, uint32_t* pts, size_t n, hipStream_t s) {
+  if (n <= 1) return hipSuccess;
+  // the partials live behind a lazily grown per-process buffer: sums are issued from one stream at a time by the protocol code
+  static uint32_t* scratch = nullptr;
+  if (!scratch && hipMalloc((void**)&scratch, group_sum_scratch_words(G_G2) * 4) != hipSuccess) return hipErrorOutOfMemory;
+  switch (grp) { case G_G1: return sum_t<FqOps>(pts, n, scratch, s); case G_G2: return sum_t<Fq2Ops>(pts, n, scratch, s); case G_SECP: return sum_t<SpOps>(pts, n, scratch, s); }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace zkt

@@ -286,29 +286,34 @@ int zkt_bp_inner_product_argument(size_t n, const zkt_secp_affine* gg, const zkt
     hipLaunchKernelGGL(k_dot<SnC>, dim3(1), dim3(256), 0, s, (const uint32_t*)Av, (const uint32_t*)(Bv + np * 8), np, dc.w());
     hipLaunchKernelGGL(k_dot<SnC>, dim3(1), dim3(256), 0, s, (const uint32_t*)(Av + np * 8), (const uint32_t*)Bv, np, dc.w() + 8);
     // L = (gg_hi * a_lo).sum() + (hh_lo * b_hi).sum() + u * cL   (:39)
-    uint32_t* T = tmp.w();
-    if (launch_group_mul(G_SECP, G + np * PW, Av, 8, T, np, s) || launch_group_mul(G_SECP, H, Bv + np * 8, 8, T + np * PW, np, s) ||
-        launch_group_mul(G_SECP, du.w(), dc.w(), 8, T + 2 * np * PW, 1, s) || launch_group_sum_inplace(G_SECP, T, 2 * np + 1, s)) return -ZKT_ERR_DEVICE;
-    if (hipMemcpyAsync(dLR.w(), T, SPB, hipMemcpyDeviceToDevice, s) != hipSuccess) return -ZKT_ERR_DEVICE;
-    // R = (gg_lo * a_hi).sum() + (hh_hi * b_lo).sum() + u * cR   (:40)
-    if (launch_group_mul(G_SECP, G, Av + np * 8, 8, T, np, s) || launch_group_mul(G_SECP, H + np * PW, Bv, 8, T + np * PW, np, s) ||
-        launch_group_mul(G_SECP, du.w(), dc.w() + 8, 8, T + 2 * np * PW, 1, s) || launch_group_sum_inplace(G_SECP, T, 2 * np + 1, s)) return -ZKT_ERR_DEVICE;
-    if (hipMemcpyAsync(dLR.w() + PW, T, SPB, hipMemcpyDeviceToDevice, s) != hipSuccess) return -ZKT_ERR_DEVICE;
+    // R = (gg_lo * a_hi).sum() + (hh_hi * b_lo).sum() + u * cR   (:40)    — all six batched multiplications in one launch
+    uint32_t *T = tmp.w(), *T2 = tmp2.w();
+    {
+      MulSegs m{};
+      m.s[0] = {G + np * PW, Av, T, (uint32_t)np, PW, 8};              m.s[1] = {H, Bv + np * 8, T + np * PW, (uint32_t)np, PW, 8};
+      m.s[2] = {du.w(), dc.w(), T + 2 * np * PW, 1, 0, 0};
+      m.s[3] = {G, Av + np * 8, T2, (uint32_t)np, PW, 8};              m.s[4] = {H + np * PW, Bv, T2 + np * PW, (uint32_t)np, PW, 8};
+      m.s[5] = {du.w(), dc.w() + 8, T2 + 2 * np * PW, 1, 0, 0};
+      m.n = 6;
+      if (launch_group_mul_segs(G_SECP, m, 8, s) || launch_group_sum_inplace(G_SECP, T, 2 * np + 1, s) || launch_group_sum_inplace(G_SECP, T2, 2 * np + 1, s)) return -ZKT_ERR_DEVICE;
+    }
+    if (hipMemcpyAsync(dLR.w(), T, SPB, hipMemcpyDeviceToDevice, s) != hipSuccess || hipMemcpyAsync(dLR.w() + PW, T2, SPB, hipMemcpyDeviceToDevice, s) != hipSuccess) return -ZKT_ERR_DEVICE;
     // challenge x (:42, injected) -> x, x^-1, x^2, x^-2
     bool zero = true; for (int j = 0; j < 4; ++j) zero = zero && xs[level * 4 + j] == 0;
     if (zero) return -ZKT_ERR_INV_ZERO;
     if ((rc = up(dx, xs + level * 4, FRB, s))) return -rc;
     hipLaunchKernelGGL(k_ipa_challenge, dim3(1), dim3(64), 0, s, (const uint32_t*)dx.w(), dch.w());
     const uint32_t *X = dch.w(), *XI = dch.w() + 8, *X2 = dch.w() + 16, *X2I = dch.w() + 24;
-    // gg' = gg_lo * x^-1 + gg_hi * x ; hh' = hh_lo * x + hh_hi * x^-1   (:44-45)
-    uint32_t* T2 = tmp2.w();
-    if (launch_group_mul(G_SECP, G, XI, 8, T, np, s, false, true) || launch_group_mul(G_SECP, G + np * PW, X, 8, T2, np, s, false, true) ||
-        launch_group_add(G_SECP, T, T2, G, np, s)) return -ZKT_ERR_DEVICE;
-    if (launch_group_mul(G_SECP, H, X, 8, T, np, s, false, true) || launch_group_mul(G_SECP, H + np * PW, XI, 8, T2, np, s, false, true) ||
-        launch_group_add(G_SECP, T, T2, H, np, s)) return -ZKT_ERR_DEVICE;
-    // P' = L x^2 + P + R x^-2   (:47)
-    if (launch_group_mul(G_SECP, dLR.w(), X2, 8, T, 1, s) || launch_group_add(G_SECP, T, dPp.w(), T, 1, s) ||
-        launch_group_mul(G_SECP, dLR.w() + PW, X2I, 8, T2, 1, s) || launch_group_add(G_SECP, T, T2, dPp.w(), 1, s)) return -ZKT_ERR_DEVICE;
+    // gg' = gg_lo * x^-1 + gg_hi * x ; hh' = hh_lo * x + hh_hi * x^-1 (:44-45);  P' = L x^2 + P + R x^-2 (:47) — again one launch
+    {
+      MulSegs m{};
+      m.s[0] = {G, XI, T, (uint32_t)np, PW, 0};                        m.s[1] = {G + np * PW, X, T + np * PW, (uint32_t)np, PW, 0};
+      m.s[2] = {H, X, T2, (uint32_t)np, PW, 0};                        m.s[3] = {H + np * PW, XI, T2 + np * PW, (uint32_t)np, PW, 0};
+      m.s[4] = {dLR.w(), X2, T + 2 * np * PW, 1, 0, 0};                m.s[5] = {dLR.w() + PW, X2I, T2 + 2 * np * PW, 1, 0, 0};
+      m.n = 6;
+      if (launch_group_mul_segs(G_SECP, m, 8, s) || launch_group_add(G_SECP, T, T + np * PW, G, np, s) || launch_group_add(G_SECP, T2, T2 + np * PW, H, np, s) ||
+          launch_group_add(G_SECP, T + 2 * np * PW, dPp.w(), T + 2 * np * PW, 1, s) || launch_group_add(G_SECP, T + 2 * np * PW, T2 + 2 * np * PW, dPp.w(), 1, s)) return -ZKT_ERR_DEVICE;
+    }
     // a' = a_lo x + a_hi x^-1 ; b' = b_lo x^-1 + b_hi x   (:49-50)
     hipLaunchKernelGGL(k_fold<SnC>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const uint32_t*)Av, (const uint32_t*)(Av + np * 8), X, XI, np, A2);
     hipLaunchKernelGGL(k_fold<SnC>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const uint32_t*)Bv, (const uint32_t*)(Bv + np * 8), XI, X, np, B2);
