@@ -157,8 +157,8 @@ template <class F> static hipError_t sum_t(uint32_t* pts, size_t n, uint32_t* sc
 size_t group_sum_scratch_words(int grp) { return (size_t)SUM_BLOCKS * 3 * (grp == G_G1 ? FqC::N : grp == G_G2 ? 2 * FqC::N : SpC::N); }
 hipError_t launch_group_sum_inplace(int grp, uint32_t* pts, size_t n, hipStream_t s) {
   if (n <= 1) return hipSuccess;
-  // the partials live behind a lazily grown per-process buffer: sums are issued from one stream at a time by the protocol code
-  static uint32_t* scratch = nullptr;
+  // block partials: one small buffer per calling thread (the ABI is thread-safe; a thread issues its sums on one stream, in order)
+  static thread_local uint32_t* scratch = nullptr;
   if (!scratch && hipMalloc((void**)&scratch, group_sum_scratch_words(G_G2) * 4) != hipSuccess) return hipErrorOutOfMemory;
   switch (grp) { case G_G1: return sum_t<FqOps>(pts, n, scratch, s); case G_G2: return sum_t<Fq2Ops>(pts, n, scratch, s); case G_SECP: return sum_t<SpOps>(pts, n, scratch, s); }
   return hipErrorInvalidValue;
