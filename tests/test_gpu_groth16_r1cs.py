@@ -110,3 +110,28 @@ def test_r1cs_sharded_proof_equals_unsharded(L):
     zk.check(L.zkt_g1_jac_sum_dev(vp(pc), shards, None, ptr(got[2])))
     for x, y, name in zip(want, got, "ABC"):
         assert (x == y).all(), f"sharded proof element {name} differs"
+
+
+def test_r1cs_path_all_wires_public(L):
+    """l = m: no witness wires, so the uvw_wit part of the C base set is empty (prover.rs:127-131 loops over nothing)."""
+    A, B, C, wit, _ = chain_circuit(3)
+    n, m = len(A), len(wit) - 1
+    l = m
+    ui, vi, wi, h, _ = qap_from_r1cs(A, B, C, wit)
+    U, V, W = dense(ui, n), dense(vi, n), dense(wi, n)
+    rng = SplitMix64(31337)
+    trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+    r, s = fr(rng.below(R - 1) + 1), fr(rng.below(R - 1) + 1)
+    wires, H = ints_to_arr(wit, 4), ints_to_arr(h, 4)
+    ocrs, obuf = alloc_crs(n, l, m)
+    assert O.zkto_groth16_setup(ctypes.byref(ocrs), ptr(U), ptr(V), ptr(W), *[ptr(t) for t in trap]) == 0
+    op = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+    assert O.zkto_groth16_prove(ctypes.byref(ocrs), ptr(U), ptr(V), ptr(wires), ptr(H), len(h), ptr(r), ptr(s), 1, *[ptr(x) for x in op]) == 0
+    vk, vbuf, pk = _r1cs_setup(L, (A, B, C), n, l, m, trap)
+    assert (obuf["g1_uvw_stmt"] == vbuf["g1_uvw_stmt"]).all()
+    gp = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+    zk.check(L.zkt_groth16_prove_r1cs(pk, wires.ctypes.data, r.ctypes.data, s.ctypes.data, *[x.ctypes.data for x in gp]))
+    for a, b, name in zip(op, gp, "ABC"):
+        assert (a == b).all(), f"proof element {name} differs"
+    assert L.zkt_groth16_verify(ctypes.byref(vk), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(wires), l + 1) == 1
+    L.zkt_groth16_pk_free(pk)
