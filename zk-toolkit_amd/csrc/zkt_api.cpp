@@ -399,18 +399,44 @@ static int jac_sum_dev(int grp, const uint32_t* dev_partials, size_t count, void
   return ZKT_OK;
 }
 // one-shot host-pointer MSM: upload, build the window-multiple table, run, free
+// one-shot host-pointer MSM (eval_with_g1_hidings called once, polynomial.rs:271-281): the table-free form — upload, kernel layout,
+// sort / accumulate / per-window reduce / join on one stream, free.  No window-multiple table is built for a single use.
+// ZKT_MSM_ONE_SHOT_TABLE=1 selects the resident-bases machinery instead (A/B and regression checks).
 static int msm_host(int grp, const void* bases, const uint64_t* scalars, size_t n, void* out) {
   if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
   if (!out || (n && (!bases || !scalars))) return ZKT_ERR_SHAPE;
   if (n == 0) { memset(out, 0, grp_pt_bytes(grp)); ((uint32_t*)out)[grp_pt_bytes(grp) / 4 - 2] = 1; return ZKT_OK; }
-  zkt_bases_impl* h = nullptr;
-  int rc = bases_upload(grp, bases, n, &h);
-  if (rc) return rc;
-  uint64_t* d_s = nullptr;
-  if (hipMalloc((void**)&d_s, n * 32) != hipSuccess) { bases_free(h); return ZKT_ERR_DEVICE; }
-  hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice);
-  rc = msm_dev(h, d_s, n, g.stream, out, nullptr);
-  hipFree(d_s); bases_free(h);
+  static const bool use_table = [] { const char* e = getenv("ZKT_MSM_ONE_SHOT_TABLE"); return e && *e == '1'; }();
+  if (use_table) {
+    zkt_bases_impl* h = nullptr;
+    int rc = bases_upload(grp, bases, n, &h);
+    if (rc) return rc;
+    uint64_t* d_s = nullptr;
+    if (hipMalloc((void**)&d_s, n * 32) != hipSuccess) { bases_free(h); return ZKT_ERR_DEVICE; }
+    hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice);
+    rc = msm_dev(h, d_s, n, g.stream, out, nullptr);
+    hipFree(d_s); bases_free(h);
+    return rc;
+  }
+  HIPCHK(hipSetDevice(g.device));
+  const MsmPlan plan = msm_plan_direct(n, grp);
+  const size_t ptb = grp_pt_bytes(grp), cb = grp_coord_bytes(grp);
+  uint8_t* blob = nullptr;                                   // [abi points | scalars | kernel-layout points | inf flags | jac | abi out | workspace]
+  const size_t o_abi = 0, o_sc = padded(n * ptb), o_tab = o_sc + padded(n * 32), o_inf = o_tab + padded(n * 2 * cb), o_jac = o_inf + padded(n),
+               o_out = o_jac + padded(4 * cb), o_ws = o_out + padded(ptb), total = o_ws + plan.ws_bytes;
+  HIPCHK(hipMalloc((void**)&blob, total));
+  hipStream_t s = g.stream;
+  int rc = ZKT_OK;
+  auto fail = [&](hipError_t e) { if (e != hipSuccess) { fprintf(stderr, "[zkt] HIP error %s in one-shot MSM\n", hipGetErrorString(e)); rc = ZKT_ERR_DEVICE; } return e != hipSuccess; };
+  if (!fail(hipMemcpyAsync(blob + o_abi, bases, n * ptb, hipMemcpyHostToDevice, s)) && !fail(hipMemcpyAsync(blob + o_sc, scalars, n * 32, hipMemcpyHostToDevice, s)) &&
+      !fail(launch_msm_to_kernel_layout(grp, (const uint32_t*)(blob + o_abi), (uint32_t*)(blob + o_tab), blob + o_inf, n, s)) &&
+      !fail(launch_msm_sort(plan, blob + o_inf, (const uint32_t*)(blob + o_sc), blob + o_ws, s)) &&
+      !fail(launch_msm_accumulate(plan, (const uint32_t*)(blob + o_tab), blob + o_ws, s)) &&
+      !fail(launch_msm_reduce(plan, blob + o_ws, (uint32_t*)(blob + o_jac), (uint32_t*)(blob + o_out), s)) &&
+      !fail(hipMemcpyAsync(out, blob + o_out, ptb, hipMemcpyDeviceToHost, s)))
+    fail(hipStreamSynchronize(s));
+  else hipStreamSynchronize(s);
+  hipFree(blob);
   return rc;
 }
 

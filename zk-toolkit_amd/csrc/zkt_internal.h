@@ -44,10 +44,15 @@ struct MsmPlan {
   int grp;             // GroupId
   int c;               // window bits
   int nwin;            // windows
-  size_t nbuckets;     // 2^(c-1), shared by all windows (window multiples are precomputed)
+  size_t nbuckets;     // resident form: 2^(c-1), shared by all windows (window multiples are precomputed); direct form: nwin * 2^(c-1)
   size_t ws_bytes;     // workspace bytes per in-flight MSM
+  int direct;          // 1 = table-free one-shot form: `table` is the n bases themselves, every window has its own 2^(c-1) buckets
+  size_t half;         // buckets per window, 2^(c-1)
 };
 MsmPlan msm_plan(size_t n, int grp);
+// table-free form for one-shot calls (zkt_*_msm with host pointers): no window-multiple table to build — nwin bucket sets, the per-window
+// sums reduced side by side (grid.y = window) and joined by nwin-1 runs of c doublings
+MsmPlan msm_plan_direct(size_t n, int grp);
 // table: nwin*n affine points (x,y raw Montgomery coordinates), inf: nwin*n bytes.  scalars: n x 8 u32.
 // Three stages so the API layer can run them on three streams (sort | accumulate | reduce) and overlap
 // consecutive MSMs; the result is a Jacobian partial (3 coordinates) and optionally the affine ABI point.

@@ -72,6 +72,25 @@ MsmPlan msm_plan(size_t n, int grp) {
   b += (p.nbuckets + ent / 128 + 2) * (8 + XYW * 4);              // task list + partial sums of split buckets
   b += 4096;
   p.ws_bytes = b;
+  p.direct = 0; p.half = p.nbuckets;
+  return p;
+}
+MsmPlan msm_plan_direct(size_t n, int grp) {
+  MsmPlan p; p.n = n; p.grp = grp;
+  const size_t XYW = 4 * (size_t)coord_words(grp);
+  int lg = 0; while ((size_t(1) << (lg + 1)) <= (n ? n : 1)) ++lg;
+  int c = lg - 3;                   // every window has its own buckets: fewer, fuller buckets than the shared form
+  if (c < 9) c = 9;                 // nwin <= 29: k_join_windows folds at most 32 windows in one wave
+  if (c > 16) c = 16;
+  p.c = c; p.nwin = (256 + 1 + c - 1) / c; p.half = size_t(1) << (c - 1); p.nbuckets = (size_t)p.nwin * p.half; p.direct = 1;
+  size_t ent = (size_t)p.nwin * n;
+  size_t b = 0;
+  b += (p.nbuckets + 1) * 4 * 3 + ent * 4 + p.nbuckets * XYW * 4;
+  b += (size_t)p.nwin * (2048 + 64 + 1) * XYW * 4;               // per-window row/col sums, bit classes, window results
+  b += (1024 + 3 * 1025) * 4 + 2 * (p.nbuckets + 1) * 4;
+  b += (p.nbuckets + ent / 128 + 2) * (8 + XYW * 4);
+  b += 8192;
+  p.ws_bytes = b;
   return p;
 }
 #endif
@@ -140,7 +159,7 @@ __device__ inline uint32_t window_bits(const uint32_t* k, int w, int c) {
 // atomics on one address: up to two rounds of wave-level aggregation elect a leader for the most common bucket id among
 // the active lanes (one atomicAdd of the population count, ranks by prefix popcount); the rest go individually.
 template <bool SCATTER>
-static __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t n, int c, int nwin,
+static __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t n, int c, int nwin, uint32_t win_buckets,
                                                 uint32_t* __restrict__ counts_or_cursor, const uint32_t* __restrict__ offsets,
                                                 uint32_t* __restrict__ entries) {
   ZKT_SIDE_PRIO;
@@ -161,9 +180,11 @@ static __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restric
     uint32_t neg = raw > half;
     uint32_t mag = neg ? (1u << c) - raw : raw;         // |digit| in [0, 2^(c-1)]
     carry = neg;
-    size_t src = (size_t)w * n + i;
+    // resident form (win_buckets = 0): entry = index into the window-multiple table, one bucket set for all windows;
+    // direct form: entry = the base itself, window w owns buckets [w * win_buckets, (w+1) * win_buckets)
+    size_t src = win_buckets ? i : (size_t)w * n + i;
     bool todo = live && mag != 0 && !inf[live ? src : 0];   // infinity and zero digits contribute nothing
-    const uint32_t b = mag - 1;
+    const uint32_t b = mag - 1 + (uint32_t)w * win_buckets;
     uint32_t pos = 0;
     for (int round = 0; round < 2; ++round) {
       unsigned long long act = __ballot(todo);
@@ -388,6 +409,7 @@ __global__ void __launch_bounds__(RED_TPB) k_marginals(const uint32_t* __restric
   constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
   __shared__ uint32_t lds[RED_TPB / 2 * XYW];
   const int lane = threadIdx.x;
+  in += (size_t)blockIdx.y * NLO * NHI * XYW; colsum += (size_t)blockIdx.y * 1024 * XYW; rowsum += (size_t)blockIdx.y * 1024 * XYW;   // grid.y = window (direct form)
   const bool is_col = blockIdx.x < NLO;
   const size_t o = is_col ? blockIdx.x : blockIdx.x - NLO;
   const size_t count = is_col ? NHI : NLO, stride_o = is_col ? 1 : NLO, stride_j = is_col ? NLO : 1;
@@ -405,6 +427,7 @@ __global__ void __launch_bounds__(RED_TPB) k_weight_bits(const uint32_t* __restr
   constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
   __shared__ uint32_t lds[RED_TPB / 2 * XYW];
   const int lane = threadIdx.x;
+  colsum += (size_t)blockIdx.y * 1024 * XYW; rowsum += (size_t)blockIdx.y * 1024 * XYW; clsA += (size_t)blockIdx.y * 32 * XYW; clsB += (size_t)blockIdx.y * 32 * XYW;
   const bool isA = (int)blockIdx.x < nbA;
   const int bit = isA ? blockIdx.x : blockIdx.x - nbA;
   const uint32_t* in = isA ? colsum : rowsum; const size_t m = isA ? NLO : NHI; const uint32_t woff = isA ? 1u : 0u;
@@ -424,6 +447,7 @@ __global__ void __launch_bounds__(64) k_combine(const uint32_t* __restrict__ cls
   constexpr int CW = Coord<F>::CW, XYW = 4 * CW; typedef Xyzz<F> XY;
   __shared__ uint32_t lds[32 * XYW];
   const int t = threadIdx.x;
+  clsA += (size_t)blockIdx.y * 32 * XYW; clsB += (size_t)blockIdx.y * 32 * XYW; out_jac += (size_t)blockIdx.y * XYW;      // window results are XYW apart
   XY v = xyzz_inf<F>();
   if (t < nbA) v = ld_xy<F>(clsA + t * XYW);
   if (t >= shift && t - shift < nbB) v = xyzz_add<F>(v, ld_xy<F>(clsB + (t - shift) * XYW));
@@ -441,10 +465,37 @@ __global__ void __launch_bounds__(64) k_combine(const uint32_t* __restrict__ cls
   }
 }
 
+// direct form: total = sum_w 2^(c w) W_w.  One wave: lane w doubles its window result c*w times (the longest lane does the
+// c*(nwin-1) <= 256 doublings a serial Horner would), then an LDS tree; lane 0 writes the Jacobian sum and its affine normalisation.
+template <class F>
+__global__ void __launch_bounds__(64) k_join_windows(const uint32_t* __restrict__ win_jac, int nwin, int c, uint32_t* __restrict__ out_jac, uint32_t* __restrict__ out_abi) {
+  ZKT_SIDE_PRIO;
+  constexpr int CW = Coord<F>::CW, XYW = 4 * CW, JW = 3 * CW;
+  __shared__ uint32_t lds[16 * JW];
+  const int t = threadIdx.x;
+  auto ldj = [](const uint32_t* p) { return Jac<F>{Coord<F>::ld(p), Coord<F>::ld(p + CW), Coord<F>::ld(p + 2 * CW)}; };
+  auto stj = [](uint32_t* p, const Jac<F>& a) { Coord<F>::st(p, a.X); Coord<F>::st(p + CW, a.Y); Coord<F>::st(p + 2 * CW, a.Z); };
+  Jac<F> v = jac_inf<F>();
+  if (t < nwin) {
+    v = ldj(win_jac + (size_t)t * XYW);
+    for (int d = 0; d < c * t; ++d) v = jac_dbl(v);
+  }
+  for (int d = 16; d >= 1; d >>= 1) {                  // nwin <= 32
+    if (t >= d && t < 2 * d) stj(lds + (t - d) * JW, v);
+    __syncthreads();
+    if (t < d) v = jac_add(v, ldj(lds + t * JW));
+    __syncthreads();
+  }
+  if (t == 0) {
+    stj(out_jac, v);
+    if (out_abi) PtIO<F>::st(out_abi, jac_to_aff(v));
+  }
+}
+
 namespace {
 struct MsmWs {   // workspace carve-up (one per in-flight MSM)
   uint32_t *zero_begin, *counts, *cursor, *size_hist, *size_off, *size_cur, *zero_end;   // [zero_begin, zero_end) is cleared per MSM
-  uint32_t *offsets, *entries, *sums, *colsum, *rowsum, *clsA, *clsB, *scan_tmp, *ntask, *task_off, *partial;
+  uint32_t *offsets, *entries, *sums, *colsum, *rowsum, *clsA, *clsB, *win_jac, *scan_tmp, *ntask, *task_off, *partial;
   uint2* order; size_t max_tasks;
 };
 MsmWs carve(const MsmPlan& P, void* workspace) {
@@ -463,10 +514,12 @@ MsmWs carve(const MsmPlan& P, void* workspace) {
   w.entries = (uint32_t*)ws; ws += (size_t)P.nwin * P.n * 4;
   ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   w.sums = (uint32_t*)ws; ws += B * XYW * 4;
-  w.colsum = (uint32_t*)ws; ws += 1024 * XYW * 4;
-  w.rowsum = (uint32_t*)ws; ws += 1024 * XYW * 4;
-  w.clsA = (uint32_t*)ws; ws += 32 * XYW * 4;
-  w.clsB = (uint32_t*)ws; ws += 32 * XYW * 4;
+  const size_t nw = P.direct ? (size_t)P.nwin : 1;                // the direct form reduces every window side by side
+  w.colsum = (uint32_t*)ws; ws += nw * 1024 * XYW * 4;
+  w.rowsum = (uint32_t*)ws; ws += nw * 1024 * XYW * 4;
+  w.clsA = (uint32_t*)ws; ws += nw * 32 * XYW * 4;
+  w.clsB = (uint32_t*)ws; ws += nw * 32 * XYW * 4;
+  w.win_jac = (uint32_t*)ws; ws += nw * XYW * 4;
   w.scan_tmp = (uint32_t*)ws; ws += 1024 * 4;
   w.ntask = (uint32_t*)ws; ws += (B + 1) * 4;
   w.task_off = (uint32_t*)ws; ws += (B + 1) * 4;
@@ -486,9 +539,10 @@ hipError_t PART(launch_msm_sort)(const MsmPlan& P, const uint8_t* inf, const uin
   if ((e = hipMemsetAsync(w.zero_begin, 0, (uint8_t*)w.zero_end - (uint8_t*)w.zero_begin, s)) != hipSuccess) return e;
   if (n) {
     const unsigned g = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_digits<false>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, w.counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    const uint32_t wb = P.direct ? (uint32_t)P.half : 0u;
+    hipLaunchKernelGGL(k_digits<false>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, wb, w.counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     launch_scan(w.counts, w.offsets, B, w.scan_tmp, s);
-    hipLaunchKernelGGL(k_digits<true>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, w.cursor, (const uint32_t*)w.offsets, w.entries);
+    hipLaunchKernelGGL(k_digits<true>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, wb, w.cursor, (const uint32_t*)w.offsets, w.entries);
   } else {
     if ((e = hipMemsetAsync(w.offsets, 0, (B + 1) * 4, s)) != hipSuccess) return e;
   }
@@ -512,12 +566,22 @@ hipError_t PART(launch_msm_accumulate)(const MsmPlan& P, const uint32_t* table, 
 }
 // stage 3 (latency bound): sum_b (b+1) S_b, b = hi*NLO + lo  ->  Jacobian partial (+ affine point if out_abi)
 hipError_t PART(launch_msm_reduce)(const MsmPlan& P, void* workspace, uint32_t* dev_result_jac, uint32_t* dev_out_abi, hipStream_t s) {
-  const size_t B = P.nbuckets;
+  const size_t B = P.direct ? P.half : P.nbuckets;          // buckets of one reduction (per window in the direct form)
   MsmWs w = carve(P, workspace);
   const size_t NLO = B < 1024 ? B : 1024, NHI = B / NLO;
   int lo_bits = 0; while ((size_t(1) << lo_bits) < NLO) ++lo_bits;
   int hi_bits = 0; while ((size_t(1) << hi_bits) < NHI) ++hi_bits;
   const int nbA = lo_bits + 1, nbB = NHI > 1 ? hi_bits : 0;     // weights lo+1 in [1,NLO]; hi in [0,NHI)
+  if (P.direct) {                                          // every window reduced side by side (grid.y), then joined
+    const unsigned ny = (unsigned)P.nwin;
+    MSM_DISPATCH(P.grp,
+      hipLaunchKernelGGL(k_merge_partials<F>, dim3((unsigned)(P.nbuckets < 2048 ? P.nbuckets : 2048)), dim3(RED_TPB), 0, s, (const uint32_t*)w.task_off, P.nbuckets, (const uint32_t*)w.partial, w.sums);
+      hipLaunchKernelGGL(k_marginals<F>, dim3((unsigned)(NLO + (NHI > 1 ? NHI : 0)), ny), dim3(RED_TPB), 0, s, (const uint32_t*)w.sums, NLO, NHI, w.colsum, w.rowsum);
+      hipLaunchKernelGGL(k_weight_bits<F>, dim3((unsigned)(nbA + nbB), ny), dim3(RED_TPB), 0, s, (const uint32_t*)w.colsum, NLO, nbA, (const uint32_t*)w.rowsum, NHI, w.clsA, w.clsB);
+      hipLaunchKernelGGL(k_combine<F>, dim3(1, ny), dim3(64), 0, s, (const uint32_t*)w.clsA, nbA, (const uint32_t*)w.clsB, nbB, lo_bits, w.win_jac, (uint32_t*)nullptr);
+      hipLaunchKernelGGL(k_join_windows<F>, dim3(1), dim3(64), 0, s, (const uint32_t*)w.win_jac, P.nwin, P.c, dev_result_jac, dev_out_abi));
+    return hipGetLastError();
+  }
   MSM_DISPATCH(P.grp,
     hipLaunchKernelGGL(k_merge_partials<F>, dim3((unsigned)(B < 2048 ? B : 2048)), dim3(RED_TPB), 0, s, (const uint32_t*)w.task_off, B, (const uint32_t*)w.partial, w.sums);
     hipLaunchKernelGGL(k_marginals<F>, dim3((unsigned)(NLO + (NHI > 1 ? NHI : 0))), dim3(RED_TPB), 0, s, (const uint32_t*)w.sums, NLO, NHI, w.colsum, w.rowsum);
