@@ -120,5 +120,5 @@ t0 = time.perf_counter(); zk.check(L.zkt_pinocchio_prove(ctypes.byref(crs), ptr(
 t0 = time.perf_counter(); okp = L.zkt_pinocchio_verify(ctypes.byref(crs), ctypes.byref(pf), ptr(wires[:n_io].copy())); t_v = time.perf_counter() - t0
 assert okp == 1
 res["pinocchio"] = {"constraints": nn, "setup_s": t_s, "prove_s": t_p, "verify_s": t_v, "accepts": True,
-                    "note": "host-pointer MSM entry points (window tables rebuilt per call); latency of a single small proof, not a throughput figure"}
+                    "note": "host-pointer one-shot MSM entry points; latency of a single small proof, not a throughput figure"}
 print(json.dumps(res, indent=1))
