@@ -18,7 +18,7 @@
  *   zkt_g1_affine / zkt_g2_affine / zkt_secp_affine: {x, y, is_infinity} mirroring
  *        enum {Rational{x,y}, AtInfinity} (g1_point.rs:32-36, g2_point.rs:30-34,
  *        secp256k1/affine_point.rs:23-27); x = y = 0 when is_infinity != 0.
- * Montgomery form, projective coordinates and 32-bit limbs are internal to the kernels.
+ * Montgomery form, projective coordinates and the limb layout (28-bit limbs for Fq, 32-bit for the 256-bit fields) are internal to the kernels.
  *
  * Errors: the reference panics (inverse of zero prime_field_elem.rs:380-382,434-436;
  * line through / evaluation at infinity rational_function.rs:36,59; index mismatch
@@ -199,7 +199,7 @@ int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, c
                        const uint64_t* rnd, const zkt_secp_affine* u, const uint64_t* xs, zkt_secp_affine* out_pts);
 
 /* ---- device-resident entry points (inputs/outputs already in HBM) -------------------- */
-/* Bases kept on the device in kernel layout (Montgomery x,y, 96 B each) — the analogue of
+/* Bases kept on the device in kernel layout (internal limb form, x and y, 112 B per G1 point) — the analogue of
  * a CRS that is uploaded once (crs.rs:85-135) and reused by every prove call. */
 typedef struct zkt_g1_bases zkt_g1_bases;
 int zkt_g1_bases_upload(const zkt_g1_affine* host_bases, size_t n, zkt_g1_bases** out);

@@ -7,14 +7,17 @@
 // MI355X-first design:
 //  * bases are device-resident (a CRS is uploaded once and reused by every proof) and,
 //    because HBM is 288 GB, every base is stored together with its window multiples
-//    2^(c*w) * P_i  (nwin * n affine points, 96 B each).  All windows then share ONE set
+//    2^(c*w) * P_i  (nwin * n affine points, 112 B each for G1).  All windows then share ONE set
 //    of 2^(c-1) buckets: there is no per-window bucket reduction and no final Horner
 //    chain of 256 serial doublings — on this machine a serial Fq multiply costs ~1.1 us
 //    per lane, so serial chains, not FLOPs, are what must be designed away.
 //  * signed c-bit digits (scalars used as-is, 256 bits: macros.rs:10-21), counting sort of
 //    (bucket, point) pairs, one bucket per lane accumulating in XYZZ coordinates with
-//    complete mixed additions (P+P, P+(-P), infinity: macros.rs:43-63), gather of 96-byte
+//    complete mixed additions (P+P, P+(-P), infinity: macros.rs:43-63), gather of 112-byte
 //    affine points, then a two-level bucket reduction built from short trees.
+//  * one-shot calls with host pointers use the DIRECT form instead (msm_plan_direct): no table, every window owns its
+//    buckets, all windows are reduced side by side (grid.y) and joined by one wave — the serial doubling chain is paid once
+//    per call instead of a table build that costs 40x a resident MSM.
 #include <cstdlib>
 #include "abi.h"
 #include "zkt_internal.h"
