@@ -245,3 +245,20 @@ def test_msm_adversarial_pool(L, name, W, order, gen_fn):
     for i in range(n):
         nxt = np.zeros_like(acc); assert getattr(O, f"zkto_{name}_add_batch")(ptr(acc), ptr(tmp[i:i + 1].copy()), ptr(nxt), 1) == 0; acc = nxt
     assert (got == acc).all()
+
+
+@pytest.mark.parametrize("n", [4097, 70001, 300000])
+def test_g1_one_shot_msm_sizes_by_linearity(L, n):
+    """One-shot calls use the table-free form whose window size follows n (msm_plan_direct: c = 9..16): odd sizes on both sides of the
+    window-size steps, checked by linearity — bases k_i*G, so the sum is (sum k_i s_i mod r)*G in python integers."""
+    rng = np.random.Generator(np.random.PCG64(2024 + n))
+    ks = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64); ks[:, 3] >>= np.uint64(2)
+    ss = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64); ss[:, 3] >>= np.uint64(2)
+    ss[0] = 0; ss[1] = [1, 0, 0, 0]; ss[n - 1] = int_to_limbs(R - 1, 4)
+    g = g1_arr([G1_GEN])
+    bases = np.zeros((n, G1W), np.uint64)
+    zk.check(L.zkt_g1_mul_batch(ptr(np.repeat(g, n, axis=0)), ptr(ks), 4, ptr(bases), n))
+    got = np.zeros((1, G1W), np.uint64)
+    zk.check(L.zkt_g1_msm(ptr(bases), ptr(ss), n, ptr(got)))
+    tot = sum(limbs_to_int(a) * limbs_to_int(b) for a, b in zip(ks, ss)) % R
+    assert (got == g1_arr([py_g1_mul(G1_GEN, tot)])).all()
