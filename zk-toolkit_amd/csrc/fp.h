@@ -302,8 +302,13 @@ template <class C, bool SUB> ZKT_HD Fp<C> fp_mul2_impl(const Fp<C>& a, const Fp<
 #if !defined(ZKT_INLINE_MUL)
 template <class C> ZKT_FN Fp<C> fp_mul(Fp<C> a, Fp<C> b) { return fp_mul_impl(a, b); }
 template <class C> ZKT_FN Fp<C> fp_sqr_fn(Fp<C> a) { return fp_sqr_impl(a); }
+#if defined(ZKT_INLINE_MUL2)     // four 14-register operands exceed the 32 argument VGPRs of the calling convention: inline the two-product form only
+template <class C> ZKT_HD Fp<C> fp_mulsub_fn(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d) { return fp_mul2_impl<C, true>(a, b, c, d); }
+template <class C> ZKT_HD Fp<C> fp_muladd_fn(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c, const Fp<C>& d) { return fp_mul2_impl<C, false>(a, b, c, d); }
+#else
 template <class C> ZKT_FN Fp<C> fp_mulsub_fn(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d) { return fp_mul2_impl<C, true>(a, b, c, d); }
 template <class C> ZKT_FN Fp<C> fp_muladd_fn(Fp<C> a, Fp<C> b, Fp<C> c, Fp<C> d) { return fp_mul2_impl<C, false>(a, b, c, d); }
+#endif
 #else
 template <class C> ZKT_HD Fp<C> fp_mul(const Fp<C>& a, const Fp<C>& b) { return fp_mul_impl(a, b); }
 template <class C> ZKT_HD Fp<C> fp_sqr_fn(const Fp<C>& a) { return fp_sqr_impl(a); }
