@@ -70,7 +70,7 @@ template <class F> ZKT_HD Jac<F> jac_dbl(const Jac<F>& p) {
   E Ee = F::add(F::dbl(A), A);
   E Ff = F::sqr(Ee);
   Jac<F> r;
-  r.X = F::sub(Ff, F::dbl(D));
+  r.X = F::sub2(Ff, F::zero(), D);
   E C8 = F::dbl(F::dbl(F::dbl(C)));
   r.Y = F::sub(F::mul(Ee, F::sub(D, r.X)), C8);
   r.Z = F::dbl(F::mul(p.Y, p.Z));
@@ -94,8 +94,8 @@ template <class F> ZKT_HD Jac<F> jac_add_aff(const Jac<F>& p, const Aff<F>& q) {
   }
   E HH = F::sqr(H), HHH = F::mul(H, HH), V = F::mul(p.X, HH);
   Jac<F> r;
-  r.X = F::sub(F::sub(F::sqr(Rr), HHH), F::dbl(V));
-  r.Y = F::sub(F::mul(Rr, F::sub(V, r.X)), F::mul(p.Y, HHH));
+  r.X = F::sub2(F::sqr(Rr), HHH, V);
+  r.Y = F::mulsub(Rr, F::sub(V, r.X), p.Y, HHH);
   r.Z = F::mul(p.Z, H);
   return r;
 }
@@ -115,8 +115,8 @@ template <class F> ZKT_HD Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
   }
   E HH = F::sqr(H), HHH = F::mul(H, HH), V = F::mul(U1, HH);
   Jac<F> r;
-  r.X = F::sub(F::sub(F::sqr(Rr), HHH), F::dbl(V));
-  r.Y = F::sub(F::mul(Rr, F::sub(V, r.X)), F::mul(S1, HHH));
+  r.X = F::sub2(F::sqr(Rr), HHH, V);
+  r.Y = F::mulsub(Rr, F::sub(V, r.X), S1, HHH);
   r.Z = F::mul(F::mul(p.Z, q.Z), H);
   return r;
 }

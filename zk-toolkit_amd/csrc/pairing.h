@@ -37,7 +37,7 @@ ZKT_FN void miller_dbl_step(MillerPt& V, const Fq2& Xq, const Fq2& Yq, MillerLin
   Fq t = fp_sqr(fp_add(X, B));
   Fq D = fp_dbl(fp_sub(fp_sub(t, A), C));
   Fq E = fp_add(fp_dbl(A), A);
-  Fq X3 = fp_sub(fp_sqr(E), fp_dbl(D));
+  Fq X3 = fp_sub2(fp_sqr(E), fp_zero<FqC>(), D);
   Fq Y3 = fp_sub(fp_mul(E, fp_sub(D, X3)), fp_dbl(fp_dbl(fp_dbl(C))));
   Fq Z3 = fp_dbl(fp_mul(Y, Z));
   l.a = fp_sub(fp_mul(E, X), fp_dbl(B));
@@ -50,10 +50,10 @@ ZKT_FN void miller_add_step(MillerPt& V, const Fq& xp, const Fq& yp, const Fq2& 
   const Fq X = V.X, Y = V.Y, Z = V.Z;
   Fq ZZ = fp_sqr(Z), H = fp_sub(fp_mul(xp, ZZ), X), Rr = fp_sub(fp_mul(fp_mul(yp, ZZ), Z), Y);
   Fq HH = fp_sqr(H), HHH = fp_mul(H, HH), Vv = fp_mul(X, HH);
-  Fq X3 = fp_sub(fp_sub(fp_sqr(Rr), HHH), fp_dbl(Vv));
-  Fq Y3 = fp_sub(fp_mul(Rr, fp_sub(Vv, X3)), fp_mul(Y, HHH));
+  Fq X3 = fp_sub2(fp_sqr(Rr), HHH, Vv);
+  Fq Y3 = fp_mulsub(Rr, fp_sub(Vv, X3), Y, HHH);
   Fq Z3 = fp_mul(Z, H);
-  l.a = fp_sub(fp_mul(Rr, xp), fp_mul(Z3, yp));
+  l.a = fp_mulsub(Rr, xp, Z3, yp);
   l.b = fq2_mul_fq(Xq, fp_neg(Rr));
   l.c = fq2_mul_fq(Yq, Z3);
   V.X = X3; V.Y = Y3; V.Z = Z3;
