@@ -49,7 +49,7 @@ def _fq_program_model(seed, steps, regs):
     r = list(regs)
     for _ in range(steps):
         st = (st * 6364136223846793005 + 1442695040888963407) & (2**64 - 1)
-        op, d, a, b = (st >> 33) % 13, (st >> 40) & 3, (st >> 42) & 3, (st >> 44) & 3
+        op, d, a, b = (st >> 33) % 16, (st >> 40) & 3, (st >> 42) & 3, (st >> 44) & 3
         if op in (0, 1): r[d] = (r[a] + r[b]) % Q
         elif op in (2, 3): r[d] = (r[a] - r[b]) % Q
         elif op == 4: r[d] = -r[a] % Q
@@ -60,6 +60,9 @@ def _fq_program_model(seed, steps, regs):
         elif op == 10: r[d] = (r[a] - r[b] - 2 * r[(b + 1) & 3]) % Q
         elif op == 11: r[d] = (r[a] * r[b] - r[(a + 1) & 3] * r[(b + 2) & 3]) % Q
         elif op == 12: r[d] = (r[a] * r[b] + r[(a + 1) & 3] * r[(b + 2) & 3]) % Q
+        elif op == 13: r[d] = (r[a] + r[b] + r[(b + 1) & 3]) % Q
+        elif op == 14: r[d] = (r[a] + r[b] - r[(b + 1) & 3]) % Q
+        elif op == 15: r[d] = (r[a] - r[b] - r[(b + 1) & 3]) % Q
         else: r[d] = 1 if r[a] == r[b] else (r[a] + 1) % Q
     return r
 

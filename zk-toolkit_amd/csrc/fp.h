@@ -164,6 +164,34 @@ template <class C> ZKT_HD bool fp_eq(const Fp<C>& a, const Fp<C>& b) {
   }
 }
 template <class C> ZKT_HD Fp<C> fp_dbl(const Fp<C>& a) { return fp_add(a, a); }
+// three-term sums in ONE reduction pass (the tower's Karatsuba recombinations): all operands normalised (< 4p, limbs < 2^28)
+//   fp_add3   a + b + c          limbs < 3*2^28, value < 12p
+//   fp_addsub a + b - c          a + b + 8p - c < 16p
+//   fp_subsub a - b - c          a + 16p - b - c < 20p (the 16p spread covers two subtrahend limbs)
+template <class C> ZKT_HD Fp<C> fp_add3(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c) {
+  if constexpr (C::W == 28) {
+    uint32_t v[C::N];
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) v[i] = a.v[i] + b.v[i] + c.v[i];
+    return fp_lazy_reduce<C>(v);
+  } else return fp_add(fp_add(a, b), c);
+}
+template <class C> ZKT_HD Fp<C> fp_addsub(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c) {
+  if constexpr (C::W == 28) {
+    uint32_t v[C::N];
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) v[i] = a.v[i] + b.v[i] + C::subk(i) - c.v[i];
+    return fp_lazy_reduce<C>(v);
+  } else return fp_sub(fp_add(a, b), c);
+}
+template <class C> ZKT_HD Fp<C> fp_subsub(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c) {
+  if constexpr (C::W == 28) {
+    uint32_t v[C::N];
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) v[i] = a.v[i] + C::subk3(i) - b.v[i] - c.v[i];
+    return fp_lazy_reduce<C>(v);
+  } else return fp_sub(fp_sub(a, b), c);
+}
 // a - b - 2c in one reduction pass (the x-coordinate of every addition formula).  W = 28: a + 16p - b - 2c with 16p spread so that
 // no limb borrows (limbs < 2^31, value < 20p: the quotient estimate of fp_lazy_reduce still leaves < 4p, tests/test_hostcheck.py).
 template <class C> ZKT_HD Fp<C> fp_sub2(const Fp<C>& a, const Fp<C>& b, const Fp<C>& c) {

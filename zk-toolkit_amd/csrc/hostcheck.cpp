@@ -34,7 +34,7 @@ int zkt_hostcheck_fq_program(uint64_t seed, int steps, const uint32_t* in4, uint
   uint64_t st = seed;
   for (int k = 0; k < steps; ++k) {
     st = st * 6364136223846793005ull + 1442695040888963407ull;
-    const int op = (int)((st >> 33) % 13), d = (int)((st >> 40) & 3), a = (int)((st >> 42) & 3), b = (int)((st >> 44) & 3), j = (int)((st >> 46) % 3);
+    const int op = (int)((st >> 33) % 16), d = (int)((st >> 40) & 3), a = (int)((st >> 42) & 3), b = (int)((st >> 44) & 3), j = (int)((st >> 46) % 3);
     switch (op) {
       case 0: case 1: r[d] = fp_add(r[a], r[b]); break;
       case 2: case 3: r[d] = fp_sub(r[a], r[b]); break;
@@ -46,6 +46,9 @@ int zkt_hostcheck_fq_program(uint64_t seed, int steps, const uint32_t* in4, uint
       case 10: r[d] = fp_sub2(r[a], r[b], r[(b + 1) & 3]); break;                       // a - b - 2c, one reduction
       case 11: r[d] = fp_mulsub(r[a], r[b], r[(a + 1) & 3], r[(b + 2) & 3]); break;     // a b - c d, one Montgomery reduction
       case 12: r[d] = fp_muladd(r[a], r[b], r[(a + 1) & 3], r[(b + 2) & 3]); break;     // a b + c d
+      case 13: r[d] = fp_add3(r[a], r[b], r[(b + 1) & 3]); break;
+      case 14: r[d] = fp_addsub(r[a], r[b], r[(b + 1) & 3]); break;
+      case 15: r[d] = fp_subsub(r[a], r[b], r[(b + 1) & 3]); break;
       default: {                                           // predicates must see through the representative
         Fq z = fp_sub(fq_lift(r[a], j), r[a]);
         if (!fp_is_zero(z) || !fp_eq(fq_lift(r[a], j), r[a]) || fp_is_zero(r[a]) != fp_is_zero(fq_lift(r[a], (j + 1) % 3))) ++bad;

@@ -48,6 +48,10 @@ ZKT_FQ2 Fq2 fq2_sqr(const Fq2& a) {                                      // fq2.
 ZKT_HD Fq2 fq2_mul_fq(const Fq2& a, const Fq& s) { return Fq2{fp_mul(a.c0, s), fp_mul(a.c1, s)}; }
 ZKT_HD Fq2 fq2_sub2(const Fq2& a, const Fq2& b, const Fq2& c) { return Fq2{fp_sub2(a.c0, b.c0, c.c0), fp_sub2(a.c1, b.c1, c.c1)}; }   // a - b - 2c
 ZKT_HD Fq2 fq2_mulsub(const Fq2& a, const Fq2& b, const Fq2& c, const Fq2& d) { return fq2_sub(fq2_mul(a, b), fq2_mul(c, d)); }          // a b - c d
+ZKT_HD Fq2 fq2_subsub(const Fq2& a, const Fq2& b, const Fq2& c) { return Fq2{fp_subsub(a.c0, b.c0, c.c0), fp_subsub(a.c1, b.c1, c.c1)}; }   // a - b - c, one pass
+ZKT_HD Fq2 fq2_add_mul_xi(const Fq2& v, const Fq2& t) { return Fq2{fp_addsub(v.c0, t.c0, t.c1), fp_add3(v.c1, t.c0, t.c1)}; }               // v + xi t, one pass
+ZKT_HD Fq2 fq2_subsub_mul_xi(const Fq2& a, const Fq2& b, const Fq2& t) {                                                                        // a - b - xi t
+  return Fq2{fp_addsub(a.c0, t.c1, fp_add(b.c0, t.c0)), fp_subsub(a.c1, b.c1, fp_add(t.c0, t.c1))}; }
 ZKT_HD Fq2 fq2_from_fq(const Fq& a) { return Fq2{a, fp_zero<FqC>()}; }
 // an Fq2 constant from its two limb tables
 template <class F0, class F1> ZKT_HD Fq2 fq2_const(F0 c0_limb, F1 c1_limb) {
@@ -107,6 +111,7 @@ __device__ inline Fq2 fq2_mul(const Fq2& a, const Fq2& b) {
   return Fq2{fp_muladd(a.h, y1, oa, nd)};                 // nd may carry 30-bit limbs: the second factor of fp_mul2 need not be normalised
 }
 __device__ inline Fq2 fq2_mulsub(const Fq2& a, const Fq2& b, const Fq2& c, const Fq2& d) { return fq2_sub(fq2_mul(a, b), fq2_mul(c, d)); }
+__device__ inline Fq2 fq2_subsub(const Fq2& a, const Fq2& b, const Fq2& c) { return Fq2{fp_subsub(a.h, b.h, c.h)}; }
 // even: (a0 + a1)(a0 - a1)        odd: (a1 + a1) a0
 __device__ inline Fq2 fq2_sqr(const Fq2& a) {
   const bool odd = fq2_odd();
@@ -123,6 +128,8 @@ __device__ inline Fq2 fq2_mul_xi(const Fq2& a) {
   for (int i = 0; i < FqC::N; ++i) v[i] = a.h.v[i] + (odd ? oa.v[i] : FqC::subk(i) - oa.v[i]);
   return Fq2{fp_lazy_reduce<FqC>(v)};
 }
+__device__ inline Fq2 fq2_add_mul_xi(const Fq2& v, const Fq2& t) { return fq2_add(v, fq2_mul_xi(t)); }
+__device__ inline Fq2 fq2_subsub_mul_xi(const Fq2& a, const Fq2& b, const Fq2& t) { return fq2_subsub(a, b, fq2_mul_xi(t)); }
 __device__ inline __attribute__((noinline)) Fq2 fq2_inv(const Fq2& a) {   // fq2.rs:26-32: conj / norm; both lanes invert the same norm
   const Fq sq = fp_sqr(a.h);
   const Fq t = fp_inv(fp_add(sq, fq_partner(sq)));
@@ -141,10 +148,10 @@ ZKT_HD Fq6 fq6_mul_v(const Fq6& a) { return Fq6{fq2_mul_xi(a.c2), a.c0, a.c1}; }
 // fq6.rs:148-166 is the 9-product schoolbook; Karatsuba (6 products) gives the same element
 ZKT_HD Fq6 fq6_mul_inl(const Fq6& a, const Fq6& b) {
   Fq2 v0 = fq2_mul(a.c0, b.c0), v1 = fq2_mul(a.c1, b.c1), v2 = fq2_mul(a.c2, b.c2);
-  Fq2 t0 = fq2_sub(fq2_sub(fq2_mul(fq2_add(a.c1, a.c2), fq2_add(b.c1, b.c2)), v1), v2);
-  Fq2 t1 = fq2_sub(fq2_sub(fq2_mul(fq2_add(a.c0, a.c1), fq2_add(b.c0, b.c1)), v0), v1);
-  Fq2 t2 = fq2_sub(fq2_sub(fq2_mul(fq2_add(a.c0, a.c2), fq2_add(b.c0, b.c2)), v0), v2);
-  return Fq6{fq2_add(v0, fq2_mul_xi(t0)), fq2_add(t1, fq2_mul_xi(v2)), fq2_add(t2, v1)};
+  Fq2 t0 = fq2_subsub(fq2_mul(fq2_add(a.c1, a.c2), fq2_add(b.c1, b.c2)), v1, v2);      // three-term recombinations: one reduction pass each
+  Fq2 t1 = fq2_subsub(fq2_mul(fq2_add(a.c0, a.c1), fq2_add(b.c0, b.c1)), v0, v1);
+  Fq2 t2 = fq2_subsub(fq2_mul(fq2_add(a.c0, a.c2), fq2_add(b.c0, b.c2)), v0, v2);
+  return Fq6{fq2_add_mul_xi(v0, t0), fq2_add_mul_xi(t1, v2), fq2_add(t2, v1)};
 }
 ZKT_FN Fq6 fq6_mul(const Fq6& a, const Fq6& b) { return fq6_mul_inl(a, b); }
 // inside the Fq12 square/product the Fq6 products are inlined (ZKT_FQ6_INLINE): operands and partial results stay in the
@@ -172,12 +179,17 @@ ZKT_HD Fq12 fq12_conj(const Fq12& a) { return Fq12{a.c0, fq6_neg(a.c1)}; }
 ZKT_FN Fq12 fq12_mul(const Fq12& a, const Fq12& b) {
   Fq6 v0 = FQ6_MUL12(a.c0, b.c0), v1 = FQ6_MUL12(a.c1, b.c1);
   Fq6 s = FQ6_MUL12(fq6_add(a.c0, a.c1), fq6_add(b.c0, b.c1));
-  return Fq12{fq6_add(v0, fq6_mul_v(v1)), fq6_sub(fq6_sub(s, v0), v1)};
+  Fq12 r;
+  r.c0.c0 = fq2_add_mul_xi(v0.c0, v1.c2); r.c0.c1 = fq2_add(v0.c1, v1.c0); r.c0.c2 = fq2_add(v0.c2, v1.c1);                   // v0 + v * v1
+  r.c1.c0 = fq2_subsub(s.c0, v0.c0, v1.c0); r.c1.c1 = fq2_subsub(s.c1, v0.c1, v1.c1); r.c1.c2 = fq2_subsub(s.c2, v0.c2, v1.c2);
+  return r;
 }
 // complex squaring: (a0 + a1 w)^2 = (a0+a1)(a0+v a1) - v0 - v v0 + 2 v0 w,  v0 = a0 a1
 ZKT_FN Fq12 fq12_sqr(const Fq12& a) {
   Fq6 v0 = FQ6_MUL12(a.c0, a.c1);
   Fq6 t = FQ6_MUL12(fq6_add(a.c0, a.c1), fq6_add(a.c0, fq6_mul_v(a.c1)));
+  // (left as two-term passes: restructuring this return into three-term passes trips an AMDGPU backend error at -O1 —
+  //  "Illegal instruction detected: Operand has incorrect register class ... $src_private_base" — in the verification kernels)
   return Fq12{fq6_sub(fq6_sub(t, v0), fq6_mul_v(v0)), fq6_add(v0, v0)};
 }
 ZKT_FN Fq12 fq12_inv(const Fq12& a) {                                    // fq12.rs:31-40
