@@ -273,6 +273,10 @@ int zkt_groth16_prove_r1cs(zkt_groth16_pk* pk, const uint64_t* wires, const uint
 /* the same with the wires already in HBM (device pointer) */
 int zkt_groth16_prove_r1cs_dev(zkt_groth16_pk* pk, const uint64_t* dev_wires, const uint64_t* r, const uint64_t* s,
                                zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* C);
+/* Pipelined form: two proofs in flight on one (unsharded) key, the Fr stage of the next proof under the MSMs of the current one.
+ * slot is 0 or 1; collect a slot before submitting it again. */
+int zkt_groth16_prove_r1cs_submit(zkt_groth16_pk* pk, int slot, const uint64_t* dev_wires, const uint64_t* r, const uint64_t* s);
+int zkt_groth16_prove_r1cs_collect(zkt_groth16_pk* pk, int slot, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* C);
 /* Multi-GPU form (BASELINE config 4): rank `shard` of `nshards` keeps a contiguous index range of each resident base set.  A proof is
  * then zkt_groth16_prove_r1cs_partials on every rank (dev_partials: ZKT_GROTH16_PARTIAL_WORDS u32 = the Jacobian partials of A, B, C),
  * an all_gather of those, and zkt_g1_jac_sum_dev / zkt_g2_jac_sum_dev / zkt_g1_jac_sum_dev over the gathered A, B, C columns

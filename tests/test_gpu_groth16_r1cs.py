@@ -135,3 +135,32 @@ def test_r1cs_path_all_wires_public(L):
         assert (a == b).all(), f"proof element {name} differs"
     assert L.zkt_groth16_verify(ctypes.byref(vk), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(wires), l + 1) == 1
     L.zkt_groth16_pk_free(pk)
+
+
+def test_r1cs_pipelined_proofs_equal_sequential(L):
+    """zkt_groth16_prove_r1cs_submit / _collect: two proofs in flight on one key give the very proofs the blocking call gives."""
+    import torch
+    n = 300
+    mats, wires, l, m = chain_circuit_sparse(n, seed=21)
+    rng = SplitMix64(555)
+    trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+    vk, vbuf, pk = _r1cs_setup(L, mats, n, l, m, trap)
+    d_w = torch.from_numpy(wires.view(np.int64)).cuda()
+    rs = [(fr(rng.below(R - 1) + 1), fr(rng.below(R - 1) + 1)) for _ in range(5)]
+    new = lambda: (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+    seq = []
+    for r, s in rs:
+        p = new(); zk.check(L.zkt_groth16_prove_r1cs_dev(pk, d_w.data_ptr(), r.ctypes.data, s.ctypes.data, *[x.ctypes.data for x in p])); seq.append(p)
+    pip = [new() for _ in rs]
+    zk.check(L.zkt_groth16_prove_r1cs_submit(pk, 0, d_w.data_ptr(), rs[0][0].ctypes.data, rs[0][1].ctypes.data))
+    assert L.zkt_groth16_prove_r1cs_submit(pk, 0, d_w.data_ptr(), rs[0][0].ctypes.data, rs[0][1].ctypes.data) == ZKT_ERR_SHAPE     # slot still in flight
+    for i in range(len(rs)):
+        if i + 1 < len(rs):
+            zk.check(L.zkt_groth16_prove_r1cs_submit(pk, (i + 1) % 2, d_w.data_ptr(), rs[i + 1][0].ctypes.data, rs[i + 1][1].ctypes.data))
+        zk.check(L.zkt_groth16_prove_r1cs_collect(pk, i % 2, *[x.ctypes.data for x in pip[i]]))
+    for a, b in zip(seq, pip):
+        assert all((x == y).all() for x, y in zip(a, b))
+    assert len({seq[i][0].tobytes() for i in range(len(rs))}) == len(rs)          # different r, s -> different proofs
+    stmt = wires[:l + 1].copy()
+    assert L.zkt_groth16_verify(ctypes.byref(vk), ptr(pip[-1][0]), ptr(pip[-1][1]), ptr(pip[-1][2]), ptr(stmt), l + 1) == 1
+    L.zkt_groth16_pk_free(pk)

@@ -57,6 +57,8 @@ def lib():
         L.zkt_groth16_prove_r1cs_dev.argtypes = [vp] * 7
         L.zkt_groth16_setup_r1cs_sharded.argtypes = [ctypes.c_size_t] * 3 + [vp] * 8 + [ctypes.c_size_t] * 2 + [vp] * 2
         L.zkt_groth16_prove_r1cs_partials.argtypes = [vp] * 5
+        L.zkt_groth16_prove_r1cs_submit.argtypes = [vp, ctypes.c_int, vp, vp, vp]
+        L.zkt_groth16_prove_r1cs_collect.argtypes = [vp, ctypes.c_int, vp, vp, vp]
         L.zkt_groth16_pk_free.argtypes = [vp]; L.zkt_groth16_pk_free.restype = None
         sz = ctypes.c_size_t
         L.zkt_pairing_product_check_batch.argtypes = [vp, vp, vp, sz, sz, vp]

@@ -382,7 +382,11 @@ struct zkt_groth16_pk {
   size_t nA = 0, nC = 0;
   size_t loA = 0, hiA = 0, loC = 0, hiC = 0;     // this shard's index range of the A/B sets and of the C set (whole sets when unsharded)
   size_t shard = 0, nshards = 1;
-  DBuf wires_c, wires_m, z_m[3], f[3], sA, sB, sC, rs;   // per-proof work buffers
+  // per-proof work buffers.  The MSM scalar vectors (and r, s) are double-buffered: proof k+1's Fr stage may run while the MSMs of proof k
+  // are still reading theirs (zkt_groth16_prove_r1cs_submit / _collect); everything else is consumed in stream order before it is rewritten.
+  static constexpr int PSLOTS = 2;
+  DBuf wires_c, wires_m, z_m[3], f[3], sA[PSLOTS], sB[PSLOTS], sC[PSLOTS], rs[PSLOTS];
+  bool pending[PSLOTS] = {false, false};
   hipStream_t s = nullptr;
   ~zkt_groth16_pk() {
     if (setA) zkt_g1_bases_free(setA); if (setC) zkt_g1_bases_free(setC); if (setB) zkt_g2_bases_free(setB);
@@ -501,8 +505,8 @@ int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_spars
   vk->n = n; vk->l = l; vk->m = m;
 
   // ---- per-proof work buffers ----
-  ZCHK(pk->wires_c.alloc(rows * FRB)); ZCHK(pk->wires_m.alloc(rows * FRB)); ZCHK(pk->rs.alloc(2 * FRB));
-  ZCHK(pk->sA.alloc(nA * FRB)); ZCHK(pk->sB.alloc(nA * FRB)); ZCHK(pk->sC.alloc(nC * FRB));
+  ZCHK(pk->wires_c.alloc(rows * FRB)); ZCHK(pk->wires_m.alloc(rows * FRB));
+  for (int k = 0; k < zkt_groth16_pk::PSLOTS; ++k) { ZCHK(pk->rs[k].alloc(2 * FRB)); ZCHK(pk->sA[k].alloc(nA * FRB)); ZCHK(pk->sB[k].alloc(nA * FRB)); ZCHK(pk->sC[k].alloc(nC * FRB)); }
   for (int k = 0; k < 3; ++k) { ZCHK(pk->z_m[k].alloc(n * FRB)); ZCHK(pk->f[k].alloc(N * FRB)); }
   *out = pk.release();
   return ZKT_OK;
@@ -516,25 +520,25 @@ int zkt_groth16_setup_r1cs(size_t n, size_t l, size_t m, const zkt_sparse_rows* 
 void zkt_groth16_pk_free(zkt_groth16_pk* pk) { delete pk; }
 
 // Prover::prove (prover.rs:96-147) with r, s injected; wires = a_0..a_m canonical, on the host or (…_dev) already in HBM.
-static int prove_impl(zkt_groth16_pk* pk, const uint64_t* wires, bool wires_on_device, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp,
-                      uint32_t* dev_partials = nullptr) {
+// enqueue one proof: the Fr stage on the key's stream, the three MSMs on their base sets' pipelines (MSM slot = proof slot)
+static int prove_submit(zkt_groth16_pk* pk, int ps, const uint64_t* wires, bool wires_on_device, const uint64_t* r, const uint64_t* s_) {
   if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
-  if (!pk || !wires || !r || !s_) return ZKT_ERR_SHAPE;
-  if (dev_partials ? false : (!A || !B || !Cp || pk->nshards != 1)) return ZKT_ERR_SHAPE;      // a shard can only produce partials
+  if (!pk || !wires || !r || !s_ || ps < 0 || ps >= zkt_groth16_pk::PSLOTS || pk->pending[ps]) return ZKT_ERR_SHAPE;
   const size_t n = pk->n, l = pk->l, m = pk->m, rows = m + 1, N = pk->N, nw = m - l;
   hipStream_t s = pk->s;
+  DBuf &sA = pk->sA[ps], &sB = pk->sB[ps], &sC = pk->sC[ps], &drs = pk->rs[ps];
   uint64_t rs[8]; memcpy(rs, r, 32); memcpy(rs + 4, s_, 32);
-  RCHK(hipMemcpyAsync(pk->rs.p, rs, 64, hipMemcpyHostToDevice, s));
+  RCHK(hipMemcpyAsync(drs.p, rs, 64, hipMemcpyHostToDevice, s));
   RCHK(hipMemcpyAsync(pk->wires_c.p, wires, rows * FRB, wires_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_to_mont, dim3(nb(rows)), dim3(256), 0, s, (const uint32_t*)pk->wires_c.w(), pk->wires_m.w(), rows);
   Csr* M[3] = {&pk->A, &pk->B, &pk->Cm};
   for (int k = 0; k < 3; ++k) spmv(*M[k], pk->wires_m.w(), pk->z_m[k].w(), s);
   hipLaunchKernelGGL(k_prove_scalars, dim3(nb(n + nw + 1)), dim3(256), 0, s, (const uint32_t*)pk->z_m[0].w(), (const uint32_t*)pk->z_m[1].w(), (const uint32_t*)pk->wires_c.w(),
-                     (const uint32_t*)pk->rs.w(), n, l, m, pk->sA.w(), pk->sB.w(), pk->sC.w());
+                     (const uint32_t*)drs.w(), n, l, m, sA.w(), sB.w(), sC.w());
   RCHK(hipGetLastError());
   // A and B only need (A w) and (B w): they start now and run under the quotient stage
-  ZCHK(zkt_g2_msm_submit(pk->setB, (const uint64_t*)(pk->sB.w() + pk->loA * FW), pk->hiA - pk->loA, s, 0));
-  ZCHK(zkt_g1_msm_submit(pk->setA, (const uint64_t*)(pk->sA.w() + pk->loA * FW), pk->hiA - pk->loA, s, 0));
+  ZCHK(zkt_g2_msm_submit(pk->setB, (const uint64_t*)(sB.w() + pk->loA * FW), pk->hiA - pk->loA, s, ps));
+  ZCHK(zkt_g1_msm_submit(pk->setA, (const uint64_t*)(sA.w() + pk->loA * FW), pk->hiA - pk->loA, s, ps));
   if (n >= 2) {
     for (int k = 0; k < 3; ++k) {
       hipLaunchKernelGGL(k_prep_f, dim3(nb(N)), dim3(256), 0, s, (const uint32_t*)pk->z_m[k].w(), (const uint32_t*)pk->cinv.w(), n, N, pk->f[k].w());
@@ -542,20 +546,44 @@ static int prove_impl(zkt_groth16_pk* pk, const uint64_t* wires, bool wires_on_d
       ZCHK(ntt_inverse(pk->f[k].w(), pk->logN, pk->twinv.w(), s));
     }
     hipLaunchKernelGGL(k_hvals, dim3(nb(n - 1)), dim3(256), 0, s, (const uint32_t*)pk->f[0].w(), (const uint32_t*)pk->f[1].w(), (const uint32_t*)pk->f[2].w(), (const uint32_t*)pk->P.w(), n,
-                       pk->sC.w() + (n + nw) * FW);
+                       sC.w() + (n + nw) * FW);
     RCHK(hipGetLastError());
   }
-  ZCHK(zkt_g1_msm_submit(pk->setC, (const uint64_t*)(pk->sC.w() + pk->loC * FW), pk->hiC - pk->loC, s, 0));
+  ZCHK(zkt_g1_msm_submit(pk->setC, (const uint64_t*)(sC.w() + pk->loC * FW), pk->hiC - pk->loC, s, ps));
+  pk->pending[ps] = true;
+  return ZKT_OK;
+}
+static int prove_collect(zkt_groth16_pk* pk, int ps, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp, uint32_t* dev_partials) {
+  if (!pk || ps < 0 || ps >= zkt_groth16_pk::PSLOTS || !pk->pending[ps]) return ZKT_ERR_SHAPE;
+  if (dev_partials ? false : (!A || !B || !Cp || pk->nshards != 1)) return ZKT_ERR_SHAPE;      // a shard can only produce partials
+  pk->pending[ps] = false;
   if (dev_partials) {            // [A: ZKT_G1_PARTIAL_WORDS | B: ZKT_G2_PARTIAL_WORDS | C: ZKT_G1_PARTIAL_WORDS]
-    ZCHK(zkt_g1_msm_collect(pk->setA, 0, nullptr, dev_partials)); ZCHK(zkt_g2_msm_collect(pk->setB, 0, nullptr, dev_partials + ZKT_G1_PARTIAL_WORDS));
-    ZCHK(zkt_g1_msm_collect(pk->setC, 0, nullptr, dev_partials + ZKT_G1_PARTIAL_WORDS + ZKT_G2_PARTIAL_WORDS));
+    ZCHK(zkt_g1_msm_collect(pk->setA, ps, nullptr, dev_partials)); ZCHK(zkt_g2_msm_collect(pk->setB, ps, nullptr, dev_partials + ZKT_G1_PARTIAL_WORDS));
+    ZCHK(zkt_g1_msm_collect(pk->setC, ps, nullptr, dev_partials + ZKT_G1_PARTIAL_WORDS + ZKT_G2_PARTIAL_WORDS));
     return ZKT_OK;
   }
-  ZCHK(zkt_g1_msm_collect(pk->setA, 0, A, nullptr)); ZCHK(zkt_g2_msm_collect(pk->setB, 0, B, nullptr)); ZCHK(zkt_g1_msm_collect(pk->setC, 0, Cp, nullptr));
+  ZCHK(zkt_g1_msm_collect(pk->setA, ps, A, nullptr)); ZCHK(zkt_g2_msm_collect(pk->setB, ps, B, nullptr)); ZCHK(zkt_g1_msm_collect(pk->setC, ps, Cp, nullptr));
   return ZKT_OK;
+}
+// Prover::prove (prover.rs:96-147) with r, s injected; wires = a_0..a_m canonical, on the host or (…_dev) already in HBM.
+static int prove_impl(zkt_groth16_pk* pk, const uint64_t* wires, bool wires_on_device, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp,
+                      uint32_t* dev_partials = nullptr) {
+  if (!pk) return ZKT_ERR_SHAPE;
+  if (dev_partials ? false : (!A || !B || !Cp || pk->nshards != 1)) return ZKT_ERR_SHAPE;
+  ZCHK(prove_submit(pk, 0, wires, wires_on_device, r, s_));
+  return prove_collect(pk, 0, A, B, Cp, dev_partials);
 }
 int zkt_groth16_prove_r1cs(zkt_groth16_pk* pk, const uint64_t* wires, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp) {
   return prove_impl(pk, wires, false, r, s_, A, B, Cp);
+}
+// Pipelined form: two proofs in flight on one key — the Fr stage of proof k+1 runs under the MSMs of proof k.  slot in {0, 1}; a slot
+// must be collected before it is submitted again.  (Single-GPU keys only; wires already in HBM.)
+int zkt_groth16_prove_r1cs_submit(zkt_groth16_pk* pk, int slot, const uint64_t* dev_wires, const uint64_t* r, const uint64_t* s_) {
+  if (pk && pk->nshards != 1) return ZKT_ERR_SHAPE;
+  return prove_submit(pk, slot, dev_wires, true, r, s_);
+}
+int zkt_groth16_prove_r1cs_collect(zkt_groth16_pk* pk, int slot, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp) {
+  return prove_collect(pk, slot, A, B, Cp, nullptr);
 }
 // one shard's share of a proof: the three un-normalised Jacobian partial sums, on the device
 int zkt_groth16_prove_r1cs_partials(zkt_groth16_pk* pk, const uint64_t* dev_wires, const uint64_t* r, const uint64_t* s_, uint32_t* dev_partials) {
