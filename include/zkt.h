@@ -119,6 +119,11 @@ int zkt_tate_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* o
 int zkt_miller_g1g2_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out_fq12, size_t n);
 int zkt_miller_g2g1_batch(const zkt_g2_affine* g2, const zkt_g1_affine* g1, uint64_t* out_fq12, size_t n);
 int zkt_weil_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out_fq12, size_t n);
+/* Diagnostic (no reference counterpart): `count` independent runs of the self-test program of the lazily reduced Fq arithmetic
+ * (csrc/fq_program.h: a pseudo-random straight-line program of field operations over four registers, seeds seed0 + i), one per lane.
+ * in/out: count x 4 canonical Fq; violations[i] = limb/size invariant violations seen by run i.  The test-suite replays the program
+ * in python integers (tests/test_hostcheck.py for the host build of the same header, tests/test_gpu_parity.py for the device). */
+int zkt_selftest_fq_program(uint64_t seed0, int steps, const uint64_t* in, uint64_t* out, int32_t* violations, size_t count);
 /* a15: GTPoint == gt_point.rs:33-39 (all 12 coefficients); returns 1/0, or <0 = -status */
 int zkt_gt_eq(const uint64_t* a_fq12, const uint64_t* b_fq12);
 

@@ -299,3 +299,21 @@ def test_plain_c_consumer_of_the_abi(L, tmp_path):
                            "-L", libdir, "-lzkt_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "abi_consumer ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_fq_lazy_limb_programs_on_device(L):
+    """The self-test program of the lazily reduced Fq arithmetic (csrc/fq_program.h) compiled for the DEVICE: 256 lanes x 3000 steps of
+    add/sub/mul/fused ops over non-canonical representatives must keep the limb/size invariants and match plain mod-p arithmetic
+    (the host build of the same header is checked by tests/test_hostcheck.py; the model is shared with it)."""
+    from test_hostcheck import _fq_program_model
+    count, steps, seed0 = 256, 3000, 424242
+    rng = SplitMix64(8080)
+    edge = [0, 1, Q - 1, Q - 2, 2, (Q + 1) // 2, (1 << 380), (1 << 364) - 1, Q - (1 << 364), (1 << 28) - 1, Q >> 1]
+    regs = [[edge[(i + k) % len(edge)] if (i + k) % 5 == 0 else rng.below(Q) for k in range(4)] for i in range(count)]
+    a = ints_to_arr([v for r in regs for v in r], 6); o = np.zeros_like(a); bad = np.zeros(count, np.int32)
+    L.zkt_selftest_fq_program.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    zk.check(L.zkt_selftest_fq_program(seed0, steps, a.ctypes.data, o.ctypes.data, bad.ctypes.data, count))
+    assert not bad.any(), f"invariant violations on lanes {np.nonzero(bad)[0][:8]}"
+    got = arr_to_ints(o)
+    for i in range(0, count, 1):
+        assert got[4 * i:4 * i + 4] == _fq_program_model(seed0 + i, steps, regs[i]), i

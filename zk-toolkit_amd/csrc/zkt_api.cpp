@@ -229,6 +229,26 @@ int zkt_fq12_pow_batch(const uint64_t* a, const uint32_t* e, size_t nl, uint64_t
   return ZKT_OK;
 }
 
+// diagnostic: the lazy-limb Fq self-test program (fq_program.h) on the device, one run per lane
+int zkt_selftest_fq_program(uint64_t seed0, int steps, const uint64_t* in, uint64_t* out, int32_t* violations, size_t count) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (count == 0) return ZKT_OK;
+  if (!in || !out || !violations || steps < 0) return ZKT_ERR_SHAPE;
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCHK(hipSetDevice(g.device));
+  const size_t eb = 4 * 48;
+  int rc = arena_reserve(padded(eb * count) * 2 + padded(4 * count) + 1024);
+  if (rc) return rc;
+  Carver cv(g.arena);
+  uint32_t* din = cv.take<uint32_t>(eb * count); uint32_t* dout = cv.take<uint32_t>(eb * count); int* dbad = (int*)cv.take<uint32_t>(4 * count);
+  HIPCHK(hipMemcpyAsync(din, in, eb * count, hipMemcpyHostToDevice, g.stream));
+  HIPCHK(launch_selftest_fq_program(seed0, steps, din, dout, dbad, count, g.stream));
+  HIPCHK(hipMemcpyAsync(out, dout, eb * count, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipMemcpyAsync(violations, dbad, 4 * count, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return ZKT_OK;
+}
+
 static int group_add(int grp, const void* a, const void* b, void* out, size_t n) {
   size_t w = pt_bytes(grp);
   return staged(a, w, b, w, out, w, n, ZKT_ERR_SHAPE,

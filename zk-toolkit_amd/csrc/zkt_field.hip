@@ -2,6 +2,7 @@
 // Rows a1–a6 of SURVEY §8: PrimeFieldElem ops (prime_field_elem.rs:278-457), Fq2/Fq6/Fq12
 // ops (fq2.rs, fq6.rs, fq12.rs).  Inputs/outputs are canonical residues (include/zkt.h).
 #include "abi.h"
+#include "fq_program.h"
 #include "zkt_internal.h"
 
 namespace zkt {
@@ -71,6 +72,19 @@ hipError_t launch_fp_op(int field, int op, const uint32_t* a, const uint32_t* b,
     case F_SN: return launch_fp_c<SnC>(op, a, b, o, n, err, s);
   }
   return hipErrorInvalidValue;
+}
+
+// diagnostic: `count` independent runs of the fp.h self-test program (fq_program.h), one per lane, seeds seed0 + lane
+__global__ void __launch_bounds__(64) k_selftest_fq_program(unsigned long long seed0, int steps, const uint32_t* __restrict__ in4, uint32_t* __restrict__ out4,
+                                                            int* __restrict__ bad, size_t count) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= count) return;
+  bad[i] = fq_program(seed0 + i, steps, in4 + i * 4 * FqC::ABI_N, out4 + i * 4 * FqC::ABI_N);
+}
+hipError_t launch_selftest_fq_program(unsigned long long seed0, int steps, const uint32_t* in4, uint32_t* out4, int* bad, size_t count, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_selftest_fq_program, dim3(nblocks(count, 64)), dim3(64), 0, s, seed0, steps, in4, out4, bad, count);
+  return hipGetLastError();
 }
 
 // ---- tower ---------------------------------------------------------------------

@@ -17,6 +17,7 @@ static constexpr unsigned long long NO_ERR = ~0ull;
 
 hipError_t launch_fp_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n,
                         unsigned long long* err, hipStream_t s);
+hipError_t launch_selftest_fq_program(unsigned long long seed0, int steps, const uint32_t* in4, uint32_t* out4, int* bad, size_t count, hipStream_t s);
 hipError_t launch_tower_op(int deg, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n,
                            unsigned long long* err, hipStream_t s);
 hipError_t launch_fq12_pow(const uint32_t* a, const uint32_t* exp_dev, int exp_nlimbs, uint32_t* out, size_t n, hipStream_t s);
