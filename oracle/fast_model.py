@@ -101,6 +101,22 @@ XI_INV = f2_inv((1, 1))
 L_BITS = [int(c) for c in bin(R - 1)[3:]]          # pairing.rs:58-73
 
 
+def _naf(k):
+    """non-adjacent form, least significant digit first"""
+    d = []
+    while k:
+        z = (2 - (k % 4)) if k & 1 else 0
+        k -= z; d.append(z); k //= 2
+    return d
+
+
+# The fast loop may use ANY addition chain for r-1: a chain with subtractions (V <- V - P, the chord through V and -P) differs from
+# the reference's double-and-add only by vertical lines, whose values at an untwisted Q lie in Fq6 and die in the final exponentiation
+# (SURVEY Appendix A).  NAF(r-1) has 59 non-zero digits against 133 one bits: 58 instead of 132 addition steps, two more doublings.
+L_NAF = _naf(R - 1)[::-1][1:]                        # most significant first, leading 1 dropped
+assert sum(d << (len(L_NAF) - 1 - i) for i, d in enumerate(L_NAF)) + (1 << len(L_NAF)) == R - 1
+
+
 def miller_fast(P, Qp):
     """f_{r-1,P}(untwist(Q)) up to Fq6 factors.  P=(x,y) in Fq, Qp=((x0,x1),(y0,y1)) c0/c1 order."""
     xp, yp = P
@@ -112,7 +128,7 @@ def miller_fast(P, Qp):
     def sparse(a, b, c):           # a + b v^2 + c v w,  a in Fq
         return (((a, 0), F2_0, b), (F2_0, c, F2_0))
 
-    for bit in L_BITS:
+    for bit in L_NAF:
         # tangent at V, scaled by 2YZ^3:  (3X^3-2Y^2) - 3X^2 Z^2 * X' + Z3 Z^2 * Y'
         A = X * X % Q; B = Y * Y % Q; C = B * B % Q; ZZ = Z * Z % Q
         D = 2 * ((X + B) ** 2 - A - C) % Q; E = 3 * A % Q
@@ -121,7 +137,8 @@ def miller_fast(P, Qp):
         f = f12_mul(f12_sqr(f), sparse(a, f2_muls(Xq, -E * ZZ % Q), f2_muls(Yq, Z3 * ZZ % Q)))
         X, Y, Z = X3, Y3, Z3
         if bit:
-            # chord through V and P, scaled by Z*H: (R xp - Z3 yp) - R X' + Z3 Y'
+            # chord through V and +-P, scaled by Z*H: (R xp - Z3 yp) - R X' + Z3 Y'   (digit -1: the point is -P = (xp, -yp))
+            yp = P[1] if bit > 0 else -P[1] % Q
             ZZ = Z * Z % Q; H = (xp * ZZ - X) % Q; Rr = (yp * ZZ * Z - Y) % Q
             HH = H * H % Q; HHH = H * HH % Q; V = X * HH % Q
             X3 = (Rr * Rr - HHH - 2 * V) % Q; Y3 = (Rr * (V - X3) - Y * HHH) % Q; Z3 = Z * H % Q

@@ -66,16 +66,19 @@ ZKT_FN Fq12 miller_g1_g2(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& y
   MillerPt V{xp, yp, fp_one<FqC>()};
   MillerLine l;
   Fq12 f = fq12_one(), ft;          // ping-pong f <-> ft: a destination never aliases a source
-  for (int i = 0; i < MILLER_NBITS; ++i) {
-    uint32_t w = 0;
+  const Fq yn = fp_neg(yp);
+  // signed digits of r-1 (NAF: 58 additions/subtractions instead of the 132 additions of the binary chain; a digit -1 adds -P).
+  // The chains differ by vertical lines only, which the final exponentiation kills (oracle/fast_model.py, tests/test_fast_model.py).
+  for (int i = 0; i < MILLER_NAF_DIGITS; ++i) {
+    uint32_t nz = 0, ng = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w = (j == (i >> 5)) ? miller_bits_word(j) : w;
-    const bool bit = (w >> (i & 31)) & 1;          // wave-uniform (compile-time table)
+    for (int j = 0; j < 8; ++j) { nz = (j == (i >> 5)) ? miller_naf_nz_word(j) : nz; ng = (j == (i >> 5)) ? miller_naf_neg_word(j) : ng; }
+    const bool bit = (nz >> (i & 31)) & 1, neg = (ng >> (i & 31)) & 1;          // wave-uniform (compile-time tables)
     miller_dbl_step(V, Xq, Yq, l);
     ft = fq12_sqr(f);
     f = fq12_mul_line(ft, l.a, l.b, l.c);
     if (bit) {
-      miller_add_step(V, xp, yp, Xq, Yq, l);
+      miller_add_step(V, xp, neg ? yn : yp, Xq, Yq, l);
       ft = fq12_mul_line(f, l.a, l.b, l.c);
       f = ft;
     }
@@ -92,11 +95,13 @@ ZKT_FN Fq12 miller_g1_g2_multi(const Fq* xp, const Fq* yp, const Fq2* xq, const 
   for (int k = 0; k < K; ++k) { Xq[k] = fq2_mul(xq[k], xi_inv); Yq[k] = fq2_mul(yq[k], xi_inv); V[k] = MillerPt{xp[k], yp[k], fp_one<FqC>()}; }
   MillerLine l;
   Fq12 f = fq12_one(), ft;
-  for (int i = 0; i < MILLER_NBITS; ++i) {
-    uint32_t w = 0;
+  Fq yn[K];
+  for (int k = 0; k < K; ++k) yn[k] = fp_neg(yp[k]);
+  for (int i = 0; i < MILLER_NAF_DIGITS; ++i) {                                  // signed digits of r-1, as in miller_g1_g2
+    uint32_t nz = 0, ng = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w = (j == (i >> 5)) ? miller_bits_word(j) : w;
-    const bool bit = (w >> (i & 31)) & 1;
+    for (int j = 0; j < 8; ++j) { nz = (j == (i >> 5)) ? miller_naf_nz_word(j) : nz; ng = (j == (i >> 5)) ? miller_naf_neg_word(j) : ng; }
+    const bool bit = (nz >> (i & 31)) & 1, neg = (ng >> (i & 31)) & 1;
     ft = fq12_sqr(f); f = ft;
     for (int k = 0; k < K; ++k) {
       miller_dbl_step(V[k], Xq[k], Yq[k], l);
@@ -104,7 +109,7 @@ ZKT_FN Fq12 miller_g1_g2_multi(const Fq* xp, const Fq* yp, const Fq2* xq, const 
     }
     if (bit) {
       for (int k = 0; k < K; ++k) {
-        miller_add_step(V[k], xp[k], yp[k], Xq[k], Yq[k], l);
+        miller_add_step(V[k], xp[k], neg ? yn[k] : yp[k], Xq[k], Yq[k], l);
         ft = fq12_mul_line(f, l.a, l.b, l.c); f = ft;
       }
     }
