@@ -217,13 +217,35 @@ template <class F> ZKT_HD Jac<F> xyzz_to_jac(const Xyzz<F>& p) {
 // k*P for an affine P and an nbits-wide scalar (little-endian u32 limbs, used as-is,
 // no reduction mod r: macros.rs:10-21).  MSB-first double-and-add with mixed
 // additions; the reference's LSB-first loop computes the same group element.
+// k * P with k given as `nlimbs` 32-bit words, used as-is (macros.rs:10-21 runs LSB-first double-and-add on the stored integer; the
+// group element is the same).  The scalar is recoded on the fly into its non-adjacent form — one third instead of one half of the
+// digits are non-zero, a digit -1 adds -P — and scanned from the top: nlimbs*32 doublings at most, ~nlimbs*32/3 mixed additions.
+static constexpr int SCALAR_MAX_LIMBS = 12;          // the ABI allows up to 384-bit scalars
 template <class F> ZKT_HD Jac<F> scalar_mul_aff(const Aff<F>& p, const uint32_t* k, int nlimbs) {
   Jac<F> acc = jac_inf<F>();
   if (p.inf) return acc;
+  // NAF by the carry recurrence: with x = k + carry, digit = 0 if x even, else 2 - (x mod 4); carry' = (x - digit) / 2 ... done on bits
+  uint32_t nz[SCALAR_MAX_LIMBS + 1], ng[SCALAR_MAX_LIMBS + 1];
+  uint32_t carry = 0;
+  for (int w = 0; w <= nlimbs; ++w) {
+    const uint32_t cur = w < nlimbs ? k[w] : 0u, nxt = w + 1 < nlimbs ? k[w + 1] : 0u;
+    uint32_t znz = 0, zng = 0;
+    for (int b = 0; b < 32; ++b) {
+      const uint32_t b0 = (cur >> b) & 1, b1 = b < 31 ? (cur >> (b + 1)) & 1 : nxt & 1;
+      const uint32_t x0 = b0 ^ carry;                       // low bit of (k >> pos) + carry
+      // x odd: digit = +1 if the next bit of the sum is 0, else -1 (and a carry is generated)
+      const uint32_t sum1 = b1 ^ (b0 & carry);              // second bit of (k >> pos) + carry
+      const uint32_t neg = x0 & sum1;
+      znz |= x0 << b; zng |= neg << b;
+      carry = (b0 & carry) | (neg);                         // carry into the next position: from the addition, or from rounding up
+    }
+    nz[w] = znz; ng[w] = zng;
+  }
+  Aff<F> q = p; q.y = F::neg(p.y);
   bool started = false;
-  for (int i = nlimbs * 32 - 1; i >= 0; --i) {
+  for (int i = nlimbs * 32; i >= 0; --i) {
     if (started) acc = jac_dbl(acc);
-    if ((k[i >> 5] >> (i & 31)) & 1) { acc = jac_add_aff(acc, p); started = true; }
+    if ((nz[i >> 5] >> (i & 31)) & 1) { acc = jac_add_aff(acc, ((ng[i >> 5] >> (i & 31)) & 1) ? q : p); started = true; }
   }
   return acc;
 }

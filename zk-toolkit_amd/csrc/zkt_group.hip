@@ -36,19 +36,7 @@ __global__ void __launch_bounds__(64) k_group_mul(const uint32_t* __restrict__ p
   constexpr int W = PtIO<F>::WORDS;
   Aff<F> p = PtIO<F>::ld(pts + i * (size_t)pt_stride);   // pt_stride = W, or 0 for one fixed base (g * y_i, crs.rs:85-135)
   const uint32_t* k = scalars + i * (size_t)k_stride;   // k_stride = kw, or 0 for one scalar for every point (gg * x, bulletproofs.rs:44)
-  // MSB-first double-and-add (see curve.h::scalar_mul_aff), scalar read from global per bit word
-  Jac<F> acc = jac_inf<F>();
-  bool started = false;
-  if (!p.inf) {
-    for (int w = kw - 1; w >= 0; --w) {
-      uint32_t word = k[w];
-      for (int bit = 31; bit >= 0; --bit) {
-        if (started) acc = jac_dbl(acc);
-        if ((word >> bit) & 1) { acc = jac_add_aff(acc, p); started = true; }
-      }
-    }
-  }
-  PtIO<F>::st(out + i * W, jac_to_aff(acc));
+  PtIO<F>::st(out + i * W, jac_to_aff(scalar_mul_aff<F>(p, k, kw)));     // NAF double-and-add, curve.h
 }
 
 template <class F> static hipError_t add_t(const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n, hipStream_t s) {
