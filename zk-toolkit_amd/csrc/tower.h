@@ -248,18 +248,25 @@ template <int K> ZKT_FN Fq12 fq12_frob(const Fq12& a) {
 // f * (a + b v^2 + c v w) with a in Fq, b,c in Fq2: the value of a Miller line at
 // an untwisted G2 point has exactly these slots (g12_point.rs:47-68).
 ZKT_FN Fq12 fq12_mul_line(const Fq12& f, const Fq& a, const Fq2& b, const Fq2& c) {
+  // (x + y w)(a + b v^2 + c v w), w^2 = v, v^3 = xi:
+  //   c0 = x a + x b v^2 + y c v^2         c1 = y a + x c v + y b v^2
+  // The six products x_i b and y_i c serve c0; the cross terms of c1 pair up slot by slot — x2 c + y1 b, x1 c + y0 b and
+  // x0 c + xi y2 b — so each pair is one Karatsuba product with (b + c): 9 Fq2 products instead of 12.
   const Fq6 &x = f.c0, &y = f.c1;
-  // x*l0, l0 = a + b v^2
-  Fq6 xl0{fq2_add(fq2_mul_fq(x.c0, a), fq2_mul_xi(fq2_mul(x.c1, b))),
-          fq2_add(fq2_mul_fq(x.c1, a), fq2_mul_xi(fq2_mul(x.c2, b))),
-          fq2_add(fq2_mul_fq(x.c2, a), fq2_mul(x.c0, b))};
-  Fq6 yl0{fq2_add(fq2_mul_fq(y.c0, a), fq2_mul_xi(fq2_mul(y.c1, b))),
-          fq2_add(fq2_mul_fq(y.c1, a), fq2_mul_xi(fq2_mul(y.c2, b))),
-          fq2_add(fq2_mul_fq(y.c2, a), fq2_mul(y.c0, b))};
-  // *l1, l1 = c v
-  Fq6 xl1{fq2_mul_xi(fq2_mul(x.c2, c)), fq2_mul(x.c0, c), fq2_mul(x.c1, c)};
-  Fq6 yl1{fq2_mul_xi(fq2_mul(y.c2, c)), fq2_mul(y.c0, c), fq2_mul(y.c1, c)};
-  return Fq12{fq6_add(xl0, fq6_mul_v(yl1)), fq6_add(xl1, yl0)};
+  const Fq2 xb0 = fq2_mul(x.c0, b), xb1 = fq2_mul(x.c1, b), xb2 = fq2_mul(x.c2, b);
+  const Fq2 yc0 = fq2_mul(y.c0, c), yc1 = fq2_mul(y.c1, c), yc2 = fq2_mul(y.c2, c);
+  const Fq2 bc = fq2_add(b, c);
+  const Fq2 k0 = fq2_mul(fq2_add(x.c2, y.c1), bc);                       // x2 b + x2 c + y1 b + y1 c
+  const Fq2 k1 = fq2_mul(fq2_add(x.c0, fq2_mul_xi(y.c2)), bc);            // x0 b + x0 c + xi y2 b + xi y2 c
+  const Fq2 k2 = fq2_mul(fq2_add(x.c1, y.c0), bc);                       // x1 b + x1 c + y0 b + y0 c
+  Fq12 r;
+  r.c0.c0 = fq2_add_mul_xi(fq2_mul_fq(x.c0, a), fq2_add(xb1, yc1));      // x0 a + xi (x1 b + y1 c)
+  r.c0.c1 = fq2_add_mul_xi(fq2_mul_fq(x.c1, a), fq2_add(xb2, yc2));      // x1 a + xi (x2 b + y2 c)
+  r.c0.c2 = fq2_add(fq2_mul_fq(x.c2, a), fq2_add(xb0, yc0));             // x2 a + x0 b + y0 c
+  r.c1.c0 = fq2_add_mul_xi(fq2_mul_fq(y.c0, a), fq2_subsub(k0, xb2, yc1));             // y0 a + xi (x2 c + y1 b)
+  r.c1.c1 = fq2_add(fq2_mul_fq(y.c1, a), fq2_subsub(k1, xb0, fq2_mul_xi(yc2)));        // y1 a + x0 c + xi y2 b
+  r.c1.c2 = fq2_add(fq2_mul_fq(y.c2, a), fq2_subsub(k2, xb1, yc0));                    // y2 a + x1 c + y0 b
+  return r;
 }
 
 // square-and-multiply by a run-time exponent (u32 limbs, little endian), MSB first.
