@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
-PAIRING_VALU_INSTR = 24.37e6    # k_tate: VALU instructions per pairing (measured: SQ_INSTS_VALU / SQ_WAVES)
+PAIRING_VALU_INSTR = 23.13e6    # k_tate: VALU instructions per pairing (measured: SQ_INSTS_VALU / SQ_WAVES)
 VALU_INSTR_PER_ADD, NWIN_2P20 = 5450, 13     # k_accumulate: instructions per XYZZ mixed add on the hot path (ISA count, 3.6 k of them v_mad_u64_u32); windows at n = 2^20 (c = 20)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MSM_BYTES_PER_TERM = 128       # 96 B affine base + 32 B scalar
@@ -289,7 +289,7 @@ def main():
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             result["pairing"] = {"metric": "Tate pairings/sec", "value": m / dt, "batch": m, "kernel_ms": L.zkt_last_kernel_ms(),
                                  "hbm_achieved_GBs": PAIRING_BYTES * m / dt / 1e9, "hbm_frac": PAIRING_BYTES * m / dt / 1e9 / HBM_PEAK_GBS,
-                                 # VALU issue roof: 24.37 M instructions per pairing lane (SQ_INSTS_VALU / SQ_WAVES of k_tate, rocprofv3 --pmc)
+                                 # VALU issue roof: 23.13 M instructions per pairing lane (SQ_INSTS_VALU / SQ_WAVES of k_tate, rocprofv3 --pmc)
                                  "valu": {"achieved": PAIRING_VALU_INSTR * m / dt / 1e12, "peak": 39.3, "unit": "T lane-instr/s", "frac": PAIRING_VALU_INSTR * m / dt / 1e12 / 39.3,
                                           "note": "one wave per SIMD (512 registers per lane): a single wave issues a v_mad_u64_u32 every ~10 clk, other VALU every ~4-5 clk; SQ_WAIT_ANY is 8.5 % of the wave's cycles"}}
 
