@@ -195,6 +195,14 @@ int zkt_pinocchio_verify(const zkt_pinocchio_crs* crs, const zkt_pinocchio_proof
 int zkt_bp_inner_product_argument(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u,
                                   const zkt_secp_affine* P, const uint64_t* a, const uint64_t* b, const uint64_t* xs,
                                   zkt_secp_affine* out_trace);
+/* The same argument with the generators resident: gg, hh, u are fixed for a deployment (the reference rebuilds nothing either — its callers
+ * pass the same AffinePoints every time, bulletproofs.rs:139), so their window-multiple table and the work buffers are built once.
+ * A context serves one call at a time; results are identical to zkt_bp_inner_product_argument. */
+typedef struct zkt_bp_ipa_ctx zkt_bp_ipa_ctx;
+int zkt_bp_ipa_ctx_create(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u, zkt_bp_ipa_ctx** out);
+void zkt_bp_ipa_ctx_free(zkt_bp_ipa_ctx* ctx);
+int zkt_bp_inner_product_argument_ctx(zkt_bp_ipa_ctx* ctx, const zkt_secp_affine* P, const uint64_t* a, const uint64_t* b, const uint64_t* xs,
+                                      zkt_secp_affine* out_trace);
 
 /* a18: Bulletproofs::range_proof bulletproofs.rs:58-147 (n = bit length, a power of two; aL = the value's bits).  rnd =
  * alpha, rho, y, z, tau1, tau2, x, sL[n], sR[n] (the values the reference draws at :76,:79-81,:84-85,:97-98,:102);

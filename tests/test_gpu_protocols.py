@@ -117,6 +117,29 @@ def test_ipa_transcript_vs_oracle(L, n):            # bulletproofs.rs:19-55, lev
     assert L.zkt_bp_inner_product_argument(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b2), ptr(xs), None) == 0
 
 
+@pytest.mark.parametrize("n", [1, 8, 256])
+def test_ipa_resident_generators(L, n):             # zkt_bp_ipa_ctx: one context, several arguments, same transcript as the one-shot form and the oracle
+    gg, hh, u, P, a, b, xs, levels = ipa_instance(L, n, 900 + n)
+    ctx = ctypes.c_void_p()
+    zk.check(L.zkt_bp_ipa_ctx_create(n, ptr(gg), ptr(hh), ptr(u), ctypes.byref(ctx)))
+    try:
+        gt, ot = np.zeros((levels * 3, 9), np.uint64), np.zeros((levels * 3, 9), np.uint64)
+        assert O.zkto_bp_ipa(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b), ptr(xs), ptr(ot)) == 1
+        for _ in range(2):                            # the context is reusable
+            gt[:] = 0
+            assert L.zkt_bp_inner_product_argument_ctx(ctx, ptr(P), ptr(a), ptr(b), ptr(xs), ptr(gt)) == 1
+            if n > 1: assert (gt == ot).all()
+        assert L.zkt_bp_inner_product_argument_ctx(ctx, ptr(P), ptr(a), ptr(b), ptr(xs), None) == 1           # no-trace path (block sum of the products)
+        b2 = b.copy(); b2[n - 1, 1] ^= 4
+        assert L.zkt_bp_inner_product_argument_ctx(ctx, ptr(P), ptr(a), ptr(b2), ptr(xs), None) == 0
+        if n > 1:
+            x0 = xs.copy(); x0[levels - 1] = 0        # a non-invertible challenge is refused and leaves the context usable
+            assert L.zkt_bp_inner_product_argument_ctx(ctx, ptr(P), ptr(a), ptr(b), ptr(x0), None) < 0
+        assert L.zkt_bp_inner_product_argument_ctx(ctx, ptr(P), ptr(a), ptr(b), ptr(xs), None) == 1
+    finally:
+        L.zkt_bp_ipa_ctx_free(ctx)
+
+
 def test_ipa_full_size_accepts(L):                  # BASELINE config 5 shape: n = 64*1024 generators, 16 levels
     n = 1 << 16
     gg, hh, u, P, a, b, xs, levels = ipa_instance(L, n, 77)

@@ -96,13 +96,20 @@ xs = rand_scalars(14, 16, SECP_N); xs[:, 0] |= np.uint64(1)
 assert L.zkt_bp_inner_product_argument(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b), ptr(xs), None) == 1
 t0 = time.perf_counter(); r = L.zkt_bp_inner_product_argument(n, ptr(gg), ptr(hh), ptr(u), ptr(P), ptr(a), ptr(b), ptr(xs), None); t_ipa = time.perf_counter() - t0
 assert r == 1
+ctx = ctypes.c_void_p()
+t0 = time.perf_counter(); zk.check(L.zkt_bp_ipa_ctx_create(n, ptr(gg), ptr(hh), ptr(u), ctypes.byref(ctx))); t_ipa_setup = time.perf_counter() - t0
+assert L.zkt_bp_inner_product_argument_ctx(ctx, ptr(P), ptr(a), ptr(b), ptr(xs), None) == 1
+t0 = time.perf_counter()
+for _ in range(4): assert L.zkt_bp_inner_product_argument_ctx(ctx, ptr(P), ptr(a), ptr(b), ptr(xs), None) == 1
+t_ipa_res = (time.perf_counter() - t0) / 4
+L.zkt_bp_ipa_ctx_free(ctx)
 nc = 256                           # CPU baseline at 256 generators (8 levels); the reference's cost is linear in the number of generators
 ot = np.zeros((8 * 3, 9), np.uint64)
 Pc = np.zeros((1, 9), np.uint64); assert O.zkto_bp_commit(nc, ptr(gg[:nc].copy()), ptr(hh[:nc].copy()), ptr(u), ptr(a[:nc].copy()), ptr(b[:nc].copy()), ptr(Pc)) == 0
 t0 = time.perf_counter()
 assert O.zkto_bp_ipa(nc, ptr(gg[:nc].copy()), ptr(hh[:nc].copy()), ptr(u), ptr(Pc), ptr(a[:nc].copy()), ptr(b[:nc].copy()), ptr(xs[:8].copy()), ptr(ot)) == 1
 t_cpu = time.perf_counter() - t0
-res["bulletproofs_ipa"] = {"generators": n, "levels": 16, "seconds": t_ipa, "accepts": True,
+res["bulletproofs_ipa"] = {"generators": n, "levels": 16, "seconds": t_ipa, "seconds_resident_generators": t_ipa_res, "generator_setup_seconds": t_ipa_setup, "accepts": True,
                            "cpu_baseline": {"generators": nc, "seconds": t_cpu, "cores": 1, "kind": "port",
                                             "sample": "oracle's reference algorithm at %d generators; x%d for %d generators = %.0f s" % (nc, n // nc, n, t_cpu * n / nc)}}
 

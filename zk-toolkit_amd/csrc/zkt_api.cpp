@@ -118,8 +118,8 @@ struct zkt_bases_impl {               // one resident base set of any group; zkt
   // software pipeline: the three stages of consecutive MSMs run on three streams (sort | accumulate | reduce),
   // chained by events, so the atomic-bound sort and the latency-bound reduce of neighbours hide under the
   // VALU-bound accumulation of the current one.
-  static constexpr int NTAIL = 2;   // reduce chains of alternate MSMs run side by side: each is latency-bound, not throughput-bound
-  hipStream_t s_sort = nullptr, s_acc = nullptr, s_tail[NTAIL] = {nullptr, nullptr};
+  static constexpr int NTAIL = 8;   // reduce chains of alternate MSMs run side by side: each is latency-bound, not throughput-bound (large MSMs use two of them)
+  hipStream_t s_sort = nullptr, s_acc = nullptr, s_tail[NTAIL] = {};
   MsmSlot slot[MSM_SLOTS];
 };
 struct zkt_g1_bases : zkt_bases_impl {};
@@ -338,7 +338,8 @@ static void bases_free(zkt_bases_impl* h) {
   if (!h) return;
   if (h->table) hipFree(h->table);
   if (h->inf) hipFree(h->inf);
-  for (hipStream_t st : {h->s_sort, h->s_acc, h->s_tail[0], h->s_tail[1]}) if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+  for (hipStream_t st : {h->s_sort, h->s_acc}) if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+  for (hipStream_t st : h->s_tail) if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
   for (MsmSlot& S : h->slot) {
     for (hipEvent_t ev : {S.e_in, S.e_sorted, S.e_acc0, S.e_acc1, S.e_done}) if (ev) hipEventDestroy(ev);
     if (S.workspace) hipFree(S.workspace); if (S.d_result_jac) hipFree(S.d_result_jac); if (S.d_out_abi) hipFree(S.d_out_abi);
@@ -373,14 +374,19 @@ static int msm_submit(zkt_bases_impl* h, const uint64_t* dev_scalars, size_t n, 
   MsmSlot& S = h->slot[slot];
   // inputs are produced on the caller's stream: order the sort stage behind it
   HIPCHK(hipEventRecord(S.e_in, (hipStream_t)stream));
-  HIPCHK(hipStreamWaitEvent(h->s_sort, S.e_in, 0));
-  HIPCHK(launch_msm_sort(h->plan, h->inf, (const uint32_t*)dev_scalars, S.workspace, h->s_sort));
-  HIPCHK(hipEventRecord(S.e_sorted, h->s_sort));
-  HIPCHK(hipStreamWaitEvent(h->s_acc, S.e_sorted, 0));
-  HIPCHK(hipEventRecord(S.e_acc0, h->s_acc));
-  HIPCHK(launch_msm_accumulate(h->plan, h->table, S.workspace, h->s_acc));
-  HIPCHK(hipEventRecord(S.e_acc1, h->s_acc));
-  hipStream_t st = h->s_tail[slot % zkt_bases_impl::NTAIL];
+  const bool small = h->n < (size_t(1) << 19);
+  hipStream_t st = h->s_tail[small ? slot % zkt_bases_impl::NTAIL : slot % 2];
+  hipStream_t ss = small ? st : h->s_sort;
+  HIPCHK(hipStreamWaitEvent(ss, S.e_in, 0));
+  HIPCHK(launch_msm_sort(h->plan, h->inf, (const uint32_t*)dev_scalars, S.workspace, ss));
+  HIPCHK(hipEventRecord(S.e_sorted, ss));
+  // a large MSM fills the chip, so its stages queue on per-stage streams (sort of MSM k+1 under the accumulation of MSM k); below 2^19 terms every
+  // stage is a latency-bound sliver of the chip (one short wave per SIMD), so each slot runs its whole MSM on its own stream, side by side with the others
+  hipStream_t sa = small ? st : h->s_acc;
+  HIPCHK(hipStreamWaitEvent(sa, S.e_sorted, 0));
+  HIPCHK(hipEventRecord(S.e_acc0, sa));
+  HIPCHK(launch_msm_accumulate(h->plan, h->table, S.workspace, sa));
+  HIPCHK(hipEventRecord(S.e_acc1, sa));
   HIPCHK(hipStreamWaitEvent(st, S.e_acc1, 0));
   HIPCHK(launch_msm_reduce(h->plan, S.workspace, S.d_result_jac, S.d_out_abi, st));
   HIPCHK(hipMemcpyAsync(S.h_out, S.d_out_abi, grp_pt_bytes(h->grp), hipMemcpyDeviceToHost, st));

@@ -111,15 +111,18 @@ __global__ void __launch_bounds__(64) k_to_kernel_layout(const uint32_t* __restr
   Coord<F>::st(mont + i * 2 * CW, p.x); Coord<F>::st(mont + i * 2 * CW + CW, p.y);
   inf[i] = p.inf ? 1 : 0;
 }
-// This file is compiled twice (Makefile): -DZKT_MSM_PART_G1 -DZKT_INLINE_MUL instantiates the G1 kernels with the field
-// multiply inlined (the headline path) and defines the public launch_msm_* dispatchers; -DZKT_MSM_PART_OTHER instantiates
-// G2 and secp256k1 with a called multiply (an inlined Fq2 XYZZ add would be ~200 KB of code and minutes of compile time).
+// This file is compiled three times (Makefile): -DZKT_MSM_PART_G1 -DZKT_INLINE_MUL instantiates the G1 kernels with the field
+// multiply inlined (the headline path) and defines the public launch_msm_* dispatchers; -DZKT_MSM_PART_SECP -DZKT_INLINE_MUL does the
+// same for secp256k1; -DZKT_MSM_PART_OTHER instantiates G2 with a called multiply (an inlined Fq2 XYZZ add would be ~200 KB of code
+// and minutes of compile time).
 #if defined(ZKT_MSM_PART_G1)
 #define MSM_DISPATCH(grp, CALL) switch (grp) { case G_G1: { typedef FqOps F; CALL; } break; default: return hipErrorInvalidValue; }
 #define PART(x) x##_g1
+#elif defined(ZKT_MSM_PART_SECP)     // secp256k1, multiply inlined like G1 (8-limb field: small code; a called multiply is latency bound at the low
+#define MSM_DISPATCH(grp, CALL) switch (grp) { case G_SECP: { typedef SpOps F; CALL; } break; default: return hipErrorInvalidValue; }   // occupancy of 2^17-term MSMs)
+#define PART(x) x##_secp
 #else
-#define MSM_DISPATCH(grp, CALL) switch (grp) { case G_G2: { typedef Fq2Ops F; CALL; } break; case G_SECP: { typedef SpOps F; CALL; } break; \
-                                               default: return hipErrorInvalidValue; }
+#define MSM_DISPATCH(grp, CALL) switch (grp) { case G_G2: { typedef Fq2Ops F; CALL; } break; default: return hipErrorInvalidValue; }
 #define PART(x) x##_other
 #endif
 hipError_t PART(launch_msm_to_kernel_layout)(int grp, const uint32_t* abi, uint32_t* mont, uint8_t* inf, size_t n, hipStream_t s) {
@@ -619,25 +622,22 @@ hipError_t PART(launch_msm_jac_sum_to_affine)(int grp, const uint32_t* parts, si
 
 
 #if defined(ZKT_MSM_PART_G1)
-// public entry points: G1 lives in this object, G2 / secp256k1 in the PART_OTHER object
-hipError_t launch_msm_to_kernel_layout_other(int, const uint32_t*, uint32_t*, uint8_t*, size_t, hipStream_t);
-hipError_t launch_msm_precompute_other(int, uint32_t*, uint8_t*, size_t, int, int, hipStream_t);
-hipError_t launch_msm_sort_other(const MsmPlan&, const uint8_t*, const uint32_t*, void*, hipStream_t);
-hipError_t launch_msm_accumulate_other(const MsmPlan&, const uint32_t*, void*, hipStream_t);
-hipError_t launch_msm_reduce_other(const MsmPlan&, void*, uint32_t*, uint32_t*, hipStream_t);
-hipError_t launch_msm_jac_sum_to_affine_other(int, const uint32_t*, size_t, uint32_t*, hipStream_t);
-hipError_t launch_msm_to_kernel_layout(int grp, const uint32_t* a, uint32_t* t, uint8_t* i, size_t n, hipStream_t s) {
-  return grp == G_G1 ? launch_msm_to_kernel_layout_g1(grp, a, t, i, n, s) : launch_msm_to_kernel_layout_other(grp, a, t, i, n, s); }
-hipError_t launch_msm_precompute(int grp, uint32_t* t, uint8_t* i, size_t n, int c, int nw, hipStream_t s) {
-  return grp == G_G1 ? launch_msm_precompute_g1(grp, t, i, n, c, nw, s) : launch_msm_precompute_other(grp, t, i, n, c, nw, s); }
-hipError_t launch_msm_sort(const MsmPlan& P, const uint8_t* i, const uint32_t* k, void* w, hipStream_t s) {
-  return P.grp == G_G1 ? launch_msm_sort_g1(P, i, k, w, s) : launch_msm_sort_other(P, i, k, w, s); }
-hipError_t launch_msm_accumulate(const MsmPlan& P, const uint32_t* t, void* w, hipStream_t s) {
-  return P.grp == G_G1 ? launch_msm_accumulate_g1(P, t, w, s) : launch_msm_accumulate_other(P, t, w, s); }
-hipError_t launch_msm_reduce(const MsmPlan& P, void* w, uint32_t* j, uint32_t* o, hipStream_t s) {
-  return P.grp == G_G1 ? launch_msm_reduce_g1(P, w, j, o, s) : launch_msm_reduce_other(P, w, j, o, s); }
-hipError_t launch_msm_jac_sum_to_affine(int grp, const uint32_t* p, size_t c, uint32_t* o, hipStream_t s) {
-  return grp == G_G1 ? launch_msm_jac_sum_to_affine_g1(grp, p, c, o, s) : launch_msm_jac_sum_to_affine_other(grp, p, c, o, s); }
+// public entry points: G1 lives in this object, secp256k1 in the PART_SECP object, G2 in the PART_OTHER object
+#define ZKT_MSM_FWD(SUF) \
+  hipError_t launch_msm_to_kernel_layout##SUF(int, const uint32_t*, uint32_t*, uint8_t*, size_t, hipStream_t); \
+  hipError_t launch_msm_precompute##SUF(int, uint32_t*, uint8_t*, size_t, int, int, hipStream_t); \
+  hipError_t launch_msm_sort##SUF(const MsmPlan&, const uint8_t*, const uint32_t*, void*, hipStream_t); \
+  hipError_t launch_msm_accumulate##SUF(const MsmPlan&, const uint32_t*, void*, hipStream_t); \
+  hipError_t launch_msm_reduce##SUF(const MsmPlan&, void*, uint32_t*, uint32_t*, hipStream_t); \
+  hipError_t launch_msm_jac_sum_to_affine##SUF(int, const uint32_t*, size_t, uint32_t*, hipStream_t);
+ZKT_MSM_FWD(_other) ZKT_MSM_FWD(_secp)
+#define ZKT_MSM_BY_GROUP(grp, NAME, ...) ((grp) == G_G1 ? NAME##_g1(__VA_ARGS__) : (grp) == G_SECP ? NAME##_secp(__VA_ARGS__) : NAME##_other(__VA_ARGS__))
+hipError_t launch_msm_to_kernel_layout(int grp, const uint32_t* a, uint32_t* t, uint8_t* i, size_t n, hipStream_t s) { return ZKT_MSM_BY_GROUP(grp, launch_msm_to_kernel_layout, grp, a, t, i, n, s); }
+hipError_t launch_msm_precompute(int grp, uint32_t* t, uint8_t* i, size_t n, int c, int nw, hipStream_t s) { return ZKT_MSM_BY_GROUP(grp, launch_msm_precompute, grp, t, i, n, c, nw, s); }
+hipError_t launch_msm_sort(const MsmPlan& P, const uint8_t* i, const uint32_t* k, void* w, hipStream_t s) { return ZKT_MSM_BY_GROUP(P.grp, launch_msm_sort, P, i, k, w, s); }
+hipError_t launch_msm_accumulate(const MsmPlan& P, const uint32_t* t, void* w, hipStream_t s) { return ZKT_MSM_BY_GROUP(P.grp, launch_msm_accumulate, P, t, w, s); }
+hipError_t launch_msm_reduce(const MsmPlan& P, void* w, uint32_t* j, uint32_t* o, hipStream_t s) { return ZKT_MSM_BY_GROUP(P.grp, launch_msm_reduce, P, w, j, o, s); }
+hipError_t launch_msm_jac_sum_to_affine(int grp, const uint32_t* p, size_t c, uint32_t* o, hipStream_t s) { return ZKT_MSM_BY_GROUP(grp, launch_msm_jac_sum_to_affine, grp, p, c, o, s); }
 #endif
 
 }  // namespace zkt

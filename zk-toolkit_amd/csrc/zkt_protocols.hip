@@ -7,6 +7,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <memory>
 #include "abi.h"
 #include "zkt_internal.h"
 #include "../../include/zkt.h"
@@ -52,11 +53,60 @@ __global__ void k_groth16_setup_scalars(const uint32_t* __restrict__ ue, const u
 // r*s etc. are group-side in the reference (delta*r*s = two scalar muls), nothing to do here.
 
 // IPA scalar stage: [x, x^-1, x^2, x^-2] canonical
-__global__ void k_ipa_challenge(const uint32_t* __restrict__ x, uint32_t* __restrict__ out4) {
+__global__ void k_ipa_challenge(const uint32_t* __restrict__ x, uint32_t* __restrict__ out4, uint32_t* __restrict__ sq2) {
   typedef SnC C;
   if (threadIdx.x || blockIdx.x) return;
-  Fp<C> xm = ld_fp<C>(x), xi = fp_inv(xm), x2 = fp_sqr(xm), x2i = fp_inv(x2);
+  Fp<C> xm = ld_fp<C>(x), xi = fp_inv(xm), x2 = fp_sqr(xm), x2i = fp_sqr(xi);      // (x^2)^-1 = (x^-1)^2: one inversion
   st_fp<C>(out4, xm); st_fp<C>(out4 + 8, xi); st_fp<C>(out4 + 16, x2); st_fp<C>(out4 + 24, x2i);
+  st_fp<C>(sq2, x2); st_fp<C>(sq2 + 8, x2i);
+}
+// The inner-product argument over the ORIGINAL generators.  After j folds (bulletproofs.rs:44-45) the generator at folded index i is
+//   gg^(j)[i] = sum_{k = i mod n_j} wG[k] gg[k],  wG[k] = prod_l (bit_l(k) ? x_l : x_l^-1)   (hh: the inverse factors),
+// so L and R of every level (:39-40) are two multi-scalar multiplications over the fixed base set [gg | hh | u] with the scalars
+// a^(j)[..] wG[k], b^(j)[..] wH[k] — each original generator enters exactly one of L, R — and no generator is ever folded.
+// All vectors hold canonical residues (fp_mul(ld_fp(s), ld_raw(v)) = s v, as in k_fold).
+__global__ void __launch_bounds__(256) k_ipa_w_init(size_t N, uint32_t* __restrict__ wG, uint32_t* __restrict__ wH) {
+  size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; if (k >= N) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { wG[k * 8 + j] = j == 0; wH[k * 8 + j] = j == 0; }
+}
+// sL, sR: 2N+1 scalars each for the base set [gg | hh | u];  L = gg_hi*a_lo + hh_lo*b_hi + u cL,  R = gg_lo*a_hi + hh_hi*b_lo + u cR
+__global__ void __launch_bounds__(256) k_ipa_level_scalars(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ wG,
+                                                           const uint32_t* __restrict__ wH, const uint32_t* __restrict__ cLR, size_t N, size_t n,
+                                                           uint32_t* __restrict__ sL, uint32_t* __restrict__ sR) {
+  typedef SnC C;
+  size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; if (k > N) return;
+  if (k == N) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sL[2 * N * 8 + j] = cLR[j]; sR[2 * N * 8 + j] = cLR[8 + j]; }
+    return;
+  }
+  const size_t np = n / 2, i = k & (n - 1); const bool hi = i >= np; const size_t j = hi ? i - np : i;
+  const Fp<C> zero = fp_zero<C>();
+  const Fp<C> sg = fp_mul(ld_fp<C>(a + (hi ? j : np + j) * 8), ld_raw<C>(wG + k * 8));
+  const Fp<C> sh = fp_mul(ld_fp<C>(b + (hi ? j : np + j) * 8), ld_raw<C>(wH + k * 8));
+  st_raw<C>(sL + k * 8, hi ? sg : zero);        st_raw<C>(sR + k * 8, hi ? zero : sg);
+  st_raw<C>(sL + (N + k) * 8, hi ? zero : sh);  st_raw<C>(sR + (N + k) * 8, hi ? sh : zero);
+}
+// gg' = gg_lo x^-1 + gg_hi x,  hh' = hh_lo x + hh_hi x^-1  (:44-45) on the coefficient vectors
+__global__ void __launch_bounds__(256) k_ipa_w_fold(const uint32_t* __restrict__ X, const uint32_t* __restrict__ XI, size_t N, size_t n,
+                                                    uint32_t* __restrict__ wG, uint32_t* __restrict__ wH) {
+  typedef SnC C;
+  size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; if (k >= N) return;
+  const bool hi = (k & (n - 1)) >= n / 2;
+  const Fp<C> x = ld_fp<C>(X), xi = ld_fp<C>(XI);
+  st_raw<C>(wG + k * 8, fp_mul(hi ? x : xi, ld_raw<C>(wG + k * 8)));
+  st_raw<C>(wH + k * 8, fp_mul(hi ? xi : x, ld_raw<C>(wH + k * 8)));
+}
+// base case (:28-32): g a + h b + u (a b) with g = sum wG[k] gg[k], h = sum wH[k] hh[k]
+__global__ void __launch_bounds__(256) k_ipa_final_scalars(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ wG,
+                                                           const uint32_t* __restrict__ wH, size_t N, uint32_t* __restrict__ sF) {
+  typedef SnC C;
+  size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; if (k > N) return;
+  const Fp<C> am = ld_fp<C>(a), bm = ld_fp<C>(b);
+  if (k == N) { st_raw<C>(sF + 2 * N * 8, fp_mul(am, ld_raw<C>(b))); return; }
+  st_raw<C>(sF + k * 8, fp_mul(am, ld_raw<C>(wG + k * 8)));
+  st_raw<C>(sF + (N + k) * 8, fp_mul(bm, ld_raw<C>(wH + k * 8)));
 }
 // dot = sum_i a[i]*b[i] (one block); PrimeFieldElems * PrimeFieldElems then sum (prime_field_elems.rs:90-174)
 template <class C>
@@ -266,70 +316,150 @@ int zkt_groth16_verify(const zkt_groth16_crs* c, const zkt_g1_affine* A, const z
 
 // Bulletproofs::inner_product_argument (bulletproofs.rs:19-55); xs = one injected challenge per level (log2 n of them).
 // out_trace (optional, host): per level L, R and the folded P' (3 zkt_secp_affine) for level-by-level parity.
-int zkt_bp_inner_product_argument(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u, const zkt_secp_affine* P,
-                                  const uint64_t* a, const uint64_t* b, const uint64_t* xs, zkt_secp_affine* out_trace) {
-  if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
-  if (n == 0 || (n & (n - 1)) || !gg || !hh || !u || !P || !a || !b || (n > 1 && !xs)) return -ZKT_ERR_SHAPE;
+// Runs on the original generators (see k_ipa_level_scalars): one resident base set [gg | hh | u], two MSMs per level and one for the base case.
+// The reference draws x independently of L and R (:42), so a level's scalar algebra does not wait for its MSMs: the scalar stage runs ahead on
+// the caller's stream and up to IPA_SLOTS MSMs are in flight; L x^2 and R x^-2 (:47) are multiplied on side streams as results arrive.
+// The generators are the long-lived input (one set per deployment): zkt_bp_ipa_ctx keeps their window-multiple table and every work buffer
+// resident, and zkt_bp_inner_product_argument (the reference's signature) is create + run + free.
+}  // extern "C"
+struct zkt_bp_ipa_ctx {
+  static constexpr int PW = 18, IPA_SLOTS = 8;
+  static constexpr size_t IPA_BATCH = 4;   // levels per product launch: a 256-bit double-and-add is ~4 ms however few points it covers
+  size_t N, NB, levels, lv1;
+  Dev dbase, da, db, da2, db2, dwG, dwH, dsc, dPp, dx, dch, dsq, dc, dlr, dm, dt;
+  zkt_secp_bases* set = nullptr;
+  std::vector<hipStream_t> side;           // one stream per product batch, so the batches overlap each other and the MSMs
+  hipEvent_t ev = nullptr;
+  static size_t log2z(size_t n) { size_t l = 0; for (size_t t = n; t > 1; t >>= 1) ++l; return l; }
+  explicit zkt_bp_ipa_ctx(size_t n)
+      : N(n), NB(2 * n + 1), levels(log2z(n)), lv1(levels ? levels : 1), dbase(NB * SPB), da(N * FRB), db(N * FRB), da2(N * FRB), db2(N * FRB), dwG(N * FRB), dwH(N * FRB),
+        dsc((size_t)IPA_SLOTS * NB * FRB), dPp(SPB), dx(lv1 * FRB), dch(4 * FRB), dsq(lv1 * 2 * FRB), dc(2 * FRB), dlr(lv1 * 2 * SPB), dm(lv1 * 2 * SPB), dt(SPB) {}
+  bool ok() const { return dbase.p && da.p && db.p && da2.p && db2.p && dwG.p && dwH.p && dsc.p && dPp.p && dx.p && dch.p && dsq.p && dc.p && dlr.p && dm.p && dt.p; }
+  ~zkt_bp_ipa_ctx() {
+    for (hipStream_t x : side) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
+    if (ev) hipEventDestroy(ev);
+    if (set) zkt_secp_bases_free(set);
+  }
+};
+extern "C" {
+int zkt_bp_ipa_ctx_create(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u, zkt_bp_ipa_ctx** out) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (n == 0 || (n & (n - 1)) || n > (size_t(1) << 24) || !gg || !hh || !u || !out) return ZKT_ERR_SHAPE;
   hipStream_t s = nullptr;
-  const int PW = 18;
-  Dev dg(n * SPB), dh(n * SPB), da(n * FRB), db(n * FRB), du(SPB), dPp(SPB), dx(FRB), dch(4 * FRB), dc(2 * FRB);
-  Dev tmp((n + 2) * SPB), tmp2((n + 2) * SPB), dLR(2 * SPB), da2(n * FRB), db2(n * FRB);
+  std::unique_ptr<zkt_bp_ipa_ctx> c(new zkt_bp_ipa_ctx(n));
+  if (!c->ok()) return ZKT_ERR_DEVICE;
+  const size_t N = n;
+  PCHK(hipMemcpyAsync(c->dbase.p, gg, N * SPB, hipMemcpyHostToDevice, s));
+  PCHK(hipMemcpyAsync((char*)c->dbase.p + N * SPB, hh, N * SPB, hipMemcpyHostToDevice, s));
+  PCHK(hipMemcpyAsync((char*)c->dbase.p + 2 * N * SPB, u, SPB, hipMemcpyHostToDevice, s));
+  c->side.assign((c->levels + zkt_bp_ipa_ctx::IPA_BATCH - 1) / zkt_bp_ipa_ctx::IPA_BATCH, nullptr);
+  for (hipStream_t& x : c->side) PCHK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+  PCHK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+  int rc = zkt_secp_bases_from_device((const zkt_secp_affine*)c->dbase.p, c->NB, s, &c->set);
+  if (rc) return rc;
+  *out = c.release();
+  return ZKT_OK;
+}
+void zkt_bp_ipa_ctx_free(zkt_bp_ipa_ctx* c) { delete c; }
+
+// one argument over the context's generators; a context serves one call at a time.  Returns 1 / 0 like the reference's bool, negative = -status.
+int zkt_bp_inner_product_argument_ctx(zkt_bp_ipa_ctx* c, const zkt_secp_affine* P, const uint64_t* a, const uint64_t* b, const uint64_t* xs, zkt_secp_affine* out_trace) {
+  if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
+  if (!c || !P || !a || !b || (c->N > 1 && !xs)) return -ZKT_ERR_SHAPE;
+  hipStream_t s = nullptr;
+  constexpr int PW = zkt_bp_ipa_ctx::PW, IPA_SLOTS = zkt_bp_ipa_ctx::IPA_SLOTS;
+  constexpr size_t IPA_BATCH = zkt_bp_ipa_ctx::IPA_BATCH;
+  const size_t N = c->N, NB = c->NB, levels = c->levels;
+  size_t n = N;
+  for (size_t lv = 0; lv < levels; ++lv) {                    // challenge x (:42, injected) must be invertible
+    bool zero = true; for (int j = 0; j < 4; ++j) zero = zero && xs[lv * 4 + j] == 0;
+    if (zero) return -ZKT_ERR_INV_ZERO;
+  }
+  Dev &da = c->da, &db = c->db, &da2 = c->da2, &db2 = c->db2, &dwG = c->dwG, &dwH = c->dwH, &dsc = c->dsc, &dPp = c->dPp, &dx = c->dx, &dch = c->dch, &dsq = c->dsq, &dc = c->dc,
+      &dlr = c->dlr, &dm = c->dm, &dt = c->dt;
   int rc;
-  if ((rc = up(dg, gg, n * SPB, s)) || (rc = up(dh, hh, n * SPB, s)) || (rc = up(da, a, n * FRB, s)) || (rc = up(db, b, n * FRB, s)) ||
-      (rc = up(du, u, SPB, s)) || (rc = up(dPp, P, SPB, s))) return -rc;
-  if (!tmp.p || !tmp2.p || !dLR.p || !da2.p || !db2.p || !dch.p || !dc.p || !dx.p) return -ZKT_ERR_DEVICE;
-  uint32_t *G = dg.w(), *H = dh.w(), *Av = da.w(), *Bv = db.w(), *A2 = da2.w(), *B2 = db2.w();
+  if ((rc = up(da, a, N * FRB, s)) || (rc = up(db, b, N * FRB, s)) || (rc = up(dPp, P, SPB, s)) || (rc = up(dx, xs, levels * FRB, s))) return -rc;
+  const unsigned gN = (unsigned)((N + 256) / 256);            // N + 1 threads
+  hipLaunchKernelGGL(k_ipa_w_init, dim3(gN), dim3(256), 0, s, N, dwG.w(), dwH.w());
+  uint32_t *Av = da.w(), *Bv = db.w(), *A2 = da2.w(), *B2 = db2.w();
+  std::vector<zkt_secp_affine> lr(2 * levels + 1);            // L_0, R_0, L_1, R_1, ..., base-case right-hand side
+  const size_t n_msm = 2 * levels + 1;
+  size_t collected = 0, submitted = 0;
+  struct Drain { zkt_bp_ipa_ctx* c; size_t *col, *sub; ~Drain() { for (; *col < *sub; ++*col) zkt_secp_msm_collect(c->set, (int)(*col % zkt_bp_ipa_ctx::IPA_SLOTS), nullptr, nullptr); } } drain{c, &collected, &submitted};
+  // MSM m uses slot m % IPA_SLOTS and that slot's scalar buffer; results are collected in order, and once IPA_BATCH levels are in, their products start
+  auto collect_next = [&]() -> int {
+    const size_t m = collected;
+    int r = zkt_secp_msm_collect(c->set, (int)(m % IPA_SLOTS), &lr[m], nullptr);
+    ++collected;
+    if (r) return r;
+    if (m < 2 * levels && (m & 1) && ((m / 2 + 1) % IPA_BATCH == 0 || m / 2 + 1 == levels)) {
+      const size_t lv = m / 2, lv0 = lv / IPA_BATCH * IPA_BATCH, cnt = 2 * (lv + 1 - lv0);
+      hipStream_t st = c->side[lv / IPA_BATCH];
+      if (hipEventRecord(c->ev, s) != hipSuccess || hipStreamWaitEvent(st, c->ev, 0) != hipSuccess ||                   // x^2, x^-2 of these levels exist
+          hipMemcpyAsync(dlr.w() + 2 * lv0 * PW, &lr[2 * lv0], cnt * SPB, hipMemcpyHostToDevice, st) != hipSuccess ||
+          launch_group_mul(G_SECP, dlr.w() + 2 * lv0 * PW, dsq.w() + lv0 * 16, 8, dm.w() + 2 * lv0 * PW, cnt, st)) return ZKT_ERR_DEVICE;
+    }
+    return ZKT_OK;
+  };
+  auto slot_buf = [&](size_t m) -> uint32_t* { return dsc.w() + (m % IPA_SLOTS) * NB * 8; };
+  auto free_slot = [&](size_t m) -> int { while (m >= collected + IPA_SLOTS) { int r = collect_next(); if (r) return r; } return ZKT_OK; };
+  auto submit = [&](size_t m) -> int { int r = zkt_secp_msm_submit(c->set, (const uint64_t*)slot_buf(m), NB, s, (int)(m % IPA_SLOTS)); if (!r) ++submitted; return r; };
   size_t level = 0;
   while (n > 1) {
-    const size_t np = n / 2;
+    const size_t np = n / 2, m = 2 * level;
+    if ((rc = free_slot(m + 1))) return -rc;
     // cL = <a_lo, b_hi>, cR = <a_hi, b_lo>  (:36-37)
     hipLaunchKernelGGL(k_dot<SnC>, dim3(1), dim3(256), 0, s, (const uint32_t*)Av, (const uint32_t*)(Bv + np * 8), np, dc.w());
     hipLaunchKernelGGL(k_dot<SnC>, dim3(1), dim3(256), 0, s, (const uint32_t*)(Av + np * 8), (const uint32_t*)Bv, np, dc.w() + 8);
     // L = (gg_hi * a_lo).sum() + (hh_lo * b_hi).sum() + u * cL   (:39)
-    // R = (gg_lo * a_hi).sum() + (hh_hi * b_lo).sum() + u * cR   (:40)    — all six batched multiplications in one launch
-    uint32_t *T = tmp.w(), *T2 = tmp2.w();
-    {
-      MulSegs m{};
-      m.s[0] = {G + np * PW, Av, T, (uint32_t)np, PW, 8};              m.s[1] = {H, Bv + np * 8, T + np * PW, (uint32_t)np, PW, 8};
-      m.s[2] = {du.w(), dc.w(), T + 2 * np * PW, 1, 0, 0};
-      m.s[3] = {G, Av + np * 8, T2, (uint32_t)np, PW, 8};              m.s[4] = {H + np * PW, Bv, T2 + np * PW, (uint32_t)np, PW, 8};
-      m.s[5] = {du.w(), dc.w() + 8, T2 + 2 * np * PW, 1, 0, 0};
-      m.n = 6;
-      if (launch_group_mul_segs(G_SECP, m, 8, s) || launch_group_sum_inplace(G_SECP, T, 2 * np + 1, s) || launch_group_sum_inplace(G_SECP, T2, 2 * np + 1, s)) return -ZKT_ERR_DEVICE;
-    }
-    if (hipMemcpyAsync(dLR.w(), T, SPB, hipMemcpyDeviceToDevice, s) != hipSuccess || hipMemcpyAsync(dLR.w() + PW, T2, SPB, hipMemcpyDeviceToDevice, s) != hipSuccess) return -ZKT_ERR_DEVICE;
-    // challenge x (:42, injected) -> x, x^-1, x^2, x^-2
-    bool zero = true; for (int j = 0; j < 4; ++j) zero = zero && xs[level * 4 + j] == 0;
-    if (zero) return -ZKT_ERR_INV_ZERO;
-    if ((rc = up(dx, xs + level * 4, FRB, s))) return -rc;
-    hipLaunchKernelGGL(k_ipa_challenge, dim3(1), dim3(64), 0, s, (const uint32_t*)dx.w(), dch.w());
-    const uint32_t *X = dch.w(), *XI = dch.w() + 8, *X2 = dch.w() + 16, *X2I = dch.w() + 24;
-    // gg' = gg_lo * x^-1 + gg_hi * x ; hh' = hh_lo * x + hh_hi * x^-1 (:44-45);  P' = L x^2 + P + R x^-2 (:47) — again one launch
-    {
-      MulSegs m{};
-      m.s[0] = {G, XI, T, (uint32_t)np, PW, 0};                        m.s[1] = {G + np * PW, X, T + np * PW, (uint32_t)np, PW, 0};
-      m.s[2] = {H, X, T2, (uint32_t)np, PW, 0};                        m.s[3] = {H + np * PW, XI, T2 + np * PW, (uint32_t)np, PW, 0};
-      m.s[4] = {dLR.w(), X2, T + 2 * np * PW, 1, 0, 0};                m.s[5] = {dLR.w() + PW, X2I, T2 + 2 * np * PW, 1, 0, 0};
-      m.n = 6;
-      if (launch_group_mul_segs(G_SECP, m, 8, s) || launch_group_add(G_SECP, T, T + np * PW, G, np, s) || launch_group_add(G_SECP, T2, T2 + np * PW, H, np, s) ||
-          launch_group_add(G_SECP, T + 2 * np * PW, dPp.w(), T + 2 * np * PW, 1, s) || launch_group_add(G_SECP, T + 2 * np * PW, T2 + 2 * np * PW, dPp.w(), 1, s)) return -ZKT_ERR_DEVICE;
-    }
-    // a' = a_lo x + a_hi x^-1 ; b' = b_lo x^-1 + b_hi x   (:49-50)
+    // R = (gg_lo * a_hi).sum() + (hh_hi * b_lo).sum() + u * cR   (:40)
+    hipLaunchKernelGGL(k_ipa_level_scalars, dim3(gN), dim3(256), 0, s, (const uint32_t*)Av, (const uint32_t*)Bv, (const uint32_t*)dwG.w(), (const uint32_t*)dwH.w(),
+                       (const uint32_t*)dc.w(), N, n, slot_buf(m), slot_buf(m + 1));
+    if (hipGetLastError() != hipSuccess) return -ZKT_ERR_DEVICE;
+    if ((rc = submit(m)) || (rc = submit(m + 1))) return -rc;
+    // x, x^-1, x^2, x^-2; generator coefficients and a' = a_lo x + a_hi x^-1 ; b' = b_lo x^-1 + b_hi x   (:44-45, :49-50)
+    hipLaunchKernelGGL(k_ipa_challenge, dim3(1), dim3(64), 0, s, (const uint32_t*)(dx.w() + level * 8), dch.w(), dsq.w() + level * 16);
+    const uint32_t *X = dch.w(), *XI = dch.w() + 8;
+    hipLaunchKernelGGL(k_ipa_w_fold, dim3(gN), dim3(256), 0, s, X, XI, N, n, dwG.w(), dwH.w());
     hipLaunchKernelGGL(k_fold<SnC>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const uint32_t*)Av, (const uint32_t*)(Av + np * 8), X, XI, np, A2);
     hipLaunchKernelGGL(k_fold<SnC>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const uint32_t*)Bv, (const uint32_t*)(Bv + np * 8), XI, X, np, B2);
     std::swap(Av, A2); std::swap(Bv, B2);
-    if (out_trace) { if ((rc = down(out_trace + level * 3, dLR.p, 2 * SPB, s)) || (rc = down(out_trace + level * 3 + 2, dPp.p, SPB, s))) return -rc; }
     n = np; ++level;
   }
-  // base case (:28-32): c = a*b; P == g*a + h*b + u*c
-  hipLaunchKernelGGL(k_dot<SnC>, dim3(1), dim3(256), 0, s, (const uint32_t*)Av, (const uint32_t*)Bv, (size_t)1, dc.w());
-  uint32_t* T = tmp.w();
-  if (launch_group_mul(G_SECP, G, Av, 8, T, 1, s) || launch_group_mul(G_SECP, H, Bv, 8, T + PW, 1, s) || launch_group_mul(G_SECP, du.w(), dc.w(), 8, T + 2 * PW, 1, s) ||
-      launch_group_sum_inplace(G_SECP, T, 3, s)) return -ZKT_ERR_DEVICE;
-  zkt_secp_affine rhs, lhs;
-  if ((rc = down(&rhs, T, SPB, s)) || (rc = down(&lhs, dPp.p, SPB, s))) return -rc;
+  // base case (:28-32): c = a*b; rhs = g*a + h*b + u*c over the original generators
+  if ((rc = free_slot(n_msm - 1))) return -rc;
+  hipLaunchKernelGGL(k_ipa_final_scalars, dim3(gN), dim3(256), 0, s, (const uint32_t*)Av, (const uint32_t*)Bv, (const uint32_t*)dwG.w(), (const uint32_t*)dwH.w(), N, slot_buf(n_msm - 1));
+  if (hipGetLastError() != hipSuccess) return -ZKT_ERR_DEVICE;
+  if ((rc = submit(n_msm - 1))) return -rc;
+  while (collected < n_msm) if ((rc = collect_next())) return -rc;
+  // P' = L x^2 + P + R x^-2 (:47): the products are ready on the side streams; the running sum level by level for the trace, one block sum otherwise
+  if (levels) {
+    for (hipStream_t x : c->side) if (hipStreamSynchronize(x) != hipSuccess) return -ZKT_ERR_DEVICE;
+    if (out_trace) {
+      for (size_t lv = 0; lv < levels; ++lv) {
+        if (launch_group_add(G_SECP, dm.w() + 2 * lv * PW, dPp.w(), dt.w(), 1, s) || launch_group_add(G_SECP, dt.w(), dm.w() + (2 * lv + 1) * PW, dPp.w(), 1, s)) return -ZKT_ERR_DEVICE;
+        out_trace[lv * 3] = lr[2 * lv]; out_trace[lv * 3 + 1] = lr[2 * lv + 1];
+        if ((rc = down(out_trace + lv * 3 + 2, dPp.p, SPB, s))) return -rc;
+      }
+    } else {
+      if (launch_group_sum_inplace(G_SECP, dm.w(), 2 * levels, s) || launch_group_add(G_SECP, dm.w(), dPp.w(), dt.w(), 1, s) ||
+          hipMemcpyAsync(dPp.p, dt.p, SPB, hipMemcpyDeviceToDevice, s) != hipSuccess) return -ZKT_ERR_DEVICE;
+    }
+  }
+  zkt_secp_affine lhs;
+  if ((rc = down(&lhs, dPp.p, SPB, s))) return -rc;
   if (hipStreamSynchronize(s) != hipSuccess) return -ZKT_ERR_DEVICE;
-  return memcmp(&rhs, &lhs, SPB) == 0 ? 1 : 0;
+  return memcmp(&lr[n_msm - 1], &lhs, SPB) == 0 ? 1 : 0;
+}
+int zkt_bp_inner_product_argument(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u, const zkt_secp_affine* P,
+                                  const uint64_t* a, const uint64_t* b, const uint64_t* xs, zkt_secp_affine* out_trace) {
+  if (n == 0 || (n & (n - 1)) || !gg || !hh || !u || !P || !a || !b || (n > 1 && !xs)) return -ZKT_ERR_SHAPE;
+  zkt_bp_ipa_ctx* c = nullptr;
+  int rc = zkt_bp_ipa_ctx_create(n, gg, hh, u, &c);
+  if (rc) return -rc;
+  rc = zkt_bp_inner_product_argument_ctx(c, P, a, b, xs, out_trace);
+  zkt_bp_ipa_ctx_free(c);
+  return rc;
 }
 
 
