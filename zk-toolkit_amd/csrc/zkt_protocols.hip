@@ -500,30 +500,38 @@ int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, c
   unsigned long long ne = NO_ERR; hipMemcpyAsync(derr.p, &ne, 8, hipMemcpyHostToDevice, s);
   const uint64_t one64[4] = {1, 0, 0, 0}, two64[4] = {2, 0, 0, 0};
   if ((rnd[8] | rnd[9] | rnd[10] | rnd[11]) == 0) return -ZKT_ERR_INV_ZERO;   // y must be invertible (:109); the reference draws non-zero values
-  // points on the device: [gg | hh | hhp | g h V u | scratch]
-  Dev pts((3 * n + 8) * SPB), tmp((2 * n + 8) * SPB), res(16 * SPB);
+  // points on the device: [gg | hh | hhp | g h V u]; tmp = four n-vectors of products; res = A S T1 T2 P | single-point scratch
+  Dev pts((3 * n + 8) * SPB), tmp((4 * n + 8) * SPB), res(48 * SPB);
   if (!pts.p || !tmp.p || !res.p) return -ZKT_ERR_DEVICE;
   uint32_t *GG = pts.w(), *HH = GG + n * PW, *HHP = HH + n * PW, *Gp = HHP + n * PW, *Hp = Gp + PW, *Vp = Hp + PW, *Up = Vp + PW;
   hipMemcpyAsync(GG, gg, n * SPB, hipMemcpyHostToDevice, s); hipMemcpyAsync(HH, hh, n * SPB, hipMemcpyHostToDevice, s);
   hipMemcpyAsync(Gp, g, SPB, hipMemcpyHostToDevice, s); hipMemcpyAsync(Hp, h, SPB, hipMemcpyHostToDevice, s); hipMemcpyAsync(Vp, V, SPB, hipMemcpyHostToDevice, s);
   if (use_ipa) hipMemcpyAsync(Up, u, SPB, hipMemcpyHostToDevice, s);
-  uint32_t* R = res.w(); int ri = 0;
-  auto newp = [&]() { return R + (size_t)(ri++) * PW; };
-  // sum_i pts[i]*k[i] (+ extra terms): scalar-mul batch then pairwise tree (AffinePoints * PrimeFieldElems).sum()
-  auto msm = [&](const uint32_t* P, const uint32_t* k) { uint32_t* T = tmp.w(); launch_group_mul(G_SECP, P, k, 8, T, n, s); launch_group_sum_inplace(G_SECP, T, n, s);
-                                                         uint32_t* o = newp(); hipMemcpyAsync(o, T, SPB, hipMemcpyDeviceToDevice, s); return o; };
-  auto pmul = [&](const uint32_t* P, const uint32_t* k) { uint32_t* o = newp(); launch_group_mul(G_SECP, P, k, 8, o, 1, s); return o; };
-  auto padd = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = newp(); launch_group_add(G_SECP, a, b, o, 1, s); return o; };
+  uint32_t* R = res.w();
+  uint32_t *Ak = R, *Sk = R + PW, *T1k = R + 2 * PW, *T2k = R + 3 * PW, *Pk = R + 4 * PW;        // out_pts order
+  auto Q = [&](int i) { return R + (size_t)(8 + i) * PW; };                                       // single-point scratch
+  uint32_t *TA = tmp.w(), *TB = TA + n * PW, *TC = TB + n * PW, *TD = TC + n * PW;
+  // A scalar multiplication is a ~4-6 ms dependent chain however few points a launch covers, so the proof's multiplications are issued in three
+  // launches (everything independent of earlier POINTS goes together); (AffinePoints * PrimeFieldElems).sum() = one segment + a block sum.
+  bool okl = true;
+  auto seg = [&](const uint32_t* P, const uint32_t* k, uint32_t* out, size_t cnt) { return MulSeg{P, k, out, (uint32_t)cnt, cnt > 1 ? (uint32_t)PW : 0u, cnt > 1 ? 8u : 0u}; };
+  auto run = [&](const MulSegs& m) { okl = okl && launch_group_mul_segs(G_SECP, m, 8, s) == hipSuccess; };
+  auto vsum_pts = [&](uint32_t* T) { okl = okl && launch_group_sum_inplace(G_SECP, T, n, s) == hipSuccess; };      // result in T[0]
+  auto padd = [&](const uint32_t* a, const uint32_t* b, uint32_t* o) { okl = okl && launch_group_add(G_SECP, a, b, o, 1, s) == hipSuccess; return o; };
 
   uint32_t *d_aL = vput(aL), *d_sL = vput(rnd + 28), *d_sR = vput(rnd + 28 + 4 * n);
   uint32_t *alpha = sput(rnd), *rho = sput(rnd + 4), *y = sput(rnd + 8), *z = sput(rnd + 12), *tau1 = sput(rnd + 16), *tau2 = sput(rnd + 20), *x = sput(rnd + 24);
   uint32_t *d_gamma = sput(gamma), *one = sput(one64), *two = sput(two64);
   uint32_t *one_n = vpow(one), *two_n = vpow(two);                                   // :72-73
   uint32_t* aR = vsub(d_aL, one_n);                                                   // :75
-  uint32_t* A = padd(padd(pmul(Hp, alpha), msm(GG, d_aL)), msm(HH, aR));              // :77
-  ri = 0; uint32_t* Ak = newp(); hipMemcpyAsync(Ak, A, SPB, hipMemcpyDeviceToDevice, s);
-  uint32_t* S = padd(padd(pmul(Hp, rho), msm(GG, d_sL)), msm(HH, d_sR));              // :82
-  ri = 1; uint32_t* Sk = newp(); hipMemcpyAsync(Sk, S, SPB, hipMemcpyDeviceToDevice, s);
+  {                                                                                   // A (:77), S (:82)
+    MulSegs m{}; m.n = 6;
+    m.s[0] = seg(Hp, alpha, Q(0), 1); m.s[1] = seg(GG, d_aL, TA, n); m.s[2] = seg(HH, aR, TB, n);
+    m.s[3] = seg(Hp, rho, Q(1), 1);   m.s[4] = seg(GG, d_sL, TC, n); m.s[5] = seg(HH, d_sR, TD, n);
+    run(m); vsum_pts(TA); vsum_pts(TB); vsum_pts(TC); vsum_pts(TD);
+    padd(padd(Q(0), TA, Q(2)), TB, Ak);
+    padd(padd(Q(1), TC, Q(3)), TD, Sk);
+  }
   uint32_t* y_n = vpow(y);                                                            // :87
   uint32_t* z2 = smul(z, z);
   uint32_t* onez = vscl(one_n, z);
@@ -533,49 +541,56 @@ int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, c
   uint32_t* r0 = vadd(vhad(y_n, aRz), twoz2);                                         // :90
   uint32_t* r1 = vhad(y_n, d_sR);                                                     // :91
   uint32_t *t0 = vdot(l0, r0), *t1 = sadd(vdot(d_sL, r0), vdot(l0, r1)), *t2 = vdot(d_sL, r1);   // :93-95
-  ri = 2;
-  uint32_t* T1 = padd(pmul(Gp, t1), pmul(Hp, tau1)); ri = 2; uint32_t* T1k = newp(); hipMemcpyAsync(T1k, T1, SPB, hipMemcpyDeviceToDevice, s);   // :99
-  uint32_t* T2 = padd(pmul(Gp, t2), pmul(Hp, tau2)); ri = 3; uint32_t* T2k = newp(); hipMemcpyAsync(T2k, T2, SPB, hipMemcpyDeviceToDevice, s);   // :100
   uint32_t* x2 = smul(x, x);
   uint32_t* t_hat = sadd(sadd(t0, smul(t1, x)), smul(t2, x2));                        // :104
   uint32_t* tau_x = sadd(sadd(smul(tau2, x2), smul(tau1, x)), smul(z2, d_gamma));     // :105
   uint32_t* mu = sadd(alpha, smul(rho, x));                                           // :106
   uint32_t* yinv_n = vpow(sinv(y));
-  launch_group_mul(G_SECP, HH, yinv_n, 8, HHP, n, s);                                 // :109 hh' = hh * y^-i
   uint32_t* z3 = smul(z2, z);
   uint32_t* delta_yz = ssub(smul(ssub(z, z2), vsum(y_n)), smul(z3, vsum(two_n)));     // :112 (one_n o v = v)
-  ri = 4;
-  uint32_t* lhs65 = padd(pmul(Gp, t_hat), pmul(Hp, tau_x));                           // :114
-  uint32_t* lhsk = R + 12 * PW; hipMemcpyAsync(lhsk, lhs65, SPB, hipMemcpyDeviceToDevice, s);
-  ri = 4;
-  uint32_t* rhs65 = padd(padd(padd(pmul(Vp, z2), pmul(Gp, delta_yz)), pmul(T1k, x)), pmul(T2k, x2));   // :115
-  uint32_t* rhsk = R + 13 * PW; hipMemcpyAsync(rhsk, rhs65, SPB, hipMemcpyDeviceToDevice, s);
+  uint32_t* negz_n = vscl(one_n, sneg(z));
+  uint32_t* mu_signed = use_ipa ? sneg(mu) : mu;
+  {                                                                                   // T1 (:99), T2 (:100), hh' (:109), both sides of :114-115, the scalar-only parts of P
+    MulSegs m{}; m.n = 11;
+    m.s[0] = seg(Gp, t1, Q(4), 1);     m.s[1] = seg(Hp, tau1, Q(5), 1);  m.s[2] = seg(Gp, t2, Q(6), 1);    m.s[3] = seg(Hp, tau2, Q(7), 1);
+    m.s[4] = seg(Gp, t_hat, Q(8), 1);  m.s[5] = seg(Hp, tau_x, Q(9), 1); m.s[6] = seg(Vp, z2, Q(10), 1);   m.s[7] = seg(Gp, delta_yz, Q(11), 1);
+    m.s[8] = seg(HH, yinv_n, HHP, n);  m.s[9] = seg(GG, negz_n, TA, n);  m.s[10] = seg(Hp, mu_signed, Q(12), 1);
+    run(m); vsum_pts(TA);
+    padd(Q(4), Q(5), T1k); padd(Q(6), Q(7), T2k);
+    padd(Q(8), Q(9), Q(13));                                                          // lhs of :116
+  }
   uint32_t* l = vadd(l0, vscl(d_sL, x));                                              // :121
   uint32_t* r = vadd(vhad(y_n, vadd(aRz, vscl(d_sR, x))), twoz2);                     // :122
-  ri = 4;
-  uint32_t* Pm = padd(padd(padd(Ak, pmul(Sk, x)), msm(GG, vscl(one_n, sneg(z)))), msm(HHP, vadd(vscl(y_n, z), twoz2)));   // :124-128
-  uint32_t* Pk = R + 4 * PW; hipMemcpyAsync(Pk, Pm, SPB, hipMemcpyDeviceToDevice, s);
+  uint32_t* lr = vdot(l, r);
+  {                                                                                   // the products that need T1, T2, S, hh'
+    MulSegs m{}; m.n = use_ipa ? 5 : 6;
+    m.s[0] = seg(T1k, x, Q(14), 1); m.s[1] = seg(T2k, x2, Q(15), 1); m.s[2] = seg(Sk, x, Q(16), 1);
+    m.s[3] = seg(HHP, vadd(vscl(y_n, z), twoz2), TB, n);
+    if (use_ipa) m.s[4] = seg(Up, lr, Q(17), 1);
+    else { m.s[4] = seg(GG, l, TC, n); m.s[5] = seg(HHP, r, TD, n); }
+    run(m); vsum_pts(TB);
+    if (!use_ipa) { vsum_pts(TC); vsum_pts(TD); }
+    padd(padd(padd(Q(10), Q(11), Q(18)), Q(14), Q(19)), Q(15), Q(20));                // rhs of :115
+    padd(padd(padd(Ak, Q(16), Q(21)), TA, Q(22)), TB, Pk);                            // P (:124-128)
+  }
   zkt_secp_affine hl, hr;
   int rc;
-  if ((rc = down(&hl, lhsk, SPB, s)) || (rc = down(&hr, rhsk, SPB, s))) return -rc;
+  if ((rc = down(&hl, Q(13), SPB, s)) || (rc = down(&hr, Q(20), SPB, s))) return -rc;
   if (out_pts && (rc = down(out_pts, R, 5 * SPB, s))) return -rc;
-  if (hipStreamSynchronize(s) != hipSuccess || vi > NV || si > NS) return -ZKT_ERR_DEVICE;
+  if (hipStreamSynchronize(s) != hipSuccess || !okl || vi > NV || si > NS) return -ZKT_ERR_DEVICE;
   if (memcmp(&hl, &hr, SPB) != 0) return 0;                                           // :116-118
   if (use_ipa) {
-    ri = 5;
-    uint32_t* Pp = padd(padd(Pk, pmul(Hp, sneg(mu))), pmul(Up, vdot(l, r)));          // :138
+    uint32_t* Pp = padd(padd(Pk, Q(12), Q(23)), Q(17), Q(24));                        // :138  P h^-mu u^<l,r>
     std::vector<zkt_secp_affine> hgg(n), hhhp(n); std::vector<uint64_t> hl2(n * 4), hr2(n * 4); zkt_secp_affine hu, hP;
     if ((rc = down(hgg.data(), GG, n * SPB, s)) || (rc = down(hhhp.data(), HHP, n * SPB, s)) || (rc = down(hl2.data(), l, n * FRB, s)) ||
         (rc = down(hr2.data(), r, n * FRB, s)) || (rc = down(&hu, Up, SPB, s)) || (rc = down(&hP, Pp, SPB, s))) return -rc;
-    if (hipStreamSynchronize(s) != hipSuccess || si > NS) return -ZKT_ERR_DEVICE;
+    if (hipStreamSynchronize(s) != hipSuccess || !okl) return -ZKT_ERR_DEVICE;
     return zkt_bp_inner_product_argument(n, hgg.data(), hhhp.data(), &hu, &hP, hl2.data(), hr2.data(), xs, nullptr);   // :139
   }
-  ri = 5;
-  uint32_t* rhs = padd(padd(pmul(Hp, mu), msm(GG, l)), msm(HHP, r));                  // :142
-  uint32_t* lr = vdot(l, r);
+  uint32_t* rhs = padd(padd(Q(12), TC, Q(23)), TD, Q(24));                            // :142
   zkt_secp_affine hP, hrhs; uint64_t hth[4], hlr[4];
   if ((rc = down(&hP, Pk, SPB, s)) || (rc = down(&hrhs, rhs, SPB, s)) || (rc = down(hth, t_hat, FRB, s)) || (rc = down(hlr, lr, FRB, s))) return -rc;
-  if (hipStreamSynchronize(s) != hipSuccess || si > NS) return -ZKT_ERR_DEVICE;
+  if (hipStreamSynchronize(s) != hipSuccess || !okl) return -ZKT_ERR_DEVICE;
   if (memcmp(&hP, &hrhs, SPB) != 0) return 0;
   return memcmp(hth, hlr, FRB) == 0 ? 1 : 0;                                          // :147-149
 }
