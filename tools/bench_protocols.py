@@ -113,6 +113,28 @@ res["bulletproofs_ipa"] = {"generators": n, "levels": 16, "seconds": t_ipa, "sec
                            "cpu_baseline": {"generators": nc, "seconds": t_cpu, "cores": 1, "kind": "port",
                                             "sample": "oracle's reference algorithm at %d generators; x%d for %d generators = %.0f s" % (nc, n // nc, n, t_cpu * n / nc)}}
 
+# ---- Bulletproofs range proof (a18, BASELINE config 5 shape: 64 bits x 1024 values = one 65,536-bit opening) ------------------
+rbits = [int(v) for v in (rand_scalars(15, n, 2)[:, 0] & np.uint64(1))]
+rvalue = sum(bt << i for i, bt in enumerate(rbits))
+extra = np.zeros((2, 9), np.uint64)
+zk.check(L.zkt_secp_mul_batch(ptr(np.repeat(O_g, 2, axis=0)), ptr(rand_scalars(16, 2, SECP_N)), 4, ptr(extra), 2))
+g_r, h_r = extra[0:1].copy(), extra[1:2].copy()
+aL = ints_to_arr(rbits, 4); gamma = rand_scalars(17, 1, SECP_N)
+tmp2 = np.zeros((2, 9), np.uint64); V = np.zeros((1, 9), np.uint64)
+zk.check(L.zkt_secp_mul_batch(ptr(np.concatenate([g_r, h_r])), ptr(np.concatenate([ints_to_arr([rvalue % SECP_N], 4), gamma])), 4, ptr(tmp2), 2))
+zk.check(L.zkt_secp_add_batch(ptr(tmp2[0:1].copy()), ptr(tmp2[1:2].copy()), ptr(V), 1))
+rnd_r = rand_scalars(18, 7 + 2 * n, SECP_N); rnd_r[:, 0] |= np.uint64(1)
+t_rp = {}
+for use_ipa in (0, 1):
+    assert L.zkt_bp_range_proof(n, ptr(V), ptr(aL), ptr(gamma), ptr(g_r), ptr(h_r), ptr(gg), ptr(hh), use_ipa, ptr(rnd_r), ptr(u), ptr(xs), None) == 1
+    t0 = time.perf_counter()
+    assert L.zkt_bp_range_proof(n, ptr(V), ptr(aL), ptr(gamma), ptr(g_r), ptr(h_r), ptr(gg), ptr(hh), use_ipa, ptr(rnd_r), ptr(u), ptr(xs), None) == 1
+    t_rp[use_ipa] = time.perf_counter() - t0
+bad = aL.copy(); bad[7, 0] ^= np.uint64(1)
+assert L.zkt_bp_range_proof(n, ptr(V), ptr(bad), ptr(gamma), ptr(g_r), ptr(h_r), ptr(gg), ptr(hh), 1, ptr(rnd_r), ptr(u), ptr(xs), None) == 0
+res["bulletproofs_range_proof"] = {"bits": n, "seconds_without_ipa": t_rp[0], "seconds_with_ipa": t_rp[1], "accepts": True, "rejects_wrong_opening": True,
+                                   "note": "Bulletproofs::range_proof (bulletproofs.rs:58-147), every random draw injected; host-pointer API, PCIe included"}
+
 # ---- Pinocchio (f-4): chain circuit with 32 constraints ---------------------------------------------------------------------
 A_, B_, C_, wit, l = chain_circuit(32)
 nn, n_io = len(A_), l + 1
