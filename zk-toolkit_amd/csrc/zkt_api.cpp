@@ -330,8 +330,12 @@ static int bases_build(zkt_bases_impl* h, const uint32_t* dev_abi, hipStream_t s
   HIPCHK(hipMalloc((void**)&h->table, tot * 2 * grp_coord_bytes(h->grp)));
   HIPCHK(hipMalloc((void**)&h->inf, tot));
   HIPCHK(launch_msm_to_kernel_layout(h->grp, dev_abi, h->table, h->inf, n, s));
-  HIPCHK(launch_msm_precompute(h->grp, h->table, h->inf, n, h->plan.c, h->plan.nwin, s));
-  HIPCHK(hipStreamSynchronize(s));
+  uint32_t* tmp = nullptr;                                   // Z and prefix products of the per-lane batched normalisation
+  if (h->plan.nwin > 1) HIPCHK(hipMalloc((void**)&tmp, (size_t)(h->plan.nwin - 1) * (n ? n : 1) * 2 * grp_coord_bytes(h->grp)));
+  hipError_t e = launch_msm_precompute(h->grp, h->table, h->inf, n, h->plan.c, h->plan.nwin, tmp, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (tmp) hipFree(tmp);
+  HIPCHK(e);
   return ZKT_OK;
 }
 static void bases_free(zkt_bases_impl* h) {

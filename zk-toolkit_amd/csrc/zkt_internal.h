@@ -58,7 +58,8 @@ MsmPlan msm_plan_direct(size_t n, int grp);
 // Three stages so the API layer can run them on three streams (sort | accumulate | reduce) and overlap
 // consecutive MSMs; the result is a Jacobian partial (3 coordinates) and optionally the affine ABI point.
 hipError_t launch_msm_to_kernel_layout(int grp, const uint32_t* abi_pts, uint32_t* table, uint8_t* base_inf, size_t n, hipStream_t s);
-hipError_t launch_msm_precompute(int grp, uint32_t* table, uint8_t* inf, size_t n, int c, int nwin, hipStream_t s);
+// tmp: (nwin - 1) * n * 2 coordinates of scratch (same layout as the table rows 1..nwin-1), only needed during the call
+hipError_t launch_msm_precompute(int grp, uint32_t* table, uint8_t* inf, size_t n, int c, int nwin, uint32_t* tmp, hipStream_t s);
 hipError_t launch_msm_sort(const MsmPlan& plan, const uint8_t* base_inf, const uint32_t* scalars, void* workspace, hipStream_t s);
 hipError_t launch_msm_accumulate(const MsmPlan& plan, const uint32_t* table, void* workspace, hipStream_t s);
 hipError_t launch_msm_reduce(const MsmPlan& plan, void* workspace, uint32_t* dev_result_jac, uint32_t* dev_out_abi, hipStream_t s);

@@ -132,20 +132,38 @@ hipError_t PART(launch_msm_to_kernel_layout)(int grp, const uint32_t* abi, uint3
 }
 
 // table[w*n + i] = 2^(c*w) * P_i (affine, Montgomery); infinity flags likewise.
+// One lane walks one point through all windows in Jacobian coordinates (255 doublings) and normalises the nwin-1 results with ONE
+// inversion (Montgomery's trick along the lane's own chain): X_w, Y_w wait in their table slots, Z_w and prod_{v<w} Z_v in `tmp`
+// (two coordinates per entry, freed after the build).  An inversion per window made the build 3x longer than the doublings alone.
 template <class F>
-__global__ void __launch_bounds__(64) k_precompute(uint32_t* __restrict__ table, uint8_t* __restrict__ inf, size_t n, int c, int nwin) {
+__global__ void __launch_bounds__(64) k_precompute(uint32_t* __restrict__ table, uint8_t* __restrict__ inf, size_t n, int c, int nwin, uint32_t* __restrict__ tmp) {
   size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || nwin < 2) return;
   constexpr int CW = Coord<F>::CW, PW = 2 * CW;
+  typedef typename F::E E;
   Aff<F> a; a.x = Coord<F>::ld(table + i * PW); a.y = Coord<F>::ld(table + i * PW + CW); a.inf = inf[i] != 0;
   Jac<F> j = jac_from_aff(a);
+  E acc = F::one();
   for (int w = 1; w < nwin; ++w) {
     for (int d = 0; d < c; ++d) j = jac_dbl(j);
-    Aff<F> r = jac_to_aff(j);
-    size_t o = (size_t)w * n + i;
-    Coord<F>::st(table + o * PW, r.x); Coord<F>::st(table + o * PW + CW, r.y);
-    inf[o] = r.inf ? 1 : 0;
-    if (!r.inf) { j.X = r.x; j.Y = r.y; j.Z = F::one(); }
+    const size_t o = (size_t)w * n + i, t = (size_t)(w - 1) * n + i;
+    const bool isinf = jac_is_inf(j);
+    const E z = isinf ? F::one() : j.Z;
+    Coord<F>::st(table + o * PW, j.X); Coord<F>::st(table + o * PW + CW, j.Y);
+    Coord<F>::st(tmp + t * PW, z); Coord<F>::st(tmp + t * PW + CW, acc);
+    inf[o] = isinf ? 1 : 0;
+    acc = F::mul(acc, z);
+  }
+  E inv = F::inv(acc);                                      // 1 / (Z_1 ... Z_{nwin-1}), no factor is zero
+  for (int w = nwin - 1; w >= 1; --w) {
+    const size_t o = (size_t)w * n + i, t = (size_t)(w - 1) * n + i;
+    const E z = Coord<F>::ld(tmp + t * PW), pre = Coord<F>::ld(tmp + t * PW + CW);
+    const E zi = F::mul(inv, pre);                          // 1 / Z_w
+    inv = F::mul(inv, z);
+    const E zi2 = F::sqr(zi);
+    E x = F::mul(Coord<F>::ld(table + o * PW), zi2), y = F::mul(Coord<F>::ld(table + o * PW + CW), F::mul(zi2, zi));
+    if (inf[o]) { x = F::zero(); y = F::zero(); }
+    Coord<F>::st(table + o * PW, x); Coord<F>::st(table + o * PW + CW, y);
   }
 }
 
@@ -597,9 +615,9 @@ hipError_t PART(launch_msm_reduce)(const MsmPlan& P, void* workspace, uint32_t* 
 }
 
 // window-multiple table build
-hipError_t PART(launch_msm_precompute)(int grp, uint32_t* table, uint8_t* inf, size_t n, int c, int nwin, hipStream_t s) {
+hipError_t PART(launch_msm_precompute)(int grp, uint32_t* table, uint8_t* inf, size_t n, int c, int nwin, uint32_t* tmp, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  MSM_DISPATCH(grp, hipLaunchKernelGGL(k_precompute<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, table, inf, n, c, nwin));
+  MSM_DISPATCH(grp, hipLaunchKernelGGL(k_precompute<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, table, inf, n, c, nwin, tmp));
   return hipGetLastError();
 }
 
@@ -625,7 +643,7 @@ hipError_t PART(launch_msm_jac_sum_to_affine)(int grp, const uint32_t* parts, si
 // public entry points: G1 lives in this object, secp256k1 in the PART_SECP object, G2 in the PART_OTHER object
 #define ZKT_MSM_FWD(SUF) \
   hipError_t launch_msm_to_kernel_layout##SUF(int, const uint32_t*, uint32_t*, uint8_t*, size_t, hipStream_t); \
-  hipError_t launch_msm_precompute##SUF(int, uint32_t*, uint8_t*, size_t, int, int, hipStream_t); \
+  hipError_t launch_msm_precompute##SUF(int, uint32_t*, uint8_t*, size_t, int, int, uint32_t*, hipStream_t); \
   hipError_t launch_msm_sort##SUF(const MsmPlan&, const uint8_t*, const uint32_t*, void*, hipStream_t); \
   hipError_t launch_msm_accumulate##SUF(const MsmPlan&, const uint32_t*, void*, hipStream_t); \
   hipError_t launch_msm_reduce##SUF(const MsmPlan&, void*, uint32_t*, uint32_t*, hipStream_t); \
@@ -633,7 +651,7 @@ hipError_t PART(launch_msm_jac_sum_to_affine)(int grp, const uint32_t* parts, si
 ZKT_MSM_FWD(_other) ZKT_MSM_FWD(_secp)
 #define ZKT_MSM_BY_GROUP(grp, NAME, ...) ((grp) == G_G1 ? NAME##_g1(__VA_ARGS__) : (grp) == G_SECP ? NAME##_secp(__VA_ARGS__) : NAME##_other(__VA_ARGS__))
 hipError_t launch_msm_to_kernel_layout(int grp, const uint32_t* a, uint32_t* t, uint8_t* i, size_t n, hipStream_t s) { return ZKT_MSM_BY_GROUP(grp, launch_msm_to_kernel_layout, grp, a, t, i, n, s); }
-hipError_t launch_msm_precompute(int grp, uint32_t* t, uint8_t* i, size_t n, int c, int nw, hipStream_t s) { return ZKT_MSM_BY_GROUP(grp, launch_msm_precompute, grp, t, i, n, c, nw, s); }
+hipError_t launch_msm_precompute(int grp, uint32_t* t, uint8_t* i, size_t n, int c, int nw, uint32_t* tmp, hipStream_t s) { return ZKT_MSM_BY_GROUP(grp, launch_msm_precompute, grp, t, i, n, c, nw, tmp, s); }
 hipError_t launch_msm_sort(const MsmPlan& P, const uint8_t* i, const uint32_t* k, void* w, hipStream_t s) { return ZKT_MSM_BY_GROUP(P.grp, launch_msm_sort, P, i, k, w, s); }
 hipError_t launch_msm_accumulate(const MsmPlan& P, const uint32_t* t, void* w, hipStream_t s) { return ZKT_MSM_BY_GROUP(P.grp, launch_msm_accumulate, P, t, w, s); }
 hipError_t launch_msm_reduce(const MsmPlan& P, void* w, uint32_t* j, uint32_t* o, hipStream_t s) { return ZKT_MSM_BY_GROUP(P.grp, launch_msm_reduce, P, w, j, o, s); }
