@@ -197,7 +197,8 @@ int zkt_bp_inner_product_argument(size_t n, const zkt_secp_affine* gg, const zkt
                                   zkt_secp_affine* out_trace);
 /* The same argument with the generators resident: gg, hh, u are fixed for a deployment (the reference rebuilds nothing either — its callers
  * pass the same AffinePoints every time, bulletproofs.rs:139), so their window-multiple table and the work buffers are built once.
- * A context serves one call at a time; results are identical to zkt_bp_inner_product_argument. */
+ * A context serves one call at a time; results are identical to zkt_bp_inner_product_argument.  gg, hh, u, P, a, b may be host or device
+ * pointers here (xs: host). */
 typedef struct zkt_bp_ipa_ctx zkt_bp_ipa_ctx;
 int zkt_bp_ipa_ctx_create(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u, zkt_bp_ipa_ctx** out);
 void zkt_bp_ipa_ctx_free(zkt_bp_ipa_ctx* ctx);

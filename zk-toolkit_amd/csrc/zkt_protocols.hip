@@ -349,9 +349,9 @@ int zkt_bp_ipa_ctx_create(size_t n, const zkt_secp_affine* gg, const zkt_secp_af
   std::unique_ptr<zkt_bp_ipa_ctx> c(new zkt_bp_ipa_ctx(n));
   if (!c->ok()) return ZKT_ERR_DEVICE;
   const size_t N = n;
-  PCHK(hipMemcpyAsync(c->dbase.p, gg, N * SPB, hipMemcpyHostToDevice, s));
-  PCHK(hipMemcpyAsync((char*)c->dbase.p + N * SPB, hh, N * SPB, hipMemcpyHostToDevice, s));
-  PCHK(hipMemcpyAsync((char*)c->dbase.p + 2 * N * SPB, u, SPB, hipMemcpyHostToDevice, s));
+  PCHK(hipMemcpyAsync(c->dbase.p, gg, N * SPB, hipMemcpyDefault, s));                        // host or device pointers (the range proof hands over hh' in HBM)
+  PCHK(hipMemcpyAsync((char*)c->dbase.p + N * SPB, hh, N * SPB, hipMemcpyDefault, s));
+  PCHK(hipMemcpyAsync((char*)c->dbase.p + 2 * N * SPB, u, SPB, hipMemcpyDefault, s));
   c->side.assign((c->levels + zkt_bp_ipa_ctx::IPA_BATCH - 1) / zkt_bp_ipa_ctx::IPA_BATCH, nullptr);
   for (hipStream_t& x : c->side) PCHK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
   PCHK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
@@ -378,7 +378,9 @@ int zkt_bp_inner_product_argument_ctx(zkt_bp_ipa_ctx* c, const zkt_secp_affine* 
   Dev &da = c->da, &db = c->db, &da2 = c->da2, &db2 = c->db2, &dwG = c->dwG, &dwH = c->dwH, &dsc = c->dsc, &dPp = c->dPp, &dx = c->dx, &dch = c->dch, &dsq = c->dsq, &dc = c->dc,
       &dlr = c->dlr, &dm = c->dm, &dt = c->dt;
   int rc;
-  if ((rc = up(da, a, N * FRB, s)) || (rc = up(db, b, N * FRB, s)) || (rc = up(dPp, P, SPB, s)) || (rc = up(dx, xs, levels * FRB, s))) return -rc;
+  if (hipMemcpyAsync(da.p, a, N * FRB, hipMemcpyDefault, s) != hipSuccess || hipMemcpyAsync(db.p, b, N * FRB, hipMemcpyDefault, s) != hipSuccess ||
+      hipMemcpyAsync(dPp.p, P, SPB, hipMemcpyDefault, s) != hipSuccess) return -ZKT_ERR_DEVICE;                                  // P, a, b: host or device
+  if ((rc = up(dx, xs, levels * FRB, s))) return -rc;
   const unsigned gN = (unsigned)((N + 256) / 256);            // N + 1 threads
   hipLaunchKernelGGL(k_ipa_w_init, dim3(gN), dim3(256), 0, s, N, dwG.w(), dwH.w());
   uint32_t *Av = da.w(), *Bv = db.w(), *A2 = da2.w(), *B2 = db2.w();
@@ -581,11 +583,12 @@ int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, c
   if (memcmp(&hl, &hr, SPB) != 0) return 0;                                           // :116-118
   if (use_ipa) {
     uint32_t* Pp = padd(padd(Pk, Q(12), Q(23)), Q(17), Q(24));                        // :138  P h^-mu u^<l,r>
-    std::vector<zkt_secp_affine> hgg(n), hhhp(n); std::vector<uint64_t> hl2(n * 4), hr2(n * 4); zkt_secp_affine hu, hP;
-    if ((rc = down(hgg.data(), GG, n * SPB, s)) || (rc = down(hhhp.data(), HHP, n * SPB, s)) || (rc = down(hl2.data(), l, n * FRB, s)) ||
-        (rc = down(hr2.data(), r, n * FRB, s)) || (rc = down(&hu, Up, SPB, s)) || (rc = down(&hP, Pp, SPB, s))) return -rc;
-    if (hipStreamSynchronize(s) != hipSuccess || !okl) return -ZKT_ERR_DEVICE;
-    return zkt_bp_inner_product_argument(n, hgg.data(), hhhp.data(), &hu, &hP, hl2.data(), hr2.data(), xs, nullptr);   // :139
+    if (!okl) return -ZKT_ERR_DEVICE;
+    zkt_bp_ipa_ctx* c = nullptr;                                                      // gg, hh', u, P, l, r stay in HBM
+    if ((rc = zkt_bp_ipa_ctx_create(n, (const zkt_secp_affine*)GG, (const zkt_secp_affine*)HHP, (const zkt_secp_affine*)Up, &c))) return -rc;
+    rc = zkt_bp_inner_product_argument_ctx(c, (const zkt_secp_affine*)Pp, (const uint64_t*)l, (const uint64_t*)r, xs, nullptr);   // :139
+    zkt_bp_ipa_ctx_free(c);
+    return rc;
   }
   uint32_t* rhs = padd(padd(Q(12), TC, Q(23)), TD, Q(24));                            // :142
   zkt_secp_affine hP, hrhs; uint64_t hth[4], hlr[4];
