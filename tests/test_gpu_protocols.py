@@ -245,6 +245,38 @@ def test_sharded_msm_partials_combine(L, name, W, order, gen_fn, pw):
     assert (got == want).all()
 
 
+@pytest.mark.parametrize("name,W", [("g1", G1W), ("g2", G2W), ("secp", 9)])
+def test_msm_eight_slots_in_flight(L, name, W):
+    """zkt_*_msm_submit / _collect with every pipeline slot busy on one small resident base set (below 2^19 terms each slot runs its whole
+    MSM on its own stream): eight different scalar vectors, some with zero halves like the inner-product argument's, collected in a shuffled
+    order, each identical to the one-shot MSM of the same inputs (itself checked against the oracle by the tests above)."""
+    import torch
+    n, slots = 700, 8
+    rng = np.random.Generator(np.random.PCG64(4242))
+    order = SECP_N if name == "secp" else R
+    g = np.zeros((1, W), np.uint64); getattr(O, f"zkto_{name}_generator")(ptr(g))
+    ks = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64); ks[:, 3] >>= np.uint64(2)
+    bases = np.zeros((n, W), np.uint64)
+    zk.check(getattr(L, f"zkt_{name}_mul_batch")(ptr(np.repeat(g, n, axis=0)), ptr(ks), 4, ptr(bases), n))
+    bases[5] = 0; bases[5, W - 1] = 1                          # a base at infinity
+    h = ctypes.c_void_p(); zk.check(getattr(L, f"zkt_{name}_bases_upload")(ptr(bases), n, ctypes.byref(h)))
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    try:
+        for rnd in range(2):                                    # slots are reusable
+            ss = [rand_scalars(9000 + 10 * rnd + k, n, order) for k in range(slots)]
+            ss[1][: n // 2] = 0; ss[2][n // 2:] = 0; ss[3][:] = 0; ss[4][:, 1:] = 0      # zero halves, all zero, 64-bit scalars
+            d = [torch.from_numpy(x.view(np.int64)).cuda() for x in ss]
+            for k in range(slots): zk.check(getattr(L, f"zkt_{name}_msm_submit")(h, vp(d[k]), n, None, k))
+            assert getattr(L, f"zkt_{name}_msm_submit")(h, vp(d[0]), n, None, 0) != 0           # a busy slot is refused
+            for k in [3, 0, 7, 1, 6, 2, 5, 4]:
+                got, want = np.zeros((1, W), np.uint64), np.zeros((1, W), np.uint64)
+                zk.check(getattr(L, f"zkt_{name}_msm_collect")(h, k, ptr(got), None))
+                zk.check(getattr(L, f"zkt_{name}_msm")(ptr(bases), ptr(ss[k]), n, ptr(want)))
+                assert (got == want).all(), (name, rnd, k)
+    finally:
+        getattr(L, f"zkt_{name}_bases_free")(h)
+
+
 @pytest.mark.parametrize("name,W,order,gen_fn", [("g1", G1W, R, "zkto_g1_generator"), ("g2", G2W, R, "zkto_g2_generator"), ("secp", 9, SECP_N, "zkto_secp_generator")])
 def test_msm_adversarial_pool(L, name, W, order, gen_fn):
     """Bases drawn from a tiny pool {P1..P3, -P1, -P2, infinity} with scalars from {0, 1, 2, order-1, a few random values}: almost every

@@ -66,6 +66,9 @@ def lib():
         L.zkt_bls_hash_to_g2_batch.argtypes = [vp, vp, sz, vp]
         L.zkt_bls_sign_batch.argtypes = [vp, vp, vp, sz, vp]
         L.zkt_bls_verify_batch.argtypes = [vp, vp, vp, vp, sz, vp]
+        for grp in ("g1", "g2", "secp"):
+            getattr(L, f"zkt_{grp}_msm_submit").argtypes = [vp, vp, sz, vp, ctypes.c_int]
+            getattr(L, f"zkt_{grp}_msm_collect").argtypes = [vp, ctypes.c_int, vp, vp]
         L.zkt_bp_ipa_ctx_create.argtypes = [sz, vp, vp, vp, vp]
         L.zkt_bp_ipa_ctx_free.argtypes = [vp]; L.zkt_bp_ipa_ctx_free.restype = None
         L.zkt_bp_inner_product_argument_ctx.argtypes = [vp] * 6
