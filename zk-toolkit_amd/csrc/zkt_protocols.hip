@@ -65,10 +65,11 @@ __global__ void k_ipa_challenge(const uint32_t* __restrict__ x, uint32_t* __rest
 // so L and R of every level (:39-40) are two multi-scalar multiplications over the fixed base set [gg | hh | u] with the scalars
 // a^(j)[..] wG[k], b^(j)[..] wH[k] — each original generator enters exactly one of L, R — and no generator is ever folded.
 // All vectors hold canonical residues (fp_mul(ld_fp(s), ld_raw(v)) = s v, as in k_fold).
-__global__ void __launch_bounds__(256) k_ipa_w_init(size_t N, uint32_t* __restrict__ wG, uint32_t* __restrict__ wH) {
+// wH0 (optional): the hh generators of the argument are wH0[k] * hh[k] (the range proof's hh' = hh * y^-i, bulletproofs.rs:109, never materialised)
+__global__ void __launch_bounds__(256) k_ipa_w_init(size_t N, const uint32_t* __restrict__ wH0, uint32_t* __restrict__ wG, uint32_t* __restrict__ wH) {
   size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; if (k >= N) return;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { wG[k * 8 + j] = j == 0; wH[k * 8 + j] = j == 0; }
+  for (int j = 0; j < 8; ++j) { wG[k * 8 + j] = j == 0; wH[k * 8 + j] = wH0 ? wH0[k * 8 + j] : (j == 0); }
 }
 // sL, sR: 2N+1 scalars each for the base set [gg | hh | u];  L = gg_hi*a_lo + hh_lo*b_hi + u cL,  R = gg_lo*a_hi + hh_hi*b_lo + u cR
 __global__ void __launch_bounds__(256) k_ipa_level_scalars(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ wG,
@@ -363,7 +364,7 @@ int zkt_bp_ipa_ctx_create(size_t n, const zkt_secp_affine* gg, const zkt_secp_af
 void zkt_bp_ipa_ctx_free(zkt_bp_ipa_ctx* c) { delete c; }
 
 // one argument over the context's generators; a context serves one call at a time.  Returns 1 / 0 like the reference's bool, negative = -status.
-int zkt_bp_inner_product_argument_ctx(zkt_bp_ipa_ctx* c, const zkt_secp_affine* P, const uint64_t* a, const uint64_t* b, const uint64_t* xs, zkt_secp_affine* out_trace) {
+static int ipa_run(zkt_bp_ipa_ctx* c, const zkt_secp_affine* P, const uint64_t* a, const uint64_t* b, const uint64_t* xs, zkt_secp_affine* out_trace, const uint32_t* wH0) {
   if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
   if (!c || !P || !a || !b || (c->N > 1 && !xs)) return -ZKT_ERR_SHAPE;
   hipStream_t s = nullptr;
@@ -382,7 +383,7 @@ int zkt_bp_inner_product_argument_ctx(zkt_bp_ipa_ctx* c, const zkt_secp_affine* 
       hipMemcpyAsync(dPp.p, P, SPB, hipMemcpyDefault, s) != hipSuccess) return -ZKT_ERR_DEVICE;                                  // P, a, b: host or device
   if ((rc = up(dx, xs, levels * FRB, s))) return -rc;
   const unsigned gN = (unsigned)((N + 256) / 256);            // N + 1 threads
-  hipLaunchKernelGGL(k_ipa_w_init, dim3(gN), dim3(256), 0, s, N, dwG.w(), dwH.w());
+  hipLaunchKernelGGL(k_ipa_w_init, dim3(gN), dim3(256), 0, s, N, wH0, dwG.w(), dwH.w());
   uint32_t *Av = da.w(), *Bv = db.w(), *A2 = da2.w(), *B2 = db2.w();
   std::vector<zkt_secp_affine> lr(2 * levels + 1);            // L_0, R_0, L_1, R_1, ..., base-case right-hand side
   const size_t n_msm = 2 * levels + 1;
@@ -453,6 +454,9 @@ int zkt_bp_inner_product_argument_ctx(zkt_bp_ipa_ctx* c, const zkt_secp_affine* 
   if (hipStreamSynchronize(s) != hipSuccess) return -ZKT_ERR_DEVICE;
   return memcmp(&lr[n_msm - 1], &lhs, SPB) == 0 ? 1 : 0;
 }
+int zkt_bp_inner_product_argument_ctx(zkt_bp_ipa_ctx* c, const zkt_secp_affine* P, const uint64_t* a, const uint64_t* b, const uint64_t* xs, zkt_secp_affine* out_trace) {
+  return ipa_run(c, P, a, b, xs, out_trace, nullptr);
+}
 int zkt_bp_inner_product_argument(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u, const zkt_secp_affine* P,
                                   const uint64_t* a, const uint64_t* b, const uint64_t* xs, zkt_secp_affine* out_trace) {
   if (n == 0 || (n & (n - 1)) || !gg || !hh || !u || !P || !a || !b || (n > 1 && !xs)) return -ZKT_ERR_SHAPE;
@@ -502,38 +506,51 @@ int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, c
   unsigned long long ne = NO_ERR; hipMemcpyAsync(derr.p, &ne, 8, hipMemcpyHostToDevice, s);
   const uint64_t one64[4] = {1, 0, 0, 0}, two64[4] = {2, 0, 0, 0};
   if ((rnd[8] | rnd[9] | rnd[10] | rnd[11]) == 0) return -ZKT_ERR_INV_ZERO;   // y must be invertible (:109); the reference draws non-zero values
-  // points on the device: [gg | hh | hhp | g h V u]; tmp = four n-vectors of products; res = A S T1 T2 P | single-point scratch
-  Dev pts((3 * n + 8) * SPB), tmp((4 * n + 8) * SPB), res(48 * SPB);
-  if (!pts.p || !tmp.p || !res.p) return -ZKT_ERR_DEVICE;
-  uint32_t *GG = pts.w(), *HH = GG + n * PW, *HHP = HH + n * PW, *Gp = HHP + n * PW, *Hp = Gp + PW, *Vp = Hp + PW, *Up = Vp + PW;
-  hipMemcpyAsync(GG, gg, n * SPB, hipMemcpyHostToDevice, s); hipMemcpyAsync(HH, hh, n * SPB, hipMemcpyHostToDevice, s);
+  // The generators stay resident for the whole proof: one base set [gg | hh | u] (zkt_bp_ipa_ctx) serves every (AffinePoints * PrimeFieldElems).sum()
+  // as an MSM and the inner-product argument itself.  hh' = hh * y^-i (:109) is never materialised: a sum over hh' with scalars v is the sum over hh
+  // with scalars v o y^-n, and the argument starts from the coefficients y^-i on hh.  res = A S T1 T2 P | single-point scratch.
+  zkt_secp_affine inf_pt; memset(&inf_pt, 0, sizeof inf_pt); inf_pt.is_infinity = 1;
+  zkt_bp_ipa_ctx* c = nullptr;
+  struct CtxGuard { zkt_bp_ipa_ctx*& c; ~CtxGuard() { if (c) zkt_bp_ipa_ctx_free(c); } } guard{c};
+  int rc;
+  if ((rc = zkt_bp_ipa_ctx_create(n, gg, hh, use_ipa ? u : &inf_pt, &c))) return -rc;
+  const size_t NB = c->NB;
+  Dev pts(8 * SPB), res(48 * SPB);
+  if (!pts.p || !res.p) return -ZKT_ERR_DEVICE;
+  uint32_t *Gp = pts.w(), *Hp = Gp + PW, *Vp = Hp + PW, *Up = c->dbase.w() + 2 * n * PW;
   hipMemcpyAsync(Gp, g, SPB, hipMemcpyHostToDevice, s); hipMemcpyAsync(Hp, h, SPB, hipMemcpyHostToDevice, s); hipMemcpyAsync(Vp, V, SPB, hipMemcpyHostToDevice, s);
-  if (use_ipa) hipMemcpyAsync(Up, u, SPB, hipMemcpyHostToDevice, s);
   uint32_t* R = res.w();
   uint32_t *Ak = R, *Sk = R + PW, *T1k = R + 2 * PW, *T2k = R + 3 * PW, *Pk = R + 4 * PW;        // out_pts order
   auto Q = [&](int i) { return R + (size_t)(8 + i) * PW; };                                       // single-point scratch
-  uint32_t *TA = tmp.w(), *TB = TA + n * PW, *TC = TB + n * PW, *TD = TC + n * PW;
-  // A scalar multiplication is a ~4-6 ms dependent chain however few points a launch covers, so the proof's multiplications are issued in three
-  // launches (everything independent of earlier POINTS goes together); (AffinePoints * PrimeFieldElems).sum() = one segment + a block sum.
+  // A scalar multiplication is a ~4-6 ms dependent chain however few points a launch covers, so the single-point multiplications go out in two
+  // launches (everything independent of earlier POINTS first) while the MSMs run on the base set's streams.
   bool okl = true;
-  auto seg = [&](const uint32_t* P, const uint32_t* k, uint32_t* out, size_t cnt) { return MulSeg{P, k, out, (uint32_t)cnt, cnt > 1 ? (uint32_t)PW : 0u, cnt > 1 ? 8u : 0u}; };
+  auto seg = [&](const uint32_t* P, const uint32_t* k, uint32_t* out) { return MulSeg{P, k, out, 1u, 0u, 0u}; };
   auto run = [&](const MulSegs& m) { okl = okl && launch_group_mul_segs(G_SECP, m, 8, s) == hipSuccess; };
-  auto vsum_pts = [&](uint32_t* T) { okl = okl && launch_group_sum_inplace(G_SECP, T, n, s) == hipSuccess; };      // result in T[0]
   auto padd = [&](const uint32_t* a, const uint32_t* b, uint32_t* o) { okl = okl && launch_group_add(G_SECP, a, b, o, 1, s) == hipSuccess; return o; };
+  // sum_k gg[k] vg[k] + hh[k] vh[k] in MSM slot `slot` (scalars [vg | vh | 0] in the slot's buffer)
+  int n_sub = 0;
+  auto msm_sub = [&](int slot, const uint32_t* vg, const uint32_t* vh) {
+    uint32_t* buf = c->dsc.w() + (size_t)slot * NB * 8;
+    okl = okl && hipMemcpyAsync(buf, vg, n * FRB, hipMemcpyDeviceToDevice, s) == hipSuccess && hipMemcpyAsync(buf + n * 8, vh, n * FRB, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+          hipMemsetAsync(buf + 2 * n * 8, 0, FRB, s) == hipSuccess && zkt_secp_msm_submit(c->set, (const uint64_t*)buf, NB, s, slot) == ZKT_OK;
+    if (okl) n_sub = slot + 1;
+  };
+  zkt_secp_affine hres[4];
+  int n_col = 0;
+  struct Drain { zkt_bp_ipa_ctx* c; int *col, *sub; ~Drain() { for (; *col < *sub; ++*col) zkt_secp_msm_collect(c->set, *col, nullptr, nullptr); } } drain{c, &n_col, &n_sub};
+  auto msm_col = [&](int slot, uint32_t* dev_out) {                                               // slots are collected in order
+    okl = okl && slot == n_col && zkt_secp_msm_collect(c->set, slot, &hres[slot], nullptr) == ZKT_OK; n_col = slot + 1;
+    okl = okl && hipMemcpyAsync(dev_out, &hres[slot], SPB, hipMemcpyHostToDevice, s) == hipSuccess;
+  };
 
   uint32_t *d_aL = vput(aL), *d_sL = vput(rnd + 28), *d_sR = vput(rnd + 28 + 4 * n);
   uint32_t *alpha = sput(rnd), *rho = sput(rnd + 4), *y = sput(rnd + 8), *z = sput(rnd + 12), *tau1 = sput(rnd + 16), *tau2 = sput(rnd + 20), *x = sput(rnd + 24);
   uint32_t *d_gamma = sput(gamma), *one = sput(one64), *two = sput(two64);
   uint32_t *one_n = vpow(one), *two_n = vpow(two);                                   // :72-73
   uint32_t* aR = vsub(d_aL, one_n);                                                   // :75
-  {                                                                                   // A (:77), S (:82)
-    MulSegs m{}; m.n = 6;
-    m.s[0] = seg(Hp, alpha, Q(0), 1); m.s[1] = seg(GG, d_aL, TA, n); m.s[2] = seg(HH, aR, TB, n);
-    m.s[3] = seg(Hp, rho, Q(1), 1);   m.s[4] = seg(GG, d_sL, TC, n); m.s[5] = seg(HH, d_sR, TD, n);
-    run(m); vsum_pts(TA); vsum_pts(TB); vsum_pts(TC); vsum_pts(TD);
-    padd(padd(Q(0), TA, Q(2)), TB, Ak);
-    padd(padd(Q(1), TC, Q(3)), TD, Sk);
-  }
+  msm_sub(0, d_aL, aR);                                                               // (gg*aL).sum() + (hh*aR).sum()   of A (:77)
+  msm_sub(1, d_sL, d_sR);                                                             // (gg*sL).sum() + (hh*sR).sum()   of S (:82)
   uint32_t* y_n = vpow(y);                                                            // :87
   uint32_t* z2 = smul(z, z);
   uint32_t* onez = vscl(one_n, z);
@@ -547,36 +564,40 @@ int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, c
   uint32_t* t_hat = sadd(sadd(t0, smul(t1, x)), smul(t2, x2));                        // :104
   uint32_t* tau_x = sadd(sadd(smul(tau2, x2), smul(tau1, x)), smul(z2, d_gamma));     // :105
   uint32_t* mu = sadd(alpha, smul(rho, x));                                           // :106
-  uint32_t* yinv_n = vpow(sinv(y));
+  uint32_t* yinv_n = vpow(sinv(y));                                                   // hh' = hh * y^-i (:109), as coefficients
   uint32_t* z3 = smul(z2, z);
   uint32_t* delta_yz = ssub(smul(ssub(z, z2), vsum(y_n)), smul(z3, vsum(two_n)));     // :112 (one_n o v = v)
-  uint32_t* negz_n = vscl(one_n, sneg(z));
   uint32_t* mu_signed = use_ipa ? sneg(mu) : mu;
-  {                                                                                   // T1 (:99), T2 (:100), hh' (:109), both sides of :114-115, the scalar-only parts of P
-    MulSegs m{}; m.n = 11;
-    m.s[0] = seg(Gp, t1, Q(4), 1);     m.s[1] = seg(Hp, tau1, Q(5), 1);  m.s[2] = seg(Gp, t2, Q(6), 1);    m.s[3] = seg(Hp, tau2, Q(7), 1);
-    m.s[4] = seg(Gp, t_hat, Q(8), 1);  m.s[5] = seg(Hp, tau_x, Q(9), 1); m.s[6] = seg(Vp, z2, Q(10), 1);   m.s[7] = seg(Gp, delta_yz, Q(11), 1);
-    m.s[8] = seg(HH, yinv_n, HHP, n);  m.s[9] = seg(GG, negz_n, TA, n);  m.s[10] = seg(Hp, mu_signed, Q(12), 1);
-    run(m); vsum_pts(TA);
-    padd(Q(4), Q(5), T1k); padd(Q(6), Q(7), T2k);
-    padd(Q(8), Q(9), Q(13));                                                          // lhs of :116
-  }
   uint32_t* l = vadd(l0, vscl(d_sL, x));                                              // :121
   uint32_t* r = vadd(vhad(y_n, vadd(aRz, vscl(d_sR, x))), twoz2);                     // :122
   uint32_t* lr = vdot(l, r);
-  {                                                                                   // the products that need T1, T2, S, hh'
-    MulSegs m{}; m.n = use_ipa ? 5 : 6;
-    m.s[0] = seg(T1k, x, Q(14), 1); m.s[1] = seg(T2k, x2, Q(15), 1); m.s[2] = seg(Sk, x, Q(16), 1);
-    m.s[3] = seg(HHP, vadd(vscl(y_n, z), twoz2), TB, n);
-    if (use_ipa) m.s[4] = seg(Up, lr, Q(17), 1);
-    else { m.s[4] = seg(GG, l, TC, n); m.s[5] = seg(HHP, r, TD, n); }
-    run(m); vsum_pts(TB);
-    if (!use_ipa) { vsum_pts(TC); vsum_pts(TD); }
-    padd(padd(padd(Q(10), Q(11), Q(18)), Q(14), Q(19)), Q(15), Q(20));                // rhs of :115
-    padd(padd(padd(Ak, Q(16), Q(21)), TA, Q(22)), TB, Pk);                            // P (:124-128)
+  // gg * (-z 1^n) + hh' * (z y^n + z^2 2^n)  of P (:126-127)
+  msm_sub(2, vscl(one_n, sneg(z)), vhad(vadd(vscl(y_n, z), twoz2), yinv_n));
+  if (!use_ipa) msm_sub(3, l, vhad(r, yinv_n));                                       // (gg*l).sum() + (hh'*r).sum()  (:142)
+  {                                                                                   // every product of a fixed point with a scalar
+    MulSegs m{}; m.n = 11;
+    m.s[0] = seg(Hp, alpha, Q(0));     m.s[1] = seg(Hp, rho, Q(1));
+    m.s[2] = seg(Gp, t1, Q(4));        m.s[3] = seg(Hp, tau1, Q(5));   m.s[4] = seg(Gp, t2, Q(6));     m.s[5] = seg(Hp, tau2, Q(7));
+    m.s[6] = seg(Gp, t_hat, Q(8));     m.s[7] = seg(Hp, tau_x, Q(9));  m.s[8] = seg(Vp, z2, Q(10));    m.s[9] = seg(Gp, delta_yz, Q(11));
+    m.s[10] = seg(Hp, mu_signed, Q(12));
+    run(m);
   }
+  msm_col(0, Q(2)); msm_col(1, Q(3));
+  padd(Q(0), Q(2), Ak);                                                               // A (:77)
+  padd(Q(1), Q(3), Sk);                                                               // S (:82)
+  padd(Q(4), Q(5), T1k); padd(Q(6), Q(7), T2k);                                       // T1 (:99), T2 (:100)
+  padd(Q(8), Q(9), Q(13));                                                            // lhs of :116
+  {                                                                                   // the products that need T1, T2, S
+    MulSegs m{}; m.n = use_ipa ? 4 : 3;
+    m.s[0] = seg(T1k, x, Q(14)); m.s[1] = seg(T2k, x2, Q(15)); m.s[2] = seg(Sk, x, Q(16));
+    if (use_ipa) m.s[3] = seg(Up, lr, Q(17));
+    run(m);
+  }
+  msm_col(2, Q(22));
+  if (!use_ipa) msm_col(3, Q(25));
+  padd(padd(padd(Q(10), Q(11), Q(18)), Q(14), Q(19)), Q(15), Q(20));                  // rhs of :115
+  padd(padd(Ak, Q(16), Q(21)), Q(22), Pk);                                            // P (:124-128)
   zkt_secp_affine hl, hr;
-  int rc;
   if ((rc = down(&hl, Q(13), SPB, s)) || (rc = down(&hr, Q(20), SPB, s))) return -rc;
   if (out_pts && (rc = down(out_pts, R, 5 * SPB, s))) return -rc;
   if (hipStreamSynchronize(s) != hipSuccess || !okl || vi > NV || si > NS) return -ZKT_ERR_DEVICE;
@@ -584,13 +605,9 @@ int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, c
   if (use_ipa) {
     uint32_t* Pp = padd(padd(Pk, Q(12), Q(23)), Q(17), Q(24));                        // :138  P h^-mu u^<l,r>
     if (!okl) return -ZKT_ERR_DEVICE;
-    zkt_bp_ipa_ctx* c = nullptr;                                                      // gg, hh', u, P, l, r stay in HBM
-    if ((rc = zkt_bp_ipa_ctx_create(n, (const zkt_secp_affine*)GG, (const zkt_secp_affine*)HHP, (const zkt_secp_affine*)Up, &c))) return -rc;
-    rc = zkt_bp_inner_product_argument_ctx(c, (const zkt_secp_affine*)Pp, (const uint64_t*)l, (const uint64_t*)r, xs, nullptr);   // :139
-    zkt_bp_ipa_ctx_free(c);
-    return rc;
+    return ipa_run(c, (const zkt_secp_affine*)Pp, (const uint64_t*)l, (const uint64_t*)r, xs, nullptr, yinv_n);   // :139, over gg, hh' = y^-i hh, u
   }
-  uint32_t* rhs = padd(padd(Q(12), TC, Q(23)), TD, Q(24));                            // :142
+  uint32_t* rhs = padd(Q(12), Q(25), Q(26));                                          // :142
   zkt_secp_affine hP, hrhs; uint64_t hth[4], hlr[4];
   if ((rc = down(&hP, Pk, SPB, s)) || (rc = down(&hrhs, rhs, SPB, s)) || (rc = down(hth, t_hat, FRB, s)) || (rc = down(hlr, lr, FRB, s))) return -rc;
   if (hipStreamSynchronize(s) != hipSuccess || !okl) return -ZKT_ERR_DEVICE;
