@@ -99,6 +99,21 @@ __global__ void __launch_bounds__(256) k_ipa_w_fold(const uint32_t* __restrict__
   st_raw<C>(wG + k * 8, fp_mul(hi ? x : xi, ld_raw<C>(wG + k * 8)));
   st_raw<C>(wH + k * 8, fp_mul(hi ? xi : x, ld_raw<C>(wH + k * 8)));
 }
+// Without a trace only the verdict P_final == g a + h b + u c is observable, and P_final = P + sum_j (x_j^2 L_j + x_j^-2 R_j) (:47) is itself an MSM over the
+// base set: comb[k] accumulates x_j^2 sL_j[k] + x_j^-2 sR_j[k], and the verdict is MSM(sF - comb) == P — no point multiplication after the last level.
+__global__ void __launch_bounds__(256) k_ipa_comb(const uint32_t* __restrict__ sL, const uint32_t* __restrict__ sR, const uint32_t* __restrict__ X2, const uint32_t* __restrict__ X2I,
+                                                  size_t NB, int first, uint32_t* __restrict__ comb) {
+  typedef SnC C;
+  size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; if (k >= NB) return;
+  Fp<C> v = fp_add(fp_mul(ld_fp<C>(X2), ld_raw<C>(sL + k * 8)), fp_mul(ld_fp<C>(X2I), ld_raw<C>(sR + k * 8)));
+  if (!first) v = fp_add(v, ld_raw<C>(comb + k * 8));
+  st_raw<C>(comb + k * 8, v);
+}
+__global__ void __launch_bounds__(256) k_ipa_sub(const uint32_t* __restrict__ comb, size_t NB, uint32_t* __restrict__ sF) {
+  typedef SnC C;
+  size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; if (k >= NB) return;
+  st_raw<C>(sF + k * 8, fp_sub(ld_raw<C>(sF + k * 8), ld_raw<C>(comb + k * 8)));
+}
 // base case (:28-32): g a + h b + u (a b) with g = sum wG[k] gg[k], h = sum wH[k] hh[k]
 __global__ void __launch_bounds__(256) k_ipa_final_scalars(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ wG,
                                                            const uint32_t* __restrict__ wH, size_t N, uint32_t* __restrict__ sF) {
@@ -319,7 +334,7 @@ int zkt_groth16_verify(const zkt_groth16_crs* c, const zkt_g1_affine* A, const z
 // out_trace (optional, host): per level L, R and the folded P' (3 zkt_secp_affine) for level-by-level parity.
 // Runs on the original generators (see k_ipa_level_scalars): one resident base set [gg | hh | u], two MSMs per level and one for the base case.
 // The reference draws x independently of L and R (:42), so a level's scalar algebra does not wait for its MSMs: the scalar stage runs ahead on
-// the caller's stream and up to IPA_SLOTS MSMs are in flight; L x^2 and R x^-2 (:47) are multiplied on side streams as results arrive.
+// the caller's stream and up to IPA_SLOTS MSMs are in flight; for a trace, L x^2 and R x^-2 (:47) are multiplied on side streams as results arrive.
 // The generators are the long-lived input (one set per deployment): zkt_bp_ipa_ctx keeps their window-multiple table and every work buffer
 // resident, and zkt_bp_inner_product_argument (the reference's signature) is create + run + free.
 }  // extern "C"
@@ -327,15 +342,15 @@ struct zkt_bp_ipa_ctx {
   static constexpr int PW = 18, IPA_SLOTS = 8;
   static constexpr size_t IPA_BATCH = 4;   // levels per product launch: a 256-bit double-and-add is ~4 ms however few points it covers
   size_t N, NB, levels, lv1;
-  Dev dbase, da, db, da2, db2, dwG, dwH, dsc, dPp, dx, dch, dsq, dc, dlr, dm, dt;
+  Dev dbase, da, db, da2, db2, dwG, dwH, dsc, dPp, dx, dch, dsq, dc, dlr, dm, dt, dcomb;
   zkt_secp_bases* set = nullptr;
   std::vector<hipStream_t> side;           // one stream per product batch, so the batches overlap each other and the MSMs
   hipEvent_t ev = nullptr;
   static size_t log2z(size_t n) { size_t l = 0; for (size_t t = n; t > 1; t >>= 1) ++l; return l; }
   explicit zkt_bp_ipa_ctx(size_t n)
       : N(n), NB(2 * n + 1), levels(log2z(n)), lv1(levels ? levels : 1), dbase(NB * SPB), da(N * FRB), db(N * FRB), da2(N * FRB), db2(N * FRB), dwG(N * FRB), dwH(N * FRB),
-        dsc((size_t)IPA_SLOTS * NB * FRB), dPp(SPB), dx(lv1 * FRB), dch(4 * FRB), dsq(lv1 * 2 * FRB), dc(2 * FRB), dlr(lv1 * 2 * SPB), dm(lv1 * 2 * SPB), dt(SPB) {}
-  bool ok() const { return dbase.p && da.p && db.p && da2.p && db2.p && dwG.p && dwH.p && dsc.p && dPp.p && dx.p && dch.p && dsq.p && dc.p && dlr.p && dm.p && dt.p; }
+        dsc((size_t)IPA_SLOTS * NB * FRB), dPp(SPB), dx(lv1 * FRB), dch(4 * FRB), dsq(lv1 * 2 * FRB), dc(2 * FRB), dlr(lv1 * 2 * SPB), dm(lv1 * 2 * SPB), dt(SPB), dcomb(NB * FRB) {}
+  bool ok() const { return dbase.p && da.p && db.p && da2.p && db2.p && dwG.p && dwH.p && dsc.p && dPp.p && dx.p && dch.p && dsq.p && dc.p && dlr.p && dm.p && dt.p && dcomb.p; }
   ~zkt_bp_ipa_ctx() {
     for (hipStream_t x : side) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
     if (ev) hipEventDestroy(ev);
@@ -395,7 +410,7 @@ static int ipa_run(zkt_bp_ipa_ctx* c, const zkt_secp_affine* P, const uint64_t* 
     int r = zkt_secp_msm_collect(c->set, (int)(m % IPA_SLOTS), &lr[m], nullptr);
     ++collected;
     if (r) return r;
-    if (m < 2 * levels && (m & 1) && ((m / 2 + 1) % IPA_BATCH == 0 || m / 2 + 1 == levels)) {
+    if (out_trace && m < 2 * levels && (m & 1) && ((m / 2 + 1) % IPA_BATCH == 0 || m / 2 + 1 == levels)) {
       const size_t lv = m / 2, lv0 = lv / IPA_BATCH * IPA_BATCH, cnt = 2 * (lv + 1 - lv0);
       hipStream_t st = c->side[lv / IPA_BATCH];
       if (hipEventRecord(c->ev, s) != hipSuccess || hipStreamWaitEvent(st, c->ev, 0) != hipSuccess ||                   // x^2, x^-2 of these levels exist
@@ -423,6 +438,8 @@ static int ipa_run(zkt_bp_ipa_ctx* c, const zkt_secp_affine* P, const uint64_t* 
     // x, x^-1, x^2, x^-2; generator coefficients and a' = a_lo x + a_hi x^-1 ; b' = b_lo x^-1 + b_hi x   (:44-45, :49-50)
     hipLaunchKernelGGL(k_ipa_challenge, dim3(1), dim3(64), 0, s, (const uint32_t*)(dx.w() + level * 8), dch.w(), dsq.w() + level * 16);
     const uint32_t *X = dch.w(), *XI = dch.w() + 8;
+    if (!out_trace) hipLaunchKernelGGL(k_ipa_comb, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, s, (const uint32_t*)slot_buf(m), (const uint32_t*)slot_buf(m + 1),
+                                       (const uint32_t*)(dch.w() + 16), (const uint32_t*)(dch.w() + 24), NB, level == 0 ? 1 : 0, c->dcomb.w());
     hipLaunchKernelGGL(k_ipa_w_fold, dim3(gN), dim3(256), 0, s, X, XI, N, n, dwG.w(), dwH.w());
     hipLaunchKernelGGL(k_fold<SnC>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const uint32_t*)Av, (const uint32_t*)(Av + np * 8), X, XI, np, A2);
     hipLaunchKernelGGL(k_fold<SnC>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const uint32_t*)Bv, (const uint32_t*)(Bv + np * 8), XI, X, np, B2);
@@ -432,22 +449,20 @@ static int ipa_run(zkt_bp_ipa_ctx* c, const zkt_secp_affine* P, const uint64_t* 
   // base case (:28-32): c = a*b; rhs = g*a + h*b + u*c over the original generators
   if ((rc = free_slot(n_msm - 1))) return -rc;
   hipLaunchKernelGGL(k_ipa_final_scalars, dim3(gN), dim3(256), 0, s, (const uint32_t*)Av, (const uint32_t*)Bv, (const uint32_t*)dwG.w(), (const uint32_t*)dwH.w(), N, slot_buf(n_msm - 1));
+  if (!out_trace && levels) hipLaunchKernelGGL(k_ipa_sub, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, s, (const uint32_t*)c->dcomb.w(), NB, slot_buf(n_msm - 1));
   if (hipGetLastError() != hipSuccess) return -ZKT_ERR_DEVICE;
   if ((rc = submit(n_msm - 1))) return -rc;
   while (collected < n_msm) if ((rc = collect_next())) return -rc;
-  // P' = L x^2 + P + R x^-2 (:47): the products are ready on the side streams; the running sum level by level for the trace, one block sum otherwise
+  // P' = L x^2 + P + R x^-2 (:47) level by level for the trace (products ready on the side streams); without one the sum is inside the last MSM (k_ipa_comb)
   if (levels) {
-    for (hipStream_t x : c->side) if (hipStreamSynchronize(x) != hipSuccess) return -ZKT_ERR_DEVICE;
     if (out_trace) {
+      for (hipStream_t x : c->side) if (hipStreamSynchronize(x) != hipSuccess) return -ZKT_ERR_DEVICE;
       for (size_t lv = 0; lv < levels; ++lv) {
         if (launch_group_add(G_SECP, dm.w() + 2 * lv * PW, dPp.w(), dt.w(), 1, s) || launch_group_add(G_SECP, dt.w(), dm.w() + (2 * lv + 1) * PW, dPp.w(), 1, s)) return -ZKT_ERR_DEVICE;
         out_trace[lv * 3] = lr[2 * lv]; out_trace[lv * 3 + 1] = lr[2 * lv + 1];
         if ((rc = down(out_trace + lv * 3 + 2, dPp.p, SPB, s))) return -rc;
       }
-    } else {
-      if (launch_group_sum_inplace(G_SECP, dm.w(), 2 * levels, s) || launch_group_add(G_SECP, dm.w(), dPp.w(), dt.w(), 1, s) ||
-          hipMemcpyAsync(dPp.p, dt.p, SPB, hipMemcpyDeviceToDevice, s) != hipSuccess) return -ZKT_ERR_DEVICE;
-    }
+    }                                                         // without a trace lr[n_msm - 1] already is rhs - sum_j (x_j^2 L_j + x_j^-2 R_j): compare with P itself
   }
   zkt_secp_affine lhs;
   if ((rc = down(&lhs, dPp.p, SPB, s))) return -rc;
