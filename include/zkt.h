@@ -43,7 +43,7 @@ extern "C" {
 #define ZKT_OK 0
 #define ZKT_ERR_INV_ZERO 1   /* inverse of zero */
 #define ZKT_ERR_INFINITY 2   /* pairing argument at infinity */
-#define ZKT_ERR_SHAPE 3      /* bad size / null pointer / non-canonical input */
+#define ZKT_ERR_SHAPE 3      /* bad size / null pointer / index mismatch (polynomial.rs:277-279) */
 #define ZKT_ERR_DEVICE 4     /* no HIP device, HIP error, or library not initialised */
 
 typedef struct { uint64_t x[6], y[6]; uint32_t is_infinity, _pad; } zkt_g1_affine;    /* 104 B */
@@ -57,19 +57,54 @@ int zkt_version(void);
 const char* zkt_strerror(int status);
 size_t zkt_last_error_index(void);        /* thread-local; valid after a non-OK return */
 
-/* a1–a3: PrimeFieldElem::{plus,minus,times,sq,negate,inv} prime_field_elem.rs:278-457 */
+/* a1–a3: PrimeFieldElem::{plus,minus,times,sq,cube,negate,inv,pow,pow_seq,repeat} prime_field_elem.rs:278-457, over the four prime fields
+ * the reference instantiates: fq / fr = BLS12-381 base field and subgroup order (params.rs:8-16), sp / sn = secp256k1 base field and group
+ * order (secp256k1/affine_point.rs:30-47).  Elements are 6 limbs (fq) or 4 limbs (fr, sp, sn).  A limb vector that is not below the field
+ * order is reduced on load, exactly as PrimeFieldElem::new does (prime_field_elem.rs:263-272); outputs are always canonical.
+ *   inv        ZKT_ERR_INV_ZERO (+ index) on a zero, like safe_inv / inv (:379-382, :434-436)
+ *   pow        out[i] = a[i] ^ e_i with e_i = exp_limbs little-endian u64 limbs at exps + i*exp_limbs (exp_shared != 0: one exponent at
+ *              exps for every element); exponent 0 gives 1 for every base (:311-328)
+ *   pow_seq    out[i] = base^i, i < n (:346-361);  repeat  out[i] = base (:363-376) */
 int zkt_fq_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int zkt_fq_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int zkt_fq_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int zkt_fq_sqr_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_fq_cube_batch(const uint64_t* a, uint64_t* out, size_t n);
 int zkt_fq_neg_batch(const uint64_t* a, uint64_t* out, size_t n);
-int zkt_fq_inv_batch(const uint64_t* a, uint64_t* out, size_t n);     /* ZKT_ERR_INV_ZERO on a zero */
+int zkt_fq_inv_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_fq_pow_batch(const uint64_t* a, const uint64_t* exps, size_t exp_limbs, int exp_shared, uint64_t* out, size_t n);
+int zkt_fq_pow_seq(const uint64_t* base, size_t n, uint64_t* out);
+int zkt_fq_repeat(const uint64_t* base, size_t n, uint64_t* out);
 int zkt_fr_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int zkt_fr_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int zkt_fr_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int zkt_fr_sqr_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_fr_cube_batch(const uint64_t* a, uint64_t* out, size_t n);
 int zkt_fr_neg_batch(const uint64_t* a, uint64_t* out, size_t n);
 int zkt_fr_inv_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_fr_pow_batch(const uint64_t* a, const uint64_t* exps, size_t exp_limbs, int exp_shared, uint64_t* out, size_t n);
+int zkt_fr_pow_seq(const uint64_t* base, size_t n, uint64_t* out);
+int zkt_fr_repeat(const uint64_t* base, size_t n, uint64_t* out);
+int zkt_sp_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_sp_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_sp_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_sp_sqr_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_sp_cube_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_sp_neg_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_sp_inv_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_sp_pow_batch(const uint64_t* a, const uint64_t* exps, size_t exp_limbs, int exp_shared, uint64_t* out, size_t n);
+int zkt_sp_pow_seq(const uint64_t* base, size_t n, uint64_t* out);
+int zkt_sp_repeat(const uint64_t* base, size_t n, uint64_t* out);
+int zkt_sn_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_sn_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_sn_mul_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+int zkt_sn_sqr_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_sn_cube_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_sn_neg_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_sn_inv_batch(const uint64_t* a, uint64_t* out, size_t n);
+int zkt_sn_pow_batch(const uint64_t* a, const uint64_t* exps, size_t exp_limbs, int exp_shared, uint64_t* out, size_t n);
+int zkt_sn_pow_seq(const uint64_t* base, size_t n, uint64_t* out);
+int zkt_sn_repeat(const uint64_t* base, size_t n, uint64_t* out);
 
 /* a4–a6: Fq2 fq2.rs:21-151, Fq6 fq6.rs:22-171, Fq12 fq12.rs:23-172 */
 int zkt_fq2_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);

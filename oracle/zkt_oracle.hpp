@@ -191,6 +191,9 @@ struct Fp {
     return sum;
   }
 
+  // cube (:337-344): e*e % p, then *e % p
+  Fp cube() const { return ((*this) * (*this)) * (*this); }
+
   // safe_inv (:379-432): extended Euclid; Err on zero.  Restated as the binary
   // extended Euclid for an odd modulus — the inverse in [0,order) is unique.
   bool safe_inv(Fp& out) const {

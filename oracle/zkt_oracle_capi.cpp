@@ -73,6 +73,32 @@ template <class T> int field_unop(int op, const uint64_t* a, uint64_t* o, size_t
   }
   return OK;
 }
+// a1-a3 over any of the four fields the reference instantiates (field: 0 Fq, 1 Fr, 2 secp256k1 p, 3 secp256k1 n).
+// op: 0 plus 1 minus 2 times 3 sq 4 negate 5 inv 6 cube (prime_field_elem.rs:278-344,379-457)
+template <class T> int field_op_t(int op, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n, int w, size_t* err_index) {
+  for (size_t i = 0; i < n; ++i) {
+    T x = ld<T>(a + i * w, w), y = b ? ld<T>(b + i * w, w) : T(), r;
+    switch (op) {
+      case 0: r = x + y; break; case 1: r = x - y; break; case 2: r = x * y; break; case 3: r = x.sq(); break; case 4: r = x.negate(); break;
+      case 5: if (!x.safe_inv(r)) { if (err_index) *err_index = i; return ERR_INV_ZERO; } break;
+      case 6: r = x.cube(); break;
+      default: return ERR_SHAPE;
+    }
+    st(o + i * w, r, w);
+  }
+  return OK;
+}
+// pow (prime_field_elem.rs:311-328): out[i] = a[i] ^ e_i, exponents of e_limbs u64 limbs each (exp_shared: one exponent for all)
+template <class T> int field_pow_t(const uint64_t* a, const uint64_t* e, int e_limbs, int shared, uint64_t* o, size_t n, int w) {
+  for (size_t i = 0; i < n; ++i) st(o + i * w, ld<T>(a + i * w, w).pow_limbs(e + (shared ? 0 : i * e_limbs), e_limbs), w);
+  return OK;
+}
+// pow_seq (prime_field_elem.rs:346-361): 1, x, x^2, ... by the running product x = x * self.e;  repeat (:363-376): n clones
+template <class T> int field_pow_seq_t(const uint64_t* a, size_t n, uint64_t* o, int w, bool repeat) {
+  T base = ld<T>(a, w), x(1);
+  for (size_t i = 0; i < n; ++i) { st(o + i * w, repeat ? base : x, w); x = x * base; }
+  return OK;
+}
 }  // namespace
 
 extern "C" {
@@ -113,6 +139,37 @@ int zkto_dyn_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* o) {
 }
 int zkto_fq_pow(const uint64_t* a, const uint64_t* e, int e_limbs, uint64_t* o) {
   init_fields(); Fq1 r = ld<Fq1>(a, FQ).pow_limbs(e, e_limbs); st(o, r, FQ); return OK;
+}
+
+int zkto_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n, size_t* err_index) {
+  init_fields();
+  switch (field) {
+    case 0: return field_op_t<Fq1>(op, a, b, o, n, FQ, err_index);
+    case 1: return field_op_t<Fr>(op, a, b, o, n, FR, err_index);
+    case 2: return field_op_t<Sp>(op, a, b, o, n, 4, err_index);
+    case 3: return field_op_t<Fp<SnTag>>(op, a, b, o, n, 4, err_index);
+  }
+  return ERR_SHAPE;
+}
+int zkto_field_pow_batch(int field, const uint64_t* a, const uint64_t* e, int e_limbs, int shared, uint64_t* o, size_t n) {
+  init_fields();
+  switch (field) {
+    case 0: return field_pow_t<Fq1>(a, e, e_limbs, shared, o, n, FQ);
+    case 1: return field_pow_t<Fr>(a, e, e_limbs, shared, o, n, FR);
+    case 2: return field_pow_t<Sp>(a, e, e_limbs, shared, o, n, 4);
+    case 3: return field_pow_t<Fp<SnTag>>(a, e, e_limbs, shared, o, n, 4);
+  }
+  return ERR_SHAPE;
+}
+int zkto_field_pow_seq(int field, const uint64_t* a, size_t n, uint64_t* o, int repeat) {
+  init_fields();
+  switch (field) {
+    case 0: return field_pow_seq_t<Fq1>(a, n, o, FQ, repeat != 0);
+    case 1: return field_pow_seq_t<Fr>(a, n, o, FR, repeat != 0);
+    case 2: return field_pow_seq_t<Sp>(a, n, o, 4, repeat != 0);
+    case 3: return field_pow_seq_t<Fp<SnTag>>(a, n, o, 4, repeat != 0);
+  }
+  return ERR_SHAPE;
 }
 
 // --- a4-a6: tower -------------------------------------------------------------

@@ -50,6 +50,82 @@ def test_field_batch_ops(L, pre, mod, w):
     zk.check(getattr(L, f"zkt_{pre}_mul_batch")(ptr(a), ptr(b), ptr(got), 0))
 
 
+FIELD_IDS = {"fq": 0, "fr": 1, "sp": 2, "sn": 3}
+
+
+@pytest.mark.parametrize("pre,mod,w", [("fq", Q, 6), ("fr", R, 4), ("sp", SECP_P, 4), ("sn", SECP_N, 4)])
+def test_field_pow_cube_seq_repeat(L, pre, mod, w):
+    """row a3: PrimeFieldElem::{pow, cube, pow_seq, repeat} (prime_field_elem.rs:311-376) for the four fields, against the oracle;
+    the reference's pow KAT table (:888-909) straight through the GPU; a1/a2 for the two secp256k1 fields as well."""
+    f = FIELD_IDS[pre]; n = 500
+    a = _rand_field(7 + f, n, mod, w)
+    rng = SplitMix64(900 + f)
+    es = [rng.below(1 << (64 * k)) for k in (1, 2, 3, 4) for _ in range(n // 4 - 1)] + [0, 1, (mod - 1) % (1 << 256), (mod - 2) % (1 << 256)]
+    e = ints_to_arr(es, 4)
+    got, want = np.zeros_like(a), np.zeros_like(a)
+    zk.check(getattr(L, f"zkt_{pre}_pow_batch")(ptr(a), ptr(e), 4, 0, ptr(got), n))
+    assert O.zkto_field_pow_batch(f, ptr(a), ptr(e), 4, 0, ptr(want), n) == 0
+    assert (got == want).all()
+    zk.check(getattr(L, f"zkt_{pre}_pow_batch")(ptr(a), ptr(e[3:4].copy()), 4, 1, ptr(got), n))      # shared exponent
+    assert O.zkto_field_pow_batch(f, ptr(a), ptr(e[3:4].copy()), 4, 1, ptr(want), n) == 0
+    assert (got == want).all()
+    zk.check(getattr(L, f"zkt_{pre}_cube_batch")(ptr(a), ptr(got), n))
+    assert O.zkto_field_op(f, 6, ptr(a), None, ptr(want), n, None) == 0
+    assert (got == want).all()
+    m = 65536 + 3                                        # the range proof's y.pow_seq(n), bulletproofs.rs:87, at BASELINE config 5's length
+    seq, wseq = np.zeros((m, w), dtype=np.uint64), np.zeros((m, w), dtype=np.uint64)
+    zk.check(getattr(L, f"zkt_{pre}_pow_seq")(ptr(a[1:2].copy()), m, ptr(seq)))
+    assert O.zkto_field_pow_seq(f, ptr(a[1:2].copy()), m, ptr(wseq), 0) == 0
+    assert (seq == wseq).all()
+    zk.check(getattr(L, f"zkt_{pre}_repeat")(ptr(a[1:2].copy()), 100, ptr(seq)))
+    assert (seq[:100] == a[1]).all()
+    k = K["pow_various"]; mm = int(k["order"])           # results below every field order: a^e mod p is the integer a^e
+    b = ints_to_arr([c[0] for c in k["cases"]], w); ex = ints_to_arr([c[1] for c in k["cases"]], 1); o = np.zeros_like(b)
+    zk.check(getattr(L, f"zkt_{pre}_pow_batch")(ptr(b), ptr(ex), 1, 0, ptr(o), len(b)))
+    assert [v % mm for v in arr_to_ints(o)] == [c[2] for c in k["cases"]]
+    zk.check(getattr(L, f"zkt_{pre}_pow_batch")(ptr(a), ptr(e), 4, 0, ptr(got), 0))                  # empty batch
+    # a1/a2 on the same inputs (the secp256k1 fields have no other field-level test)
+    b2 = _rand_field(55 + f, n, mod, w)[::-1].copy()
+    for op, code in (("add", 0), ("sub", 1), ("mul", 2)):
+        zk.check(getattr(L, f"zkt_{pre}_{op}_batch")(ptr(a), ptr(b2), ptr(got), n))
+        assert O.zkto_field_op(f, code, ptr(a), ptr(b2), ptr(want), n, None) == 0
+        assert (got == want).all(), op
+    for op, code in (("sqr", 3), ("neg", 4)):
+        zk.check(getattr(L, f"zkt_{pre}_{op}_batch")(ptr(a), ptr(got), n))
+        assert O.zkto_field_op(f, code, ptr(a), None, ptr(want), n, None) == 0
+        assert (got == want).all(), op
+    nz = a[(a != 0).any(axis=1)].copy(); got, want = np.zeros_like(nz), np.zeros_like(nz)
+    zk.check(getattr(L, f"zkt_{pre}_inv_batch")(ptr(nz), ptr(got), len(nz)))
+    assert O.zkto_field_op(f, 5, ptr(nz), None, ptr(want), len(nz), None) == 0
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("pre,mod,w", [("fq", Q, 6), ("fr", R, 4), ("sp", SECP_P, 4), ("sn", SECP_N, 4)])
+def test_field_inputs_are_reduced_like_prime_field_elem_new(L, pre, mod, w):
+    """PrimeFieldElem::new reduces e mod order (prime_field_elem.rs:263-272): limb vectors at or above the order give the result of
+    their residue, for every operand position."""
+    top = 1 << (64 * w)
+    raw = [mod, mod + 5, top - 1, 2 * mod + 1 if 2 * mod + 1 < top else mod + 1, 7]
+    red = [x % mod for x in raw]
+    a, ar = ints_to_arr(raw, w), ints_to_arr(red, w)
+    b, br = ints_to_arr(raw[::-1], w), ints_to_arr(red[::-1], w)
+    for op in ("add", "sub", "mul"):
+        g1, g2 = np.zeros_like(a), np.zeros_like(a)
+        zk.check(getattr(L, f"zkt_{pre}_{op}_batch")(ptr(a), ptr(b), ptr(g1), len(raw)))
+        zk.check(getattr(L, f"zkt_{pre}_{op}_batch")(ptr(ar), ptr(br), ptr(g2), len(raw)))
+        f = {"add": lambda x, y: (x + y) % mod, "sub": lambda x, y: (x - y) % mod, "mul": lambda x, y: x * y % mod}[op]
+        assert arr_to_ints(g1) == arr_to_ints(g2) == [f(x, y) for x, y in zip(red, red[::-1])], op
+    for op, f in (("sqr", lambda x: x * x % mod), ("neg", lambda x: -x % mod), ("cube", lambda x: pow(x, 3, mod))):
+        g1 = np.zeros_like(a)
+        zk.check(getattr(L, f"zkt_{pre}_{op}_batch")(ptr(a), ptr(g1), len(raw)))
+        assert arr_to_ints(g1) == [f(x) for x in red], op
+    g1 = np.zeros_like(a)
+    rc = getattr(L, f"zkt_{pre}_inv_batch")(ptr(a), ptr(g1), len(raw))      # element 0 is the order itself = 0
+    assert rc == ZKT_ERR_INV_ZERO and L.zkt_last_error_index() == 0
+    zk.check(getattr(L, f"zkt_{pre}_inv_batch")(ptr(a[1:].copy()), ptr(g1[1:]), len(raw) - 1))
+    assert arr_to_ints(g1[1:]) == [pow(x, -1, mod) for x in red[1:]]
+
+
 def test_fq_mul_large_kat(L):                   # prime_field_elem.rs:600-617 is mod secp-n; here the Fq2..12 KAT inputs
     a1, b1 = Q - 3, Q - 5
     a = ints_to_arr([a1], 6); b = ints_to_arr([b1], 6); o = np.zeros_like(a)

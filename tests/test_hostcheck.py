@@ -28,7 +28,7 @@ def H():
     return ctypes.CDLL(so)
 
 
-@pytest.mark.parametrize("field,mod,w,pre", [(0, Q, 6, "fq"), (1, R, 4, "fr")])
+@pytest.mark.parametrize("field,mod,w,pre", [(0, Q, 6, "fq"), (1, R, 4, "fr"), (2, SECP_P, 4, "sp"), (3, SECP_N, 4, "sn")])
 def test_field_ops(H, field, mod, w, pre):
     rng = SplitMix64(31 + field)
     xs = [rng.below(mod) for _ in range(64)] + [0, 1, mod - 1, mod - 1, 2]
@@ -40,7 +40,13 @@ def test_field_ops(H, field, mod, w, pre):
         assert H.zkt_hostcheck_fp(field, op, p32(a), p32(b), p32(o), len(xs)) == 0
         assert arr_to_ints(o) == [f(x, y) for x, y in zip(xs, ys)], op
     nz = ints_to_arr([x for x in xs if x] + [2**k for k in (1, 31, 32, 33, 64, 200)] + [mod - 2**k for k in (0, 1, 32, 100)], w)
-    for op in (5, 6):                                  # binary-Euclid inverse and Fermat inverse
+    o = np.zeros_like(a)                               # a3: cube, pow with one exponent per element (fp_pow, the kernels' routine)
+    assert H.zkt_hostcheck_fp(field, 7, p32(a), None, p32(o), len(xs)) == 0
+    assert arr_to_ints(o) == [pow(x, 3, mod) for x in xs]
+    es = [rng.below(mod) for _ in range(len(xs) - 3)] + [0, 1, mod - 1]
+    assert H.zkt_hostcheck_fp(field, 8, p32(a), p32(ints_to_arr(es, w)), p32(o), len(xs)) == 0
+    assert arr_to_ints(o) == [pow(x, e, mod) for x, e in zip(xs, es)]
+    for op in (5, 6):                                  # binary-Euclid inverse and x^(p-2) through fp_pow
         o = np.zeros_like(nz)
         assert H.zkt_hostcheck_fp(field, op, p32(nz), None, p32(o), len(nz)) == 0
         assert arr_to_ints(o) == [pow(x, -1, mod) for x in arr_to_ints(nz)], op

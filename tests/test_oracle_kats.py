@@ -266,3 +266,34 @@ def test_secp_kats():                    # secp256k1/affine_point.rs:190-203, 29
     k = K["secp_add_large"]
     p1, p2, p3 = [(int(k[n][0], 16), int(k[n][1], 16)) for n in ("p1", "p2", "p3")]
     assert sp_from(add(sp_arr([p1]), sp_arr([p2]))) == [p3]
+
+
+# ---- row a3 through the four-field entry points (zkto_field_*) -------------------------------------------------
+FIELDS = [(0, Q, 6), (1, R, 4), (2, SECP_P, 4), (3, SECP_N, 4)]
+
+
+@pytest.mark.parametrize("field,mod,w", FIELDS)
+def test_field_pow_cube_seq_vs_python_ints(field, mod, w):
+    """pow / cube / pow_seq / repeat (prime_field_elem.rs:311-376) of the oracle against python integers, and the
+    reference's own pow KATs (:888-909, :911-921) replayed in each field: all results are below every field order,
+    so a^e mod p is the plain integer a^e and must agree with the reference's table after `% 10^8`."""
+    rng = SplitMix64(77 + field)
+    xs = [rng.below(mod) for _ in range(24)] + [0, 1, mod - 1, 2]
+    es = [rng.below(1 << 256) for _ in range(24)] + [0, 0, (mod - 1) % (1 << 256), (mod - 2) % (1 << 256)]
+    a, e = ints_to_arr(xs, w), ints_to_arr(es, 4)
+    o = np.zeros_like(a)
+    assert O.zkto_field_pow_batch(field, ptr(a), ptr(e), 4, 0, ptr(o), len(xs)) == 0
+    assert arr_to_ints(o) == [pow(x, k, mod) for x, k in zip(xs, es)]
+    assert O.zkto_field_pow_batch(field, ptr(a), ptr(e[5:6].copy()), 4, 1, ptr(o), len(xs)) == 0          # one shared exponent
+    assert arr_to_ints(o) == [pow(x, es[5], mod) for x in xs]
+    assert O.zkto_field_op(field, 6, ptr(a), None, ptr(o), len(xs), None) == 0                              # cube
+    assert arr_to_ints(o) == [x * x % mod * x % mod for x in xs]
+    seq = np.zeros((40, w), dtype=np.uint64)
+    assert O.zkto_field_pow_seq(field, ptr(a[3:4].copy()), 40, ptr(seq), 0) == 0
+    assert arr_to_ints(seq) == [pow(xs[3], i, mod) for i in range(40)]
+    assert O.zkto_field_pow_seq(field, ptr(a[3:4].copy()), 7, ptr(seq), 1) == 0                             # repeat
+    assert arr_to_ints(seq[:7]) == [xs[3]] * 7
+    k = K["pow_various"]; m = int(k["order"])
+    b = ints_to_arr([c[0] for c in k["cases"]], w); ex = ints_to_arr([c[1] for c in k["cases"]], 1); o = np.zeros_like(b)
+    assert O.zkto_field_pow_batch(field, ptr(b), ptr(ex), 1, 0, ptr(o), len(b)) == 0
+    assert [v % m for v in arr_to_ints(o)] == [c[2] for c in k["cases"]]

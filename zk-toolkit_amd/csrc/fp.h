@@ -373,6 +373,7 @@ template <class C> ZKT_HD Fp<C> fp_from_words(const uint32_t* w) {
   } else {
 #pragma unroll
     for (int i = 0; i < C::N; ++i) x.v[i] = w[i];
+    x = fp_canon32(x);
   }
   return fp_mul(x, r2);
 }
@@ -401,31 +402,13 @@ template <class C> ZKT_HD void fp_to_words(const Fp<C>& a, uint32_t* w) {
     for (int i = 0; i < C::N; ++i) w[i] = x.v[i];
   }
 }
-// is a canonical input really < p ?  (ABI contract check)
-template <class C> ZKT_HD bool fp_words_canonical(const uint32_t* w) {
-  uint32_t bw = 0;
-#pragma unroll
-  for (int i = 0; i < C::ABI_N; ++i) (void)subb(w[i], C::mod32(i), bw);
-  return bw != 0;
-}
-
-// a^(p-2): inverse of a non-zero element (Montgomery domain in and out).
-// safe_inv (prime_field_elem.rs:379-432) returns the unique inverse in [0,p);
-// Fermat gives the same residue.  The exponent is a compile-time constant, so
-// the branch is wave-uniform.
-template <class C> ZKT_FN Fp<C> fp_inv_fermat(Fp<C> a) {
-  Fp<C> r = fp_one<C>();
-  bool started = false;
-  for (int i = C::ABI_N * 32 - 1; i >= 0; --i) {
-    uint32_t w = 0;
-    // constant table lookup with a run-time index: select via unrolled compare
-#pragma unroll
-    for (int j = 0; j < C::ABI_N; ++j) w = (j == (i >> 5)) ? C::pm2(j) : w;
-    bool bit = (w >> (i & 31)) & 1;
-    if (started) r = fp_sqr(r);
-    if (bit) { r = started ? fp_mul(r, a) : a; started = true; }
-  }
-  return r;
+// W = 32 fields keep canonical values: an ABI word vector may be any 256-bit integer (PrimeFieldElem::new reduces e mod order,
+// prime_field_elem.rs:263-272).  2^256 < 3r and < 2p, 2n for the secp256k1 fields: two conditional subtractions reduce it.
+// (W = 28: fp_from_words needs no such step — the Montgomery product by R^2 accepts any 384-bit integer and returns its residue.)
+template <class C> ZKT_HD Fp<C> fp_canon32(Fp<C> x) {
+  static_assert(C::W == 32, "canonical 32-bit-limb fields only");
+  fp_cond_sub(x, 0); fp_cond_sub(x, 0);
+  return x;
 }
 
 // Inverse by the binary extended Euclid on the plain integers (odd p): ~2*bits iterations of
@@ -486,11 +469,13 @@ template <class C> ZKT_FN Fp<C> fp_inv(Fp<C> a) {
   }
 }
 
-// generic power with a run-time exponent of `nlimbs` 32-bit limbs (MSB-first
-// square-and-multiply; pow, prime_field_elem.rs:311-328, computes the same residue)
+// generic power with a run-time exponent of `nlimbs` 32-bit limbs (MSB-first square-and-multiply; pow, prime_field_elem.rs:311-328,
+// runs LSB-first on the same bits and computes the same residue; exponent 0 gives 1 for every base, 0 included, as there)
 template <class C> ZKT_FN Fp<C> fp_pow(Fp<C> a, const uint32_t* e, int nlimbs) {
   Fp<C> r = fp_one<C>();
-  for (int i = nlimbs * 32 - 1; i >= 0; --i) {
+  int top = nlimbs * 32 - 1;
+  while (top >= 0 && !((e[top >> 5] >> (top & 31)) & 1)) --top;      // squaring 1 through the leading zero bits changes nothing
+  for (int i = top; i >= 0; --i) {
     r = fp_sqr(r);
     if ((e[i >> 5] >> (i & 31)) & 1) r = fp_mul(r, a);
   }

@@ -9,7 +9,7 @@ using namespace zkt;
 
 extern "C" {
 int zkt_hostcheck_fq_program(uint64_t seed, int steps, const uint32_t* in4, uint32_t* out4) { return fq_program(seed, steps, in4, out4); }
-// op: 0 add 1 sub 2 mul 3 sqr 4 neg 5 inv (binary Euclid) 6 inv (Fermat)
+// op: 0 add 1 sub 2 mul 3 sqr 4 neg 5 inv (binary Euclid) 6 inv as x^(p-2) through fp_pow 7 cube 8 pow (b = exponent, ABI_N words per element)
 int zkt_hostcheck_fp(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n) {
   auto run = [&](auto tag) {
     typedef decltype(tag) C;
@@ -17,7 +17,8 @@ int zkt_hostcheck_fp(int field, int op, const uint32_t* a, const uint32_t* b, ui
       Fp<C> x = ld_fp<C>(a + i * C::ABI_N), y = b ? ld_fp<C>(b + i * C::ABI_N) : fp_zero<C>(), r;
       switch (op) {
         case 0: r = fp_add(x, y); break; case 1: r = fp_sub(x, y); break; case 2: r = fp_mul(x, y); break;
-        case 3: r = fp_sqr(x); break; case 4: r = fp_neg(x); break; case 6: r = fp_inv_fermat(x); break; default: r = fp_inv(x);
+        case 3: r = fp_sqr(x); break; case 4: r = fp_neg(x); break; case 6: { uint32_t e[C::ABI_N]; for (int j = 0; j < C::ABI_N; ++j) e[j] = C::pm2(j); r = fp_pow(x, e, C::ABI_N); } break;
+        case 7: r = fp_mul(fp_sqr(x), x); break; case 8: r = fp_pow(x, b + i * C::ABI_N, C::ABI_N); break; default: r = fp_inv(x);
       }
       st_fp<C>(o + i * C::ABI_N, r);
     }

@@ -62,33 +62,54 @@ int fetch_err(hipStream_t s, int code_if_set) {
   return ZKT_OK;
 }
 
-// generic host-staged elementwise op: in_a, in_b (optional) -> out, fixed bytes per element
+// generic host-staged op: in_a, in_b (optional) -> out, sizes in bytes
+template <class Launch>
+int staged_raw(const void* a, size_t a_total, const void* b, size_t b_total, void* out, size_t out_total, int err_code, Launch launch) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!a || !out || (b_total && !b)) return ZKT_ERR_SHAPE;
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCHK(hipSetDevice(g.device));
+  int rc = arena_reserve(padded(a_total) + padded(b_total) + padded(out_total) + 1024);
+  if (rc) return rc;
+  Carver cv(g.arena);
+  uint32_t* da = cv.take<uint32_t>(a_total);
+  uint32_t* db = b_total ? cv.take<uint32_t>(b_total) : nullptr;
+  uint32_t* dout = cv.take<uint32_t>(out_total);
+  HIPCHK(hipMemcpyAsync(da, a, a_total, hipMemcpyHostToDevice, g.stream));
+  if (db) HIPCHK(hipMemcpyAsync(db, b, b_total, hipMemcpyHostToDevice, g.stream));
+  if ((rc = reset_err(g.stream))) return rc;
+  HIPCHK(launch(da, db, dout, g.stream));
+  HIPCHK(hipMemcpyAsync(out, dout, out_total, hipMemcpyDeviceToHost, g.stream));
+  return fetch_err(g.stream, err_code);
+}
+// elementwise form: fixed bytes per element
 template <class Launch>
 int staged(const void* a, size_t a_bytes, const void* b, size_t b_bytes, void* out, size_t out_bytes, size_t n, int err_code, Launch launch) {
   if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
   if (n == 0) return ZKT_OK;
-  if (!a || !out || (b_bytes && !b)) return ZKT_ERR_SHAPE;
-  std::lock_guard<std::mutex> lk(g.mu);
-  HIPCHK(hipSetDevice(g.device));
-  int rc = arena_reserve(padded(a_bytes * n) + padded(b_bytes * n) + padded(out_bytes * n) + 1024);
-  if (rc) return rc;
-  Carver cv(g.arena);
-  uint32_t* da = cv.take<uint32_t>(a_bytes * n);
-  uint32_t* db = b_bytes ? cv.take<uint32_t>(b_bytes * n) : nullptr;
-  uint32_t* dout = cv.take<uint32_t>(out_bytes * n);
-  HIPCHK(hipMemcpyAsync(da, a, a_bytes * n, hipMemcpyHostToDevice, g.stream));
-  if (db) HIPCHK(hipMemcpyAsync(db, b, b_bytes * n, hipMemcpyHostToDevice, g.stream));
-  if ((rc = reset_err(g.stream))) return rc;
-  HIPCHK(launch(da, db, dout, g.stream));
-  HIPCHK(hipMemcpyAsync(out, dout, out_bytes * n, hipMemcpyDeviceToHost, g.stream));
-  return fetch_err(g.stream, err_code);
+  return staged_raw(a, a_bytes * n, b, b_bytes * n, out, out_bytes * n, err_code, launch);
 }
 
+size_t field_bytes(int field) { return field == F_FQ ? 48 : 32; }
 int fp_batch(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  const size_t w = field == F_FQ ? 48 : 32;
+  const size_t w = field_bytes(field);
   const bool binary = op == OP_ADD || op == OP_SUB || op == OP_MUL;
   return staged(a, w, binary ? b : nullptr, binary ? w : 0, out, w, n, ZKT_ERR_INV_ZERO,
                 [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_fp_op(field, op, da, db, dout, n, g.d_err, s); });
+}
+// a3: pow with per-element or shared exponents of exp_limbs u64 limbs; pow_seq / repeat from one base element
+int fp_pow_batch(int field, const uint64_t* a, const uint64_t* exps, size_t exp_limbs, int exp_shared, uint64_t* out, size_t n) {
+  if (exp_limbs == 0 || exp_limbs > 64) return ZKT_ERR_SHAPE;
+  if (n == 0) return ensure_ready();
+  const size_t w = field_bytes(field);
+  return staged_raw(a, w * n, exps, exp_limbs * 8 * (exp_shared ? 1 : n), out, w * n, ZKT_ERR_SHAPE,
+                    [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_fp_pow(field, da, db, (int)exp_limbs * 2, exp_shared != 0, dout, n, s); });
+}
+int fp_pow_seq(int field, const uint64_t* base, size_t n, uint64_t* out, bool repeat) {
+  if (n == 0) return ensure_ready();
+  const size_t w = field_bytes(field);
+  return staged_raw(base, w, nullptr, 0, out, w * n, ZKT_ERR_SHAPE,
+                    [&](uint32_t* da, uint32_t*, uint32_t* dout, hipStream_t s) { return launch_fp_pow_seq(field, da, dout, n, repeat, s); });
 }
 int tower_batch(int deg, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
   const size_t w = (size_t)deg * 48;
@@ -195,10 +216,16 @@ void zkt_shutdown(void) {
 
 #define FP_BIN(name, field, op) int name(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return fp_batch(field, op, a, b, out, n); }
 #define FP_UN(name, field, op) int name(const uint64_t* a, uint64_t* out, size_t n) { return fp_batch(field, op, a, nullptr, out, n); }
-FP_BIN(zkt_fq_add_batch, F_FQ, OP_ADD) FP_BIN(zkt_fq_sub_batch, F_FQ, OP_SUB) FP_BIN(zkt_fq_mul_batch, F_FQ, OP_MUL)
-FP_UN(zkt_fq_sqr_batch, F_FQ, OP_SQR) FP_UN(zkt_fq_neg_batch, F_FQ, OP_NEG) FP_UN(zkt_fq_inv_batch, F_FQ, OP_INV)
-FP_BIN(zkt_fr_add_batch, F_FR, OP_ADD) FP_BIN(zkt_fr_sub_batch, F_FR, OP_SUB) FP_BIN(zkt_fr_mul_batch, F_FR, OP_MUL)
-FP_UN(zkt_fr_sqr_batch, F_FR, OP_SQR) FP_UN(zkt_fr_neg_batch, F_FR, OP_NEG) FP_UN(zkt_fr_inv_batch, F_FR, OP_INV)
+// the four prime fields the reference instantiates: BLS12-381 Fq and Fr, secp256k1's base field (sp) and group order (sn)
+#define FP_FIELD_API(P, F)                                                                                       \
+  FP_BIN(zkt_##P##_add_batch, F, OP_ADD) FP_BIN(zkt_##P##_sub_batch, F, OP_SUB) FP_BIN(zkt_##P##_mul_batch, F, OP_MUL) \
+  FP_UN(zkt_##P##_sqr_batch, F, OP_SQR) FP_UN(zkt_##P##_neg_batch, F, OP_NEG) FP_UN(zkt_##P##_inv_batch, F, OP_INV)     \
+  FP_UN(zkt_##P##_cube_batch, F, OP_CUBE)                                                                        \
+  int zkt_##P##_pow_batch(const uint64_t* a, const uint64_t* exps, size_t exp_limbs, int exp_shared, uint64_t* out, size_t n) { \
+    return fp_pow_batch(F, a, exps, exp_limbs, exp_shared, out, n); }                                            \
+  int zkt_##P##_pow_seq(const uint64_t* base, size_t n, uint64_t* out) { return fp_pow_seq(F, base, n, out, false); }  \
+  int zkt_##P##_repeat(const uint64_t* base, size_t n, uint64_t* out) { return fp_pow_seq(F, base, n, out, true); }
+FP_FIELD_API(fq, F_FQ) FP_FIELD_API(fr, F_FR) FP_FIELD_API(sp, F_SP) FP_FIELD_API(sn, F_SN)
 
 #define TW_BIN(name, deg, op) int name(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return tower_batch(deg, op, a, b, out, n); }
 #define TW_UN(name, deg, op) int name(const uint64_t* a, uint64_t* out, size_t n) { return tower_batch(deg, op, a, nullptr, out, n); }

@@ -23,30 +23,29 @@ __global__ void __launch_bounds__(TPB) k_fp_op(const uint32_t* __restrict__ a, c
     else if (OP == OP_NEG) r = fp_neg(x);
     else if (OP == OP_MUL) r = fp_mul(x, ld_fp<C>(b + i * A));
     else if (OP == OP_SQR) r = fp_sqr(x);
+    else if (OP == OP_CUBE) r = fp_mul(fp_sqr(x), x);
     else if (fp_is_zero(x)) { atomicMin(err, (unsigned long long)i); r = x; }
     else r = fp_inv(x);
     st_fp<C>(out + i * A, r);
-    return;
-  }
-  Fp<C> x = ld_raw<C>(a + i * C::N), r;
-  if (OP == OP_ADD) r = fp_add(x, ld_raw<C>(b + i * C::N));          // canonical in, canonical out
-  else if (OP == OP_SUB) r = fp_sub(x, ld_raw<C>(b + i * C::N));
+  } else {
+  // canonical 32-bit-limb fields: any 256-bit input is first reduced mod the order, as PrimeFieldElem::new does (prime_field_elem.rs:263-272)
+  Fp<C> x = fp_canon32(ld_raw<C>(a + i * C::N)), r, r2;
+  for (int j = 0; j < C::N; ++j) r2.v[j] = C::r2(j);
+  if (OP == OP_ADD) r = fp_add(x, fp_canon32(ld_raw<C>(b + i * C::N)));          // canonical in, canonical out
+  else if (OP == OP_SUB) r = fp_sub(x, fp_canon32(ld_raw<C>(b + i * C::N)));
   else if (OP == OP_NEG) r = fp_neg(x);
-  else if (OP == OP_MUL) {                                             // (a b R^-1) R^2 R^-1 = a b
-    Fp<C> r2; for (int j = 0; j < C::N; ++j) r2.v[j] = C::r2(j);
-    r = fp_mul(fp_mul(x, ld_raw<C>(b + i * C::N)), r2);
-  } else if (OP == OP_SQR) {
-    Fp<C> r2; for (int j = 0; j < C::N; ++j) r2.v[j] = C::r2(j);
-    r = fp_mul(fp_mul(x, x), r2);
-  } else {                                                             // safe_inv: Err on zero (prime_field_elem.rs:379-382)
+  else if (OP == OP_MUL) r = fp_mul(fp_mul(x, fp_canon32(ld_raw<C>(b + i * C::N))), r2);     // (a b R^-1) R^2 R^-1 = a b
+  else if (OP == OP_SQR) r = fp_mul(fp_mul(x, x), r2);
+  else if (OP == OP_CUBE) { Fp<C> xm = fp_mul(x, r2); r = fp_mul(fp_mul(xm, xm), x); }        // (xR)(xR)/R = x^2 R;  x^2 R * x / R = x^3
+  else {                                                             // safe_inv: Err on zero (prime_field_elem.rs:379-382)
     if (fp_is_zero(x)) { atomicMin(err, (unsigned long long)i); r = x; }
     else {
-      Fp<C> r2, one = fp_zero<C>(); one.v[0] = 1;
-      for (int j = 0; j < C::N; ++j) r2.v[j] = C::r2(j);
+      Fp<C> one = fp_zero<C>(); one.v[0] = 1;
       r = fp_mul(fp_inv(fp_mul(x, r2)), one);
     }
   }
   st_raw<C>(out + i * C::N, r);
+  }
 }
 
 template <class C>
@@ -60,6 +59,7 @@ static hipError_t launch_fp_c(int op, const uint32_t* a, const uint32_t* b, uint
     case OP_SQR: hipLaunchKernelGGL((k_fp_op<C, OP_SQR>), g, t, 0, s, a, b, o, n, err); break;
     case OP_NEG: hipLaunchKernelGGL((k_fp_op<C, OP_NEG>), g, t, 0, s, a, b, o, n, err); break;
     case OP_INV: hipLaunchKernelGGL((k_fp_op<C, OP_INV>), g, t, 0, s, a, b, o, n, err); break;
+    case OP_CUBE: hipLaunchKernelGGL((k_fp_op<C, OP_CUBE>), g, t, 0, s, a, b, o, n, err); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -72,6 +72,50 @@ hipError_t launch_fp_op(int field, int op, const uint32_t* a, const uint32_t* b,
     case F_SN: return launch_fp_c<SnC>(op, a, b, o, n, err, s);
   }
   return hipErrorInvalidValue;
+}
+
+// pow / pow_seq / repeat (row a3).  One element per lane; the exponent is scanned from its top set bit, so lanes of a wave run
+// as long as the widest exponent among them.
+template <class C>
+__global__ void __launch_bounds__(TPB) k_fp_pow(const uint32_t* __restrict__ a, const uint32_t* __restrict__ e, int e_words, int shared,
+                                                uint32_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  constexpr int A = C::ABI_N;
+  st_fp<C>(out + i * A, fp_pow(ld_fp<C>(a + i * A), e + (shared ? 0 : i * (size_t)e_words), e_words));
+}
+template <class C>
+__global__ void __launch_bounds__(TPB) k_fp_pow_seq(const uint32_t* __restrict__ base, uint32_t* __restrict__ out, size_t n, int repeat) {
+  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  constexpr int A = C::ABI_N;
+  const Fp<C> b = ld_fp<C>(base);
+  const uint32_t e[2] = {(uint32_t)i, (uint32_t)((unsigned long long)i >> 32)};
+  st_fp<C>(out + i * A, repeat ? b : fp_pow(b, e, 2));              // base^i: the reference's running product reaches the same residue
+}
+hipError_t launch_fp_pow(int field, const uint32_t* a, const uint32_t* e, int e_words, bool shared, uint32_t* o, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  dim3 g(nblocks(n)), t(TPB);
+  switch (field) {
+    case F_FQ: hipLaunchKernelGGL(k_fp_pow<FqC>, g, t, 0, s, a, e, e_words, shared ? 1 : 0, o, n); break;
+    case F_FR: hipLaunchKernelGGL(k_fp_pow<FrC>, g, t, 0, s, a, e, e_words, shared ? 1 : 0, o, n); break;
+    case F_SP: hipLaunchKernelGGL(k_fp_pow<SpC>, g, t, 0, s, a, e, e_words, shared ? 1 : 0, o, n); break;
+    case F_SN: hipLaunchKernelGGL(k_fp_pow<SnC>, g, t, 0, s, a, e, e_words, shared ? 1 : 0, o, n); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_fp_pow_seq(int field, const uint32_t* base, uint32_t* o, size_t n, bool repeat, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  dim3 g(nblocks(n)), t(TPB);
+  switch (field) {
+    case F_FQ: hipLaunchKernelGGL(k_fp_pow_seq<FqC>, g, t, 0, s, base, o, n, repeat ? 1 : 0); break;
+    case F_FR: hipLaunchKernelGGL(k_fp_pow_seq<FrC>, g, t, 0, s, base, o, n, repeat ? 1 : 0); break;
+    case F_SP: hipLaunchKernelGGL(k_fp_pow_seq<SpC>, g, t, 0, s, base, o, n, repeat ? 1 : 0); break;
+    case F_SN: hipLaunchKernelGGL(k_fp_pow_seq<SnC>, g, t, 0, s, base, o, n, repeat ? 1 : 0); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 // diagnostic: `count` independent runs of the fp.h self-test program (fq_program.h), one per lane, seeds seed0 + lane

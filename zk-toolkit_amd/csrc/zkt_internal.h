@@ -8,7 +8,7 @@
 namespace zkt {
 
 enum FieldId { F_FQ = 0, F_FR = 1, F_SP = 2, F_SN = 3 };
-enum FpOp { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_SQR = 3, OP_NEG = 4, OP_INV = 5 };
+enum FpOp { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_SQR = 3, OP_NEG = 4, OP_INV = 5, OP_CUBE = 6 };
 enum TowerOp { T_ADD = 0, T_SUB = 1, T_MUL = 2, T_INV = 3, T_NEG = 4, T_REDUCE = 5 };
 enum GroupId { G_G1 = 0, G_G2 = 1, G_SECP = 2 };
 
@@ -17,6 +17,10 @@ static constexpr unsigned long long NO_ERR = ~0ull;
 
 hipError_t launch_fp_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n,
                         unsigned long long* err, hipStream_t s);
+// pow (prime_field_elem.rs:311-328): out[i] = a[i]^e_i, exponents of e_words u32 words each (shared: one exponent for all elements)
+hipError_t launch_fp_pow(int field, const uint32_t* a, const uint32_t* e, int e_words, bool shared, uint32_t* out, size_t n, hipStream_t s);
+// pow_seq (prime_field_elem.rs:346-361): out[i] = base^i for i < n;  repeat (:363-376): out[i] = base
+hipError_t launch_fp_pow_seq(int field, const uint32_t* base, uint32_t* out, size_t n, bool repeat, hipStream_t s);
 hipError_t launch_selftest_fq_program(unsigned long long seed0, int steps, const uint32_t* in4, uint32_t* out4, int* bad, size_t count, hipStream_t s);
 hipError_t launch_tower_op(int deg, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n,
                            unsigned long long* err, hipStream_t s);
