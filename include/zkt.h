@@ -25,9 +25,11 @@
  * polynomial.rs:277-279).  Here every call returns a status and zkt_last_error_index()
  * gives the first offending element; a Rust shim turns non-OK into panic!.
  *
- * Threading: zkt_init once (idempotent); calls are blocking and thread-safe; no host
- * pointer is retained past return.  There is NO CPU fallback: without a HIP device every
- * compute entry point returns ZKT_ERR_DEVICE.
+ * Threading: zkt_init once (idempotent) binds the library to ONE device; every entry point selects that device for the calling thread.
+ * Calls are blocking unless documented otherwise and may come from any thread: independent batch calls are serialised on the library's
+ * staging stream; calls on one handle (bases, proving key, context) are serialised by a per-handle lock (submit / collect of different
+ * slots of one handle may be issued from different threads).  No host pointer is retained past return.  There is NO CPU fallback:
+ * without a HIP device every compute entry point returns ZKT_ERR_DEVICE.
  *
  * `_dev` variants take DEVICE pointers in the same layouts plus a hipStream_t (as void*)
  * and are asynchronous on that stream except where they return a host result.
@@ -336,6 +338,37 @@ int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_spars
                                    size_t shard, size_t nshards, zkt_groth16_crs* vk, zkt_groth16_pk** out);
 int zkt_groth16_prove_r1cs_partials(zkt_groth16_pk* pk, const uint64_t* dev_wires, const uint64_t* r, const uint64_t* s, uint32_t* dev_partials);
 void zkt_groth16_pk_free(zkt_groth16_pk* pk);
+
+/* ---- multi-GPU: one process per GPU -------------------------------------------------------------------------------
+ * The index range of an MSM (or of the three resident base sets of a Groth16 key) is partitioned over the ranks; every rank computes the
+ * Jacobian partial sum of its shard; the only exchange is ONE all-gather of the fixed-size partials (168 B G1, 336 B G2, 672 B per proof)
+ * and a local combine on every rank — an elliptic-curve sum is not an RCCL reduction op.  Every rank returns the same affine result.
+ * Transport: RCCL over xGMI (zkt_comm_unique_id on rank 0, the id shipped by the host like ncclGetUniqueId's, zkt_comm_init on every
+ * rank after zkt_init), or a host callback for hosts that bring their own exchange (MPI, gloo, tests): fn all-gathers bytes_per_rank
+ * bytes from every rank's `send` into `recv` (rank-major) and returns 0. */
+#define ZKT_COMM_ID_BYTES 128
+typedef int (*zkt_allgather_fn)(void* ctx, const void* send, void* recv, size_t bytes_per_rank);
+int zkt_comm_unique_id(uint8_t id[ZKT_COMM_ID_BYTES]);
+int zkt_comm_init(int rank, int world, const uint8_t id[ZKT_COMM_ID_BYTES]);     /* world == 1: id may be NULL */
+int zkt_comm_init_callback(int rank, int world, zkt_allgather_fn fn, void* ctx);
+void zkt_comm_finalize(void);
+int zkt_comm_rank(void);                                                        /* -1 before zkt_comm_init */
+int zkt_comm_world(void);                                                       /* 0 before zkt_comm_init */
+/* contiguous, balanced index range [lo, hi) of `rank` (the first n % world ranks hold one extra term) */
+void zkt_comm_shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi);
+/* Polynomial::eval_with_g1_hidings (polynomial.rs:271-281) with the terms partitioned over the ranks: `bases` holds THIS rank's shard,
+ * dev_scalars its n_local scalars.  Blocking; collective (every rank must call it). */
+int zkt_g1_msm_sharded(zkt_g1_bases* bases, const uint64_t* dev_scalars, size_t n_local, void* stream, zkt_g1_affine* out);
+int zkt_g2_msm_sharded(zkt_g2_bases* bases, const uint64_t* dev_scalars, size_t n_local, void* stream, zkt_g2_affine* out);
+int zkt_secp_msm_sharded(zkt_secp_bases* bases, const uint64_t* dev_scalars, size_t n_local, void* stream, zkt_secp_affine* out);
+/* pipelined form: zkt_*_msm_submit on every rank, then this instead of zkt_*_msm_collect (collective, same slot order on every rank) */
+int zkt_g1_msm_sharded_collect(zkt_g1_bases* bases, int slot, zkt_g1_affine* out);
+int zkt_g2_msm_sharded_collect(zkt_g2_bases* bases, int slot, zkt_g2_affine* out);
+int zkt_secp_msm_sharded_collect(zkt_secp_bases* bases, int slot, zkt_secp_affine* out);
+/* Prover::prove (prover.rs:96-147) for ONE proof sharded over the ranks (BASELINE config 4): pk from zkt_groth16_setup_r1cs_sharded(…,
+ * zkt_comm_rank(), zkt_comm_world(), …).  The Fr stage (mat-vecs, NTTs) is replicated; collective. */
+int zkt_groth16_prove_r1cs_sharded(zkt_groth16_pk* pk, const uint64_t* dev_wires, const uint64_t* r, const uint64_t* s,
+                                   zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* C);
 
 int zkt_g1_mul_batch_dev(const zkt_g1_affine* dev_points, const uint64_t* dev_scalars, int scalar_limbs,
                          zkt_g1_affine* dev_out, size_t n, void* stream);

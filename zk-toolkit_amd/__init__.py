@@ -69,6 +69,19 @@ def lib():
         for grp in ("g1", "g2", "secp"):
             getattr(L, f"zkt_{grp}_msm_submit").argtypes = [vp, vp, sz, vp, ctypes.c_int]
             getattr(L, f"zkt_{grp}_msm_collect").argtypes = [vp, ctypes.c_int, vp, vp]
+        for f in ("fq", "fr", "sp", "sn"):
+            getattr(L, f"zkt_{f}_pow_batch").argtypes = [vp, vp, sz, ctypes.c_int, vp, sz]
+            getattr(L, f"zkt_{f}_pow_seq").argtypes = [vp, sz, vp]
+            getattr(L, f"zkt_{f}_repeat").argtypes = [vp, sz, vp]
+        # multi-GPU entry points (csrc/zkt_comm.cpp)
+        L.zkt_comm_init.argtypes = [ctypes.c_int, ctypes.c_int, vp]
+        L.zkt_comm_init_callback.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp]
+        L.zkt_comm_finalize.restype = None
+        L.zkt_comm_shard_range.argtypes = [sz, ctypes.c_int, ctypes.c_int, vp, vp]; L.zkt_comm_shard_range.restype = None
+        for grp in ("g1", "g2", "secp"):
+            getattr(L, f"zkt_{grp}_msm_sharded").argtypes = [vp, vp, sz, vp, vp]
+            getattr(L, f"zkt_{grp}_msm_sharded_collect").argtypes = [vp, ctypes.c_int, vp]
+        L.zkt_groth16_prove_r1cs_sharded.argtypes = [vp] * 7
         L.zkt_bp_ipa_ctx_create.argtypes = [sz, vp, vp, vp, vp]
         L.zkt_bp_ipa_ctx_free.argtypes = [vp]; L.zkt_bp_ipa_ctx_free.restype = None
         L.zkt_bp_inner_product_argument_ctx.argtypes = [vp] * 6

@@ -22,6 +22,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   unsigned long long* d_err = nullptr;
   uint8_t* arena = nullptr; size_t arena_bytes = 0;
+  uint32_t* d_small = nullptr;          // 4 KB of device scratch for one-point results (caller holds mu)
   std::mutex mu;
 };
 Ctx g;
@@ -31,7 +32,12 @@ thread_local const char* t_kernel_name = "";
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "[zkt] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return ZKT_ERR_DEVICE; } } while (0)
 
-int ensure_ready() { return g.ready ? ZKT_OK : ZKT_ERR_DEVICE; }
+// every entry point starts here: the library owns ONE device (zkt_init), and a thread's current HIP device is per-thread state,
+// so it is set on entry — handles, streams and workspaces are then always created and used on that device
+int ensure_ready() {
+  if (!g.ready) return ZKT_ERR_DEVICE;
+  return hipSetDevice(g.device) == hipSuccess ? ZKT_OK : ZKT_ERR_DEVICE;
+}
 
 // grow-only staging arena (caller holds g.mu)
 int arena_reserve(size_t bytes) {
@@ -142,6 +148,7 @@ struct zkt_bases_impl {               // one resident base set of any group; zkt
   static constexpr int NTAIL = 8;   // reduce chains of alternate MSMs run side by side: each is latency-bound, not throughput-bound (large MSMs use two of them)
   hipStream_t s_sort = nullptr, s_acc = nullptr, s_tail[NTAIL] = {};
   MsmSlot slot[MSM_SLOTS];
+  std::mutex mu;                 // slot state: calls on one handle are serialised (submit/collect of different slots may come from different threads)
 };
 struct zkt_g1_bases : zkt_bases_impl {};
 struct zkt_g2_bases : zkt_bases_impl {};
@@ -171,6 +178,8 @@ static int slot_ready(zkt_bases_impl* h, int k) {   // lazily create the slot's 
 }
 
 int zkt_internal_ready() { return ensure_ready(); }
+hipStream_t zkt_internal_stream() { return g.stream; }
+int zkt_internal_device() { return g.device; }
 void zkt_internal_set_error_index(size_t i) { t_err_index = i; }
 
 extern "C" {
@@ -201,6 +210,7 @@ int zkt_init(int device) {
   g.device = device;
   HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc((void**)&g.d_err, 64));
+  HIPCHK(hipMalloc((void**)&g.d_small, 4096));
   g.ready = true;
   return ZKT_OK;
 }
@@ -210,8 +220,9 @@ void zkt_shutdown(void) {
   (void)hipSetDevice(g.device);
   if (g.arena) (void)hipFree(g.arena);
   if (g.d_err) (void)hipFree(g.d_err);
+  if (g.d_small) (void)hipFree(g.d_small);
   if (g.stream) (void)hipStreamDestroy(g.stream);
-  g.ready = false; g.device = -1; g.stream = nullptr; g.d_err = nullptr; g.arena = nullptr; g.arena_bytes = 0;
+  g.ready = false; g.device = -1; g.stream = nullptr; g.d_err = nullptr; g.d_small = nullptr; g.arena = nullptr; g.arena_bytes = 0;
 }
 
 #define FP_BIN(name, field, op) int name(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) { return fp_batch(field, op, a, b, out, n); }
@@ -397,16 +408,20 @@ static int bases_upload(int grp, const void* host, size_t n, zkt_bases_impl** ou
   hipFree(tmp);
   return rc;
 }
-static int msm_submit(zkt_bases_impl* h, const uint64_t* dev_scalars, size_t n, void* stream, int slot) {
-  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
-  if (!h || n != h->n || (n && !dev_scalars) || slot < 0 || slot >= MSM_SLOTS) return ZKT_ERR_SHAPE;
+static hipStream_t slot_tail_stream(zkt_bases_impl* h, int slot) {
+  const bool small = h->n < (size_t(1) << 19);
+  return h->s_tail[small ? slot % zkt_bases_impl::NTAIL : slot % 2];
+}
+// caller holds h->mu
+static int msm_submit_locked(zkt_bases_impl* h, const uint64_t* dev_scalars, size_t n, void* stream, int slot) {
+  if (n != h->n || (n && !dev_scalars) || slot < 0 || slot >= MSM_SLOTS) return ZKT_ERR_SHAPE;
   if (h->slot[slot].busy) return ZKT_ERR_SHAPE;          // collect it first
   int rc = slot_ready(h, slot); if (rc) return rc;
   MsmSlot& S = h->slot[slot];
   // inputs are produced on the caller's stream: order the sort stage behind it
   HIPCHK(hipEventRecord(S.e_in, (hipStream_t)stream));
   const bool small = h->n < (size_t(1) << 19);
-  hipStream_t st = h->s_tail[small ? slot % zkt_bases_impl::NTAIL : slot % 2];
+  hipStream_t st = slot_tail_stream(h, slot);
   hipStream_t ss = small ? st : h->s_sort;
   HIPCHK(hipStreamWaitEvent(ss, S.e_in, 0));
   HIPCHK(launch_msm_sort(h->plan, h->inf, (const uint32_t*)dev_scalars, S.workspace, ss));
@@ -425,35 +440,54 @@ static int msm_submit(zkt_bases_impl* h, const uint64_t* dev_scalars, size_t n, 
   S.busy = true;
   return ZKT_OK;
 }
-static int msm_collect(zkt_bases_impl* h, int slot, void* out, uint32_t* dev_partial_jac) {
-  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
-  if (!h || slot < 0 || slot >= MSM_SLOTS || !h->slot[slot].busy) return ZKT_ERR_SHAPE;
+static int msm_collect_locked(zkt_bases_impl* h, int slot, void* out, uint32_t* dev_partial_jac) {
+  if (slot < 0 || slot >= MSM_SLOTS || !h->slot[slot].busy) return ZKT_ERR_SHAPE;
   MsmSlot& S = h->slot[slot];
   HIPCHK(hipEventSynchronize(S.e_done));
-  if (dev_partial_jac) HIPCHK(hipMemcpy(dev_partial_jac, S.d_result_jac, 3 * grp_coord_bytes(h->grp), hipMemcpyDeviceToDevice));
+  if (dev_partial_jac) {        // copied on the slot's own tail stream and waited for: complete when this returns, and never overtaken by a re-submit of the slot
+    hipStream_t st = slot_tail_stream(h, slot);
+    HIPCHK(hipMemcpyAsync(dev_partial_jac, S.d_result_jac, 3 * grp_coord_bytes(h->grp), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
   if (out) memcpy(out, S.h_out, grp_pt_bytes(h->grp));
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, S.e_acc0, S.e_acc1) == hipSuccess) { t_kernel_ms = ms; t_kernel_name = "k_accumulate"; }
   S.busy = false;
   return ZKT_OK;
 }
+static int msm_submit(zkt_bases_impl* h, const uint64_t* dev_scalars, size_t n, void* stream, int slot) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!h) return ZKT_ERR_SHAPE;
+  std::lock_guard<std::mutex> lk(h->mu);
+  return msm_submit_locked(h, dev_scalars, n, stream, slot);
+}
+static int msm_collect(zkt_bases_impl* h, int slot, void* out, uint32_t* dev_partial_jac) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!h) return ZKT_ERR_SHAPE;
+  std::lock_guard<std::mutex> lk(h->mu);
+  return msm_collect_locked(h, slot, out, dev_partial_jac);
+}
+// blocking form: slot 0, submit + collect under one hold of the handle's lock (two threads may share a handle)
 static int msm_dev(zkt_bases_impl* h, const uint64_t* dev_scalars, size_t n, void* stream, void* out, uint32_t* dev_partial_jac) {
-  if (!out && !dev_partial_jac) return ZKT_ERR_SHAPE;
-  int rc = msm_submit(h, dev_scalars, n, stream, 0);
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!h || (!out && !dev_partial_jac)) return ZKT_ERR_SHAPE;
+  std::lock_guard<std::mutex> lk(h->mu);
+  int rc = msm_submit_locked(h, dev_scalars, n, stream, 0);
   if (rc) return rc;
-  return msm_collect(h, 0, out, dev_partial_jac);
+  return msm_collect_locked(h, 0, out, dev_partial_jac);
+}
+// combine step of a sharded MSM: `count` Jacobian partials, `stride_words` u32 apart, summed by one wave and normalised
+int zkt_internal_jac_sum(int grp, const uint32_t* dev_partials, size_t count, size_t stride_words, hipStream_t s, void* out) {
+  if (!dev_partials || !out || count == 0) return ZKT_ERR_SHAPE;
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCHK(launch_msm_jac_sum_to_affine(grp, dev_partials, count, stride_words, g.d_small, s));
+  HIPCHK(hipMemcpyAsync(out, g.d_small, grp_pt_bytes(grp), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKT_OK;
 }
 static int jac_sum_dev(int grp, const uint32_t* dev_partials, size_t count, void* stream, void* out) {
   if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
-  if (!dev_partials || !out || count == 0) return ZKT_ERR_SHAPE;
-  hipStream_t s = (hipStream_t)stream;
-  uint32_t* d_out = nullptr;
-  HIPCHK(hipMalloc((void**)&d_out, grp_pt_bytes(grp)));
-  HIPCHK(launch_msm_jac_sum_to_affine(grp, dev_partials, count, d_out, s));
-  HIPCHK(hipMemcpyAsync(out, d_out, grp_pt_bytes(grp), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  hipFree(d_out);
-  return ZKT_OK;
+  return zkt_internal_jac_sum(grp, dev_partials, count, 3 * grp_coord_bytes(grp) / 4, (hipStream_t)stream, out);
 }
 // one-shot host-pointer MSM: upload, build the window-multiple table, run, free
 // one-shot host-pointer MSM (eval_with_g1_hidings called once, polynomial.rs:271-281): the table-free form — upload, kernel layout,
@@ -461,7 +495,7 @@ static int jac_sum_dev(int grp, const uint32_t* dev_partials, size_t count, void
 // ZKT_MSM_ONE_SHOT_TABLE=1 selects the resident-bases machinery instead (A/B and regression checks).
 static int msm_host(int grp, const void* bases, const uint64_t* scalars, size_t n, void* out) {
   if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
-  if (!out || (n && (!bases || !scalars))) return ZKT_ERR_SHAPE;
+  if (!out || (n && (!bases || !scalars)) || n >= (size_t(1) << 26)) return ZKT_ERR_SHAPE;      // entry offsets are 32-bit: nwin * n < 2^32
   if (n == 0) { memset(out, 0, grp_pt_bytes(grp)); ((uint32_t*)out)[grp_pt_bytes(grp) / 4 - 2] = 1; return ZKT_OK; }
   static const bool use_table = [] { const char* e = getenv("ZKT_MSM_ONE_SHOT_TABLE"); return e && *e == '1'; }();
   if (use_table) {
@@ -475,13 +509,13 @@ static int msm_host(int grp, const void* bases, const uint64_t* scalars, size_t 
     hipFree(d_s); bases_free(h);
     return rc;
   }
-  HIPCHK(hipSetDevice(g.device));
   const MsmPlan plan = msm_plan_direct(n, grp);
   const size_t ptb = grp_pt_bytes(grp), cb = grp_coord_bytes(grp);
   uint8_t* blob = nullptr;                                   // [abi points | scalars | kernel-layout points | inf flags | jac | abi out | workspace]
   const size_t o_abi = 0, o_sc = padded(n * ptb), o_tab = o_sc + padded(n * 32), o_inf = o_tab + padded(n * 2 * cb), o_jac = o_inf + padded(n),
                o_out = o_jac + padded(4 * cb), o_ws = o_out + padded(ptb), total = o_ws + plan.ws_bytes;
   HIPCHK(hipMalloc((void**)&blob, total));
+  std::lock_guard<std::mutex> lk(g.mu);                      // g.stream is the library's staging stream
   hipStream_t s = g.stream;
   int rc = ZKT_OK;
   auto fail = [&](hipError_t e) { if (e != hipSuccess) { fprintf(stderr, "[zkt] HIP error %s in one-shot MSM\n", hipGetErrorString(e)); rc = ZKT_ERR_DEVICE; } return e != hipSuccess; };

@@ -24,6 +24,7 @@
 // restatement of the reference prover on the dense QAP.
 #include <vector>
 #include <memory>
+#include <mutex>
 #include <cstring>
 #include <cstdio>
 #include "abi.h"
@@ -388,6 +389,7 @@ struct zkt_groth16_pk {
   DBuf wires_c, wires_m, z_m[3], f[3], sA[PSLOTS], sB[PSLOTS], sC[PSLOTS], rs[PSLOTS];
   bool pending[PSLOTS] = {false, false};
   hipStream_t s = nullptr;
+  std::recursive_mutex mu;       // calls on one key are serialised (include/zkt.h, Threading)
   ~zkt_groth16_pk() {
     if (setA) zkt_g1_bases_free(setA); if (setC) zkt_g1_bases_free(setC); if (setB) zkt_g2_bases_free(setB);
     if (s) hipStreamDestroy(s);
@@ -523,7 +525,9 @@ void zkt_groth16_pk_free(zkt_groth16_pk* pk) { delete pk; }
 // enqueue one proof: the Fr stage on the key's stream, the three MSMs on their base sets' pipelines (MSM slot = proof slot)
 static int prove_submit(zkt_groth16_pk* pk, int ps, const uint64_t* wires, bool wires_on_device, const uint64_t* r, const uint64_t* s_) {
   if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
-  if (!pk || !wires || !r || !s_ || ps < 0 || ps >= zkt_groth16_pk::PSLOTS || pk->pending[ps]) return ZKT_ERR_SHAPE;
+  if (!pk) return ZKT_ERR_SHAPE;
+  std::lock_guard<std::recursive_mutex> lk(pk->mu);
+  if (!wires || !r || !s_ || ps < 0 || ps >= zkt_groth16_pk::PSLOTS || pk->pending[ps]) return ZKT_ERR_SHAPE;
   const size_t n = pk->n, l = pk->l, m = pk->m, rows = m + 1, N = pk->N, nw = m - l;
   hipStream_t s = pk->s;
   DBuf &sA = pk->sA[ps], &sB = pk->sB[ps], &sC = pk->sC[ps], &drs = pk->rs[ps];
@@ -554,7 +558,9 @@ static int prove_submit(zkt_groth16_pk* pk, int ps, const uint64_t* wires, bool 
   return ZKT_OK;
 }
 static int prove_collect(zkt_groth16_pk* pk, int ps, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp, uint32_t* dev_partials) {
-  if (!pk || ps < 0 || ps >= zkt_groth16_pk::PSLOTS || !pk->pending[ps]) return ZKT_ERR_SHAPE;
+  if (!pk) return ZKT_ERR_SHAPE;
+  std::lock_guard<std::recursive_mutex> lk(pk->mu);
+  if (ps < 0 || ps >= zkt_groth16_pk::PSLOTS || !pk->pending[ps]) return ZKT_ERR_SHAPE;
   if (dev_partials ? false : (!A || !B || !Cp || pk->nshards != 1)) return ZKT_ERR_SHAPE;      // a shard can only produce partials
   pk->pending[ps] = false;
   if (dev_partials) {            // [A: ZKT_G1_PARTIAL_WORDS | B: ZKT_G2_PARTIAL_WORDS | C: ZKT_G1_PARTIAL_WORDS]
@@ -569,6 +575,7 @@ static int prove_collect(zkt_groth16_pk* pk, int ps, zkt_g1_affine* A, zkt_g2_af
 static int prove_impl(zkt_groth16_pk* pk, const uint64_t* wires, bool wires_on_device, const uint64_t* r, const uint64_t* s_, zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* Cp,
                       uint32_t* dev_partials = nullptr) {
   if (!pk) return ZKT_ERR_SHAPE;
+  std::lock_guard<std::recursive_mutex> lk(pk->mu);
   if (dev_partials ? false : (!A || !B || !Cp || pk->nshards != 1)) return ZKT_ERR_SHAPE;
   ZCHK(prove_submit(pk, 0, wires, wires_on_device, r, s_));
   return prove_collect(pk, 0, A, B, Cp, dev_partials);

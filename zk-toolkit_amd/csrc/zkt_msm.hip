@@ -621,20 +621,27 @@ hipError_t PART(launch_msm_precompute)(int grp, uint32_t* table, uint8_t* inf, s
   return hipGetLastError();
 }
 
-// combine step of a sharded MSM + affine normalisation: sum of `count` Jacobian partials (3*CW words each)
+// combine step of a sharded MSM + affine normalisation: sum of `count` Jacobian partials (3*CW words each, `stride` words apart).
+// One wave: lane t sums partials t, t+64, ..., then an LDS tree (6 levels) — 8 partials cost 3 additions of latency, not 8.
 template <class F>
-__global__ void k_jac_sum_to_affine(const uint32_t* __restrict__ parts, size_t count, uint32_t* __restrict__ out_abi) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  constexpr int CW = Coord<F>::CW;
-  Jac<F> acc = jac_inf<F>();
-  for (size_t i = 0; i < count; ++i) {
-    Jac<F> p; p.X = Coord<F>::ld(parts + i * 3 * CW); p.Y = Coord<F>::ld(parts + i * 3 * CW + CW); p.Z = Coord<F>::ld(parts + i * 3 * CW + 2 * CW);
-    acc = jac_add<F>(acc, p);
+__global__ void __launch_bounds__(64) k_jac_sum_to_affine(const uint32_t* __restrict__ parts, size_t count, size_t stride, uint32_t* __restrict__ out_abi) {
+  constexpr int CW = Coord<F>::CW, JW = 3 * CW;
+  __shared__ uint32_t lds[32 * JW];
+  const int t = threadIdx.x;
+  auto ldj = [](const uint32_t* p) { return Jac<F>{Coord<F>::ld(p), Coord<F>::ld(p + CW), Coord<F>::ld(p + 2 * CW)}; };
+  auto stj = [](uint32_t* p, const Jac<F>& a) { Coord<F>::st(p, a.X); Coord<F>::st(p + CW, a.Y); Coord<F>::st(p + 2 * CW, a.Z); };
+  Jac<F> v = jac_inf<F>();
+  for (size_t i = t; i < count; i += 64) v = jac_add<F>(v, ldj(parts + i * stride));
+  for (int d = 32; d >= 1; d >>= 1) {
+    if (t >= d && t < 2 * d) stj(lds + (t - d) * JW, v);
+    __syncthreads();
+    if (t < d && (size_t)(t + d) < count) v = jac_add<F>(v, ldj(lds + t * JW));
+    __syncthreads();
   }
-  PtIO<F>::st(out_abi, jac_to_aff(acc));
+  if (t == 0) PtIO<F>::st(out_abi, jac_to_aff(v));
 }
-hipError_t PART(launch_msm_jac_sum_to_affine)(int grp, const uint32_t* parts, size_t count, uint32_t* out_abi, hipStream_t s) {
-  MSM_DISPATCH(grp, hipLaunchKernelGGL(k_jac_sum_to_affine<F>, dim3(1), dim3(64), 0, s, parts, count, out_abi));
+hipError_t PART(launch_msm_jac_sum_to_affine)(int grp, const uint32_t* parts, size_t count, size_t stride, uint32_t* out_abi, hipStream_t s) {
+  MSM_DISPATCH(grp, hipLaunchKernelGGL(k_jac_sum_to_affine<F>, dim3(1), dim3(64), 0, s, parts, count, stride, out_abi));
   return hipGetLastError();
 }
 
@@ -647,7 +654,7 @@ hipError_t PART(launch_msm_jac_sum_to_affine)(int grp, const uint32_t* parts, si
   hipError_t launch_msm_sort##SUF(const MsmPlan&, const uint8_t*, const uint32_t*, void*, hipStream_t); \
   hipError_t launch_msm_accumulate##SUF(const MsmPlan&, const uint32_t*, void*, hipStream_t); \
   hipError_t launch_msm_reduce##SUF(const MsmPlan&, void*, uint32_t*, uint32_t*, hipStream_t); \
-  hipError_t launch_msm_jac_sum_to_affine##SUF(int, const uint32_t*, size_t, uint32_t*, hipStream_t);
+  hipError_t launch_msm_jac_sum_to_affine##SUF(int, const uint32_t*, size_t, size_t, uint32_t*, hipStream_t);
 ZKT_MSM_FWD(_other) ZKT_MSM_FWD(_secp)
 #define ZKT_MSM_BY_GROUP(grp, NAME, ...) ((grp) == G_G1 ? NAME##_g1(__VA_ARGS__) : (grp) == G_SECP ? NAME##_secp(__VA_ARGS__) : NAME##_other(__VA_ARGS__))
 hipError_t launch_msm_to_kernel_layout(int grp, const uint32_t* a, uint32_t* t, uint8_t* i, size_t n, hipStream_t s) { return ZKT_MSM_BY_GROUP(grp, launch_msm_to_kernel_layout, grp, a, t, i, n, s); }
@@ -655,7 +662,7 @@ hipError_t launch_msm_precompute(int grp, uint32_t* t, uint8_t* i, size_t n, int
 hipError_t launch_msm_sort(const MsmPlan& P, const uint8_t* i, const uint32_t* k, void* w, hipStream_t s) { return ZKT_MSM_BY_GROUP(P.grp, launch_msm_sort, P, i, k, w, s); }
 hipError_t launch_msm_accumulate(const MsmPlan& P, const uint32_t* t, void* w, hipStream_t s) { return ZKT_MSM_BY_GROUP(P.grp, launch_msm_accumulate, P, t, w, s); }
 hipError_t launch_msm_reduce(const MsmPlan& P, void* w, uint32_t* j, uint32_t* o, hipStream_t s) { return ZKT_MSM_BY_GROUP(P.grp, launch_msm_reduce, P, w, j, o, s); }
-hipError_t launch_msm_jac_sum_to_affine(int grp, const uint32_t* p, size_t c, uint32_t* o, hipStream_t s) { return ZKT_MSM_BY_GROUP(grp, launch_msm_jac_sum_to_affine, grp, p, c, o, s); }
+hipError_t launch_msm_jac_sum_to_affine(int grp, const uint32_t* p, size_t c, size_t st, uint32_t* o, hipStream_t s) { return ZKT_MSM_BY_GROUP(grp, launch_msm_jac_sum_to_affine, grp, p, c, st, o, s); }
 #endif
 
 }  // namespace zkt

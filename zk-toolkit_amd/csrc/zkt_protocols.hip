@@ -5,6 +5,7 @@
 // Fr / secp-n scalar algebra runs in small kernels here; every group operation goes through the batched
 // kernels of zkt_group.hip / zkt_msm.hip / zkt_pairing.hip.  Host code only moves buffers and sequences launches.
 #include <vector>
+#include <mutex>
 #include <cstring>
 #include <cstdio>
 #include <memory>
@@ -42,7 +43,7 @@ __global__ void k_groth16_setup_scalars(const uint32_t* __restrict__ ue, const u
   Fp<C> alpha = ld_fp<C>(trap), beta = ld_fp<C>(trap + 8), gamma = ld_fp<C>(trap + 16), delta = ld_fp<C>(trap + 24), x = ld_fp<C>(trap + 32);
   Fp<C> ginv = fp_inv(gamma), dinv = fp_inv(delta);
   for (size_t i = 0; i <= m; ++i) {
-    Fp<C> s = fp_add(fp_add(fp_mul(beta, ld_raw<C>(ue + i * 8)), fp_mul(alpha, ld_raw<C>(ve + i * 8))), ld_raw<C>(we + i * 8));
+    Fp<C> s = fp_add(fp_add(fp_mul(beta, ld_raw<C>(ue + i * 8)), fp_mul(alpha, ld_raw<C>(ve + i * 8))), fp_canon32(ld_raw<C>(we + i * 8)));   // products reduce any 256-bit operand; the bare addend is reduced explicitly
     st_fp<C>(y + i * 8, fp_mul(s, i <= l ? ginv : dinv));
   }
   Fp<C> t = fp_one<C>(), one = fp_one<C>(), ii = fp_zero<C>();
@@ -344,6 +345,7 @@ struct zkt_bp_ipa_ctx {
   size_t N, NB, levels, lv1;
   Dev dbase, da, db, da2, db2, dwG, dwH, dsc, dPp, dx, dch, dsq, dc, dlr, dm, dt, dcomb;
   zkt_secp_bases* set = nullptr;
+  std::mutex mu;                           // a context serves one call at a time: concurrent callers queue here
   std::vector<hipStream_t> side;           // one stream per product batch, so the batches overlap each other and the MSMs
   hipEvent_t ev = nullptr;
   static size_t log2z(size_t n) { size_t l = 0; for (size_t t = n; t > 1; t >>= 1) ++l; return l; }
@@ -382,6 +384,7 @@ void zkt_bp_ipa_ctx_free(zkt_bp_ipa_ctx* c) { delete c; }
 static int ipa_run(zkt_bp_ipa_ctx* c, const zkt_secp_affine* P, const uint64_t* a, const uint64_t* b, const uint64_t* xs, zkt_secp_affine* out_trace, const uint32_t* wH0) {
   if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
   if (!c || !P || !a || !b || (c->N > 1 && !xs)) return -ZKT_ERR_SHAPE;
+  std::lock_guard<std::mutex> lk(c->mu);
   hipStream_t s = nullptr;
   constexpr int PW = zkt_bp_ipa_ctx::PW, IPA_SLOTS = zkt_bp_ipa_ctx::IPA_SLOTS;
   constexpr size_t IPA_BATCH = zkt_bp_ipa_ctx::IPA_BATCH;
