@@ -135,6 +135,21 @@ int zkt_g1_neg_batch(const zkt_g1_affine* a, zkt_g1_affine* out, size_t n);
 int zkt_g2_add_batch(const zkt_g2_affine* a, const zkt_g2_affine* b, zkt_g2_affine* out, size_t n);
 int zkt_g2_neg_batch(const zkt_g2_affine* a, zkt_g2_affine* out, size_t n);
 int zkt_secp_add_batch(const zkt_secp_affine* a, const zkt_secp_affine* b, zkt_secp_affine* out, size_t n);
+/* a16: generators G1Point::g() g1_point.rs:38-59, G2Point::g() g2_point.rs:36-58, secp256k1 AffinePoint::g() affine_point.rs:40-60 (host constants) */
+void zkt_g1_generator(zkt_g1_affine* out);
+void zkt_g2_generator(zkt_g2_affine* out);
+void zkt_secp_generator(zkt_secp_affine* out);
+/* a16: RationalPoint::is_rational_point g1_point.rs:97-113, g2_point.rs:70-82, secp256k1/affine_point.rs:92-104 — out[i] = 1 iff point i is
+ * rational and satisfies y^2 = x^3 + b (false at infinity).  The constructors G1Point::new / G2Point::new do not check this, and neither do
+ * the entry points of this header: group law and pairing follow the reference's formulas on whatever coordinates they are given. */
+int zkt_g1_is_on_curve_batch(const zkt_g1_affine* points, uint32_t* out, size_t n);
+int zkt_g2_is_on_curve_batch(const zkt_g2_affine* points, uint32_t* out, size_t n);
+int zkt_secp_is_on_curve_batch(const zkt_secp_affine* points, uint32_t* out, size_t n);
+/* out[i] = 1 iff order * P_i == infinity (order = r for G1/G2, n for secp256k1): membership of the prime-order subgroup every point the
+ * reference builds lies in (g * k; get_random_point g1_point.rs:83-88).  No reference counterpart; see the pairing entry points below for why it matters. */
+int zkt_g1_in_subgroup_batch(const zkt_g1_affine* points, uint32_t* out, size_t n);
+int zkt_g2_in_subgroup_batch(const zkt_g2_affine* points, uint32_t* out, size_t n);
+int zkt_secp_in_subgroup_batch(const zkt_secp_affine* points, uint32_t* out, size_t n);
 /* a8: impl_scalar_mul_point! macros.rs:1-32 — out[i] = scalars[i] * points[i] */
 int zkt_g1_mul_batch(const zkt_g1_affine* points, const uint64_t* scalars, int scalar_limbs, zkt_g1_affine* out, size_t n);
 int zkt_g2_mul_batch(const zkt_g2_affine* points, const uint64_t* scalars, int scalar_limbs, zkt_g2_affine* out, size_t n);
@@ -149,7 +164,10 @@ int zkt_g1_msm(const zkt_g1_affine* bases, const uint64_t* scalars, size_t n, zk
 int zkt_g2_msm(const zkt_g2_affine* bases, const uint64_t* scalars, size_t n, zkt_g2_affine* out);
 int zkt_secp_msm(const zkt_secp_affine* bases, const uint64_t* scalars, size_t n, zkt_secp_affine* out);
 
-/* a10–a13: Pairing::tate pairing.rs:86-100 — out[i] = Fq12 of tate(g1[i], g2[i]) */
+/* a10–a13: Pairing::tate pairing.rs:86-100 — out[i] = Fq12 of tate(g1[i], g2[i]).
+ * Domain: bit-identical to the reference for every affine P, Q.  For P of order r (every point the reference constructs) the fast loop is used;
+ * r P != infinity is detected for free at the end of that loop and such elements are recomputed on the reference's own chain, including its
+ * panics: ZKT_ERR_INFINITY (+ index) when an argument or a multiple of P met by that chain is the point at infinity (rational_function.rs:36,59). */
 int zkt_tate_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out_fq12, size_t n);
 /* a12, a14: raw Miller values and the Weil pairing, bit-exact (the reference uses them in its tests only):
  * Pairing::calc_g1_g2 pairing.rs:54, calc_g2_g1 pairing.rs:55, weil = calc_g1_g2(P,Q) * calc_g2_g1(Q,P)^-1 pairing.rs:75-84 */
@@ -192,7 +210,10 @@ int zkt_groth16_verify(const zkt_groth16_crs* crs, const zkt_g1_affine* A, const
  * pinocchio/verifier.rs:43-84).  For each of n elements: prod_{j<k} tate(+-g1[i*k+j], g2[i*k+j]) == 1, k <= 4; negate[j] != 0
  * negates slot j's G1 point (e(-P,Q) = e(P,Q)^-1), so e(P1,Q1) == e(P2,Q2) e(P3,Q3) is k = 3, negate = {0,1,1}.  The k Miller
  * loops share one squaring chain and one final exponentiation (the decision is a bool, so this is parity-safe).  ok[i] = 1/0;
- * ZKT_ERR_INFINITY (+index) if an argument is the point at infinity (the reference's tate() panics). */
+ * ZKT_ERR_INFINITY (+index) if an argument is the point at infinity (the reference's tate() panics).
+ * Precondition shared by every verification entry point (this one, zkt_groth16_verify*, zkt_bls_verify_batch, zkt_pinocchio_verify): the
+ * rewriting of lhs == rhs as a product == 1 uses e(-P,Q) = e(P,Q)^-1, which holds for P of order r.  A G1 argument with r P != infinity is
+ * detected and the element FAILS (ok = 0) instead of being evaluated as the reference would ("Deviations"). */
 int zkt_pairing_product_check_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, const uint8_t* negate, size_t k, size_t n, uint32_t* ok);
 /* f-4: BLS signatures, Signer signature.rs:8-40.  Messages are n byte strings, concatenated, offsets[n+1].
  * G2Point::hash_to_g2point g2_point.rs:84-88 (the bytes as a big-endian integer, reduced mod r, times the G2 generator);

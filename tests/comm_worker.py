@@ -27,7 +27,8 @@ def main():
             mine = torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).clone()
             parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
             dist.all_gather(parts, mine)
-            ctypes.memmove(recv, torch.cat(parts).numpy().ctypes.data, nbytes * world)
+            buf = torch.cat(parts).numpy()                       # keep the temporary alive across the copy
+            ctypes.memmove(recv, buf.ctypes.data, nbytes * world)
             return 0
         except Exception as e:       # never let an exception cross the C boundary
             print("allgather callback failed:", repr(e), flush=True)

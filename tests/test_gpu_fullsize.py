@@ -91,8 +91,11 @@ def test_config3_tate_2p16(L):
     a = rand_scalars(5, half); b = rand_scalars(6, half)
     kp, kq = np.concatenate([a, b]), np.concatenate([b, a])                      # element i: (a_i G1, b_i G2); element i + n/2: (b_i G1, a_i G2)
     d_p = torch.empty((n, G1W), dtype=torch.int64, device="cuda"); d_q = torch.empty((n, G2W), dtype=torch.int64, device="cuda")
-    zk.check(L.zkt_g1_mul_batch_dev(vp(torch.from_numpy(_gen_rows(_g1_gen(), n).view(np.int64)).cuda()), vp(torch.from_numpy(kp.view(np.int64)).cuda()), 4, vp(d_p), n, None))
-    zk.check(L.zkt_g2_mul_batch_dev(vp(torch.from_numpy(_gen_rows(_g2_gen(), n).view(np.int64)).cuda()), vp(torch.from_numpy(kq.view(np.int64)).cuda()), 4, vp(d_q), n, None))
+    d_g1, d_kp = torch.from_numpy(_gen_rows(_g1_gen(), n).view(np.int64)).cuda(), torch.from_numpy(kp.view(np.int64)).cuda()
+    d_g2, d_kq = torch.from_numpy(_gen_rows(_g2_gen(), n).view(np.int64)).cuda(), torch.from_numpy(kq.view(np.int64)).cuda()
+    zk.check(L.zkt_g1_mul_batch_dev(vp(d_g1), vp(d_kp), 4, vp(d_p), n, None))
+    zk.check(L.zkt_g2_mul_batch_dev(vp(d_g2), vp(d_kq), 4, vp(d_q), n, None))
+    torch.cuda.synchronize()
     d_e = torch.empty((n, FQ12), dtype=torch.int64, device="cuda")
     zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), n, None))
     torch.cuda.synchronize()

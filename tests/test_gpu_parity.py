@@ -393,3 +393,62 @@ def test_fq_lazy_limb_programs_on_device(L):
     got = arr_to_ints(o)
     for i in range(0, count, 1):
         assert got[4 * i:4 * i + 4] == _fq_program_model(seed0 + i, steps, regs[i]), i
+
+
+def test_pairing_g1_argument_outside_the_subgroup(L):
+    """Degenerate pairing inputs (round-1 review, weak #8): P on the curve but outside G1.  The reference either panics — a multiple of P met
+    by its binary chain is infinity (rational_function.rs:36) — or returns a value that depends on P's order; the engine must do the same,
+    element by element, inside an otherwise honest batch."""
+    rng = SplitMix64(4711)
+    g1 = np.zeros((1, G1W), np.uint64); O.zkto_g1_generator(ptr(g1))
+    g2 = np.zeros((1, G2W), np.uint64); O.zkto_g2_generator(ptr(g2))
+    n = 70
+    P = np.zeros((n, G1W), np.uint64); Qs = np.zeros((n, G2W), np.uint64)
+    zk.check(L.zkt_g1_mul_batch(ptr(np.repeat(g1, n, axis=0)), ptr(ints_to_arr([rng.below(R - 1) + 1 for _ in range(n)], 4)), 4, ptr(P), n))
+    zk.check(L.zkt_g2_mul_batch(ptr(np.repeat(g2, n, axis=0)), ptr(ints_to_arr([rng.below(R - 1) + 1 for _ in range(n)], 4)), 4, ptr(Qs), n))
+    deg = degenerate_g1_points()
+    value_cases = [pt for _, pt in deg if O.zkto_pairing_batch(3, ptr(g1_arr([pt])), ptr(Qs[:1].copy()), ptr(np.zeros((1, FQ12), np.uint64)), 1, 1, None) == 0]
+    panic_cases = [pt for _, pt in deg if pt not in value_cases]
+    assert value_cases and panic_cases
+    # (1) points outside G1 on which the reference returns a value: the whole batch matches the oracle
+    for k, pt in enumerate(value_cases): P[3 + 29 * k] = g1_arr([pt])[0]
+    got, want = np.zeros((n, FQ12), np.uint64), np.zeros((n, FQ12), np.uint64)
+    zk.check(L.zkt_tate_batch(ptr(P), ptr(Qs), ptr(got), n))
+    assert O.zkto_pairing_batch(3, ptr(P), ptr(Qs), ptr(want), n, 16, None) == 0
+    assert (got == want).all()
+    graw, wraw = np.zeros((n, FQ12), np.uint64), np.zeros((n, FQ12), np.uint64)
+    zk.check(L.zkt_miller_g1g2_batch(ptr(P), ptr(Qs), ptr(graw), n))
+    assert O.zkto_pairing_batch(0, ptr(P), ptr(Qs), ptr(wraw), n, 16, None) == 0
+    assert (graw == wraw).all()
+    # on-curve / subgroup predicates tell these points apart
+    oc, sg = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    zk.check(L.zkt_g1_is_on_curve_batch(ptr(P), oc.ctypes.data, n)); zk.check(L.zkt_g1_in_subgroup_batch(ptr(P), sg.ctypes.data, n))
+    assert oc.all() and sg.sum() == n - len(value_cases) and all(sg[3 + 29 * k] == 0 for k in range(len(value_cases)))
+    # the verification kernels fail closed on them: e(P,Q) e(-P,Q) == 1 is only reported for P of order r
+    ok = np.zeros(n, np.uint32)
+    zk.check(L.zkt_pairing_product_check_batch(ptr(np.repeat(P, 2, axis=0)), ptr(np.repeat(Qs, 2, axis=0)), (ctypes.c_uint8 * 2)(0, 1), 2, n, ok.ctypes.data))
+    assert [int(v) for v in ok] == [int(v) for v in sg]
+    # (2) points on which the reference panics: ZKT_ERR_INFINITY with the index of the first such element
+    for k, pt in enumerate(panic_cases): P[40 + 7 * k] = g1_arr([pt])[0]
+    assert L.zkt_tate_batch(ptr(P), ptr(Qs), ptr(got), n) == ZKT_ERR_INFINITY and L.zkt_last_error_index() == 40
+    idx = ctypes.c_size_t(0)
+    assert O.zkto_pairing_batch(3, ptr(P), ptr(Qs), ptr(want), n, 1, ctypes.byref(idx)) == ZKT_ERR_INFINITY and idx.value == 40
+    assert L.zkt_miller_g1g2_batch(ptr(P), ptr(Qs), ptr(graw), n) == ZKT_ERR_INFINITY and L.zkt_last_error_index() == 40
+
+
+def test_generators_and_curve_predicates(L):
+    """a16: generators (g1_point.rs:38-59, g2_point.rs:36-58, secp256k1/affine_point.rs:40-60) and is_rational_point (g1_point.rs:97-113)"""
+    for name, W, gen in (("g1", G1W, O.zkto_g1_generator), ("g2", G2W, O.zkto_g2_generator), ("secp", 9, O.zkto_secp_generator)):
+        got, want = np.zeros((1, W), np.uint64), np.zeros((1, W), np.uint64)
+        getattr(L, f"zkt_{name}_generator")(ptr(got)); gen(ptr(want))
+        assert (got == want).all(), name
+        pts = np.repeat(got, 6, axis=0)
+        ks = ints_to_arr([1, 2, 12345, R - 1, SECP_N - 1, 7], 4)
+        zk.check(getattr(L, f"zkt_{name}_mul_batch")(ptr(np.repeat(got, 6, axis=0)), ptr(ks), 4, ptr(pts), 6))
+        pts[4, 0] ^= np.uint64(1)                                   # x tampered: off the curve
+        pts[5] = 0; pts[5, W - 1] = 1                               # infinity: not a rational point; trivially in the subgroup
+        oc, sg = np.zeros(6, np.uint32), np.zeros(6, np.uint32)
+        zk.check(getattr(L, f"zkt_{name}_is_on_curve_batch")(ptr(pts), oc.ctypes.data, 6))
+        zk.check(getattr(L, f"zkt_{name}_in_subgroup_batch")(ptr(pts), sg.ctypes.data, 6))
+        assert oc.tolist() == [1, 1, 1, 1, 0, 0], name
+        assert sg.tolist()[:4] == [1, 1, 1, 1] and sg[5] == 1, name

@@ -194,6 +194,25 @@ def test_tate_vs_oracle(H):
     assert H.zkt_hostcheck_tate(p32(g1_arr([None])), p32(qs[0:1]), p32(np.zeros((1, 72), dtype=np.uint64))) == 2
 
 
+def test_pairing_with_g1_argument_outside_the_subgroup(H):
+    """weak #8 of the round-1 review: for P outside G1 the reference's chain may meet infinity and panic (rational_function.rs:36), or
+    return a value that depends on P's order.  The engine detects r P != infinity at the end of its fast loop and re-runs such elements
+    on the reference's own chain: same value, or the same panic, as the oracle (which restates the panics as errors)."""
+    q = g2_mul(g2_gen(), 777)
+    for label, pt in degenerate_g1_points():
+        p = g1_arr([pt])
+        rc, want, _ = pair(3, p, q, threads=1)
+        got = np.zeros((1, 72), dtype=np.uint64)
+        hrc = H.zkt_hostcheck_tate(p32(p), p32(q), p32(got))
+        if rc != 0:
+            assert hrc == 2, (label, "the oracle reports the reference's panic, the engine returned", hrc)
+        else:
+            assert hrc == 100 and (got[0] == want[0]).all(), label           # 100: produced by the exact path
+        rc, want, _ = pair(0, p, q, threads=1)                               # raw Miller value, same rule
+        hrc = H.zkt_hostcheck_miller_exact(0, p32(p), p32(q), p32(got))
+        assert (hrc == 2) if rc != 0 else (hrc == 0 and (got[0] == want[0]).all()), label
+
+
 def test_exact_miller_and_weil_vs_oracle(H):         # pairing.rs:54-55,75-84 raw values
     rng = SplitMix64(81)
     p = g1_mul(g1_gen(), rng.below(R)); q = g2_mul(g2_gen(), rng.below(R))

@@ -179,3 +179,30 @@ G2_GEN = ((0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334
            0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8),
           (0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE,
            0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801))
+
+
+# ----------------------------------------- points outside the order-r subgroup ----
+G1_COFACTOR = 0x396C8C005555E1568C00AAAB0000AAAB      # #E(Fq) = h * r, h = (z-1)^2 / 3
+
+
+def py_g1_curve_point(seed):
+    """a deterministic point of E(Fq): y^2 = x^3 + 4, generic order (both an r-component and a cofactor component)"""
+    x = seed
+    while True:
+        rhs = (x * x * x + 4) % Q
+        y = pow(rhs, (Q + 1) // 4, Q)                 # q = 3 mod 4
+        if y * y % Q == rhs:
+            return (x, y)
+        x += 1
+
+
+def degenerate_g1_points():
+    """[(label, point)]: inputs on which the reference's Miller loop either panics or runs outside its intended domain"""
+    gen = py_g1_curve_point(5)
+    cof = py_g1_mul(gen, R)                           # r-component removed: order divides h
+    assert cof is not None and py_g1_mul(cof, G1_COFACTOR) is None
+    small = py_g1_mul(cof, G1_COFACTOR // (11 * 11))  # order divides 121
+    assert small is not None and py_g1_mul(small, 121) is None
+    mixed = py_g1_add(py_g1_mul(G1_GEN, 12345), cof)  # r-component and cofactor component
+    return [("generic curve point", gen), ("cofactor subgroup, large order", cof), ("order | 121", small), ("order 3: (0, 2)", (0, 2)),
+            ("G1 point + cofactor point", mixed)]

@@ -83,17 +83,26 @@ int zkt_hostcheck_group(int grp, int op, const uint32_t* a, const uint32_t* b, i
 int zkt_hostcheck_miller_exact(int which, const uint32_t* g1, const uint32_t* g2, uint32_t* o) {
   Aff<FqOps> p = PtIO<FqOps>::ld(g1); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2);
   if (p.inf || q.inf) return 2;
-  Fq12 r;
-  if (which == 0) r = miller_g1_g2_exact(p.x, p.y, q.x, q.y);
+  Fq12 r; bool bad = false;
+  if (which == 0) r = miller_g1_g2_exact(p.x, p.y, q.x, q.y, bad);
   else if (which == 1) r = miller_g2_g1_exact(q.x, q.y, p.x, p.y);
-  else r = fq12_mul(miller_g1_g2_exact(p.x, p.y, q.x, q.y), fq12_inv(miller_g2_g1_exact(q.x, q.y, p.x, p.y)));
+  else r = fq12_mul(miller_g1_g2_exact(p.x, p.y, q.x, q.y, bad), fq12_inv(miller_g2_g1_exact(q.x, q.y, p.x, p.y)));
+  if (bad) return 2;
   st_fq12(o, r);
   return 0;
 }
 int zkt_hostcheck_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* o) {
   Aff<FqOps> p = PtIO<FqOps>::ld(g1); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2);
   if (p.inf || q.inf) return 2;
-  st_fq12(o, final_exponentiation(miller_g1_g2(p.x, p.y, q.x, q.y)));
-  return 0;
+  // the two passes of launch_tate (zkt_tate.hip): fast loop for P of order r, the reference's own chain otherwise
+  bool in_g1, bad;
+  Fq12 f = miller_g1_g2(p.x, p.y, q.x, q.y, in_g1);
+  if (!in_g1) {
+    f = miller_g1_g2_exact(p.x, p.y, q.x, q.y, bad);
+    if (bad) return 2;
+    if (fq12_is_zero(f)) { for (int k = 0; k < 144; ++k) o[k] = 0; return 0; }
+  }
+  st_fq12(o, final_exponentiation(f));
+  return in_g1 ? 0 : 100;                 // 100: value produced by the exact path
 }
 }

@@ -59,8 +59,20 @@ ZKT_FN void miller_add_step(MillerPt& V, const Fq& xp, const Fq& yp, const Fq2& 
   V.X = X3; V.Y = Y3; V.Z = Z3;
 }
 
+// V == -P for a Jacobian V and an affine P?  After the signed-digit chain V = (r-1) P, so this is r P == infinity: P lies in the
+// order-r subgroup G1 — four multiplications, once per pairing.
+ZKT_FN bool miller_pt_is_neg(const MillerPt& V, const Fq& xp, const Fq& yp) {
+  if (fp_is_zero(V.Z)) return false;
+  const Fq ZZ = fp_sqr(V.Z);
+  return fp_eq(fp_mul(xp, ZZ), V.X) && fp_eq(fp_mul(fp_mul(yp, ZZ), V.Z), fp_neg(V.Y));
+}
+
 // f_{r-1,P}(untwist(Q)) up to Fq6 factors.  P, Q affine, Montgomery domain, neither at infinity.
-ZKT_FN Fq12 miller_g1_g2(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq) {
+// in_g1 <- r P == infinity.  For such P no multiple met on the way is infinity and the value equals the reference's for EVERY Q
+// (the untwisted X of any Fq2 abscissa lies in Fq6, so the dropped vertical lines die in the final exponentiation).  For P outside
+// G1 the reference's behaviour depends on the order of P (it panics when a binary prefix multiple of P is infinity,
+// rational_function.rs:36); the callers then take the exact path (miller_g1_g2_exact) or fail closed.
+ZKT_FN Fq12 miller_g1_g2(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq, bool& in_g1) {
   const Fq2 xi_inv = xi_inv_const();
   const Fq2 Xq = fq2_mul(xq, xi_inv), Yq = fq2_mul(yq, xi_inv);
   MillerPt V{xp, yp, fp_one<FqC>()};
@@ -83,13 +95,14 @@ ZKT_FN Fq12 miller_g1_g2(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& y
       f = ft;
     }
   }
+  in_g1 = miller_pt_is_neg(V, xp, yp);
   return f;
 }
 
 // prod_k f_{r-1,P_k}(untwist(Q_k)) for K pairs sharing ONE squaring chain (row f-2: the Groth16 verifier's three pairings,
 // verifier.rs:30-54, as a single multi-Miller loop + a single final exponentiation).
 template <int K>
-ZKT_FN Fq12 miller_g1_g2_multi(const Fq* xp, const Fq* yp, const Fq2* xq, const Fq2* yq) {
+ZKT_FN Fq12 miller_g1_g2_multi(const Fq* xp, const Fq* yp, const Fq2* xq, const Fq2* yq, bool& all_in_g1) {
   const Fq2 xi_inv = xi_inv_const();
   Fq2 Xq[K], Yq[K]; MillerPt V[K];
   for (int k = 0; k < K; ++k) { Xq[k] = fq2_mul(xq[k], xi_inv); Yq[k] = fq2_mul(yq[k], xi_inv); V[k] = MillerPt{xp[k], yp[k], fp_one<FqC>()}; }
@@ -114,6 +127,8 @@ ZKT_FN Fq12 miller_g1_g2_multi(const Fq* xp, const Fq* yp, const Fq2* xq, const 
       }
     }
   }
+  all_in_g1 = true;
+  for (int k = 0; k < K; ++k) all_in_g1 = all_in_g1 && miller_pt_is_neg(V[k], xp[k], yp[k]);
   return f;
 }
 
@@ -195,30 +210,42 @@ ZKT_HD bool miller_bit(int i) {
   return (w >> (i & 31)) & 1;
 }
 
-// calc_g1_g2(P, Q): Miller loop on P in G1 (Fq Jacobian), evaluated at the untwisted Q
-ZKT_FN Fq12 miller_g1_g2_exact(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq) {
+// calc_g1_g2(P, Q): Miller loop on P in G1 (Fq Jacobian), evaluated at the untwisted Q, for ANY affine P (pairing.rs:20-55).
+// `bad` <- the reference would have panicked: a multiple of P met by the binary chain is infinity ("Both points need to be rational",
+// rational_function.rs:36), or a denominator vanished (inverse of zero).  V == P inside an addition step is the reference's tangent case
+// (rational_function.rs:25-27); neither happens for P of order r.
+ZKT_FN Fq12 miller_g1_g2_exact(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq, bool& bad) {
   const Fq2 xi_inv = xi_inv_const();
   const Fq2 Xq = fq2_mul(xq, xi_inv), Yq = fq2_mul(yq, xi_inv);
   Fq X = xp, Y = yp, Z = fp_one<FqC>();
   Fq12 N = fq12_one(), D = fq12_one();
   Fq ns = fp_one<FqC>(), ds = fp_one<FqC>();
-  for (int i = 0; i < MILLER_NBITS; ++i) {
-    {
-      Fq A = fp_sqr(X), B = fp_sqr(Y), C = fp_sqr(B), ZZ = fp_sqr(Z);
-      Fq Dd = fp_dbl(fp_sub(fp_sub(fp_sqr(fp_add(X, B)), A), C));
-      Fq E = fp_add(fp_dbl(A), A);
-      Fq X3 = fp_sub(fp_sqr(E), fp_dbl(Dd));
-      Fq Y3 = fp_sub(fp_mul(E, fp_sub(Dd, X3)), fp_dbl(fp_dbl(fp_dbl(C))));
-      Fq Z3 = fp_dbl(fp_mul(Y, Z));
-      Fq s = fp_mul(Z3, ZZ), Z3Z3 = fp_sqr(Z3);
-      Fq12 lp = fq12_sparse(fq2_from_fq(fp_sub(fp_mul(E, X), fp_dbl(B))), fq2_mul_fq(Xq, fp_neg(fp_mul(E, ZZ))), fq2_mul_fq(Yq, s), fq2_zero());
-      Fq12 vp = fq12_sparse(fq2_from_fq(fp_neg(X3)), fq2_mul_fq(Xq, Z3Z3), fq2_zero(), fq2_zero());
-      N = fq12_mul(fq12_sqr(N), lp); D = fq12_mul(fq12_sqr(D), vp);
-      ns = fp_mul(fp_sqr(ns), Z3Z3); ds = fp_mul(fp_sqr(ds), s);
-      X = X3; Y = Y3; Z = Z3;
-    }
+  bad = false;
+  // tangent at V and vertical at 2V, scaled; V <- 2V.  square = the doubling step proper (f <- f^2 l/v); otherwise f <- f l/v (V == P in an addition step)
+  auto dbl = [&](bool square) {
+    Fq A = fp_sqr(X), B = fp_sqr(Y), C = fp_sqr(B), ZZ = fp_sqr(Z);
+    Fq Dd = fp_dbl(fp_sub(fp_sub(fp_sqr(fp_add(X, B)), A), C));
+    Fq E = fp_add(fp_dbl(A), A);
+    Fq X3 = fp_sub(fp_sqr(E), fp_dbl(Dd));
+    Fq Y3 = fp_sub(fp_mul(E, fp_sub(Dd, X3)), fp_dbl(fp_dbl(fp_dbl(C))));
+    Fq Z3 = fp_dbl(fp_mul(Y, Z));
+    Fq s = fp_mul(Z3, ZZ), Z3Z3 = fp_sqr(Z3);
+    Fq12 lp = fq12_sparse(fq2_from_fq(fp_sub(fp_mul(E, X), fp_dbl(B))), fq2_mul_fq(Xq, fp_neg(fp_mul(E, ZZ))), fq2_mul_fq(Yq, s), fq2_zero());
+    Fq12 vp = fq12_sparse(fq2_from_fq(fp_neg(X3)), fq2_mul_fq(Xq, Z3Z3), fq2_zero(), fq2_zero());
+    if (square) { N = fq12_mul(fq12_sqr(N), lp); D = fq12_mul(fq12_sqr(D), vp); ns = fp_mul(fp_sqr(ns), Z3Z3); ds = fp_mul(fp_sqr(ds), s); }
+    else { N = fq12_mul(N, lp); D = fq12_mul(D, vp); ns = fp_mul(ns, Z3Z3); ds = fp_mul(ds, s); }
+    X = X3; Y = Y3; Z = Z3;
+    if (fp_is_zero(Z3)) bad = true;                        // 2V = infinity
+  };
+  for (int i = 0; i < MILLER_NBITS && !bad; ++i) {
+    dbl(true);
+    if (bad) break;
     if (miller_bit(i)) {
       Fq ZZ = fp_sqr(Z), H = fp_sub(fp_mul(xp, ZZ), X), Rr = fp_sub(fp_mul(fp_mul(yp, ZZ), Z), Y);
+      if (fp_is_zero(H)) {
+        if (fp_is_zero(Rr)) { dbl(false); continue; }       // V == P: tangent, V + P = 2P
+        bad = true; break;                                  // V == -P: V + P = infinity
+      }
       Fq HH = fp_sqr(H), HHH = fp_mul(H, HH), V = fp_mul(X, HH);
       Fq X3 = fp_sub(fp_sub(fp_sqr(Rr), HHH), fp_dbl(V));
       Fq Y3 = fp_sub(fp_mul(Rr, fp_sub(V, X3)), fp_mul(Y, HHH));
@@ -230,7 +257,10 @@ ZKT_FN Fq12 miller_g1_g2_exact(const Fq& xp, const Fq& yp, const Fq2& xq, const 
       X = X3; Y = Y3; Z = Z3;
     }
   }
-  return fq12_mul(fq12_scale_fq2(N, fq2_from_fq(ns)), fq12_inv(fq12_scale_fq2(D, fq2_from_fq(ds))));
+  if (bad) return fq12_one();
+  const Fq12 den = fq12_scale_fq2(D, fq2_from_fq(ds));
+  if (fq12_is_zero(den)) { bad = true; return fq12_one(); }   // a vertical line through Q: the reference's inv() of zero
+  return fq12_mul(fq12_scale_fq2(N, fq2_from_fq(ns)), fq12_inv(den));
 }
 
 // calc_g2_g1(Q, P): Miller loop on Q in G2 (Fq2 Jacobian), evaluated at the embedded P.  With x' = (x/xi) v^2 and

@@ -171,6 +171,8 @@ ZKT_FN Fq6 fq6_inv(const Fq6& a) {                                      // fq6.r
 
 // ---- Fq12 -------------------------------------------------------------------
 ZKT_HD Fq12 fq12_one() { return Fq12{fq6_one(), fq6_zero()}; }
+ZKT_HD bool fq6_is_zero(const Fq6& a) { return fq2_is_zero(a.c0) && fq2_is_zero(a.c1) && fq2_is_zero(a.c2); }
+ZKT_HD bool fq12_is_zero(const Fq12& a) { return fq6_is_zero(a.c0) && fq6_is_zero(a.c1); }
 ZKT_HD Fq12 fq12_add(const Fq12& a, const Fq12& b) { return Fq12{fq6_add(a.c0, b.c0), fq6_add(a.c1, b.c1)}; }
 ZKT_HD Fq12 fq12_sub(const Fq12& a, const Fq12& b) { return Fq12{fq6_sub(a.c0, b.c0), fq6_sub(a.c1, b.c1)}; }
 ZKT_HD Fq12 fq12_neg(const Fq12& a) { return Fq12{fq6_neg(a.c0), fq6_neg(a.c1)}; }

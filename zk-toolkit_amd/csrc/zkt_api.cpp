@@ -312,6 +312,55 @@ int zkt_g1_mul_batch(const zkt_g1_affine* p, const uint64_t* k, int l, zkt_g1_af
 int zkt_g2_mul_batch(const zkt_g2_affine* p, const uint64_t* k, int l, zkt_g2_affine* o, size_t n) { return group_mul(G_G2, p, k, l, o, n); }
 int zkt_secp_mul_batch(const zkt_secp_affine* p, const uint64_t* k, int l, zkt_secp_affine* o, size_t n) { return group_mul(G_SECP, p, k, l, o, n); }
 
+// a16: is_rational_point / order-r membership / generators
+static int group_pred(int grp, int pred, const void* pts, uint32_t* out, size_t n) {
+  static const uint32_t R_WORDS[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};      // params.rs:14
+  static const uint32_t SN_WORDS[8] = {0xd0364141u, 0xbfd25e8cu, 0xaf48a03bu, 0xbaaedce6u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu};   // secp256k1 n
+  return staged(pts, pt_bytes(grp), grp == G_SECP ? SN_WORDS : R_WORDS, 0, out, 4, n, ZKT_ERR_SHAPE,
+                [&](uint32_t* da, uint32_t*, uint32_t* dout, hipStream_t s) -> hipError_t {
+                  uint32_t* d_order = g.d_small;                           // g.mu is held by staged_raw
+                  hipError_t e = hipMemcpyAsync(d_order, grp == G_SECP ? SN_WORDS : R_WORDS, 32, hipMemcpyHostToDevice, s);
+                  if (e != hipSuccess) return e;
+                  return launch_group_pred(grp, pred, da, d_order, 8, dout, n, s);
+                });
+}
+int zkt_g1_is_on_curve_batch(const zkt_g1_affine* p, uint32_t* out, size_t n) { return group_pred(G_G1, 0, p, out, n); }
+int zkt_g2_is_on_curve_batch(const zkt_g2_affine* p, uint32_t* out, size_t n) { return group_pred(G_G2, 0, p, out, n); }
+int zkt_secp_is_on_curve_batch(const zkt_secp_affine* p, uint32_t* out, size_t n) { return group_pred(G_SECP, 0, p, out, n); }
+int zkt_g1_in_subgroup_batch(const zkt_g1_affine* p, uint32_t* out, size_t n) { return group_pred(G_G1, 1, p, out, n); }
+int zkt_g2_in_subgroup_batch(const zkt_g2_affine* p, uint32_t* out, size_t n) { return group_pred(G_G2, 1, p, out, n); }
+int zkt_secp_in_subgroup_batch(const zkt_secp_affine* p, uint32_t* out, size_t n) { return group_pred(G_SECP, 1, p, out, n); }
+static void put_limbs(uint64_t* dst, const char* hex, int limbs) {           // big-endian hex literal -> little-endian u64 limbs
+  const size_t len = strlen(hex);
+  for (int i = 0; i < limbs; ++i) {
+    uint64_t v = 0;
+    for (int d = 0; d < 16; ++d) {
+      const long pos = (long)len - 16 * (i + 1) + d;
+      if (pos < 0) continue;
+      const char c = hex[pos];
+      v = (v << 4) | (uint64_t)(c <= '9' ? c - '0' : (c | 32) - 'a' + 10);
+    }
+    dst[i] = v;
+  }
+}
+void zkt_g1_generator(zkt_g1_affine* out) {                                   // g1_point.rs:38-47
+  memset(out, 0, sizeof(*out));
+  put_limbs(out->x, "17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb", 6);
+  put_limbs(out->y, "08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1", 6);
+}
+void zkt_g2_generator(zkt_g2_affine* out) {                                   // g2_point.rs:36-46; Fq2 = {u1, u0}
+  memset(out, 0, sizeof(*out));
+  put_limbs(out->x, "13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e", 6);
+  put_limbs(out->x + 6, "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8", 6);
+  put_limbs(out->y, "0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be", 6);
+  put_limbs(out->y + 6, "0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801", 6);
+}
+void zkt_secp_generator(zkt_secp_affine* out) {                               // secp256k1/affine_point.rs:40-47
+  memset(out, 0, sizeof(*out));
+  put_limbs(out->x, "79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798", 4);
+  put_limbs(out->y, "483ada7726a3c4655da4fbfc0e1108a8fd17b448a68554199c47d08ffb10d4b8", 4);
+}
+
 int zkt_tate_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out, size_t n) {
   return staged(g1, sizeof(zkt_g1_affine), g2, sizeof(zkt_g2_affine), out, 576, n, ZKT_ERR_INFINITY,
                 [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_tate(da, db, dout, n, g.d_err, s); });

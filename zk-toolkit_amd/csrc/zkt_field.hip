@@ -147,7 +147,6 @@ __device__ inline Fq2 t_op(int op, const Fq2& x, const Fq2& y, bool& zero_inv) {
     default: if (fq2_is_zero(x)) { zero_inv = true; return x; } return fq2_inv(x);
   }
 }
-__device__ inline bool fq6_is_zero(const Fq6& a) { return fq2_is_zero(a.c0) && fq2_is_zero(a.c1) && fq2_is_zero(a.c2); }
 __device__ inline Fq6 t_op(int op, const Fq6& x, const Fq6& y, bool& zero_inv) {
   switch (op) {
     case T_ADD: return fq6_add(x, y); case T_SUB: return fq6_sub(x, y); case T_MUL: return fq6_mul(x, y);

@@ -61,6 +61,37 @@ hipError_t launch_group_mul(int grp, const uint32_t* p, const uint32_t* k, int k
   switch (grp) { case G_G1: return mul_t<FqOps>(p, fixed_base, k, kw, fixed_scalar, o, n, s); case G_G2: return mul_t<Fq2Ops>(p, fixed_base, k, kw, fixed_scalar, o, n, s); case G_SECP: return mul_t<SpOps>(p, fixed_base, k, kw, fixed_scalar, o, n, s); }
   return hipErrorInvalidValue;
 }
+// ---- predicates (row a16) ----------------------------------------------------------------------------------------------------
+//   RationalPoint::is_rational_point   g1_point.rs:97-113, g2_point.rs:70-82, secp256k1/affine_point.rs:92-104: y^2 == x^3 + b, false at infinity
+//   order-r membership                 r P == infinity — what every G1Point / G2Point the reference builds satisfies (g * k,
+//                                      get_random_point g1_point.rs:83-88) and what the verification entry points assume
+template <class F> struct CurveB;
+template <> struct CurveB<FqOps> { __device__ static Fq b() { uint32_t w[12] = {4}; return fp_from_words<FqC>(w); } };               // y^2 = x^3 + 4
+template <> struct CurveB<Fq2Ops> { __device__ static Fq2 b() { const Fq f = CurveB<FqOps>::b(); return Fq2{f, f}; } };             // y^2 = x^3 + 4(1+u)
+template <> struct CurveB<SpOps> { __device__ static SpE b() { uint32_t w[8] = {7}; return fp_from_words<SpC>(w); } };              // y^2 = x^3 + 7
+template <class F, int PRED>
+__global__ void __launch_bounds__(64) k_group_pred(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ order, int order_words, uint32_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Aff<F> p = PtIO<F>::ld(pts + i * PtIO<F>::WORDS);
+  if (PRED == 0) {
+    out[i] = !p.inf && F::eq(F::sqr(p.y), F::add(F::mul(F::sqr(p.x), p.x), CurveB<F>::b()));
+  } else {
+    uint32_t k[SCALAR_MAX_LIMBS];
+    for (int j = 0; j < order_words; ++j) k[j] = order[j];
+    out[i] = p.inf || jac_is_inf(scalar_mul_aff<F>(p, k, order_words));
+  }
+}
+hipError_t launch_group_pred(int grp, int pred, const uint32_t* pts, const uint32_t* order, int order_words, uint32_t* out, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  dim3 g(nblk(n, 64)), t(64);
+#define ZKT_PRED(F) if (pred == 0) hipLaunchKernelGGL((k_group_pred<F, 0>), g, t, 0, s, pts, order, order_words, out, n); \
+                    else hipLaunchKernelGGL((k_group_pred<F, 1>), g, t, 0, s, pts, order, order_words, out, n)
+  switch (grp) { case G_G1: ZKT_PRED(FqOps); break; case G_G2: ZKT_PRED(Fq2Ops); break; case G_SECP: ZKT_PRED(SpOps); break; default: return hipErrorInvalidValue; }
+#undef ZKT_PRED
+  return hipGetLastError();
+}
+
 // Several independent batched scalar multiplications in ONE launch.  A 255-step double-and-add costs ~4 ms of latency however few
 // points it covers, so callers that issue many small independent ones per step (every level of the inner-product argument,
 // bulletproofs.rs:36-47) pay that latency once instead of six times.

@@ -13,10 +13,11 @@ __global__ void __launch_bounds__(64) k_miller_exact(int which, const uint32_t* 
   Aff<FqOps> p = PtIO<FqOps>::ld(g1 + i * ABI_G1_WORDS);
   Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2 + i * ABI_G2_WORDS);
   if (p.inf || q.inf) { atomicMin(err, (unsigned long long)i); return; }
-  Fq12 r;
-  if (which == 0) r = miller_g1_g2_exact(p.x, p.y, q.x, q.y);
+  Fq12 r; bool bad = false;
+  if (which == 0) r = miller_g1_g2_exact(p.x, p.y, q.x, q.y, bad);
   else if (which == 1) r = miller_g2_g1_exact(q.x, q.y, p.x, p.y);
-  else r = fq12_mul(miller_g1_g2_exact(p.x, p.y, q.x, q.y), fq12_inv(miller_g2_g1_exact(q.x, q.y, p.x, p.y)));
+  else r = fq12_mul(miller_g1_g2_exact(p.x, p.y, q.x, q.y, bad), fq12_inv(miller_g2_g1_exact(q.x, q.y, p.x, p.y)));
+  if (bad) { atomicMin(err, (unsigned long long)i); return; }          // the reference's panic on a multiple of P at infinity
   st_fq12(out + i * 144, r);
 }
 hipError_t launch_miller_exact(int which, const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s) {
@@ -45,7 +46,9 @@ __global__ void __launch_bounds__(64) k_groth16_verify(const uint32_t* __restric
   if (a.inf || b.inf || c.inf || S.inf || g.inf || d.inf) { atomicMin(err, (unsigned long long)i); ok[i] = 0; return; }   // tate() with infinity panics
   Fq xp[3] = {a.x, S.x, c.x}, yp[3] = {a.y, fp_neg(S.y), fp_neg(c.y)};
   Fq2 xq[3] = {b.x, g.x, d.x}, yq[3] = {b.y, g.y, d.y};
-  Fq12 e = final_exponentiation(miller_g1_g2_multi<3>(xp, yp, xq, yq));
+  bool in_g1;
+  Fq12 e = final_exponentiation(miller_g1_g2_multi<3>(xp, yp, xq, yq, in_g1));
+  if (!in_g1) { ok[i] = 0; return; }       // a G1 argument outside the order-r subgroup: e(-P,Q) = e(P,Q)^-1 is not available — fail closed
   uint32_t got[144]; st_fq12(got, e);
   uint32_t diff = 0;
   for (int k = 0; k < 144; ++k) diff |= got[k] ^ alpha_beta[k];
@@ -75,7 +78,9 @@ __global__ void __launch_bounds__(64) k_pairing_product_check(PairArgs a, uint32
     xp[k] = p.x; yp[k] = a.neg[k] ? fp_neg(p.y) : p.y; xq[k] = q.x; yq[k] = q.y;
   }
   if (inf) { atomicMin(err, (unsigned long long)i); ok[i] = 0; return; }
-  Fq12 e = final_exponentiation(miller_g1_g2_multi<K>(xp, yp, xq, yq));
+  bool in_g1;
+  Fq12 e = final_exponentiation(miller_g1_g2_multi<K>(xp, yp, xq, yq, in_g1));
+  if (!in_g1) { ok[i] = 0; return; }       // fail closed, as in k_groth16_verify
   uint32_t got[144]; st_fq12(got, e);
   uint32_t diff = got[132] ^ 1u;                       // canonical one: w0.v0.u0 = 1 (the last Fq of the {w1,w0} layout), all else 0
   for (int k = 0; k < 144; ++k) if (k != 132) diff |= got[k];

@@ -12,6 +12,9 @@
 
 namespace zkt {
 
+// word 11 of an output element is the top word of a canonical Fq (<= 0x1a0111ea): this value marks "not computed yet"
+static constexpr int TATE_MARK_WORD = 11;
+static constexpr uint32_t TATE_MARK = 0xffffffffu;
 #ifndef ZKT_TATE_ATTR
 #define ZKT_TATE_ATTR
 #endif
@@ -25,13 +28,32 @@ __global__ void __launch_bounds__(64) ZKT_TATE_ATTR k_tate(const uint32_t* __res
     atomicMin(err, (unsigned long long)i);
     return;
   }
-  Fq12 f = miller_g1_g2(p.x, p.y, q.x, q.y);
+  bool in_g1;
+  Fq12 f = miller_g1_g2(p.x, p.y, q.x, q.y, in_g1);
+  if (!in_g1) { out[i * 144 + TATE_MARK_WORD] = TATE_MARK; return; }        // r P != infinity: left to k_tate_exact_marked
+  st_fq12(out + i * 144, final_exponentiation(f));
+}
+// Second pass over the batch, for the elements k_tate marked: P outside the order-r subgroup.  There the reference's result depends on
+// the order of P — it panics when a multiple of P met by its binary chain is infinity (rational_function.rs:36) — so these lanes follow
+// the reference's chain step by step (miller_g1_g2_exact) and report its panics as the batch's error index.  Honest inputs never get
+// here: every lane of every wave leaves after one load.
+__global__ void __launch_bounds__(64) k_tate_exact_marked(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
+                                                          uint32_t* __restrict__ out, size_t n, unsigned long long* err) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n || out[i * 144 + TATE_MARK_WORD] != TATE_MARK) return;
+  Aff<FqOps> p = PtIO<FqOps>::ld(g1 + i * ABI_G1_WORDS);
+  Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2 + i * ABI_G2_WORDS);
+  bool bad;
+  Fq12 f = miller_g1_g2_exact(p.x, p.y, q.x, q.y, bad);
+  if (bad) { atomicMin(err, (unsigned long long)i); return; }
+  if (fq12_is_zero(f)) { for (int k = 0; k < 144; ++k) out[i * 144 + k] = 0; return; }      // 0^e = 0 (fq12.rs:42-57)
   st_fq12(out + i * 144, final_exponentiation(f));
 }
 
 hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_tate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
+  hipLaunchKernelGGL(k_tate_exact_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
   return hipGetLastError();
 }
 
