@@ -73,6 +73,10 @@ def lib():
             getattr(L, f"zkt_{f}_pow_batch").argtypes = [vp, vp, sz, ctypes.c_int, vp, sz]
             getattr(L, f"zkt_{f}_pow_seq").argtypes = [vp, sz, vp]
             getattr(L, f"zkt_{f}_repeat").argtypes = [vp, sz, vp]
+        for grp in ("g1", "g2", "secp"):
+            getattr(L, f"zkt_{grp}_is_on_curve_batch").argtypes = [vp, vp, sz]
+            getattr(L, f"zkt_{grp}_in_subgroup_batch").argtypes = [vp, vp, sz]
+            getattr(L, f"zkt_{grp}_generator").argtypes = [vp]; getattr(L, f"zkt_{grp}_generator").restype = None
         # multi-GPU entry points (csrc/zkt_comm.cpp)
         L.zkt_comm_init.argtypes = [ctypes.c_int, ctypes.c_int, vp]
         L.zkt_comm_init_callback.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp]
