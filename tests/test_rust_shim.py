@@ -1,0 +1,93 @@
+"""The Rust host side (bindings/rust/) is shipped as source — this image has no rustc — so what CAN be checked is checked here:
+  * src/ffi.rs is exactly what tools/gen_rust_ffi.py generates from include/zkt.h (not stale);
+  * its extern block declares every symbol the library exports (zk.exported_symbols()), with the arity of the C prototype;
+  * every `ffi::zkt_*` the hand-written modules use is declared there, and every call passes that many arguments;
+  * the reference's type and method names the north star asks for are present."""
+import importlib, os, re, subprocess, sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RS = os.path.join(ROOT, "bindings", "rust", "src")
+zk = importlib.import_module("zk-toolkit_amd")
+
+
+def _split_top(s):
+    """split on commas outside (), [], {}, <>"""
+    out, depth, cur = [], 0, ""
+    for i, ch in enumerate(s):
+        if ch in "([{": depth += 1
+        elif ch in ")]}": depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur); cur = ""
+        else:
+            cur += ch
+    if cur.strip(): out.append(cur)
+    return out
+
+
+def _ffi_decls():
+    txt = open(os.path.join(RS, "ffi.rs")).read()
+    block = txt[txt.index('extern "C" {'):]
+    return {m.group(1): len(_split_top(m.group(2))) for m in re.finditer(r"pub fn (zkt_\w+)\((.*?)\)(?: -> [^;]+)?;", block)}
+
+
+def _header_arity():
+    txt = re.sub(r"/\*.*?\*/", " ", open(zk.HEADER).read(), flags=re.S)
+    txt = re.sub(r"typedef[^;{]*\{.*?\}[^;]*;", " ", txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(zkt_\w+)\s*\(([^)]*)\)\s*;", txt):
+        params = m.group(2).strip()
+        out[m.group(1)] = 0 if params in ("", "void") else len(params.split(","))
+    return out
+
+
+def test_ffi_rs_is_generated_from_the_header():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_extern_block_covers_every_export_with_matching_arity():
+    decl, hdr = _ffi_decls(), _header_arity()
+    exported = zk.exported_symbols()
+    assert len(exported) >= 150
+    missing = [s for s in exported if s not in decl]
+    assert not missing, f"not declared in ffi.rs: {missing}"
+    wrong = [(s, decl[s], hdr[s]) for s in exported if decl[s] != hdr[s]]
+    assert not wrong, f"arity differs (symbol, ffi.rs, zkt.h): {wrong}"
+    L = zk.lib()                                   # and the library really exports them
+    assert all(hasattr(L, s) for s in decl)
+
+
+def test_handwritten_modules_call_declared_functions_with_the_right_arity():
+    decl = _ffi_decls()
+    types = set(re.findall(r"pub (?:struct|type) (zkt_\w+)", open(os.path.join(RS, "ffi.rs")).read()))
+    seen = set()
+    for fn in sorted(os.listdir(RS)):
+        if fn == "ffi.rs" or not fn.endswith(".rs"): continue
+        src = re.sub(r"//.*", "", open(os.path.join(RS, fn)).read())
+        for name in re.findall(r"\b(zkt_\w+)\b", src):            # also the names handed to macros without the ffi:: prefix
+            assert name in decl or name in types, f"{fn}: {name} is not declared in ffi.rs"
+            if name in decl: seen.add(name)
+        for m in re.finditer(r"ffi::(zkt_\w+)", src):
+            name = m.group(1)
+            if name in types: continue
+            rest = src[m.end():].lstrip()
+            if not rest.startswith("("): continue           # passed as a function value, not called
+            depth, j = 0, 0
+            for j, ch in enumerate(rest):
+                if ch == "(": depth += 1
+                elif ch == ")":
+                    depth -= 1
+                    if depth == 0: break
+            nargs = len(_split_top(rest[1:j])) if rest[1:j].strip() else 0
+            assert nargs == decl[name], f"{fn}: ffi::{name} called with {nargs} arguments, declared with {decl[name]}"
+    assert len(seen) >= 60, f"the shim binds only {len(seen)} entry points"
+
+
+def test_reference_names_are_present():
+    src = "".join(open(os.path.join(RS, f)).read() for f in os.listdir(RS) if f.endswith(".rs"))
+    for needle in ("pub type Fq1", "pub struct Fq2", "pub struct Fq6", "pub struct Fq12", "pub enum G1Point", "pub enum G2Point", "pub struct GTPoint", "pub struct Pairing",
+                   "pub fn tate(", "pub fn weil(", "pub fn calc_g1_g2(", "pub fn calc_g2_g1(", "pub fn eval_with_g1_hidings(", "pub fn eval_with_g2_hidings(", "pub struct CRS",
+                   "pub struct Prover", "pub fn prove(", "pub struct Verifier", "pub fn verify(", "pub struct Proof", "pub fn inner_product_argument(", "pub fn range_proof(",
+                   "pub fn pow(", "pub fn pow_seq(", "pub fn repeat(", "pub fn cube(", "pub fn safe_inv(", "pub fn init()"):
+        assert needle in src, needle
