@@ -68,7 +68,7 @@ MsmPlan msm_plan(size_t n, int grp) {
   size_t ent = (size_t)p.nwin * n;
   size_t b = 0;
   b += (p.nbuckets + 1) * 4 * 3;          // counts, offsets, cursor
-  b += ent * 4;                            // entries
+  b += 2 * ent * 4 + 256;                  // entries, slots
   b += p.nbuckets * XYW * 4;               // bucket sums
   b += (2048 + 64) * XYW * 4;              // row/col sums, bit classes
   b += (1024 + 3 * 1025) * 4 + 2 * (p.nbuckets + 1) * 4;          // scan scratch, size bins, task counts/offsets
@@ -88,7 +88,7 @@ MsmPlan msm_plan_direct(size_t n, int grp) {
   p.c = c; p.nwin = (256 + 1 + c - 1) / c; p.half = size_t(1) << (c - 1); p.nbuckets = (size_t)p.nwin * p.half; p.direct = 1;
   size_t ent = (size_t)p.nwin * n;
   size_t b = 0;
-  b += (p.nbuckets + 1) * 4 * 3 + ent * 4 + p.nbuckets * XYW * 4;
+  b += (p.nbuckets + 1) * 4 * 3 + 2 * ent * 4 + 256 + p.nbuckets * XYW * 4;
   b += (size_t)p.nwin * (2048 + 64 + 1) * XYW * 4;               // per-window row/col sums, bit classes, window results
   b += (1024 + 3 * 1025) * 4 + 2 * (p.nbuckets + 1) * 4;
   b += (p.nbuckets + ent / 128 + 2) * (8 + XYW * 4);
@@ -178,14 +178,17 @@ __device__ inline uint32_t window_bits(const uint32_t* k, int w, int c) {
   return (uint32_t)(v >> sh) & ((1u << c) - 1);
 }
 
-// One atomic per (scalar, window) on the bucket counter; the returned value is the entry's slot inside its bucket.
+// One atomic per (scalar, window) on the bucket counter; the returned value is the entry's slot inside its bucket.  The COUNT pass keeps it
+// (slot[w*n + i], a coalesced 4-byte store per window), so the SCATTER pass is atomic-free: recompute the digit, read slot and offsets[bucket],
+// write the entry (13.6 M atomics at 2^20 terms were 0.5 ms of the scatter pass).
 // Skewed inputs (a witness full of 0/1) send most lanes of a wave to the SAME counter, which would serialise a million
 // atomics on one address: up to two rounds of wave-level aggregation elect a leader for the most common bucket id among
 // the active lanes (one atomicAdd of the population count, ranks by prefix popcount); the rest go individually.
+static constexpr uint32_t NO_SLOT = 0xffffffffu;          // zero digit / infinity: no entry
 template <bool SCATTER>
 static __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t n, int c, int nwin, uint32_t win_buckets,
-                                                uint32_t* __restrict__ counts_or_cursor, const uint32_t* __restrict__ offsets,
-                                                uint32_t* __restrict__ entries) {
+                                                uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
+                                                uint32_t* __restrict__ slot, uint32_t* __restrict__ entries) {
   ZKT_SIDE_PRIO;
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = i < n;
@@ -207,9 +210,13 @@ static __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restric
     // resident form (win_buckets = 0): entry = index into the window-multiple table, one bucket set for all windows;
     // direct form: entry = the base itself, window w owns buckets [w * win_buckets, (w+1) * win_buckets)
     size_t src = win_buckets ? i : (size_t)w * n + i;
-    bool todo = live && mag != 0 && !inf[live ? src : 0];   // infinity and zero digits contribute nothing
     const uint32_t b = mag - 1 + (uint32_t)w * win_buckets;
-    uint32_t pos = 0;
+    if (SCATTER) {
+      if (live) { const uint32_t pos = slot[(size_t)w * n + i]; if (pos != NO_SLOT) entries[offsets[b] + pos] = (uint32_t)src | (neg << 31); }
+      continue;
+    }
+    bool todo = live && mag != 0 && !inf[live ? src : 0];   // infinity and zero digits contribute nothing
+    uint32_t pos = NO_SLOT;
     for (int round = 0; round < 2; ++round) {
       unsigned long long act = __ballot(todo);
       if (act == 0) break;
@@ -219,14 +226,12 @@ static __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restric
       int cnt = __popcll(same);
       if (cnt < 4) break;                               // nothing worth aggregating: fall through to individual atomics
       uint32_t base = 0;
-      if ((int)lane == leader) base = atomicAdd(&counts_or_cursor[lb], (uint32_t)cnt);
+      if ((int)lane == leader) base = atomicAdd(&counts[lb], (uint32_t)cnt);
       base = __shfl(base, leader);
-      if (todo && b == lb) { pos = base + (uint32_t)__popcll(same & lt_mask); if (SCATTER) entries[offsets[b] + pos] = (uint32_t)src | (neg << 31); todo = false; }
+      if (todo && b == lb) { pos = base + (uint32_t)__popcll(same & lt_mask); todo = false; }
     }
-    if (todo) {
-      pos = atomicAdd(&counts_or_cursor[b], 1u);
-      if (SCATTER) entries[offsets[b] + pos] = (uint32_t)src | (neg << 31);
-    }
+    if (todo) pos = atomicAdd(&counts[b], 1u);
+    if (live) slot[(size_t)w * n + i] = pos;
   }
 }
 
@@ -310,13 +315,20 @@ static __global__ void __launch_bounds__(256) k_task_count(const uint32_t* __res
   __syncthreads();
   for (int k = threadIdx.x; k < SIZE_BINS; k += 256) if (h[k]) atomicAdd(&hist[k], h[k]);
 }
-static __global__ void __launch_bounds__(256) k_task_scatter(const uint32_t* __restrict__ counts, size_t m, const uint32_t* __restrict__ binoff,
+static __global__ void __launch_bounds__(256) k_task_scatter(const uint32_t* __restrict__ counts, size_t m, const uint32_t* __restrict__ size_hist,
                                                       uint32_t* __restrict__ bincur, uint2* __restrict__ order) {
   ZKT_SIDE_PRIO;
   // rank inside the block with LDS atomics, then ONE global atomic per (block, non-empty bin): ~50 distinct sizes
-  // are shared by 2^19 buckets, so per-element global atomics would serialise.
-  __shared__ uint32_t h[SIZE_BINS], base[SIZE_BINS];
+  // are shared by 2^19 buckets, so per-element global atomics would serialise.  The exclusive scan of the SIZE_BINS-entry
+  // histogram (bin offsets in the size-ordered task list) is recomputed by every block: 129 values, cheaper than three more launches.
+  __shared__ uint32_t h[SIZE_BINS], base[SIZE_BINS], binoff[SIZE_BINS + 1], scan[256];
   for (int i = threadIdx.x; i < SIZE_BINS; i += 256) h[i] = 0;
+  {
+    static_assert(SIZE_BINS <= 256, "one histogram bin per thread");
+    uint32_t v = threadIdx.x < SIZE_BINS ? size_hist[threadIdx.x] : 0, tot;
+    uint32_t ex = block_excl_scan_256(v, scan, tot);
+    if (threadIdx.x < SIZE_BINS) binoff[threadIdx.x] = ex;
+  }
   __syncthreads();
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   uint32_t bin = 0, rank = 0, nt = 1;
@@ -395,10 +407,15 @@ __global__ void __launch_bounds__(64) ZKT_ACC_ATTR k_accumulate(const uint32_t* 
 // ---------------------------------------------------------------------------------
 // block-level tree sum of one XYZZ per lane through LDS (RED_TPB lanes -> lane 0): log2 depth
 static constexpr int RED_TPB = 64;
-template <class F> __device__ inline Xyzz<F> block_tree_sum(Xyzz<F> v, uint32_t* lds /* RED_TPB/2 * XYW words */) {
+// The reduce kernels sum full XYZZ points (12M + 2S inlined): the G1 build used 255 VGPRs + 9 AGPRs, one wave per SIMD by nine registers, so the 1536
+// blocks of k_marginals ran in two rounds at the single-wave issue rate.  Capping them at two waves per SIMD costs a few dwords of scratch.
+#ifndef ZKT_RED_ATTR
+#define ZKT_RED_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+template <class F, int TPB = RED_TPB> __device__ inline Xyzz<F> block_tree_sum(Xyzz<F> v, uint32_t* lds /* TPB/2 * XYW words */) {
   constexpr int XYW = 4 * Coord<F>::CW;
   const int lane = threadIdx.x;
-  for (int d = RED_TPB / 2; d >= 1; d >>= 1) {
+  for (int d = TPB / 2; d >= 1; d >>= 1) {
     if (lane >= d && lane < 2 * d) st_xy<F>(lds + (lane - d) * XYW, v);
     __syncthreads();
     if (lane < d) v = xyzz_add<F>(v, ld_xy<F>(lds + lane * XYW));
@@ -409,7 +426,7 @@ template <class F> __device__ inline Xyzz<F> block_tree_sum(Xyzz<F> v, uint32_t*
 // hot buckets (more than one task): sums[b] = sum of the bucket's partials.  Blocks stride over the buckets; the test is
 // block-uniform, so the barrier inside the tree is safe.
 template <class F>
-__global__ void __launch_bounds__(RED_TPB) k_merge_partials(const uint32_t* __restrict__ task_off, size_t nbuckets, const uint32_t* __restrict__ partial,
+__global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_merge_partials(const uint32_t* __restrict__ task_off, size_t nbuckets, const uint32_t* __restrict__ partial,
                                                             uint32_t* __restrict__ sums) {
   ZKT_SIDE_PRIO;
   constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
@@ -424,10 +441,11 @@ __global__ void __launch_bounds__(RED_TPB) k_merge_partials(const uint32_t* __re
   }
 }
 
-// Both marginals of the NHI x NLO bucket matrix in ONE launch: blocks [0,NLO) produce the column sums
-// C_lo = sum_hi S[hi][lo]; blocks [NLO, NLO+NHI) the row sums R_hi = sum_lo S[hi][lo].
+// Both marginals of the NHI x NLO bucket matrix in ONE launch: blocks [0,NLO) produce the column sums C_lo = sum_hi S[hi][lo];
+// blocks [NLO, NLO + RS*NHI) the row sums, every row cut into RS pieces (rowsum[RS*hi + piece]) so that row and column blocks carry chains of
+// the same length — with NLO = 1024, NHI = 512 and RS = 2 all 2048 blocks sum 512 points (8 per lane + the tree) and fill two waves per SIMD.
 template <class F>
-__global__ void __launch_bounds__(RED_TPB) k_marginals(const uint32_t* __restrict__ in, size_t NLO, size_t NHI,
+__global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_marginals(const uint32_t* __restrict__ in, size_t NLO, size_t NHI, int RS,
                                                        uint32_t* __restrict__ colsum, uint32_t* __restrict__ rowsum) {
   ZKT_SIDE_PRIO;
   constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
@@ -436,29 +454,35 @@ __global__ void __launch_bounds__(RED_TPB) k_marginals(const uint32_t* __restric
   in += (size_t)blockIdx.y * NLO * NHI * XYW; colsum += (size_t)blockIdx.y * 1024 * XYW; rowsum += (size_t)blockIdx.y * 1024 * XYW;   // grid.y = window (direct form)
   const bool is_col = blockIdx.x < NLO;
   const size_t o = is_col ? blockIdx.x : blockIdx.x - NLO;
-  const size_t count = is_col ? NHI : NLO, stride_o = is_col ? 1 : NLO, stride_j = is_col ? NLO : 1;
+  const size_t piece = NLO / RS;
+  const size_t count = is_col ? NHI : piece, stride_j = is_col ? NLO : 1;
+  const size_t first = is_col ? o : (o / RS) * NLO + (o % RS) * piece;
   XY acc = xyzz_inf<F>();
-  for (size_t j = lane; j < count; j += RED_TPB) acc = xyzz_add<F>(acc, ld_xy<F>(in + (o * stride_o + j * stride_j) * XYW));
+  for (size_t j = lane; j < count; j += RED_TPB) acc = xyzz_add<F>(acc, ld_xy<F>(in + (first + j * stride_j) * XYW));
   acc = block_tree_sum<F>(acc, lds);
   if (lane == 0) st_xy<F>((is_col ? colsum : rowsum) + o * XYW, acc);
 }
 // Bit classes of both weighted sums in one launch: blocks [0,nbA) slice colsum by the bits of (lo+1),
-// blocks [nbA, nbA+nbB) slice rowsum by the bits of hi.  D[t] for the final combine: t = bit (A) or lo_bits + bit (B).
+// blocks [nbA, nbA+nbB) slice the RS*NHI row pieces by the bits of hi = index / RS.  D[t] for the final combine: t = bit (A) or lo_bits + bit (B).
+// Only nbA + nbB (~20) blocks exist, so they are wide: WB_TPB lanes share a class (4 points per lane + an 8-level tree at 1024 entries).
+static constexpr int WB_TPB = 256;
 template <class F>
-__global__ void __launch_bounds__(RED_TPB) k_weight_bits(const uint32_t* __restrict__ colsum, size_t NLO, int nbA,
-                                                         const uint32_t* __restrict__ rowsum, size_t NHI, uint32_t* __restrict__ clsA, uint32_t* __restrict__ clsB) {
+__global__ void __launch_bounds__(WB_TPB) k_weight_bits(const uint32_t* __restrict__ colsum, size_t NLO, int nbA,
+                                                        const uint32_t* __restrict__ rowsum, size_t NROW, int RS, uint32_t* __restrict__ clsA, uint32_t* __restrict__ clsB) {
   ZKT_SIDE_PRIO;
   constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
-  __shared__ uint32_t lds[RED_TPB / 2 * XYW];
+  __shared__ uint32_t lds[WB_TPB / 2 * XYW];
   const int lane = threadIdx.x;
   colsum += (size_t)blockIdx.y * 1024 * XYW; rowsum += (size_t)blockIdx.y * 1024 * XYW; clsA += (size_t)blockIdx.y * 32 * XYW; clsB += (size_t)blockIdx.y * 32 * XYW;
   const bool isA = (int)blockIdx.x < nbA;
   const int bit = isA ? blockIdx.x : blockIdx.x - nbA;
-  const uint32_t* in = isA ? colsum : rowsum; const size_t m = isA ? NLO : NHI; const uint32_t woff = isA ? 1u : 0u;
+  const uint32_t* in = isA ? colsum : rowsum; const size_t m = isA ? NLO : NROW;
   XY acc = xyzz_inf<F>();
-  for (size_t i = lane; i < m; i += RED_TPB)
-    if (((uint32_t)i + woff) >> bit & 1) acc = xyzz_add<F>(acc, ld_xy<F>(in + i * XYW));
-  acc = block_tree_sum<F>(acc, lds);
+  for (size_t i = lane; i < m; i += WB_TPB) {
+    const uint32_t wgt = isA ? (uint32_t)i + 1u : (uint32_t)i / (uint32_t)RS;
+    if (wgt >> bit & 1) acc = xyzz_add<F>(acc, ld_xy<F>(in + i * XYW));
+  }
+  acc = block_tree_sum<F, WB_TPB>(acc, lds);
   if (lane == 0) st_xy<F>((isA ? clsA : clsB) + bit * XYW, acc);
 }
 // total = sum_{b<=shift} 2^b A_b + 2^shift sum_b 2^b B_b = sum_t 2^t D_t with D_t = A_t (t<=shift) (+) B_{t-shift} (t>=shift).
@@ -519,7 +543,7 @@ __global__ void __launch_bounds__(64) k_join_windows(const uint32_t* __restrict_
 namespace {
 struct MsmWs {   // workspace carve-up (one per in-flight MSM)
   uint32_t *zero_begin, *counts, *cursor, *size_hist, *size_off, *size_cur, *zero_end;   // [zero_begin, zero_end) is cleared per MSM
-  uint32_t *offsets, *entries, *sums, *colsum, *rowsum, *clsA, *clsB, *win_jac, *scan_tmp, *ntask, *task_off, *partial;
+  uint32_t *offsets, *entries, *slot, *sums, *colsum, *rowsum, *clsA, *clsB, *win_jac, *scan_tmp, *ntask, *task_off, *partial;
   uint2* order; size_t max_tasks;
 };
 MsmWs carve(const MsmPlan& P, void* workspace) {
@@ -536,6 +560,8 @@ MsmWs carve(const MsmPlan& P, void* workspace) {
   w.offsets = (uint32_t*)ws; ws += (B + 1) * 4;
   ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   w.entries = (uint32_t*)ws; ws += (size_t)P.nwin * P.n * 4;
+  ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  w.slot = (uint32_t*)ws; ws += (size_t)P.nwin * P.n * 4;
   ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   w.sums = (uint32_t*)ws; ws += B * XYW * 4;
   const size_t nw = P.direct ? (size_t)P.nwin : 1;                // the direct form reduces every window side by side
@@ -564,16 +590,15 @@ hipError_t PART(launch_msm_sort)(const MsmPlan& P, const uint8_t* inf, const uin
   if (n) {
     const unsigned g = (unsigned)((n + 255) / 256);
     const uint32_t wb = P.direct ? (uint32_t)P.half : 0u;
-    hipLaunchKernelGGL(k_digits<false>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, wb, w.counts, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_digits<false>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, wb, w.counts, (const uint32_t*)nullptr, w.slot, (uint32_t*)nullptr);
     launch_scan(w.counts, w.offsets, B, w.scan_tmp, s);
-    hipLaunchKernelGGL(k_digits<true>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, wb, w.cursor, (const uint32_t*)w.offsets, w.entries);
+    hipLaunchKernelGGL(k_digits<true>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, wb, (uint32_t*)nullptr, (const uint32_t*)w.offsets, w.slot, w.entries);
   } else {
     if ((e = hipMemsetAsync(w.offsets, 0, (B + 1) * 4, s)) != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k_task_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, w.ntask, w.size_hist);
   launch_scan(w.ntask, w.task_off, B, w.scan_tmp, s);
-  launch_scan(w.size_hist, w.size_off, SIZE_BINS, w.scan_tmp, s);
-  hipLaunchKernelGGL(k_task_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, (const uint32_t*)w.size_off, w.size_cur, w.order);
+  hipLaunchKernelGGL(k_task_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, (const uint32_t*)w.size_hist, w.size_cur, w.order);
   return hipGetLastError();
 }
 // stage 2 (VALU bound, the dominant kernel): one bucket per lane
@@ -596,20 +621,22 @@ hipError_t PART(launch_msm_reduce)(const MsmPlan& P, void* workspace, uint32_t* 
   int lo_bits = 0; while ((size_t(1) << lo_bits) < NLO) ++lo_bits;
   int hi_bits = 0; while ((size_t(1) << hi_bits) < NHI) ++hi_bits;
   const int nbA = lo_bits + 1, nbB = NHI > 1 ? hi_bits : 0;     // weights lo+1 in [1,NLO]; hi in [0,NHI)
+  const int RS = (NHI > 1 && NLO >= 128 && 2 * NHI <= 1024) ? 2 : 1;                 // pieces per row (k_marginals)
+  const size_t NROW = (size_t)RS * NHI;
   if (P.direct) {                                          // every window reduced side by side (grid.y), then joined
     const unsigned ny = (unsigned)P.nwin;
     MSM_DISPATCH(P.grp,
       hipLaunchKernelGGL(k_merge_partials<F>, dim3((unsigned)(P.nbuckets < 2048 ? P.nbuckets : 2048)), dim3(RED_TPB), 0, s, (const uint32_t*)w.task_off, P.nbuckets, (const uint32_t*)w.partial, w.sums);
-      hipLaunchKernelGGL(k_marginals<F>, dim3((unsigned)(NLO + (NHI > 1 ? NHI : 0)), ny), dim3(RED_TPB), 0, s, (const uint32_t*)w.sums, NLO, NHI, w.colsum, w.rowsum);
-      hipLaunchKernelGGL(k_weight_bits<F>, dim3((unsigned)(nbA + nbB), ny), dim3(RED_TPB), 0, s, (const uint32_t*)w.colsum, NLO, nbA, (const uint32_t*)w.rowsum, NHI, w.clsA, w.clsB);
+      hipLaunchKernelGGL(k_marginals<F>, dim3((unsigned)(NLO + (NHI > 1 ? NROW : 0)), ny), dim3(RED_TPB), 0, s, (const uint32_t*)w.sums, NLO, NHI, RS, w.colsum, w.rowsum);
+      hipLaunchKernelGGL(k_weight_bits<F>, dim3((unsigned)(nbA + nbB), ny), dim3(WB_TPB), 0, s, (const uint32_t*)w.colsum, NLO, nbA, (const uint32_t*)w.rowsum, NROW, RS, w.clsA, w.clsB);
       hipLaunchKernelGGL(k_combine<F>, dim3(1, ny), dim3(64), 0, s, (const uint32_t*)w.clsA, nbA, (const uint32_t*)w.clsB, nbB, lo_bits, w.win_jac, (uint32_t*)nullptr);
       hipLaunchKernelGGL(k_join_windows<F>, dim3(1), dim3(64), 0, s, (const uint32_t*)w.win_jac, P.nwin, P.c, dev_result_jac, dev_out_abi));
     return hipGetLastError();
   }
   MSM_DISPATCH(P.grp,
     hipLaunchKernelGGL(k_merge_partials<F>, dim3((unsigned)(B < 2048 ? B : 2048)), dim3(RED_TPB), 0, s, (const uint32_t*)w.task_off, B, (const uint32_t*)w.partial, w.sums);
-    hipLaunchKernelGGL(k_marginals<F>, dim3((unsigned)(NLO + (NHI > 1 ? NHI : 0))), dim3(RED_TPB), 0, s, (const uint32_t*)w.sums, NLO, NHI, w.colsum, w.rowsum);
-    hipLaunchKernelGGL(k_weight_bits<F>, dim3((unsigned)(nbA + nbB)), dim3(RED_TPB), 0, s, (const uint32_t*)w.colsum, NLO, nbA, (const uint32_t*)w.rowsum, NHI, w.clsA, w.clsB);
+    hipLaunchKernelGGL(k_marginals<F>, dim3((unsigned)(NLO + (NHI > 1 ? NROW : 0))), dim3(RED_TPB), 0, s, (const uint32_t*)w.sums, NLO, NHI, RS, w.colsum, w.rowsum);
+    hipLaunchKernelGGL(k_weight_bits<F>, dim3((unsigned)(nbA + nbB)), dim3(WB_TPB), 0, s, (const uint32_t*)w.colsum, NLO, nbA, (const uint32_t*)w.rowsum, NROW, RS, w.clsA, w.clsB);
     hipLaunchKernelGGL(k_combine<F>, dim3(1), dim3(64), 0, s, (const uint32_t*)w.clsA, nbA, (const uint32_t*)w.clsB, nbB, lo_bits, dev_result_jac, dev_out_abi));
   return hipGetLastError();
 }
