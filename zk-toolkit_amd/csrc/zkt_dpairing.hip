@@ -1,0 +1,511 @@
+// Lane-distributed Tate pairing for SMALL batches: one pairing per 12 lanes (rows a10-a13 of SURVEY §8, Pairing::tate pairing.rs:86-100).
+//
+// k_tate (zkt_tate.hip) runs one pairing per lane: 23 M instructions in sequence, ~66 ms however few pairings there are — a single
+// Groth16 verification (verifier.rs:30-54) took 107 ms.  Here an Fq12 value is spread over a GROUP of 12 lanes in the basis
+//      sum_{m<6} (x_m + y_m u) w^m,      w^6 = xi = 1 + u,  u^2 = -1        (w^2 = v: m = 2k + i is slot v^k w^i of the tower)
+// lane (m, part) holding ONE Fq coefficient (part 0: x_m, part 1: y_m).  Every Fq12 product is then 12 independent output coefficients,
+// each a sum of 12 Fq products that is accumulated UNREDUCED in 28 64-bit columns (168 products < 2^56 per column stay below 2^64) and
+// reduced ONCE (Montgomery, 196 MADs): 2,548 v_mad_u64_u32 per lane per product, no Karatsuba recombination passes, no scratch.  The
+// xi-twist of the wrapped terms is folded into precomputed s = x - y, t = x + y of the second operand, so all lanes do the same work:
+//      Re c_m = sum_{j+k=m} (x_j x'_k - y_j y'_k) + sum_{j+k=m+6} (x_j s'_k - y_j t'_k)
+//      Im c_m = sum_{j+k=m} (x_j y'_k + y_j x'_k) + sum_{j+k=m+6} (x_j t'_k + y_j s'_k)
+// Operands are exchanged through LDS ("images": X, Y, -Y, S, T of the six coefficients).  The G1 point arithmetic of the Miller loop
+// (Fq only) is spread over the lanes as well: each level of its dependency graph is one multiplication per lane on LDS slots.
+// The algorithm is that of pairing.h (signed-digit Miller loop over r-1, sparse lines, exact final exponentiation): the same field
+// elements, so the same bits as k_tate and as the reference.  rP != infinity is detected as there and handed to k_tate_exact_marked.
+#include "abi.h"
+#include "zkt_internal.h"
+
+namespace zkt {
+namespace dp {
+
+constexpr int GL = 12;            // lanes per pairing
+constexpr int GPW = 5;            // pairings per wave (60 of 64 lanes)
+constexpr int SW = 16;            // dwords per LDS slot (14 limbs + 2 pad: 64 B, b128-aligned)
+constexpr uint32_t M28 = (1u << 28) - 1;
+// image = expanded operand: slots X[6] Y[6] NY[6] S[6] T[6]
+constexpr int IX = 0, IY = 6, INY = 12, IS = 18, IT = 24, IMG_SLOTS = 30;
+constexpr int NIMG = 3;
+constexpr int PT_SLOTS = 48;
+constexpr int GROUP_SLOTS = NIMG * IMG_SLOTS + PT_SLOTS;
+constexpr int GROUP_WORDS = GROUP_SLOTS * SW;
+
+struct Role { int g, m, part; };
+
+__device__ inline void lst(uint32_t* s, const Fq& a) {
+  uint4* p = reinterpret_cast<uint4*>(s);
+  p[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]); p[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+  p[2] = make_uint4(a.v[8], a.v[9], a.v[10], a.v[11]); reinterpret_cast<uint2*>(s + 12)[0] = make_uint2(a.v[12], a.v[13]);
+}
+__device__ inline Fq lld(const uint32_t* s) {
+  const uint4* p = reinterpret_cast<const uint4*>(s);
+  uint4 a = p[0], b = p[1], c = p[2]; uint2 d = reinterpret_cast<const uint2*>(s + 12)[0];
+  Fq r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  r.v[8] = c.x; r.v[9] = c.y; r.v[10] = c.z; r.v[11] = c.w; r.v[12] = d.x; r.v[13] = d.y;
+  return r;
+}
+__device__ inline Fq fsel(bool c, const Fq& a, const Fq& b) { Fq r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+  return r; }
+__device__ inline void gsync() { __syncthreads(); }       // one wave per block: orders the LDS traffic of the group
+
+// ---- unreduced accumulation of Fq products in 28 columns, one Montgomery reduction -------------------------------------------------
+struct Cols { uint64_t c[28]; };
+__device__ inline void cols_zero(Cols& k) {
+#pragma unroll
+  for (int i = 0; i < 28; ++i) k.c[i] = 0; }
+__device__ inline void cols_mac(Cols& k, const Fq& a, const Fq& b) {       // 196 MADs; limbs < 2^28 (or one operand < 2^29, see callers)
+#pragma unroll
+  for (int i = 0; i < 14; ++i)
+#pragma unroll
+    for (int j = 0; j < 14; ++j) k.c[i + j] = mad64(a.v[i], b.v[j], k.c[i + j]);
+}
+// (sum of products + m p) / 2^392: < 1.1 p for <= 12 products of values < 4p
+__device__ inline Fq cols_reduce(Cols& k) {
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    const uint32_t m = ((uint32_t)k.c[i] * FqC::INV) & M28;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) k.c[i + j] = mad64(m, FqC::mod(j), k.c[i + j]);
+    k.c[i + 1] += k.c[i] >> 28;
+  }
+  Fq r; uint64_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) { const uint64_t t = k.c[14 + i] + carry; r.v[i] = (uint32_t)t & M28; carry = t >> 28; }
+  return r;
+}
+
+// ---- images ---------------------------------------------------------------------------------------------------------------------------
+// write the group's value (one coefficient per lane) as an expanded image: X, Y, -Y now; S = x - y, T = x + y after the exchange
+__device__ inline void expand(uint32_t* img, const Fq& me, const Role& r, uint32_t* dummy) {
+  const Fq neg = fp_neg(me);
+  lst(img + ((r.part ? IY : IX) + r.m) * SW, me);
+  lst(r.part ? img + (INY + r.m) * SW : dummy, neg);
+  gsync();
+  const Fq other = lld(img + ((r.part ? IX : IY) + r.m) * SW);           // the partner's half of coefficient m
+  // part 0 (x): S = x - y;  part 1 (y): T = x + y
+  uint32_t v[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) v[i] = me.v[i] + (r.part ? other.v[i] : FqC::subk(i) - other.v[i]);
+  lst(img + ((r.part ? IT : IS) + r.m) * SW, fp_lazy_reduce<FqC>(v));
+  gsync();
+}
+// only X, Y, -Y (the first operand of a product needs no S, T)
+__device__ inline void expand_first(uint32_t* img, const Fq& me, const Role& r, uint32_t* dummy) {
+  const Fq neg = fp_neg(me);
+  lst(img + ((r.part ? IY : IX) + r.m) * SW, me);
+  lst(r.part ? img + (INY + r.m) * SW : dummy, neg);
+  gsync();
+}
+
+// my coefficient of A * B (both images complete)
+__device__ __attribute__((noinline)) Fq dot_mul(const uint32_t* A, const uint32_t* B, int m, int part) {
+  Cols k; cols_zero(k);
+#pragma unroll 1
+  for (int j = 0; j < 6; ++j) {
+    int kk = m - j; const bool wrap = kk < 0; if (wrap) kk += 6;
+    // Re: x_j * (x'|s') + (-y_j) * (y'|t')        Im: x_j * (y'|t') + y_j * (x'|s')
+    const Fq p1 = lld(A + (IX + j) * SW);
+    const Fq u1 = lld(B + ((part ? (wrap ? IT : IY) : (wrap ? IS : IX)) + kk) * SW);
+    cols_mac(k, p1, u1);
+    const Fq p2 = lld(A + ((part ? IY : INY) + j) * SW);
+    const Fq u2 = lld(B + ((part ? (wrap ? IS : IX) : (wrap ? IT : IY)) + kk) * SW);
+    cols_mac(k, p2, u2);
+  }
+  return cols_reduce(k);
+}
+// my coefficient of A * L for a sparse second operand with coefficients 0 (in Fq: only X[0] is non-zero), 3 and 4 — a Miller line
+// a + c w^3 + b w^4.  L is an image whose slots X/Y/S/T [0], [3], [4] are filled.
+__device__ __attribute__((noinline)) Fq dot_line(const uint32_t* A, const uint32_t* L, int m, int part) {
+  Cols k; cols_zero(k);
+  // coefficient 0 of the line is real: contributes l0 * (x_m | y_m)
+  cols_mac(k, lld(A + ((part ? IY : IX) + m) * SW), lld(L + (IX + 0) * SW));
+#pragma unroll 1
+  for (int kk = 3; kk <= 4; ++kk) {
+    int j = m - kk; const bool wrap = j < 0; if (wrap) j += 6;
+    const Fq p1 = lld(A + (IX + j) * SW);
+    const Fq u1 = lld(L + ((part ? (wrap ? IT : IY) : (wrap ? IS : IX)) + kk) * SW);
+    cols_mac(k, p1, u1);
+    const Fq p2 = lld(A + ((part ? IY : INY) + j) * SW);
+    const Fq u2 = lld(L + ((part ? (wrap ? IS : IX) : (wrap ? IT : IY)) + kk) * SW);
+    cols_mac(k, p2, u2);
+  }
+  return cols_reduce(k);
+}
+
+// ---- group-level Fq12 operations (value = one Fq per lane) --------------------------------------------------------------------------
+struct Ctx {
+  uint32_t* base; uint32_t* dummy; Role r;
+  __device__ uint32_t* img(int i) const { return base + i * IMG_SLOTS * SW; }
+  __device__ uint32_t* pt(int s) const { return base + (NIMG * IMG_SLOTS + s) * SW; }
+};
+
+__device__ inline Fq d_mul(const Ctx& c, const Fq& a, const Fq& b) {        // uses images 0 and 1
+  expand_first(c.img(0), a, c.r, c.dummy);
+  expand(c.img(1), b, c.r, c.dummy);
+  return dot_mul(c.img(0), c.img(1), c.r.m, c.r.part);
+}
+__device__ inline Fq d_sqr(const Ctx& c, const Fq& a) {
+  expand(c.img(0), a, c.r, c.dummy);
+  return dot_mul(c.img(0), c.img(0), c.r.m, c.r.part);
+}
+// a * (image `bi`, already expanded): exponentiation loops keep their constant factor expanded
+__device__ inline Fq d_mul_img(const Ctx& c, const Fq& a, int bi) {
+  expand_first(c.img(0), a, c.r, c.dummy);
+  return dot_mul(c.img(0), c.img(bi), c.r.m, c.r.part);
+}
+__device__ inline Fq d_conj(const Ctx& c, const Fq& a) { return fsel(c.r.m & 1, fp_neg(a), a); }      // w -> -w
+// the partner lane's coefficient (x <-> y of the same m): lanes g and g^1 (groups start at even lanes)
+__device__ inline Fq partner(const Fq& a) { Fq r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], 0xB1, 0xF, 0xF, true);
+  return r; }
+__device__ inline Fq frob_limbs(int K, int idx, int comp) { Fq g;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      const uint32_t w = K == 1 ? (comp ? frob1_limb(t, 1, i) : frob1_limb(t, 0, i)) : frob2_limb(t, 0, i);
+      v = (t == idx) ? w : v;
+    }
+    g.v[i] = v;
+  }
+  return g; }
+// pi^1: conj_u on every coefficient, times gamma_m = g0 + g1 u:  (x - y u)(g0 + g1 u) = (x g0 + y g1) + (x g1 - y g0) u
+__device__ inline Fq d_frob1(const Ctx& c, const Fq& a) {
+  const Fq o = partner(a);
+  const Fq g0 = frob_limbs(1, c.r.m, 0), g1 = frob_limbs(1, c.r.m, 1);
+  // part 0: me = x, o = y: x g0 + y g1      part 1: me = y, o = x: x g1 + (-y) g0
+  Cols k; cols_zero(k);
+  cols_mac(k, c.r.part ? o : a, c.r.part ? g1 : g0);
+  cols_mac(k, c.r.part ? fp_neg(a) : o, c.r.part ? g0 : g1);
+  return cols_reduce(k);
+}
+__device__ inline Fq d_frob2(const Ctx& c, const Fq& a) { return fp_mul(a, frob_limbs(2, c.r.m, 0)); }     // gamma^(2) lies in Fq, no conjugation
+
+// ABI position (u32 words) of coefficient (m, part) inside an Fq12 {w1,w0}{v2,v1,v0}{u1,u0}
+__device__ inline int abi_word(int m, int part) { const int i = m & 1, k = m >> 1; return (i ? 0 : 72) + (2 - k) * 24 + (part ? 0 : 12); }
+
+// inverse: gathered into the tower form by the group's first lane (once per pairing)
+__device__ __attribute__((noinline)) Fq d_inv(const Ctx& c, const Fq& a) {
+  lst(c.img(0) + ((c.r.part ? IY : IX) + c.r.m) * SW, a);
+  gsync();
+  if (c.r.g == 0) {
+    auto co = [&](int m) { return Fq2{lld(c.img(0) + (IX + m) * SW), lld(c.img(0) + (IY + m) * SW)}; };
+    Fq12 t; t.c0 = Fq6{co(0), co(2), co(4)}; t.c1 = Fq6{co(1), co(3), co(5)};
+    const Fq12 r = fq12_inv(t);
+    auto put = [&](int m, const Fq2& v) { lst(c.img(0) + (IX + m) * SW, v.c0); lst(c.img(0) + (IY + m) * SW, v.c1); };
+    put(0, r.c0.c0); put(2, r.c0.c1); put(4, r.c0.c2); put(1, r.c1.c0); put(3, r.c1.c1); put(5, r.c1.c2);
+  }
+  gsync();
+  const Fq out = lld(c.img(0) + ((c.r.part ? IY : IX) + c.r.m) * SW);
+  gsync();
+  return out;
+}
+
+__device__ inline Ctx make_ctx(uint32_t* lds) {
+  const int lane = threadIdx.x;
+  const bool shadow = lane >= GPW * GL;                  // lanes 60-63 shadow lanes 0-3 of the last group: same loads, same (duplicate) LDS stores, no results
+  const int grp = shadow ? GPW - 1 : lane / GL, g = shadow ? lane - GPW * GL : lane % GL;
+  Ctx c; c.base = lds + grp * GROUP_WORDS; c.dummy = lds + GPW * GROUP_WORDS + (lane & 3) * SW;
+  c.r.g = shadow ? g + 100 : g;                          // a shadow is never "the group's first lane"
+  c.r.m = g >> 1; c.r.part = g & 1;
+  return c;
+}
+constexpr int LDS_WORDS = GPW * GROUP_WORDS + 4 * SW;
+
+// ---- diagnostic: Fq12 operations on the distributed form, against zkt_fq12_*_batch (tests/test_gpu_dpairing.py) --------------------
+// op: 0 mul, 1 square, 2 frobenius, 3 frobenius^2, 4 conjugate (q^6), 5 inverse
+__global__ void __launch_bounds__(64) k_dfq12_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t* __restrict__ out, size_t n) {
+  __shared__ uint32_t lds[LDS_WORDS];
+  const Ctx c = make_ctx(lds);
+  const int lane = threadIdx.x;
+  size_t e = (size_t)blockIdx.x * GPW + (lane / GL < GPW ? lane / GL : GPW - 1);
+  const bool live = e < n && lane < GPW * GL;
+  if (e >= n) e = n - 1;
+  const int w = abi_word(c.r.m, c.r.part);
+  const Fq x = ld_fp<FqC>(a + e * 144 + w), y = ld_fp<FqC>((b ? b : a) + e * 144 + w);
+  Fq r;
+  switch (op) {            // uniform
+    case 0: r = d_mul(c, x, y); break;
+    case 1: r = d_sqr(c, x); break;
+    case 2: r = d_frob1(c, x); break;
+    case 3: r = d_frob2(c, x); break;
+    case 4: r = d_conj(c, x); break;
+    default: r = d_inv(c, x); break;
+  }
+  if (live) st_fp<FqC>(out + e * 144 + w, r);
+}
+
+
+// =====================================================================================================================================
+// The G1 side of the Miller loop, spread over the lanes.  Fq values live in numbered LDS slots of the group; one LEVEL of the dependency
+// graph of a point step is one (or a sum of two) Fq products per lane on slots named by a per-lane table, plus an optional linear
+// follow-up  c1 * prod +- aux  (E = 3A, X + B, 2 Y Z, U - X ...).  Cheap linear glue between levels (D, X3, ...) is computed by every
+// lane and stored by the group's first lane.  Formulas: miller_dbl_step / miller_add_step of pairing.h.
+// =====================================================================================================================================
+constexpr int LINE_IMG = 2;
+constexpr int SL(int img, int field, int k) { return img * IMG_SLOTS + field + k; }              // absolute slot of an image entry
+constexpr int PT0 = NIMG * IMG_SLOTS;
+enum : int { P_X = PT0, P_Y, P_Z, P_XP, P_YP, P_YN, P_XQ0, P_XQ1, P_XQS, P_XQT, P_YQ0, P_YQ1, P_YQS, P_YQT, P_ZERO, P_DUMMY,
+             P_A, P_B, P_ZZ, P_YZ, P_XB, P_E, P_Z3, P_C, P_T, P_EE, P_EX, P_EZ, P_Z3Z, P_DX, P_C8, P_Y3P,
+             P_U, P_H, P_ZZZ, P_S, P_R, P_HH, P_HHH, P_VV, P_RR, P_X3, P_VX, P_END };
+static_assert(P_END - PT0 <= PT_SLOTS, "point slot file too small");
+constexpr int L_A = SL(LINE_IMG, IX, 0);                                                             // line coefficient 0 (real)
+constexpr int L_C0 = SL(LINE_IMG, IX, 3), L_C1 = SL(LINE_IMG, IY, 3), L_CS = SL(LINE_IMG, IS, 3), L_CT = SL(LINE_IMG, IT, 3);   // coefficient 3 = c (v w)
+constexpr int L_B0 = SL(LINE_IMG, IX, 4), L_B1 = SL(LINE_IMG, IY, 4), L_BS = SL(LINE_IMG, IS, 4), L_BT = SL(LINE_IMG, IT, 4);   // coefficient 4 = b (v^2)
+
+struct LOp { uint8_t a1, b1, a2, b2, dst, aux, dst2, c1, sub_aux, neg_a1, neg_a2; };
+#define NOP_ {P_ZERO, P_ZERO, P_ZERO, P_ZERO, P_DUMMY, P_ZERO, P_DUMMY, 1, 0, 0, 0}
+//                          a1      b1      a2      b2      dst     aux     dst2     c1 sub nega1 nega2
+__device__ const LOp DBL_L1[12] = {
+  {P_X, P_X, P_ZERO, P_ZERO, P_A, P_ZERO, P_E, 3, 0, 0, 0},        // A = X^2, E = 3A
+  {P_Y, P_Y, P_ZERO, P_ZERO, P_B, P_X, P_XB, 1, 0, 0, 0},          // B = Y^2, XB = X + B
+  {P_Z, P_Z, P_ZERO, P_ZERO, P_ZZ, P_ZERO, P_DUMMY, 1, 0, 0, 0},   // ZZ
+  {P_Y, P_Z, P_ZERO, P_ZERO, P_YZ, P_ZERO, P_Z3, 2, 0, 0, 0},      // YZ, Z3 = 2 Y Z
+  NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_};
+__device__ const LOp DBL_L2[12] = {
+  {P_B, P_B, P_ZERO, P_ZERO, P_C, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  {P_XB, P_XB, P_ZERO, P_ZERO, P_T, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  {P_E, P_E, P_ZERO, P_ZERO, P_EE, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  {P_E, P_X, P_ZERO, P_ZERO, P_EX, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  {P_E, P_ZZ, P_ZERO, P_ZERO, P_EZ, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  {P_Z3, P_ZZ, P_ZERO, P_ZERO, P_Z3Z, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  NOP_, NOP_, NOP_, NOP_, NOP_, NOP_};
+__device__ const LOp DBL_L3[12] = {
+  {P_E, P_DX, P_ZERO, P_ZERO, P_DUMMY, P_C8, P_Y, 1, 1, 0, 0},     // Y3 = E (D - X3) - 8C
+  {P_EZ, P_XQ0, P_ZERO, P_ZERO, L_B0, P_ZERO, P_DUMMY, 1, 0, 1, 0},   // b = Xq * (-E ZZ): four products (x, y, s, t forms)
+  {P_EZ, P_XQ1, P_ZERO, P_ZERO, L_B1, P_ZERO, P_DUMMY, 1, 0, 1, 0},
+  {P_EZ, P_XQS, P_ZERO, P_ZERO, L_BS, P_ZERO, P_DUMMY, 1, 0, 1, 0},
+  {P_EZ, P_XQT, P_ZERO, P_ZERO, L_BT, P_ZERO, P_DUMMY, 1, 0, 1, 0},
+  {P_Z3Z, P_YQ0, P_ZERO, P_ZERO, L_C0, P_ZERO, P_DUMMY, 1, 0, 0, 0},  // c = Yq * (Z3 ZZ)
+  {P_Z3Z, P_YQ1, P_ZERO, P_ZERO, L_C1, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  {P_Z3Z, P_YQS, P_ZERO, P_ZERO, L_CS, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  {P_Z3Z, P_YQT, P_ZERO, P_ZERO, L_CT, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  NOP_, NOP_, NOP_};
+// addition step V + (xp, yp'):  yp' = P_YP or P_YN (digit -1), chosen by the caller through the `ysel` offset on slots named P_YP
+__device__ const LOp ADD_L1[12] = { {P_Z, P_Z, P_ZERO, P_ZERO, P_ZZ, P_ZERO, P_DUMMY, 1, 0, 0, 0}, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_};
+__device__ const LOp ADD_L2[12] = {
+  {P_XP, P_ZZ, P_ZERO, P_ZERO, P_U, P_X, P_H, 1, 1, 0, 0},          // U = xp ZZ, H = U - X
+  {P_ZZ, P_Z, P_ZERO, P_ZERO, P_ZZZ, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_};
+__device__ const LOp ADD_L3[12] = {
+  {P_YP, P_ZZZ, P_ZERO, P_ZERO, P_S, P_Y, P_R, 1, 1, 0, 0},         // S = yp ZZZ, R = S - Y
+  {P_H, P_H, P_ZERO, P_ZERO, P_HH, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  {P_Z, P_H, P_ZERO, P_ZERO, P_Z3, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_};
+__device__ const LOp ADD_L4[12] = {
+  {P_H, P_HH, P_ZERO, P_ZERO, P_HHH, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  {P_X, P_HH, P_ZERO, P_ZERO, P_VV, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  {P_R, P_R, P_ZERO, P_ZERO, P_RR, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  {P_R, P_XP, P_YP, P_Z3, L_A, P_ZERO, P_DUMMY, 1, 0, 0, 1},       // a = R xp - Z3 yp  (two products, one reduction)
+  {P_R, P_XQ0, P_ZERO, P_ZERO, L_B0, P_ZERO, P_DUMMY, 1, 0, 1, 0},  // b = Xq * (-R)
+  {P_R, P_XQ1, P_ZERO, P_ZERO, L_B1, P_ZERO, P_DUMMY, 1, 0, 1, 0},
+  {P_R, P_XQS, P_ZERO, P_ZERO, L_BS, P_ZERO, P_DUMMY, 1, 0, 1, 0},
+  {P_R, P_XQT, P_ZERO, P_ZERO, L_BT, P_ZERO, P_DUMMY, 1, 0, 1, 0},
+  {P_Z3, P_YQ0, P_ZERO, P_ZERO, L_C0, P_ZERO, P_DUMMY, 1, 0, 0, 0}, // c = Yq * Z3
+  {P_Z3, P_YQ1, P_ZERO, P_ZERO, L_C1, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  {P_Z3, P_YQS, P_ZERO, P_ZERO, L_CS, P_ZERO, P_DUMMY, 1, 0, 0, 0},
+  {P_Z3, P_YQT, P_ZERO, P_ZERO, L_CT, P_ZERO, P_DUMMY, 1, 0, 0, 0}};
+__device__ const LOp ADD_L5[12] = {
+  {P_R, P_VX, P_Y, P_HHH, P_Y, P_ZERO, P_DUMMY, 1, 0, 0, 1},        // Y3 = R (V - X3) - Y HHH  (reads Y, writes Y: same lane)
+  NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_};
+
+// one level: prod = a1 b1 (+ a2 b2) on slots; store; optional  c1 prod +- aux  into a second slot.  `ysel` is added to every slot index
+// equal to P_YP (selects -P for a digit -1).  All lanes run the same code; g picks the table row.
+template <bool TWO>
+__device__ __attribute__((noinline)) void level(const Ctx& c, const LOp* tab, int ysel) {
+  const int g = c.r.g >= 100 ? c.r.g - 100 : c.r.g;
+  const LOp op = tab[g];
+  auto slot = [&](int s) { return c.base + (s == P_YP ? s + ysel : s) * SW; };
+  Fq a1 = lld(slot(op.a1));
+  if (op.neg_a1) a1 = fp_neg(a1);
+  const Fq b1 = lld(slot(op.b1));
+  Cols k; cols_zero(k);
+  cols_mac(k, a1, b1);
+  if (TWO) {
+    Fq a2 = lld(slot(op.a2));
+    a2 = fsel(op.neg_a2, fp_neg(a2), a2);
+    cols_mac(k, a2, lld(slot(op.b2)));
+  }
+  const Fq prod = cols_reduce(k);
+  const Fq aux = lld(slot(op.aux));
+  uint32_t v[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) v[i] = op.c1 * prod.v[i] + (op.sub_aux ? FqC::subk(i) - aux.v[i] : aux.v[i]);
+  const Fq lin = fp_lazy_reduce<FqC>(v);
+  gsync();                                   // every operand of this level has been read (a level may overwrite its own inputs)
+  if (c.r.g < 100) { lst(c.base + op.dst * SW, prod); lst(c.base + op.dst2 * SW, lin); }
+  gsync();
+}
+// NOTE: rows whose dst/dst2 is P_DUMMY all write the same slot (garbage, never read).  Rows with aux = P_ZERO and c1 = 1 write lin = prod.
+
+__device__ inline void store0(const Ctx& c, int s, const Fq& v) { if (c.r.g == 0) lst(c.base + s * SW, v); }
+__device__ inline Fq slotv(const Ctx& c, int s) { return lld(c.base + s * SW); }
+
+// V <- 2V and the tangent line into the line image
+__device__ __attribute__((noinline)) void point_dbl(const Ctx& c) {
+  level<false>(c, DBL_L1, 0);
+  level<false>(c, DBL_L2, 0);
+  {   // D = 2(t - A - C); X3 = E^2 - 2D; DX = D - X3; C8 = 8C; a = E X - 2B      (every lane computes, the first stores)
+    const Fq t = slotv(c, P_T), A = slotv(c, P_A), C = slotv(c, P_C), EE = slotv(c, P_EE), EX = slotv(c, P_EX), B = slotv(c, P_B), Z3 = slotv(c, P_Z3);
+    const Fq D = fp_dbl(fp_subsub(t, A, C));
+    const Fq X3 = fp_sub2(EE, fp_zero<FqC>(), D);
+    gsync();
+    store0(c, P_DX, fp_sub(D, X3)); store0(c, P_C8, fp_dbl(fp_dbl(fp_dbl(C)))); store0(c, L_A, fp_sub2(EX, fp_zero<FqC>(), B));
+    store0(c, P_X, X3); store0(c, P_Z, Z3);
+    gsync();
+  }
+  level<false>(c, DBL_L3, 0);
+}
+// V <- V + (xp, +-yp) and the chord line
+__device__ __attribute__((noinline)) void point_add(const Ctx& c, bool neg) {
+  const int ysel = neg ? P_YN - P_YP : 0;
+  level<false>(c, ADD_L1, ysel);
+  level<false>(c, ADD_L2, ysel);
+  level<false>(c, ADD_L3, ysel);
+  level<true>(c, ADD_L4, ysel);
+  {   // X3 = R^2 - HHH - 2V; VX = V - X3
+    const Fq RR = slotv(c, P_RR), HHH = slotv(c, P_HHH), VV = slotv(c, P_VV), Z3 = slotv(c, P_Z3);
+    const Fq X3 = fp_sub2(RR, HHH, VV);
+    gsync();
+    store0(c, P_VX, fp_sub(VV, X3)); store0(c, P_X3, X3);
+    gsync();
+  }
+  level<true>(c, ADD_L5, ysel);
+  {
+    const Fq X3 = slotv(c, P_X3), Z3 = slotv(c, P_Z3);
+    gsync();
+    store0(c, P_X, X3); store0(c, P_Z, Z3);
+    gsync();
+  }
+}
+
+// f * line, line already in the line image
+__device__ inline Fq d_mul_line(const Ctx& c, const Fq& f) {
+  expand_first(c.img(0), f, c.r, c.dummy);
+  return dot_line(c.img(0), c.img(LINE_IMG), c.r.m, c.r.part);
+}
+__device__ inline Fq d_one(const Ctx& c) { return fsel(c.r.m == 0 && c.r.part == 0, fp_one<FqC>(), fp_zero<FqC>()); }
+
+// a^|x| (cyclotomic subgroup), |x| = 0xd201000000010000;  uses image 1 for the base
+__device__ __attribute__((noinline)) Fq d_pow_xabs(const Ctx& c, const Fq& a) {
+  expand(c.img(1), a, c.r, c.dummy);
+  Fq r = a;
+#pragma unroll 1
+  for (int i = 62; i >= 0; --i) {
+    r = d_sqr(c, r);
+    if ((BLS_X_ABS >> i) & 1) r = d_mul_img(c, r, 1);
+  }
+  return r;
+}
+// a^e1, e1 = (x-1)^2/3: width-3 signed digits {0, +-1, +-3} as fq12_pow_e1;  a in image 1, a^3 in image 2;  r * conj(m) = conj(conj(r) * m)
+__device__ __attribute__((noinline)) Fq d_pow_e1(const Ctx& c, const Fq& a) {
+  const Fq a3 = d_mul(c, d_sqr(c, a), a);
+  expand(c.img(1), a, c.r, c.dummy);
+  expand(c.img(2), a3, c.r, c.dummy);
+  Fq r = a; bool started = false;
+#pragma unroll 1
+  for (int i = 0; i < E1_WNAF_DIGITS; ++i) {
+    uint32_t nz = 0, ng = 0, th = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { nz = (j == (i >> 5)) ? e1_wnaf_nz_word(j) : nz; ng = (j == (i >> 5)) ? e1_wnaf_neg_word(j) : ng; th = (j == (i >> 5)) ? e1_wnaf_three_word(j) : th; }
+    if (started) r = d_sqr(c, r);
+    if ((nz >> (i & 31)) & 1) {
+      const bool three = (th >> (i & 31)) & 1, neg = (ng >> (i & 31)) & 1;
+      if (!started) { r = three ? a3 : a; if (neg) r = d_conj(c, r); started = true; }
+      else if (neg) r = d_conj(c, d_mul_img(c, d_conj(c, r), three ? 2 : 1));
+      else r = d_mul_img(c, r, three ? 2 : 1);
+    }
+  }
+  return r;
+}
+// f^((q^12-1)/r), exact: the sequence of final_exponentiation (pairing.h)
+__device__ __attribute__((noinline)) Fq d_final_exp(const Ctx& c, const Fq& f) {
+  Fq t = d_inv(c, f);
+  Fq a = d_conj(c, f);
+  Fq g = d_mul(c, a, t);                         // ^(q^6-1)
+  t = d_frob2(c, g);
+  g = d_mul(c, t, g);                            // ^(q^2+1): easy part
+  a = d_pow_e1(c, g);
+  t = d_conj(c, d_pow_xabs(c, a));               // a^x
+  Fq b = d_frob1(c, a);
+  a = d_mul(c, t, b);                            // ^(x+q)
+  t = d_conj(c, d_pow_xabs(c, a));
+  b = d_conj(c, d_pow_xabs(c, t));               // a^(x^2)
+  t = d_frob2(c, a);
+  b = d_mul(c, b, t);
+  t = d_conj(c, a);
+  a = d_mul(c, b, t);                            // ^(x^2+q^2-1)
+  return d_mul(c, a, g);
+}
+
+// one Tate pairing per group.  Marks elements whose P is outside G1 for k_tate_exact_marked, exactly as k_tate does.
+__global__ void __launch_bounds__(64) k_dtate(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t* __restrict__ out, size_t n,
+                                              unsigned long long* err, uint32_t mark_word, uint32_t mark) {
+  __shared__ uint32_t lds[LDS_WORDS];
+  const Ctx c = make_ctx(lds);
+  const int lane = threadIdx.x;
+  size_t e = (size_t)blockIdx.x * GPW + (lane / GL < GPW ? lane / GL : GPW - 1);
+  const bool live = e < n && lane < GPW * GL;
+  if (e >= n) e = n - 1;
+  Aff<FqOps> p = PtIO<FqOps>::ld(g1 + e * ABI_G1_WORDS);
+  Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2 + e * ABI_G2_WORDS);
+  const bool inf = p.inf || q.inf;
+  if (inf) {                                   // RationalFunction::new_* / eval_with_* panic on infinity: report, then run on dummy data to keep the barriers uniform
+    if (live) atomicMin(err, (unsigned long long)e);
+    p.x = fp_one<FqC>(); p.y = fp_one<FqC>(); q.x = fq2_one(); q.y = fq2_one();
+  }
+  {   // slot file: every lane computes the same values, the group's first lane stores them
+    const Fq2 xi_inv = xi_inv_const();
+    const Fq2 Xq = fq2_mul(q.x, xi_inv), Yq = fq2_mul(q.y, xi_inv);
+    store0(c, P_X, p.x); store0(c, P_Y, p.y); store0(c, P_Z, fp_one<FqC>());
+    store0(c, P_XP, p.x); store0(c, P_YP, p.y); store0(c, P_YN, fp_neg(p.y));
+    store0(c, P_XQ0, Xq.c0); store0(c, P_XQ1, Xq.c1); store0(c, P_XQS, fp_sub(Xq.c0, Xq.c1)); store0(c, P_XQT, fp_add(Xq.c0, Xq.c1));
+    store0(c, P_YQ0, Yq.c0); store0(c, P_YQ1, Yq.c1); store0(c, P_YQS, fp_sub(Yq.c0, Yq.c1)); store0(c, P_YQT, fp_add(Yq.c0, Yq.c1));
+    store0(c, P_ZERO, fp_zero<FqC>());
+    // line coefficient 0 is real: its Y / S / T slots are never read by dot_line
+    gsync();
+  }
+  Fq f = d_one(c);
+#pragma unroll 1
+  for (int i = 0; i < MILLER_NAF_DIGITS; ++i) {
+    uint32_t nz = 0, ng = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { nz = (j == (i >> 5)) ? miller_naf_nz_word(j) : nz; ng = (j == (i >> 5)) ? miller_naf_neg_word(j) : ng; }
+    const bool bit = (nz >> (i & 31)) & 1, neg = (ng >> (i & 31)) & 1;
+    f = d_sqr(c, f);
+    point_dbl(c);
+    f = d_mul_line(c, f);
+    if (bit) { point_add(c, neg); f = d_mul_line(c, f); }
+  }
+  // r P == infinity?  V = (r-1) P must equal -P
+  const Fq X = slotv(c, P_X), Y = slotv(c, P_Y), Z = slotv(c, P_Z);
+  bool in_g1 = !fp_is_zero(Z);
+  {
+    const Fq ZZ = fp_sqr(Z);
+    in_g1 = in_g1 && fp_eq(fp_mul(p.x, ZZ), X) && fp_eq(fp_mul(fp_mul(p.y, ZZ), Z), fp_neg(Y));
+  }
+  const Fq r = d_final_exp(c, f);
+  if (!live || inf) return;
+  if (!in_g1) { if (c.r.g == 0) out[e * 144 + mark_word] = mark; return; }
+  st_fp<FqC>(out + e * 144 + abi_word(c.r.m, c.r.part), r);
+}
+}  // namespace dp
+
+hipError_t launch_dfq12_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(dp::k_dfq12_op, dim3((unsigned)((n + dp::GPW - 1) / dp::GPW)), dim3(64), 0, s, op, a, b, out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_dtate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, uint32_t mark_word, uint32_t mark, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(dp::k_dtate, dim3((unsigned)((n + dp::GPW - 1) / dp::GPW)), dim3(64), 0, s, g1, g2, out, n, err, mark_word, mark);
+  return hipGetLastError();
+}
+
+}  // namespace zkt

@@ -43,6 +43,10 @@ hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uin
 // Slot k reads its G1 point at g1[k] + i*s1[k] words (stride 0 = the same point for every element), likewise G2; neg[k] negates P_k.
 struct PairArgs { const uint32_t* g1[4]; const uint32_t* g2[4]; uint32_t s1[4], s2[4]; uint32_t neg[4]; };
 hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s);
+// lane-distributed pairing (zkt_dpairing.hip): diagnostic Fq12 ops on the distributed form
+hipError_t launch_dfq12_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n, hipStream_t s);
+// one pairing per 12 lanes; elements whose P is outside G1 get out[i*144 + mark_word] = mark (see zkt_tate.hip)
+hipError_t launch_dtate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, uint32_t mark_word, uint32_t mark, hipStream_t s);
 hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s);
 
 // ---- MSM (zkt_msm.hip), generic over the group (G_G1, G_G2, G_SECP) ------------------------------------------

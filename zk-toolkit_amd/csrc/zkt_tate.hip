@@ -7,6 +7,7 @@
 // -DZKT_TATE_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))' the extra spills (9.5 instead of 7.9 KB of scratch per lane) cost more
 // than the issue rate gains: 426 k instead of 667 k pairings/s.  The default therefore stays at one wave per SIMD until the Fq12
 // working set is cut (or spread over several lanes).
+#include <cstdlib>
 #include "abi.h"
 #include "zkt_internal.h"
 
@@ -52,6 +53,12 @@ __global__ void __launch_bounds__(64) k_tate_exact_marked(const uint32_t* __rest
 
 hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s) {
   if (n == 0) return hipSuccess;
+  // small batches: one pairing per 12 lanes (zkt_dpairing.hip) — ~10x lower latency per pairing, lower peak throughput.  ZKT_DTATE_MAX overrides the switch-over.
+  static const size_t dmax = [] { const char* e = getenv("ZKT_DTATE_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)2048; }();
+  if (n <= dmax) {
+    hipError_t e = launch_dtate(g1, g2, out, n, err, TATE_MARK_WORD, TATE_MARK, s);
+    if (e != hipSuccess) return e;
+  } else
   hipLaunchKernelGGL(k_tate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
   hipLaunchKernelGGL(k_tate_exact_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
   return hipGetLastError();
