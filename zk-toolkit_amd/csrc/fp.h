@@ -421,6 +421,12 @@ template <class C> ZKT_HD void bgcd_inverse(uint32_t* io) {
 #pragma unroll
   for (int i = 0; i < N; ++i) { u[i] = io[i]; v[i] = C::mod32(i); x1[i] = 0; x2[i] = 0; }
   u[N] = v[N] = x1[N] = x2[N] = 0; x1[0] = 1;
+  {   // zero has no inverse and would never leave the halving loop below: callers test for it, this is the backstop (result 0)
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) any |= u[i];
+    if (any == 0) return;
+  }
   auto is_one = [&](const uint32_t* t) { uint32_t o = t[0] ^ 1u;
 #pragma unroll
     for (int i = 1; i <= N; ++i) o |= t[i]; return o == 0; };

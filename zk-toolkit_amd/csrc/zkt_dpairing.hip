@@ -196,7 +196,7 @@ __device__ __attribute__((noinline)) Fq d_inv(const Ctx& c, const Fq& a) {
   if (c.r.g == 0) {
     auto co = [&](int m) { return Fq2{lld(c.img(0) + (IX + m) * SW), lld(c.img(0) + (IY + m) * SW)}; };
     Fq12 t; t.c0 = Fq6{co(0), co(2), co(4)}; t.c1 = Fq6{co(1), co(3), co(5)};
-    const Fq12 r = fq12_inv(t);
+    const Fq12 r = fq12_is_zero(t) ? t : fq12_inv(t);      // a Miller value of 0 (P outside G1, discarded later) must not reach the inversion
     auto put = [&](int m, const Fq2& v) { lst(c.img(0) + (IX + m) * SW, v.c0); lst(c.img(0) + (IY + m) * SW, v.c1); };
     put(0, r.c0.c0); put(2, r.c0.c1); put(4, r.c0.c2); put(1, r.c1.c0); put(3, r.c1.c1); put(5, r.c1.c2);
   }
@@ -443,6 +443,37 @@ __device__ __attribute__((noinline)) Fq d_final_exp(const Ctx& c, const Fq& f) {
   return d_mul(c, a, g);
 }
 
+// f_{r-1,P}(untwist(Q)) up to Fq6 factors for the group's pair, as miller_g1_g2 (pairing.h); in_g1 <- r P == infinity
+__device__ __attribute__((noinline)) Fq d_miller(const Ctx& c, const Aff<FqOps>& p, const Aff<Fq2Ops>& q, bool& in_g1) {
+  {   // slot file: every lane computes the same values, the group's first lane stores them
+    const Fq2 xi_inv = xi_inv_const();
+    const Fq2 Xq = fq2_mul(q.x, xi_inv), Yq = fq2_mul(q.y, xi_inv);
+    store0(c, P_X, p.x); store0(c, P_Y, p.y); store0(c, P_Z, fp_one<FqC>());
+    store0(c, P_XP, p.x); store0(c, P_YP, p.y); store0(c, P_YN, fp_neg(p.y));
+    store0(c, P_XQ0, Xq.c0); store0(c, P_XQ1, Xq.c1); store0(c, P_XQS, fp_sub(Xq.c0, Xq.c1)); store0(c, P_XQT, fp_add(Xq.c0, Xq.c1));
+    store0(c, P_YQ0, Yq.c0); store0(c, P_YQ1, Yq.c1); store0(c, P_YQS, fp_sub(Yq.c0, Yq.c1)); store0(c, P_YQT, fp_add(Yq.c0, Yq.c1));
+    store0(c, P_ZERO, fp_zero<FqC>());
+    gsync();                               // (line coefficient 0 is real: its Y / S / T slots are never read by dot_line)
+  }
+  Fq f = d_one(c);
+#pragma unroll 1
+  for (int i = 0; i < MILLER_NAF_DIGITS; ++i) {
+    uint32_t nz = 0, ng = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { nz = (j == (i >> 5)) ? miller_naf_nz_word(j) : nz; ng = (j == (i >> 5)) ? miller_naf_neg_word(j) : ng; }
+    const bool bit = (nz >> (i & 31)) & 1, neg = (ng >> (i & 31)) & 1;
+    f = d_sqr(c, f);
+    point_dbl(c);
+    f = d_mul_line(c, f);
+    if (bit) { point_add(c, neg); f = d_mul_line(c, f); }
+  }
+  // r P == infinity?  V = (r-1) P must equal -P
+  const Fq X = slotv(c, P_X), Y = slotv(c, P_Y), Z = slotv(c, P_Z);
+  const Fq ZZ = fp_sqr(Z);
+  in_g1 = !fp_is_zero(Z) && fp_eq(fp_mul(p.x, ZZ), X) && fp_eq(fp_mul(fp_mul(p.y, ZZ), Z), fp_neg(Y));
+  return f;
+}
+
 // one Tate pairing per group.  Marks elements whose P is outside G1 for k_tate_exact_marked, exactly as k_tate does.
 __global__ void __launch_bounds__(64) k_dtate(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t* __restrict__ out, size_t n,
                                               unsigned long long* err, uint32_t mark_word, uint32_t mark) {
@@ -459,41 +490,63 @@ __global__ void __launch_bounds__(64) k_dtate(const uint32_t* __restrict__ g1, c
     if (live) atomicMin(err, (unsigned long long)e);
     p.x = fp_one<FqC>(); p.y = fp_one<FqC>(); q.x = fq2_one(); q.y = fq2_one();
   }
-  {   // slot file: every lane computes the same values, the group's first lane stores them
-    const Fq2 xi_inv = xi_inv_const();
-    const Fq2 Xq = fq2_mul(q.x, xi_inv), Yq = fq2_mul(q.y, xi_inv);
-    store0(c, P_X, p.x); store0(c, P_Y, p.y); store0(c, P_Z, fp_one<FqC>());
-    store0(c, P_XP, p.x); store0(c, P_YP, p.y); store0(c, P_YN, fp_neg(p.y));
-    store0(c, P_XQ0, Xq.c0); store0(c, P_XQ1, Xq.c1); store0(c, P_XQS, fp_sub(Xq.c0, Xq.c1)); store0(c, P_XQT, fp_add(Xq.c0, Xq.c1));
-    store0(c, P_YQ0, Yq.c0); store0(c, P_YQ1, Yq.c1); store0(c, P_YQS, fp_sub(Yq.c0, Yq.c1)); store0(c, P_YQT, fp_add(Yq.c0, Yq.c1));
-    store0(c, P_ZERO, fp_zero<FqC>());
-    // line coefficient 0 is real: its Y / S / T slots are never read by dot_line
-    gsync();
-  }
-  Fq f = d_one(c);
-#pragma unroll 1
-  for (int i = 0; i < MILLER_NAF_DIGITS; ++i) {
-    uint32_t nz = 0, ng = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { nz = (j == (i >> 5)) ? miller_naf_nz_word(j) : nz; ng = (j == (i >> 5)) ? miller_naf_neg_word(j) : ng; }
-    const bool bit = (nz >> (i & 31)) & 1, neg = (ng >> (i & 31)) & 1;
-    f = d_sqr(c, f);
-    point_dbl(c);
-    f = d_mul_line(c, f);
-    if (bit) { point_add(c, neg); f = d_mul_line(c, f); }
-  }
-  // r P == infinity?  V = (r-1) P must equal -P
-  const Fq X = slotv(c, P_X), Y = slotv(c, P_Y), Z = slotv(c, P_Z);
-  bool in_g1 = !fp_is_zero(Z);
-  {
-    const Fq ZZ = fp_sqr(Z);
-    in_g1 = in_g1 && fp_eq(fp_mul(p.x, ZZ), X) && fp_eq(fp_mul(fp_mul(p.y, ZZ), Z), fp_neg(Y));
-  }
+  bool in_g1;
+  const Fq f = d_miller(c, p, q, in_g1);
   const Fq r = d_final_exp(c, f);
   if (!live || inf) return;
   if (!in_g1) { if (c.r.g == 0) out[e * 144 + mark_word] = mark; return; }
   st_fp<FqC>(out + e * 144 + abi_word(c.r.m, c.r.part), r);
 }
+
+// prod_k tate(+-P_k, Q_k) == target (or == 1) per element, K <= 4 pairs: the K Miller loops run side by side in K groups of one wave,
+// the group results meet in the first group's LDS image, ONE final exponentiation follows.  Same contract as k_pairing_product_check /
+// k_groth16_verify (zkt_pairing.hip): infinity -> error index, a G1 argument outside the order-r subgroup -> ok = 0.
+template <int K>
+__global__ void __launch_bounds__(64) k_dproduct(PairArgs a, const uint32_t* __restrict__ target, uint32_t* __restrict__ ok, size_t n, unsigned long long* err) {
+  __shared__ uint32_t lds[LDS_WORDS];
+  const Ctx c = make_ctx(lds);
+  constexpr int EPB = GPW / K;                                    // elements per wave
+  const int lane = threadIdx.x;
+  const int grp = lane / GL < GPW ? lane / GL : GPW - 1;
+  const bool idle = grp >= EPB * K;                               // spare groups (and lanes 60-63) repeat the first pair and never report
+  const int eb = idle ? 0 : grp / K, pair = idle ? 0 : grp % K;
+  size_t e = (size_t)blockIdx.x * EPB + eb;
+  const bool live = !idle && e < n && lane < GPW * GL;
+  if (e >= n) e = n - 1;
+  uint32_t* lead = lds + (idle ? grp : eb * K) * GROUP_WORDS;     // the element's first group
+  Aff<FqOps> p = PtIO<FqOps>::ld(a.g1[pair] + e * a.s1[pair]);
+  Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(a.g2[pair] + e * a.s2[pair]);
+  bool inf = p.inf || q.inf;
+  if (inf) { p.x = fp_one<FqC>(); p.y = fp_one<FqC>(); q.x = fq2_one(); q.y = fq2_one(); }
+  if (a.neg[pair]) p.y = fp_neg(p.y);
+  bool in_g1;
+  Fq f = d_miller(c, p, q, in_g1);
+  // element-wide flags: every lane of the element's K groups must agree
+  const int start = eb * K * GL;
+  const unsigned long long emask = (K * GL >= 64 ? ~0ull : ((1ull << (K * GL)) - 1ull)) << start;
+  const unsigned long long bad_inf = __ballot(inf) & emask, bad_g1 = __ballot(!in_g1) & emask;
+  // the other groups' Miller values into the first group's image 1, one after the other; everybody multiplies (only the first group's product is used)
+#pragma unroll 1
+  for (int k = 1; k < K; ++k) {
+    expand(pair == k && !idle ? lead + 1 * IMG_SLOTS * SW : c.img(2), f, c.r, c.dummy);
+    expand_first(c.img(0), f, c.r, c.dummy);
+    const Fq prod = dot_mul(c.img(0), lead + 1 * IMG_SLOTS * SW, c.r.m, c.r.part);
+    f = (pair == 0) ? prod : f;                                   // groups k > 0 keep their own value until it has been handed over
+  }
+  const Fq r = d_final_exp(c, f);
+  uint32_t w[12]; fp_to_words(r, w);
+  uint32_t diff = 0;
+  const int off = abi_word(c.r.m, c.r.part);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) diff |= w[i] ^ (target ? target[off + i] : (off == 132 && i == 0 ? 1u : 0u));      // canonical one: w0.v0.u0 = 1
+  const unsigned long long lmask = ((1ull << GL) - 1ull) << start;                  // the first group's lanes
+  const unsigned long long neq = __ballot(diff != 0) & lmask;
+  if (live && pair == 0 && c.r.g == 0) {
+    if (bad_inf) { atomicMin(err, (unsigned long long)e); ok[e] = 0; }
+    else ok[e] = (neq == 0 && bad_g1 == 0) ? 1u : 0u;
+  }
+}
+
 }  // namespace dp
 
 hipError_t launch_dfq12_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n, hipStream_t s) {
@@ -502,6 +555,18 @@ hipError_t launch_dfq12_op(int op, const uint32_t* a, const uint32_t* b, uint32_
   return hipGetLastError();
 }
 
+hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  auto blocks = [&](int epb) { return dim3((unsigned)((n + epb - 1) / epb)); };
+  switch (K) {
+    case 1: hipLaunchKernelGGL(dp::k_dproduct<1>, blocks(5), dim3(64), 0, s, a, target, ok, n, err); break;
+    case 2: hipLaunchKernelGGL(dp::k_dproduct<2>, blocks(2), dim3(64), 0, s, a, target, ok, n, err); break;
+    case 3: hipLaunchKernelGGL(dp::k_dproduct<3>, blocks(1), dim3(64), 0, s, a, target, ok, n, err); break;
+    case 4: hipLaunchKernelGGL(dp::k_dproduct<4>, blocks(1), dim3(64), 0, s, a, target, ok, n, err); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 hipError_t launch_dtate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, uint32_t mark_word, uint32_t mark, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(dp::k_dtate, dim3((unsigned)((n + dp::GPW - 1) / dp::GPW)), dim3(64), 0, s, g1, g2, out, n, err, mark_word, mark);

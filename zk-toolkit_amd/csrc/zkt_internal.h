@@ -39,6 +39,10 @@ hipError_t launch_miller_exact(int which, const uint32_t* g1, const uint32_t* g2
 hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
                                  const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* ok, size_t n,
                                  unsigned long long* err, hipStream_t s);
+size_t dproduct_limit();      // elements x pairs up to which the verification entry points use the lane-distributed kernels
+hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
+                                       const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* tmp, uint32_t* S, uint32_t* ok, size_t n,
+                                       unsigned long long* err, hipStream_t s);
 // prod_k tate(+-P_k, Q_k) == 1 per element, K <= 4 pairs sharing one Miller squaring chain and one final exponentiation.
 // Slot k reads its G1 point at g1[k] + i*s1[k] words (stride 0 = the same point for every element), likewise G2; neg[k] negates P_k.
 struct PairArgs { const uint32_t* g1[4]; const uint32_t* g2[4]; uint32_t s1[4], s2[4]; uint32_t neg[4]; };
@@ -47,6 +51,8 @@ hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, 
 hipError_t launch_dfq12_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n, hipStream_t s);
 // one pairing per 12 lanes; elements whose P is outside G1 get out[i*144 + mark_word] = mark (see zkt_tate.hip)
 hipError_t launch_dtate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, uint32_t mark_word, uint32_t mark, hipStream_t s);
+// prod_k tate(+-P_k, Q_k) == target (NULL: == 1) with the K Miller loops in K lane groups of one wave (small batches)
+hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s);
 hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s);
 
 // ---- MSM (zkt_msm.hip), generic over the group (G_G1, G_G2, G_SECP) ------------------------------------------

@@ -1,5 +1,6 @@
 // Pairing kernels other than the plain batched Tate pairing (zkt_tate.hip): raw Miller values / Weil (row a14), the fused
 // Groth16 verification (f-2) and pairing-product equalities (f-4).  The algorithm and why it is bit-identical to the reference are in pairing.h.
+#include <cstdlib>
 #include "abi.h"
 #include "zkt_internal.h"
 
@@ -54,6 +55,32 @@ __global__ void __launch_bounds__(64) k_groth16_verify(const uint32_t* __restric
   for (int k = 0; k < 144; ++k) diff |= got[k] ^ alpha_beta[k];
   ok[i] = diff == 0;
 }
+// S_i = sum_j terms[j*n + i] for the small-batch verification path (the terms stmt[i][j] * uvw_stmt[j] come from one batched
+// scalar multiplication, one lane per term, instead of n_stmt serial ones in the proof's lane)
+__global__ void __launch_bounds__(64) k_stmt_sums(const uint32_t* __restrict__ terms, int n_stmt, uint32_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Jac<FqOps> acc = jac_inf<FqOps>();
+  for (int j = 0; j < n_stmt; ++j) acc = jac_add_aff(acc, PtIO<FqOps>::ld(terms + ((size_t)j * n + i) * ABI_G1_WORDS));
+  PtIO<FqOps>::st(out + i * ABI_G1_WORDS, jac_to_aff(acc));
+}
+// e(A,B) == alpha_beta e(S,gamma) e(C,delta) per proof on the lane-distributed kernels; tmp: n_stmt * n G1 points, S: n G1 points (device)
+hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
+                                       const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* tmp, uint32_t* S, uint32_t* ok, size_t n,
+                                       unsigned long long* err, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  if (n_stmt < 1 || n_stmt > 12) return hipErrorInvalidValue;
+  MulSegs segs; segs.n = n_stmt;
+  for (int j = 0; j < n_stmt; ++j) segs.s[j] = MulSeg{uvw_stmt + (size_t)j * ABI_G1_WORDS, stmt + (size_t)j * 8, tmp + (size_t)j * n * ABI_G1_WORDS, (uint32_t)n, 0u, (uint32_t)(n_stmt * 8)};
+  hipError_t e = launch_group_mul_segs(G_G1, segs, 8, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_stmt_sums, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)tmp, n_stmt, S, n);
+  PairArgs a{};
+  a.g1[0] = A; a.s1[0] = ABI_G1_WORDS; a.g2[0] = B; a.s2[0] = ABI_G2_WORDS; a.neg[0] = 0;
+  a.g1[1] = S; a.s1[1] = ABI_G1_WORDS; a.g2[1] = gamma; a.s2[1] = 0; a.neg[1] = 1;
+  a.g1[2] = C; a.s1[2] = ABI_G1_WORDS; a.g2[2] = delta; a.s2[2] = 0; a.neg[2] = 1;
+  return launch_dproduct(a, 3, alpha_beta, ok, n, err, s);
+}
 hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
                                  const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* ok, size_t n,
                                  unsigned long long* err, hipStream_t s) {
@@ -86,8 +113,11 @@ __global__ void __launch_bounds__(64) k_pairing_product_check(PairArgs a, uint32
   for (int k = 0; k < 144; ++k) if (k != 132) diff |= got[k];
   ok[i] = diff == 0;
 }
+// small batches go to the lane-distributed kernels (zkt_dpairing.hip): ~10 ms per element instead of ~100 ms, lower peak throughput
+size_t dproduct_limit() { static const size_t v = [] { const char* e = getenv("ZKT_DPRODUCT_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)2048; }(); return v; }
 hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s) {
   if (n == 0) return hipSuccess;
+  if (n * (size_t)K <= dproduct_limit()) return launch_dproduct(a, K, nullptr, ok, n, err, s);
   dim3 g((unsigned)((n + 63) / 64)), t(64);
   switch (K) {
     case 1: hipLaunchKernelGGL(k_pairing_product_check<1>, g, t, 0, s, a, ok, n, err); break;
