@@ -1,0 +1,25 @@
+import ctypes, importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from zkt_testlib import *
+from qap_util import *
+zk = importlib.import_module("zk-toolkit_amd"); zk.init(); L = zk.lib()
+fr = lambda v: ints_to_arr([v], 4)
+A_, B_, C_, wit, l = example_cubic()
+nn, m = len(A_), len(wit) - 1
+ui, vi, wi, h, _ = qap_from_r1cs(A_, B_, C_, wit)
+U, V, W = dense(ui, nn), dense(vi, nn), dense(wi, nn)
+sm = SplitMix64(71); trap = [fr(sm.below(R - 1) + 1) for _ in range(5)]
+crs, buf = alloc_crs(nn, l, m)
+zk.check(L.zkt_groth16_setup(ctypes.byref(crs), ptr(U), ptr(V), ptr(W), *[ptr(t) for t in trap]))
+wires = ints_to_arr(wit, 4); H = ints_to_arr(h, 4)
+pa, pb, pc = np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64)
+zk.check(L.zkt_groth16_prove(ctypes.byref(crs), ptr(U), ptr(V), ptr(wires), ptr(H), len(h), ptr(fr(12345)), ptr(fr(6789)), ptr(pa), ptr(pb), ptr(pc)))
+stmt = ints_to_arr(wit[:l + 1], 4)
+for k in (1, 16, 256, 1024, 4096):
+    As, Bs, Cs = np.repeat(pa, k, axis=0), np.repeat(pb, k, axis=0), np.repeat(pc, k, axis=0)
+    st = np.repeat(stmt.reshape(1, -1), k, axis=0).copy(); ok = np.zeros(k, np.uint32)
+    zk.check(L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(st), l + 1, k, ok.ctypes.data))
+    t0 = time.perf_counter(); zk.check(L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(st), l + 1, k, ok.ctypes.data)); dt = time.perf_counter() - t0
+    print("groth16 verify  proofs=%5d  %.2f ms  %.0f/s  all ok=%s  (ZKT_DPRODUCT_MAX=%s)" % (k, dt * 1e3, k / dt, bool(ok.all()), os.environ.get("ZKT_DPRODUCT_MAX", "default")))
