@@ -180,7 +180,8 @@ int zkt_weil_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* o
  * in python integers (tests/test_hostcheck.py for the host build of the same header, tests/test_gpu_parity.py for the device). */
 int zkt_selftest_fq_program(uint64_t seed0, int steps, const uint64_t* in, uint64_t* out, int32_t* violations, size_t count);
 /* Diagnostic (no reference counterpart): Fq12 operations computed on the lane-distributed form of the small-batch pairing (csrc/zkt_dpairing.hip),
- * so that its building blocks can be compared with zkt_fq12_*_batch: op 0 a*b, 1 a^2, 2 a^q, 3 a^(q^2), 4 a^(q^6) (conjugate), 5 1/a. */
+ * so that its building blocks can be compared with zkt_fq12_*_batch: op 0 a*b, 1 a^2, 2 a^q, 3 a^(q^2), 4 a^(q^6) (conjugate), 5 1/a,
+ * 6 a^2 by the Granger-Scott formulas (a in the cyclotomic subgroup). */
 int zkt_debug_dfq12_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* a15: GTPoint == gt_point.rs:33-39 (all 12 coefficients); returns 1/0, or <0 = -status */
 int zkt_gt_eq(const uint64_t* a_fq12, const uint64_t* b_fq12);

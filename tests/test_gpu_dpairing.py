@@ -39,6 +39,13 @@ def test_distributed_fq12_ops(L, n):
         zk.check(L.zkt_debug_dfq12_op(op, ptr(a), None, ptr(got), n))
         zk.check(L.zkt_fq12_pow_batch(ptr(a), limbs.ctypes.data_as(ctypes.c_void_p), len(limbs), ptr(want), n))
         assert (got == want).all(), f"frobenius^{k}"
+    # Granger-Scott squaring on elements of the cyclotomic subgroup: a^((q^6-1)(q^2+1)), then square both ways
+    e = (Q ** 6 - 1) * (Q ** 2 + 1)
+    limbs = np.array([(e >> (32 * i)) & 0xFFFFFFFF for i in range((e.bit_length() + 31) // 32)], dtype=np.uint32)
+    cyc = np.zeros_like(a)
+    zk.check(L.zkt_fq12_pow_batch(ptr(b), limbs.ctypes.data_as(ctypes.c_void_p), len(limbs), ptr(cyc), n))
+    zk.check(L.zkt_debug_dfq12_op(6, ptr(cyc), None, ptr(got), n)); zk.check(L.zkt_fq12_mul_batch(ptr(cyc), ptr(cyc), ptr(want), n))
+    assert (got == want).all(), "cyclotomic square"
 
 
 @pytest.mark.parametrize("n", [1, 4, 5, 11, 64])

@@ -289,7 +289,7 @@ int zkt_selftest_fq_program(uint64_t seed0, int steps, const uint64_t* in, uint6
 
 // diagnostic: Fq12 operations of the lane-distributed pairing (zkt_dpairing.hip), same layouts as zkt_fq12_*_batch
 int zkt_debug_dfq12_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  if (op < 0 || op > 5) return ZKT_ERR_SHAPE;
+  if (op < 0 || op > 6) return ZKT_ERR_SHAPE;
   return staged(a, 576, op == 0 ? b : nullptr, op == 0 ? 576 : 0, out, 576, n, ZKT_ERR_SHAPE,
                 [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_dfq12_op(op, da, db, dout, n, s); });
 }
