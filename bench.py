@@ -367,10 +367,16 @@ def main():
             torch.cuda.synchronize(); t0 = time.perf_counter()
             zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), m, sp))
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            # latency of ONE pairing: batches this small take the lane-distributed kernel (csrc/zkt_dpairing.hip, one pairing per 12 lanes)
+            zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), 1, sp)); torch.cuda.synchronize()
+            t0 = time.perf_counter(); zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), 1, sp)); torch.cuda.synchronize(); lat1 = time.perf_counter() - t0
+            zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), m, sp)); torch.cuda.synchronize()          # restore the full batch for the CPU comparison below
             pt = load_profile(PROFILE_ROUND + "_tate_sq_counters.json") or load_profile("r01_tate_sq_counters.json") or {}
-            pinstr = pt.get("valu_instr_per_pairing")
+            pinstr = pt.get("valu_instr_per_pairing") or pt.get("valu_instructions_per_pairing") or (pt.get("kernels", {}).get("k_tate", {}).get("valu_instr_per_wave"))
             result["pairing"] = {"metric": "Tate pairings/sec", "value": m / dt, "batch": m, "kernel_ms": L.zkt_last_kernel_ms(),
-                                 "hbm_achieved_GBs": PAIRING_BYTES * m / dt / 1e9, "hbm_frac": PAIRING_BYTES * m / dt / 1e9 / HBM_PEAK_GBS}
+                                 "hbm_achieved_GBs": PAIRING_BYTES * m / dt / 1e9, "hbm_frac": PAIRING_BYTES * m / dt / 1e9 / HBM_PEAK_GBS,
+                                 "single_pairing_latency_ms": round(lat1 * 1e3, 3),
+                                 "small_batch_note": "n <= 16,384 runs one pairing per 12 lanes (lane-distributed kernel): ~8 ms for 1..2048 pairings; larger batches one pairing per lane"}
             if pinstr and sq:
                 peak = sq["valu_peak"]["int_mad_lane_ops_per_s_T"]
                 result["pairing"]["valu"] = {"achieved": pinstr * m / dt / 1e12, "peak": peak, "unit": "T lane-instr/s", "frac": pinstr * m / dt / 1e12 / peak,

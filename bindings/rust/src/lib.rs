@@ -8,6 +8,7 @@
 //!   `Polynomial`           building_block/field/polynomial.rs:271-293 (eval_with_g1_hidings / eval_with_g2_hidings)
 //!   `groth16::*`           zk/w_trusted_setup/groth16/zktoolkit_based/{crs,prover,verifier,proof}.rs
 //!   `Bulletproofs`         zk/wo_trusted_setup/bulletproofs.rs
+//!   `Signer`, `PrivateKey` building_block/curves/bls12_381/{signature,private_key}.rs
 //! and forwards to the batch-first C ABI (`ffi`, generated from include/zkt.h).  Conventions carried over from the only native
 //! backend the reference has (building_block/mcl/): one global `init` behind `Once` that panics on failure (mcl_initializer.rs:4-15),
 //! out-parameter free functions underneath, value types with operator overloads on top.  A non-OK status becomes `panic!`, because
@@ -23,6 +24,7 @@ pub mod pairing;
 pub mod polynomial;
 pub mod groth16;
 pub mod bulletproofs;
+pub mod signature;
 pub mod comm;
 
 pub use field::{Fq1, Fr, SecpFq, SecpFr, PrimeFieldElem};
@@ -31,6 +33,7 @@ pub use points::{G1Point, G2Point, SecpPoint};
 pub use pairing::{GTPoint, Pairing};
 pub use polynomial::{Polynomial, G1Bases, G2Bases};
 pub use bulletproofs::Bulletproofs;
+pub use signature::{PrivateKey, Signer};
 
 use std::ffi::CStr;
 use std::sync::Once;

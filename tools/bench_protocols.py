@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the protocol-level entry points on one MI355X, host-pointer API (PCIe included).
-Prints one JSON object; kept as profiles/r01_protocols.json."""
+Prints one JSON object; kept as profiles/r02_protocols.json."""
 import ctypes, importlib, json, os, sys, time
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
