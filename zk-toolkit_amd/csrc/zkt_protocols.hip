@@ -125,6 +125,90 @@ __global__ void __launch_bounds__(256) k_ipa_final_scalars(const uint32_t* __res
   st_raw<C>(sF + k * 8, fp_mul(am, ld_raw<C>(wG + k * 8)));
   st_raw<C>(sF + (N + k) * 8, fp_mul(bm, ld_raw<C>(wH + k * 8)));
 }
+// ---- verdict-only inner-product argument (no trace requested) ---------------------------------------------------------------------------
+// The reference's function returns a bool (bulletproofs.rs:19-55); L_j and R_j are internal.  Without a trace the verdict is
+//   MSM_{[gg|hh|u]}( sF - sum_j (x_j^2 sL_j + x_j^-2 sR_j) ) == P            (k_ipa_comb above)
+// — ONE multi-scalar multiplication.  Its scalar vector needs, per original generator k and level j, one element of the folded a^(j), b^(j)
+// and the running coefficient products wG, wH, so: all challenges up front (one inversion each, in parallel), the fold chain a^(j), b^(j)
+// alone on the critical path (levels below 2048 elements in one block), ONE kernel over the generators that walks all levels with wG, wH in
+// registers, and the 2*levels dot products for the u entry side by side.  33 MSMs and ~130 dependent launches become 1 MSM and ~12 launches.
+// challenges: out[j] = {x_j, x_j^-1, x_j^2, x_j^-2} canonical
+__global__ void __launch_bounds__(64) k_ipa_challenges_all(const uint32_t* __restrict__ xs, int levels, uint32_t* __restrict__ out) {
+  typedef SnC C;
+  const int j = blockIdx.x * 64 + threadIdx.x; if (j >= levels) return;
+  Fp<C> xm = ld_fp<C>(xs + j * 8), xi = fp_inv(xm);
+  st_fp<C>(out + j * 32, xm); st_fp<C>(out + j * 32 + 8, xi); st_fp<C>(out + j * 32 + 16, fp_sqr(xm)); st_fp<C>(out + j * 32 + 24, fp_sqr(xi));
+}
+// a' = a_lo x + a_hi x^-1, b' = b_lo x^-1 + b_hi x (:49-50) for one level, both vectors in one launch
+__global__ void __launch_bounds__(256) k_ipa_fold_ab(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ ch, size_t np,
+                                                     uint32_t* __restrict__ a2, uint32_t* __restrict__ b2) {
+  typedef SnC C;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= np) return;
+  const Fp<C> x = ld_fp<C>(ch), xi = ld_fp<C>(ch + 8);
+  st_raw<C>(a2 + i * 8, fp_add(fp_mul(x, ld_raw<C>(a + i * 8)), fp_mul(xi, ld_raw<C>(a + (np + i) * 8))));
+  st_raw<C>(b2 + i * 8, fp_add(fp_mul(xi, ld_raw<C>(b + i * 8)), fp_mul(x, ld_raw<C>(b + (np + i) * 8))));
+}
+// the remaining levels (n <= 2048) in ONE block: AL / BL hold every level's vector, level j at offset off(j) = 2N - 2N/2^j elements
+__global__ void __launch_bounds__(1024) k_ipa_fold_tail(uint32_t* __restrict__ AL, uint32_t* __restrict__ BL, const uint32_t* __restrict__ ch, size_t N, int lv0, int levels) {
+  typedef SnC C;
+  for (int j = lv0; j < levels; ++j) {
+    const size_t n = N >> j, np = n / 2, o = 2 * N - ((2 * N) >> j), o2 = 2 * N - ((2 * N) >> (j + 1));
+    const Fp<C> x = ld_fp<C>(ch + j * 32), xi = ld_fp<C>(ch + j * 32 + 8);
+    for (size_t i = threadIdx.x; i < np; i += 1024) {
+      st_raw<C>(AL + (o2 + i) * 8, fp_add(fp_mul(x, ld_raw<C>(AL + (o + i) * 8)), fp_mul(xi, ld_raw<C>(AL + (o + np + i) * 8))));
+      st_raw<C>(BL + (o2 + i) * 8, fp_add(fp_mul(xi, ld_raw<C>(BL + (o + i) * 8)), fp_mul(x, ld_raw<C>(BL + (o + np + i) * 8))));
+    }
+    __syncthreads();
+  }
+}
+// scalars of the single MSM for the generators gg[k] and hh[k]: sF - comb, all levels walked with wG[k], wH[k] in registers
+__global__ void __launch_bounds__(256) k_ipa_verdict_scalars(const uint32_t* __restrict__ AL, const uint32_t* __restrict__ BL, const uint32_t* __restrict__ ch,
+                                                             const uint32_t* __restrict__ wH0, size_t N, int levels, uint32_t* __restrict__ sF) {
+  typedef SnC C;
+  size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; if (k >= N) return;
+  Fp<C> wg = fp_one<C>(), wh = wH0 ? ld_fp<C>(wH0 + k * 8) : fp_one<C>();              // Montgomery form in registers
+  Fp<C> cg = fp_zero<C>(), chh = fp_zero<C>();
+  for (int j = 0; j < levels; ++j) {
+    const size_t n = N >> j, np = n / 2, o = 2 * N - ((2 * N) >> j), i = k & (n - 1);
+    const bool hi = i >= np; const size_t idx = hi ? i - np : np + i;                      // k_ipa_level_scalars: a[(hi ? j : np + j)]
+    const Fp<C> x = ld_fp<C>(ch + j * 32), xi = ld_fp<C>(ch + j * 32 + 8), x2 = ld_fp<C>(ch + j * 32 + 16), x2i = ld_fp<C>(ch + j * 32 + 24);
+    const Fp<C> sg = fp_mul(ld_fp<C>(AL + (o + idx) * 8), wg), sh = fp_mul(ld_fp<C>(BL + (o + idx) * 8), wh);
+    cg = fp_add(cg, fp_mul(hi ? x2 : x2i, sg));                                           // gg_hi * a_lo belongs to L (x^2), gg_lo * a_hi to R (x^-2)
+    chh = fp_add(chh, fp_mul(hi ? x2i : x2, sh));                                         // hh_lo * b_hi belongs to L, hh_hi * b_lo to R
+    wg = fp_mul(wg, hi ? x : xi); wh = fp_mul(wh, hi ? xi : x);                           // gg' = gg_lo x^-1 + gg_hi x, hh' = hh_lo x + hh_hi x^-1 (:44-45)
+  }
+  const size_t of = 2 * N - ((2 * N) >> levels);                                          // the final one-element vectors
+  st_fp<C>(sF + k * 8, fp_sub(fp_mul(ld_fp<C>(AL + of * 8), wg), cg));
+  st_fp<C>(sF + (N + k) * 8, fp_sub(fp_mul(ld_fp<C>(BL + of * 8), wh), chh));
+}
+// block (j, side): cL_j = <a_lo, b_hi> (side 0) or cR_j = <a_hi, b_lo> (side 1) of level j (:36-37), times x_j^2 / x_j^-2, into part[2j + side] (Montgomery form)
+__global__ void __launch_bounds__(256) k_ipa_u_dots(const uint32_t* __restrict__ AL, const uint32_t* __restrict__ BL, const uint32_t* __restrict__ ch, size_t N,
+                                                    uint32_t* __restrict__ part) {
+  typedef SnC C;
+  __shared__ uint32_t lds[256 * C::N];
+  const int j = blockIdx.x >> 1, side = blockIdx.x & 1, t = threadIdx.x;
+  const size_t n = N >> j, np = n / 2, o = 2 * N - ((2 * N) >> j);
+  const uint32_t* av = AL + (o + (side ? np : 0)) * 8; const uint32_t* bv = BL + (o + (side ? 0 : np)) * 8;
+  Fp<C> acc = fp_zero<C>();
+  for (size_t i = t; i < np; i += 256) acc = fp_add(acc, fp_mul(ld_fp<C>(av + i * 8), ld_fp<C>(bv + i * 8)));
+  st_raw<C>(lds + t * C::N, acc); __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (t < d) { acc = fp_add(acc, ld_raw<C>(lds + (t + d) * C::N)); st_raw<C>(lds + t * C::N, acc); }
+    __syncthreads();
+  }
+  if (t == 0) st_raw<C>(part + blockIdx.x * 8, fp_mul(acc, ld_fp<C>(ch + j * 32 + (side ? 24 : 16))));
+}
+// sF[2N] = a_fin b_fin - sum of the parts (the coefficient of u)
+__global__ void __launch_bounds__(64) k_ipa_u_scalar(const uint32_t* __restrict__ AL, const uint32_t* __restrict__ BL, const uint32_t* __restrict__ part, size_t N, int levels,
+                                                     uint32_t* __restrict__ sF) {
+  typedef SnC C;
+  if (threadIdx.x || blockIdx.x) return;
+  const size_t of = 2 * N - ((2 * N) >> levels);
+  Fp<C> v = fp_mul(ld_fp<C>(AL + of * 8), ld_fp<C>(BL + of * 8));
+  for (int i = 0; i < 2 * levels; ++i) v = fp_sub(v, ld_raw<C>(part + i * 8));
+  st_fp<C>(sF + 2 * N * 8, v);
+}
+
 // dot = sum_i a[i]*b[i] (one block); PrimeFieldElems * PrimeFieldElems then sum (prime_field_elems.rs:90-174)
 template <class C>
 __global__ void __launch_bounds__(256) k_dot(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n, uint32_t* __restrict__ out) {
@@ -354,6 +438,7 @@ struct zkt_bp_ipa_ctx {
   static constexpr size_t IPA_BATCH = 4;   // levels per product launch: a 256-bit double-and-add is ~4 ms however few points it covers
   size_t N, NB, levels, lv1;
   Dev dbase, da, db, da2, db2, dwG, dwH, dsc, dPp, dx, dch, dsq, dc, dlr, dm, dt, dcomb;
+  Dev dAL, dBL, dchall, dpart;             // verdict-only form: every level's a, b (2N elements each), all challenges, the u-entry parts
   zkt_secp_bases* set = nullptr;
   std::mutex mu;                           // a context serves one call at a time: concurrent callers queue here
   std::vector<hipStream_t> side;           // one stream per product batch, so the batches overlap each other and the MSMs
@@ -361,8 +446,9 @@ struct zkt_bp_ipa_ctx {
   static size_t log2z(size_t n) { size_t l = 0; for (size_t t = n; t > 1; t >>= 1) ++l; return l; }
   explicit zkt_bp_ipa_ctx(size_t n)
       : N(n), NB(2 * n + 1), levels(log2z(n)), lv1(levels ? levels : 1), dbase(NB * SPB), da(N * FRB), db(N * FRB), da2(N * FRB), db2(N * FRB), dwG(N * FRB), dwH(N * FRB),
-        dsc((size_t)IPA_SLOTS * NB * FRB), dPp(SPB), dx(lv1 * FRB), dch(4 * FRB), dsq(lv1 * 2 * FRB), dc(2 * FRB), dlr(lv1 * 2 * SPB), dm(lv1 * 2 * SPB), dt(SPB), dcomb(NB * FRB) {}
-  bool ok() const { return dbase.p && da.p && db.p && da2.p && db2.p && dwG.p && dwH.p && dsc.p && dPp.p && dx.p && dch.p && dsq.p && dc.p && dlr.p && dm.p && dt.p && dcomb.p; }
+        dsc((size_t)IPA_SLOTS * NB * FRB), dPp(SPB), dx(lv1 * FRB), dch(4 * FRB), dsq(lv1 * 2 * FRB), dc(2 * FRB), dlr(lv1 * 2 * SPB), dm(lv1 * 2 * SPB), dt(SPB), dcomb(NB * FRB),
+        dAL(2 * N * FRB), dBL(2 * N * FRB), dchall(lv1 * 4 * FRB), dpart(lv1 * 2 * FRB) {}
+  bool ok() const { return dbase.p && da.p && db.p && da2.p && db2.p && dwG.p && dwH.p && dsc.p && dPp.p && dx.p && dch.p && dsq.p && dc.p && dlr.p && dm.p && dt.p && dcomb.p && dAL.p && dBL.p && dchall.p && dpart.p; }
   ~zkt_bp_ipa_ctx() {
     for (hipStream_t x : side) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
     if (ev) hipEventDestroy(ev);
@@ -403,6 +489,32 @@ static int ipa_run(zkt_bp_ipa_ctx* c, const zkt_secp_affine* P, const uint64_t* 
   for (size_t lv = 0; lv < levels; ++lv) {                    // challenge x (:42, injected) must be invertible
     bool zero = true; for (int j = 0; j < 4; ++j) zero = zero && xs[lv * 4 + j] == 0;
     if (zero) return -ZKT_ERR_INV_ZERO;
+  }
+  if (!out_trace && levels >= 1) {           // verdict only: one MSM (see k_ipa_challenges_all)
+    uint32_t *AL = c->dAL.w(), *BL = c->dBL.w(), *CH = c->dchall.w();
+    if (hipMemcpyAsync(AL, a, N * FRB, hipMemcpyDefault, s) != hipSuccess || hipMemcpyAsync(BL, b, N * FRB, hipMemcpyDefault, s) != hipSuccess ||
+        hipMemcpyAsync(c->dPp.p, P, SPB, hipMemcpyDefault, s) != hipSuccess) return -ZKT_ERR_DEVICE;
+    int rc2;
+    if ((rc2 = up(c->dx, xs, levels * FRB, s))) return -rc2;
+    hipLaunchKernelGGL(k_ipa_challenges_all, dim3((unsigned)((levels + 63) / 64)), dim3(64), 0, s, (const uint32_t*)c->dx.w(), (int)levels, CH);
+    size_t lv = 0;
+    for (; lv < levels && (N >> lv) > 2048; ++lv) {
+      const size_t np = (N >> lv) / 2, o = 2 * N - ((2 * N) >> lv), o2 = 2 * N - ((2 * N) >> (lv + 1));
+      hipLaunchKernelGGL(k_ipa_fold_ab, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const uint32_t*)(AL + o * 8), (const uint32_t*)(BL + o * 8), (const uint32_t*)(CH + lv * 32), np,
+                         AL + o2 * 8, BL + o2 * 8);
+    }
+    if (lv < levels) hipLaunchKernelGGL(k_ipa_fold_tail, dim3(1), dim3(1024), 0, s, AL, BL, (const uint32_t*)CH, N, (int)lv, (int)levels);
+    uint32_t* sF = c->dsc.w();                                    // slot 0's scalar buffer
+    hipLaunchKernelGGL(k_ipa_verdict_scalars, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (const uint32_t*)AL, (const uint32_t*)BL, (const uint32_t*)CH, wH0, N, (int)levels, sF);
+    hipLaunchKernelGGL(k_ipa_u_dots, dim3((unsigned)(2 * levels)), dim3(256), 0, s, (const uint32_t*)AL, (const uint32_t*)BL, (const uint32_t*)CH, N, c->dpart.w());
+    hipLaunchKernelGGL(k_ipa_u_scalar, dim3(1), dim3(64), 0, s, (const uint32_t*)AL, (const uint32_t*)BL, (const uint32_t*)c->dpart.w(), N, (int)levels, sF);
+    if (hipGetLastError() != hipSuccess) return -ZKT_ERR_DEVICE;
+    zkt_secp_affine rhs, lhs;
+    if ((rc2 = zkt_secp_msm_submit(c->set, (const uint64_t*)sF, NB, s, 0))) return -rc2;
+    if ((rc2 = zkt_secp_msm_collect(c->set, 0, &rhs, nullptr))) return -rc2;
+    if ((rc2 = down(&lhs, c->dPp.p, SPB, s))) return -rc2;
+    if (hipStreamSynchronize(s) != hipSuccess) return -ZKT_ERR_DEVICE;
+    return memcmp(&rhs, &lhs, SPB) == 0 ? 1 : 0;
   }
   Dev &da = c->da, &db = c->db, &da2 = c->da2, &db2 = c->db2, &dwG = c->dwG, &dwH = c->dwH, &dsc = c->dsc, &dPp = c->dPp, &dx = c->dx, &dch = c->dch, &dsq = c->dsq, &dc = c->dc,
       &dlr = c->dlr, &dm = c->dm, &dt = c->dt;
