@@ -253,7 +253,8 @@ int zkt_pinocchio_verify(const zkt_pinocchio_crs* crs, const zkt_pinocchio_proof
 
 /* a18: Bulletproofs::inner_product_argument bulletproofs.rs:19-55 over secp256k1; n a power of two; a, b are 4-limb
  * residues mod the group order; xs = one challenge per level (the reference draws them at bulletproofs.rs:42).
- * out_trace (optional): per level {L, R, P'}.  Returns 1/0 like the reference's bool, negative = -status. */
+ * out_trace (optional): per level {L, R, P'}.  Returns 1/0 like the reference's bool, negative = -status.
+ * Without a trace only the bool is observable and the argument collapses to ONE multi-scalar multiplication over [gg | hh | u] (L_j, R_j are never formed). */
 int zkt_bp_inner_product_argument(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u,
                                   const zkt_secp_affine* P, const uint64_t* a, const uint64_t* b, const uint64_t* xs,
                                   zkt_secp_affine* out_trace);
@@ -273,6 +274,11 @@ int zkt_bp_inner_product_argument_ctx(zkt_bp_ipa_ctx* ctx, const zkt_secp_affine
 int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, const uint64_t* gamma, const zkt_secp_affine* g,
                        const zkt_secp_affine* h, const zkt_secp_affine* gg, const zkt_secp_affine* hh, int use_ipa,
                        const uint64_t* rnd, const zkt_secp_affine* u, const uint64_t* xs, zkt_secp_affine* out_pts);
+
+/* The same range proof over a context's resident generators (gg, hh, u of zkt_bp_ipa_ctx_create; n = the context's size): no table build and no
+ * generator upload per proof.  Results are identical to zkt_bp_range_proof. */
+int zkt_bp_range_proof_ctx(zkt_bp_ipa_ctx* ctx, const zkt_secp_affine* V, const uint64_t* aL, const uint64_t* gamma, const zkt_secp_affine* g,
+                           const zkt_secp_affine* h, int use_ipa, const uint64_t* rnd, const uint64_t* xs, zkt_secp_affine* out_pts);
 
 /* ---- device-resident entry points (inputs/outputs already in HBM) -------------------- */
 /* Bases kept on the device in kernel layout (internal limb form, x and y, 112 B per G1 point) — the analogue of

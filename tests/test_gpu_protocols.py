@@ -161,6 +161,15 @@ def test_range_proof_vs_oracle(L, n, value):          # bulletproofs.rs:58-147 /
         assert (gp == op).all()                       # A, S, T1, T2, P identical
         bad = aL.copy(); bad[1, 0] ^= 1
         assert L.zkt_bp_range_proof(n, ptr(V), ptr(bad), ptr(gamma), ptr(g), ptr(h), ptr(gg), ptr(hh), use_ipa, ptr(rnd), ptr(u), ptr(xs), None) == 0
+    # the same proofs over one context with resident generators: identical points and verdicts, the context reused across calls
+    ctx = ctypes.c_void_p(); zk.check(L.zkt_bp_ipa_ctx_create(n, ptr(gg), ptr(hh), ptr(u), ctypes.byref(ctx)))
+    for use_ipa in (0, 1, 0):
+        gp, op = np.zeros((5, 9), np.uint64), np.zeros((5, 9), np.uint64)
+        assert O.zkto_bp_range_proof(n, ptr(V), ptr(aL), ptr(gamma), ptr(g), ptr(h), ptr(gg), ptr(hh), use_ipa, ptr(rnd), ptr(u), ptr(xs), ptr(op)) == 1
+        assert L.zkt_bp_range_proof_ctx(ctx, ptr(V), ptr(aL), ptr(gamma), ptr(g), ptr(h), use_ipa, ptr(rnd), ptr(xs), ptr(gp)) == 1
+        assert (gp == op).all()
+        assert L.zkt_bp_range_proof_ctx(ctx, ptr(V), ptr(bad), ptr(gamma), ptr(g), ptr(h), use_ipa, ptr(rnd), ptr(xs), None) == 0
+    L.zkt_bp_ipa_ctx_free(ctx)
 
 
 def test_groth16_verify_batch_mixed(L):              # f-2: fused 3-pairing verification, many proofs per launch

@@ -89,6 +89,7 @@ def lib():
         L.zkt_bp_ipa_ctx_create.argtypes = [sz, vp, vp, vp, vp]
         L.zkt_bp_ipa_ctx_free.argtypes = [vp]; L.zkt_bp_ipa_ctx_free.restype = None
         L.zkt_bp_inner_product_argument_ctx.argtypes = [vp] * 6
+        L.zkt_bp_range_proof_ctx.argtypes = [vp] * 6 + [ctypes.c_int] + [vp] * 3
         _lib = L
     return _lib
 

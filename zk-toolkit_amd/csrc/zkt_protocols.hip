@@ -223,6 +223,21 @@ __global__ void __launch_bounds__(256) k_dot(const uint32_t* __restrict__ a, con
   }
   if (t == 0) st_raw<C>(out, acc);
 }
+// the same dot product over many blocks: part[blockIdx] (Montgomery-free: canonical like k_dot's output), then k_sum over the parts.
+// One 256-thread block needs 0.6 ms for 65,536 elements; the range proof computes six of them on its critical path.
+template <class C>
+__global__ void __launch_bounds__(256) k_dot_parts(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n, uint32_t* __restrict__ part) {
+  __shared__ uint32_t lds[256 * C::N];
+  const int t = threadIdx.x;
+  Fp<C> acc = fp_zero<C>();
+  for (size_t i = (size_t)blockIdx.x * 256 + t; i < n; i += (size_t)gridDim.x * 256) acc = fp_add(acc, fp_mul(ld_fp<C>(a + i * C::N), ld_raw<C>(b + i * C::N)));
+  st_raw<C>(lds + t * C::N, acc); __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (t < d) { acc = fp_add(acc, ld_raw<C>(lds + (t + d) * C::N)); st_raw<C>(lds + t * C::N, acc); }
+    __syncthreads();
+  }
+  if (t == 0) st_raw<C>(part + blockIdx.x * C::N, acc);
+}
 // out[i] = a[i]*s0 + b[i]*s1 (a' = a_lo x + a_hi x^-1, bulletproofs.rs:49-50)
 template <class C>
 __global__ void __launch_bounds__(256) k_fold(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ s0,
@@ -440,7 +455,7 @@ struct zkt_bp_ipa_ctx {
   Dev dbase, da, db, da2, db2, dwG, dwH, dsc, dPp, dx, dch, dsq, dc, dlr, dm, dt, dcomb;
   Dev dAL, dBL, dchall, dpart;             // verdict-only form: every level's a, b (2N elements each), all challenges, the u-entry parts
   zkt_secp_bases* set = nullptr;
-  std::mutex mu;                           // a context serves one call at a time: concurrent callers queue here
+  std::recursive_mutex mu;                 // a context serves one call at a time: concurrent callers queue here (the range proof re-enters for its inner-product argument)
   std::vector<hipStream_t> side;           // one stream per product batch, so the batches overlap each other and the MSMs
   hipEvent_t ev = nullptr;
   static size_t log2z(size_t n) { size_t l = 0; for (size_t t = n; t > 1; t >>= 1) ++l; return l; }
@@ -480,7 +495,7 @@ void zkt_bp_ipa_ctx_free(zkt_bp_ipa_ctx* c) { delete c; }
 static int ipa_run(zkt_bp_ipa_ctx* c, const zkt_secp_affine* P, const uint64_t* a, const uint64_t* b, const uint64_t* xs, zkt_secp_affine* out_trace, const uint32_t* wH0) {
   if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
   if (!c || !P || !a || !b || (c->N > 1 && !xs)) return -ZKT_ERR_SHAPE;
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
   hipStream_t s = nullptr;
   constexpr int PW = zkt_bp_ipa_ctx::PW, IPA_SLOTS = zkt_bp_ipa_ctx::IPA_SLOTS;
   constexpr size_t IPA_BATCH = zkt_bp_ipa_ctx::IPA_BATCH;
@@ -612,11 +627,32 @@ int zkt_bp_inner_product_argument(size_t n, const zkt_secp_affine* gg, const zkt
 // Bulletproofs::range_proof (bulletproofs.rs:58-147) over secp256k1, every random draw injected.
 // rnd = alpha, rho, y, z, tau1, tau2, x, sL[n], sR[n] (4-limb residues mod the group order); u = the random point of :137;
 // xs = IPA challenges.  out_pts (optional) = A, S, T1, T2, P.  Returns 1/0 like the reference's bool, negative = -status.
+static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const uint64_t* aL, const uint64_t* gamma, const zkt_secp_affine* g, const zkt_secp_affine* h,
+                            int use_ipa, const uint64_t* rnd, const uint64_t* xs, zkt_secp_affine* out_pts);
 int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, const uint64_t* gamma, const zkt_secp_affine* g, const zkt_secp_affine* h,
                        const zkt_secp_affine* gg, const zkt_secp_affine* hh, int use_ipa, const uint64_t* rnd, const zkt_secp_affine* u, const uint64_t* xs,
                        zkt_secp_affine* out_pts) {
   if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
   if (n == 0 || (n & (n - 1)) || !V || !aL || !gamma || !g || !h || !gg || !hh || !rnd || (use_ipa && (!u || (n > 1 && !xs)))) return -ZKT_ERR_SHAPE;
+  zkt_secp_affine inf_pt; memset(&inf_pt, 0, sizeof inf_pt); inf_pt.is_infinity = 1;
+  zkt_bp_ipa_ctx* c = nullptr;
+  int rc = zkt_bp_ipa_ctx_create(n, gg, hh, use_ipa ? u : &inf_pt, &c);
+  if (rc) return -rc;
+  rc = range_proof_core(c, V, aL, gamma, g, h, use_ipa, rnd, xs, out_pts);
+  zkt_bp_ipa_ctx_free(c);
+  return rc;
+}
+// the same proof over a context's resident generators gg, hh, u (zkt_bp_ipa_ctx_create): no table build, no generator upload per proof
+int zkt_bp_range_proof_ctx(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const uint64_t* aL, const uint64_t* gamma, const zkt_secp_affine* g, const zkt_secp_affine* h,
+                           int use_ipa, const uint64_t* rnd, const uint64_t* xs, zkt_secp_affine* out_pts) {
+  if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
+  if (!c || !V || !aL || !gamma || !g || !h || !rnd || (use_ipa && c->N > 1 && !xs)) return -ZKT_ERR_SHAPE;
+  return range_proof_core(c, V, aL, gamma, g, h, use_ipa, rnd, xs, out_pts);
+}
+static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const uint64_t* aL, const uint64_t* gamma, const zkt_secp_affine* g, const zkt_secp_affine* h,
+                            int use_ipa, const uint64_t* rnd, const uint64_t* xs, zkt_secp_affine* out_pts) {
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  const size_t n = c->N;
   hipStream_t s = nullptr;
   const int PW = 18;
   unsigned long long* noerr = nullptr;
@@ -635,7 +671,14 @@ int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, c
   auto vscl = [&](const uint32_t* a, const uint32_t* k) { uint32_t* o = newv(); hipLaunchKernelGGL(k_scale<SnC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, k, n, o); return o; };
   auto vpow = [&](const uint32_t* b) { uint32_t* o = newv(); hipLaunchKernelGGL(k_powseq<SnC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, b, n, o); return o; };
   auto vsum = [&](const uint32_t* a) { uint32_t* o = news(); hipLaunchKernelGGL(k_sum<SnC>, dim3(1), dim3(256), 0, s, a, n, o); return o; };
-  auto vdot = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = news(); hipLaunchKernelGGL(k_dot<SnC>, dim3(1), dim3(256), 0, s, a, b, n, o); return o; };
+  Dev dparts(64 * FRB);
+  if (!dparts.p) return -ZKT_ERR_DEVICE;
+  auto vdot = [&](const uint32_t* a, const uint32_t* b) {
+    uint32_t* o = news();
+    if (n < 4096) { hipLaunchKernelGGL(k_dot<SnC>, dim3(1), dim3(256), 0, s, a, b, n, o); return o; }
+    hipLaunchKernelGGL(k_dot_parts<SnC>, dim3(64), dim3(256), 0, s, a, b, n, dparts.w());          // stream order keeps the shared parts buffer safe
+    hipLaunchKernelGGL(k_sum<SnC>, dim3(1), dim3(256), 0, s, (const uint32_t*)dparts.w(), (size_t)64, o);
+    return o; };
   auto sadd = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = news(); op(OP_ADD, a, b, o, 1); return o; };
   auto ssub = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = news(); op(OP_SUB, a, b, o, 1); return o; };
   auto smul = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = news(); op(OP_MUL, a, b, o, 1); return o; };
@@ -649,11 +692,7 @@ int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, c
   // The generators stay resident for the whole proof: one base set [gg | hh | u] (zkt_bp_ipa_ctx) serves every (AffinePoints * PrimeFieldElems).sum()
   // as an MSM and the inner-product argument itself.  hh' = hh * y^-i (:109) is never materialised: a sum over hh' with scalars v is the sum over hh
   // with scalars v o y^-n, and the argument starts from the coefficients y^-i on hh.  res = A S T1 T2 P | single-point scratch.
-  zkt_secp_affine inf_pt; memset(&inf_pt, 0, sizeof inf_pt); inf_pt.is_infinity = 1;
-  zkt_bp_ipa_ctx* c = nullptr;
-  struct CtxGuard { zkt_bp_ipa_ctx*& c; ~CtxGuard() { if (c) zkt_bp_ipa_ctx_free(c); } } guard{c};
   int rc;
-  if ((rc = zkt_bp_ipa_ctx_create(n, gg, hh, use_ipa ? u : &inf_pt, &c))) return -rc;
   const size_t NB = c->NB;
   Dev pts(8 * SPB), res(48 * SPB);
   if (!pts.p || !res.p) return -ZKT_ERR_DEVICE;
