@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--groth16-log2n", type=int, default=20, help="constraints (log2) of the Groth16 prove+verify leg (0 = skip)")
     ap.add_argument("--groth16-proofs", type=int, default=8)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-bulletproofs", dest="bulletproofs", action="store_false", help="skip the Bulletproofs leg (BASELINE config 5)")
     ap.add_argument("--scalar-dist", default="uniform", choices=["uniform", "ones", "bits"],
                     help="uniform in [0,r) (the metric) | all ones | random 0/1 (skew stress: one hot bucket)")
     args = ap.parse_args()
@@ -382,6 +383,40 @@ def main():
                 result["pairing"]["valu"] = {"achieved": pinstr * m / dt / 1e12, "peak": peak, "unit": "T lane-instr/s", "frac": pinstr * m / dt / 1e12 / peak,
                                              "source": "SQ_INSTS_VALU / SQ_WAVES of the pairing kernel (committed rocprofv3 --pmc summary)"}
 
+        # BASELINE config 5: Bulletproofs range proof over 65,536 bits (64 bits x 1024 values) and its inner-product argument, generators resident
+        if world == 1 and args.bulletproofs:
+            try:
+                from zkt_testlib import SECP_N, rand_u64_array, ints_to_arr, ptr as _p, SplitMix64 as _SM
+                bn = 1 << 16
+                g0 = np.zeros((1, 9), np.uint64); L.zkt_secp_generator(g0.ctypes.data_as(ctypes.c_void_p))
+                ks = rand_u64_array(11, (2 * bn + 3, 4)); ks[:, 3] >>= np.uint64(1)
+                pts = np.zeros((2 * bn + 3, 9), np.uint64)
+                zk.check(L.zkt_secp_mul_batch(_p(np.repeat(g0, 2 * bn + 3, axis=0)), _p(ks), 4, _p(pts), 2 * bn + 3))
+                gg, hh, uu, g_r, h_r = pts[:bn].copy(), pts[bn:2 * bn].copy(), pts[2 * bn:2 * bn + 1].copy(), pts[2 * bn + 1:2 * bn + 2].copy(), pts[2 * bn + 2:].copy()
+                bits = [int(v) for v in (rand_u64_array(15, (bn,)) & np.uint64(1))]
+                val = sum(bt << i for i, bt in enumerate(bits)); aL = ints_to_arr(bits, 4); gam = ints_to_arr([_SM(17).below(SECP_N)], 4)
+                tmp2, Vv = np.zeros((2, 9), np.uint64), np.zeros((1, 9), np.uint64)
+                zk.check(L.zkt_secp_mul_batch(_p(np.concatenate([g_r, h_r])), _p(np.concatenate([ints_to_arr([val % SECP_N], 4), gam])), 4, _p(tmp2), 2))
+                zk.check(L.zkt_secp_add_batch(_p(tmp2[0:1].copy()), _p(tmp2[1:2].copy()), _p(Vv), 1))
+                rnd = rand_u64_array(18, (7 + 2 * bn, 4)); rnd[:, 3] >>= np.uint64(1); rnd[:, 0] |= np.uint64(1)
+                xs = rand_u64_array(14, (16, 4)); xs[:, 3] >>= np.uint64(1); xs[:, 0] |= np.uint64(1)
+                bctx = ctypes.c_void_p(); t0 = time.perf_counter(); zk.check(L.zkt_bp_ipa_ctx_create(bn, _p(gg), _p(hh), _p(uu), ctypes.byref(bctx))); t_ctx = time.perf_counter() - t0
+                bp = {"metric": "Bulletproofs range proofs/sec, 65,536 bits (64-bit x 1024 values), generators resident", "generator_setup_ms": round(t_ctx * 1e3, 2)}
+                for use_ipa in (0, 1):
+                    okp = L.zkt_bp_range_proof_ctx(bctx, _p(Vv), _p(aL), _p(gam), _p(g_r), _p(h_r), use_ipa, _p(rnd), _p(xs), None)
+                    ts = []
+                    for _ in range(3):
+                        t0 = time.perf_counter(); okp &= L.zkt_bp_range_proof_ctx(bctx, _p(Vv), _p(aL), _p(gam), _p(g_r), _p(h_r), use_ipa, _p(rnd), _p(xs), None); ts.append(time.perf_counter() - t0)
+                    bp["ms_with_ipa" if use_ipa else "ms_without_ipa"] = round(min(ts) * 1e3, 3)
+                    bp["accepts"] = bool(okp == 1) and bp.get("accepts", True)
+                bad = aL.copy(); bad[777, 0] ^= np.uint64(1)
+                bp["rejects_wrong_opening"] = bool(L.zkt_bp_range_proof_ctx(bctx, _p(Vv), _p(bad), _p(gam), _p(g_r), _p(h_r), 1, _p(rnd), _p(xs), None) == 0)
+                bp["value"] = 1e3 / bp["ms_with_ipa"]
+                L.zkt_bp_ipa_ctx_free(bctx)
+                result["bulletproofs"] = bp
+                failed = failed or not (bp["accepts"] and bp["rejects_wrong_opening"])
+            except Exception as e:
+                result["bulletproofs"] = {"error": repr(e)}
         if g16 is not None:
             result["groth16"] = g16
             failed = failed or g16.get("verifies") is False or "error" in g16

@@ -33,7 +33,7 @@ hipError_t launch_group_pred(int grp, int pred, const uint32_t* pts, const uint3
 hipError_t launch_group_sum_inplace(int grp, uint32_t* pts, size_t n, hipStream_t s);
 // several independent batched scalar multiplications in one launch (strides in u32 words, 0 = broadcast one point / one scalar)
 struct MulSeg { const uint32_t* pts; const uint32_t* k; uint32_t* out; uint32_t count, pt_stride, k_stride; };
-struct MulSegs { MulSeg s[12]; int n; };
+struct MulSegs { MulSeg s[16]; int n; };
 hipError_t launch_group_mul_segs(int grp, const MulSegs& segs, int scalar_words, hipStream_t s);
 hipError_t launch_miller_exact(int which, const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s);
 hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,

@@ -715,7 +715,7 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
           hipMemsetAsync(buf + 2 * n * 8, 0, FRB, s) == hipSuccess && zkt_secp_msm_submit(c->set, (const uint64_t*)buf, NB, s, slot) == ZKT_OK;
     if (okl) n_sub = slot + 1;
   };
-  zkt_secp_affine hres[4];
+  zkt_secp_affine hres[5];
   int n_col = 0;
   struct Drain { zkt_bp_ipa_ctx* c; int *col, *sub; ~Drain() { for (; *col < *sub; ++*col) zkt_secp_msm_collect(c->set, *col, nullptr, nullptr); } } drain{c, &n_col, &n_sub};
   auto msm_col = [&](int slot, uint32_t* dev_out) {                                               // slots are collected in order
@@ -746,43 +746,50 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   uint32_t* yinv_n = vpow(sinv(y));                                                   // hh' = hh * y^-i (:109), as coefficients
   uint32_t* z3 = smul(z2, z);
   uint32_t* delta_yz = ssub(smul(ssub(z, z2), vsum(y_n)), smul(z3, vsum(two_n)));     // :112 (one_n o v = v)
-  uint32_t* mu_signed = use_ipa ? sneg(mu) : mu;
   uint32_t* l = vadd(l0, vscl(d_sL, x));                                              // :121
   uint32_t* r = vadd(vhad(y_n, vadd(aRz, vscl(d_sR, x))), twoz2);                     // :122
   uint32_t* lr = vdot(l, r);
+  // Every single-point product is a ~4 ms dependent chain however few points a launch covers, so ALL of them go out in ONE launch: the products the
+  // reference takes of T1, T2 and S (:115, :124) are rewritten on the fixed points — T1 x = g (t1 x) + h (tau1 x), S x = h (rho x) + sum over the
+  // generators with scalars sL x, sR x (one more MSM) — the same group elements, so A, S, T1, T2, P keep their bits.
+  uint32_t *t1x = smul(t1, x), *t2x2 = smul(t2, x2);
+  uint32_t* k_g = sadd(sadd(delta_yz, t1x), t2x2);                                    // rhs of :115 = V z^2 + g (delta + t1 x + t2 x^2) + h (tau1 x + tau2 x^2)
+  uint32_t* k_h = sadd(smul(tau1, x), smul(tau2, x2));
   // gg * (-z 1^n) + hh' * (z y^n + z^2 2^n)  of P (:126-127)
   msm_sub(2, vscl(one_n, sneg(z)), vhad(vadd(vscl(y_n, z), twoz2), yinv_n));
-  if (!use_ipa) msm_sub(3, l, vhad(r, yinv_n));                                       // (gg*l).sum() + (hh'*r).sum()  (:142)
-  {                                                                                   // every product of a fixed point with a scalar
-    MulSegs m{}; m.n = 11;
-    m.s[0] = seg(Hp, alpha, Q(0));     m.s[1] = seg(Hp, rho, Q(1));
-    m.s[2] = seg(Gp, t1, Q(4));        m.s[3] = seg(Hp, tau1, Q(5));   m.s[4] = seg(Gp, t2, Q(6));     m.s[5] = seg(Hp, tau2, Q(7));
-    m.s[6] = seg(Gp, t_hat, Q(8));     m.s[7] = seg(Hp, tau_x, Q(9));  m.s[8] = seg(Vp, z2, Q(10));    m.s[9] = seg(Gp, delta_yz, Q(11));
-    m.s[10] = seg(Hp, mu_signed, Q(12));
+  msm_sub(3, vscl(d_sL, x), vscl(d_sR, x));                                           // x * ((gg*sL).sum() + (hh*sR).sum()): the generator part of S x (:124)
+  if (!use_ipa) msm_sub(4, l, vhad(r, yinv_n));                                       // (gg*l).sum() + (hh'*r).sum()  (:142)
+  {
+    MulSegs m{}; int k = 0;
+    m.s[k++] = seg(Gp, t_hat, Q(8));   m.s[k++] = seg(Hp, tau_x, Q(9));               // lhs of :116
+    m.s[k++] = seg(Vp, z2, Q(10));     m.s[k++] = seg(Gp, k_g, Q(11));  m.s[k++] = seg(Hp, k_h, Q(14));
+    m.s[k++] = seg(Hp, mu, Q(12));                                                    // h mu = h alpha + x (h rho)
+    if (use_ipa) m.s[k++] = seg(Up, lr, Q(17));
+    if (out_pts) {
+      m.s[k++] = seg(Hp, alpha, Q(0)); m.s[k++] = seg(Hp, rho, Q(1));
+      m.s[k++] = seg(Gp, t1, Q(4));    m.s[k++] = seg(Hp, tau1, Q(5));  m.s[k++] = seg(Gp, t2, Q(6));  m.s[k++] = seg(Hp, tau2, Q(7));
+    }
+    m.n = k;
     run(m);
   }
-  msm_col(0, Q(2)); msm_col(1, Q(3));
-  padd(Q(0), Q(2), Ak);                                                               // A (:77)
-  padd(Q(1), Q(3), Sk);                                                               // S (:82)
-  padd(Q(4), Q(5), T1k); padd(Q(6), Q(7), T2k);                                       // T1 (:99), T2 (:100)
+  msm_col(0, Q(2)); msm_col(1, Q(3)); msm_col(2, Q(22)); msm_col(3, Q(16));
+  if (!use_ipa) msm_col(4, Q(25));
   padd(Q(8), Q(9), Q(13));                                                            // lhs of :116
-  {                                                                                   // the products that need T1, T2, S
-    MulSegs m{}; m.n = use_ipa ? 4 : 3;
-    m.s[0] = seg(T1k, x, Q(14)); m.s[1] = seg(T2k, x2, Q(15)); m.s[2] = seg(Sk, x, Q(16));
-    if (use_ipa) m.s[3] = seg(Up, lr, Q(17));
-    run(m);
+  padd(padd(Q(10), Q(11), Q(18)), Q(14), Q(20));                                      // rhs of :115
+  padd(padd(Q(2), Q(16), Q(19)), Q(22), Q(21));                                       // P h^-mu: the three generator sums of A, S x and :126-127
+  padd(Q(21), Q(12), Pk);                                                             // P (:124-128) = h mu + those
+  if (out_pts) {
+    padd(Q(0), Q(2), Ak);                                                             // A (:77)
+    padd(Q(1), Q(3), Sk);                                                             // S (:82)
+    padd(Q(4), Q(5), T1k); padd(Q(6), Q(7), T2k);                                     // T1 (:99), T2 (:100)
   }
-  msm_col(2, Q(22));
-  if (!use_ipa) msm_col(3, Q(25));
-  padd(padd(padd(Q(10), Q(11), Q(18)), Q(14), Q(19)), Q(15), Q(20));                  // rhs of :115
-  padd(padd(Ak, Q(16), Q(21)), Q(22), Pk);                                            // P (:124-128)
   zkt_secp_affine hl, hr;
   if ((rc = down(&hl, Q(13), SPB, s)) || (rc = down(&hr, Q(20), SPB, s))) return -rc;
   if (out_pts && (rc = down(out_pts, R, 5 * SPB, s))) return -rc;
   if (hipStreamSynchronize(s) != hipSuccess || !okl || vi > NV || si > NS) return -ZKT_ERR_DEVICE;
   if (memcmp(&hl, &hr, SPB) != 0) return 0;                                           // :116-118
   if (use_ipa) {
-    uint32_t* Pp = padd(padd(Pk, Q(12), Q(23)), Q(17), Q(24));                        // :138  P h^-mu u^<l,r>
+    uint32_t* Pp = padd(Q(21), Q(17), Q(24));                                         // :138  P h^-mu u^<l,r>
     if (!okl) return -ZKT_ERR_DEVICE;
     return ipa_run(c, (const zkt_secp_affine*)Pp, (const uint64_t*)l, (const uint64_t*)r, xs, nullptr, yinv_n);   // :139, over gg, hh' = y^-i hh, u
   }
