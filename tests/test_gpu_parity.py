@@ -452,3 +452,55 @@ def test_generators_and_curve_predicates(L):
         zk.check(getattr(L, f"zkt_{name}_in_subgroup_batch")(ptr(pts), sg.ctypes.data, 6))
         assert oc.tolist() == [1, 1, 1, 1, 0, 0], name
         assert sg.tolist()[:4] == [1, 1, 1, 1] and sg[5] == 1, name
+
+
+def test_calls_from_several_threads(L):
+    """include/zkt.h, Threading: entry points may be called from any thread (each selects the library's device); independent batch calls are
+    serialised on the staging stream, calls on one handle by its lock.  Four threads hammer different entry points and two of them share ONE
+    resident base set; every result must equal the single-threaded one."""
+    import threading, torch
+    n = 2000
+    rng = np.random.Generator(np.random.PCG64(9))
+    ks = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64); ks[:, 3] >>= np.uint64(2)
+    ss = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64); ss[:, 3] >>= np.uint64(2)
+    g = np.zeros((1, G1W), np.uint64); O.zkto_g1_generator(ptr(g))
+    bases = np.zeros((n, G1W), np.uint64)
+    zk.check(L.zkt_g1_mul_batch(ptr(np.repeat(g, n, axis=0)), ptr(ks), 4, ptr(bases), n))
+    h = ctypes.c_void_p(); zk.check(L.zkt_g1_bases_upload(ptr(bases), n, ctypes.byref(h)))
+    d_s = torch.from_numpy(ss.view(np.int64)).cuda()
+    want_msm = np.zeros((1, G1W), np.uint64)
+    zk.check(L.zkt_g1_msm_dev(h, ctypes.c_void_p(d_s.data_ptr()), n, None, ptr(want_msm), None))
+    a, b = _rand_field(3, 800, Q, 6), _rand_field(4, 800, Q, 6)
+    want_mul = np.zeros_like(a); zk.check(L.zkt_fq_mul_batch(ptr(a), ptr(b), ptr(want_mul), 800))
+    P = bases[:3].copy(); Qs = np.zeros((3, G2W), np.uint64)
+    g2 = np.zeros((1, G2W), np.uint64); O.zkto_g2_generator(ptr(g2))
+    zk.check(L.zkt_g2_mul_batch(ptr(np.repeat(g2, 3, axis=0)), ptr(ks[:3].copy()), 4, ptr(Qs), 3))
+    want_e = np.zeros((3, FQ12), np.uint64); zk.check(L.zkt_tate_batch(ptr(P), ptr(Qs), ptr(want_e), 3))
+    errors = []
+
+    def msm_worker():
+        try:
+            for _ in range(6):
+                got = np.zeros((1, G1W), np.uint64)
+                zk.check(L.zkt_g1_msm_dev(h, ctypes.c_void_p(d_s.data_ptr()), n, None, ptr(got), None))
+                assert (got == want_msm).all()
+        except Exception as e: errors.append(("msm", repr(e)))
+
+    def mul_worker():
+        try:
+            for _ in range(20):
+                got = np.zeros_like(a); zk.check(L.zkt_fq_mul_batch(ptr(a), ptr(b), ptr(got), 800)); assert (got == want_mul).all()
+        except Exception as e: errors.append(("mul", repr(e)))
+
+    def tate_worker():
+        try:
+            for _ in range(3):
+                got = np.zeros((3, FQ12), np.uint64); zk.check(L.zkt_tate_batch(ptr(P), ptr(Qs), ptr(got), 3)); assert (got == want_e).all()
+        except Exception as e: errors.append(("tate", repr(e)))
+
+    ts = [threading.Thread(target=f) for f in (msm_worker, msm_worker, mul_worker, tate_worker)]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=300)
+    L.zkt_g1_bases_free(h)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in ts)
