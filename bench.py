@@ -105,25 +105,19 @@ def main():
 
     # ---- the exchange step lives in the C ABI: RCCL communicator of the library (or, for a one-GPU rehearsal, the callback transport over gloo)
     _cb_keep = []
+    transport = "none"
     if world > 1:
-        if backend == "nccl":
-            ident = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                buf = (ctypes.c_uint8 * 128)()
-                zk.check(L.zkt_comm_unique_id(buf))
-                ident = torch.tensor(list(buf), dtype=torch.uint8)
-            ident = ident.to(dev); dist.broadcast(ident, 0)
-            idb = (ctypes.c_uint8 * 128)(*ident.cpu().tolist())
-            zk.check(L.zkt_comm_init(rank, world, ctypes.cast(idb, ctypes.c_void_p)))
-        else:
+        def init_callback_transport():
+            """the library's host-callback transport, carried by torch.distributed (gloo tensors, or nccl through a device staging tensor)"""
             CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 
             def allgather(_ctx, send, recv, nbytes):
                 try:
                     mine = torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).clone()
-                    parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                    if backend == "nccl": mine = mine.to(dev)
+                    parts = [torch.empty_like(mine) for _ in range(world)]
                     dist.all_gather(parts, mine)
-                    buf = torch.cat(parts).numpy()
+                    buf = torch.cat(parts).cpu().numpy()
                     ctypes.memmove(recv, buf.ctypes.data, nbytes * world)
                     return 0
                 except Exception as e:
@@ -131,6 +125,28 @@ def main():
                     return 1
             cb = CB(allgather); _cb_keep.append(cb)
             zk.check(L.zkt_comm_init_callback(rank, world, ctypes.cast(cb, ctypes.c_void_p), None))
+
+        if backend == "nccl":
+            # RCCL communicator inside the library; the unique id travels over torch.distributed.  If any rank cannot create it, every rank
+            # falls back to the callback transport together (the data path is the same, only the wire differs).
+            ident = torch.zeros(128, dtype=torch.uint8)
+            rc_id = 0
+            if rank == 0:
+                buf = (ctypes.c_uint8 * 128)()
+                rc_id = L.zkt_comm_unique_id(buf)
+                ident = torch.tensor(list(buf), dtype=torch.uint8)
+            ident = ident.to(dev); dist.broadcast(ident, 0)
+            idb = (ctypes.c_uint8 * 128)(*ident.cpu().tolist())
+            rc_init = L.zkt_comm_init(rank, world, ctypes.cast(idb, ctypes.c_void_p)) if all_ok(rc_id == 0) else -1
+            if all_ok(rc_init == 0):
+                transport = "rccl (libzkt_hip.so's own communicator)"
+            else:
+                L.zkt_comm_finalize()
+                init_callback_transport()
+                transport = "callback over torch.distributed/nccl (RCCL communicator inside the library could not be created: rc %d)" % rc_init
+        else:
+            init_callback_transport()
+            transport = "callback over torch.distributed/" + backend
 
     # ---- synthetic inputs, resident in HBM: P_i = k_i * G1 (seed 3 + rank), s_i uniform in [0,r) (seed 4 + rank)
     from zkt_testlib import G1_GEN, int_to_limbs, limbs_to_int, py_g1_mul, g1_arr
@@ -314,7 +330,8 @@ def main():
         "dtype": "u32 limbs (384-bit Montgomery integer)", "data": "synthetic",
         "config": {"workload": "Batched G1 Pippenger MSM, 2^%d random bases/scalars per GPU, bases device-resident with window multiples" % args.log2n,
                    "terms_per_gpu": n, "scalar_bits": 255, "scalar_dist": args.scalar_dist,
-                   "sharding": "index range per rank; RCCL all-gather of 168-B Jacobian partials + on-device combine inside the C ABI (zkt_g1_msm_sharded_collect)" if world > 1 else "none",
+                   "sharding": "index range per rank; all-gather of 168-B Jacobian partials + on-device combine inside the C ABI (zkt_g1_msm_sharded_collect)" if world > 1 else "none",
+                   "exchange_transport": transport,
                    "bases_setup_s": round(setup_s, 3), "msms_in_flight": DEPTH,
                    "single_msm_latency_ms": round(latency_ms, 3) if latency_ms is not None else None},
         "roofline": {"bound": "hbm", "kernel": L.zkt_last_kernel_name().decode(),

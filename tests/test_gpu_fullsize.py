@@ -180,6 +180,15 @@ def test_config5_range_proof_65536_bits(L):
     bad = aL.copy(); bad[40000, 0] ^= np.uint64(1)                               # a bit vector that does not open V
     for use_ipa in (0, 1):
         assert L.zkt_bp_range_proof(n, ptr(V), ptr(bad), ptr(gamma), ptr(g_r), ptr(h_r), ptr(gg), ptr(hh), use_ipa, ptr(rnd), ptr(u), ptr(xs), None) == 0
+    # the same proof over a resident-generator context (the form bench.py times)
+    rctx = ctypes.c_void_p(); zk.check(L.zkt_bp_ipa_ctx_create(n, ptr(gg), ptr(hh), ptr(u), ctypes.byref(rctx)))
+    pts_a, pts_b = np.zeros((5, 9), np.uint64), np.zeros((5, 9), np.uint64)
+    assert L.zkt_bp_range_proof(n, ptr(V), ptr(aL), ptr(gamma), ptr(g_r), ptr(h_r), ptr(gg), ptr(hh), 1, ptr(rnd), ptr(u), ptr(xs), ptr(pts_a)) == 1
+    for use_ipa in (0, 1):
+        assert L.zkt_bp_range_proof_ctx(rctx, ptr(V), ptr(aL), ptr(gamma), ptr(g_r), ptr(h_r), use_ipa, ptr(rnd), ptr(xs), ptr(pts_b)) == 1
+        assert (pts_a == pts_b).all()                                            # A, S, T1, T2, P identical through both entry points
+        assert L.zkt_bp_range_proof_ctx(rctx, ptr(V), ptr(bad), ptr(gamma), ptr(g_r), ptr(h_r), use_ipa, ptr(rnd), ptr(xs), None) == 0
+    L.zkt_bp_ipa_ctx_free(rctx)
     # inner-product argument alone at 65,536 generators, resident generators: accept, and reject after one coefficient changes
     a, b = rand_u64_array(12, (n, 4)), rand_u64_array(13, (n, 4))
     a[:, 3] >>= np.uint64(1); b[:, 3] >>= np.uint64(1)
@@ -188,6 +197,9 @@ def test_config5_range_proof_65536_bits(L):
     zk.check(L.zkt_secp_msm(ptr(np.concatenate([gg, hh, u])), ptr(np.concatenate([a, b, ints_to_arr([c], 4)])), 2 * n + 1, ptr(P)))
     ctx = ctypes.c_void_p(); zk.check(L.zkt_bp_ipa_ctx_create(n, ptr(gg), ptr(hh), ptr(u), ctypes.byref(ctx)))
     assert L.zkt_bp_inner_product_argument_ctx(ctx, ptr(P), ptr(a), ptr(b), ptr(xs), None) == 1
+    trace = np.zeros((16 * 3, 9), np.uint64)                                        # with a trace: the level-by-level form (32 L/R MSMs), same verdict
+    assert L.zkt_bp_inner_product_argument_ctx(ctx, ptr(P), ptr(a), ptr(b), ptr(xs), ptr(trace)) == 1
+    assert (trace[:, 8] == 0).all()
     a2 = a.copy(); a2[123, 0] ^= np.uint64(1)
     assert L.zkt_bp_inner_product_argument_ctx(ctx, ptr(P), ptr(a2), ptr(b), ptr(xs), None) == 0
     L.zkt_bp_ipa_ctx_free(ctx)
