@@ -15,17 +15,36 @@ def p32(a):
     return a.ctypes.data_as(_u32p) if a is not None else None
 
 
-@pytest.fixture(scope="module")
-def H():
+# two host builds of the same headers: the default Fq2 product (four product scans) and -DZKT_FQ2_KARATSUBA (three), which the
+# pairing objects of the product library are compiled with (zk-toolkit_amd/Makefile)
+@pytest.fixture(scope="module", params=["plain", "kara"])
+def H(request):
     if os.environ.get("ZKT_HOSTCHECK_SO"):          # e.g. a -fsanitize=undefined build of csrc/hostcheck.cpp
+        if request.param != "plain":
+            pytest.skip("one externally supplied build")
         return ctypes.CDLL(os.environ["ZKT_HOSTCHECK_SO"])
-    so = os.path.join(ROOT, "zk-toolkit_amd", "libzkt_hostcheck.so")
+    kara = request.param == "kara"
+    so = os.path.join(ROOT, "zk-toolkit_amd", "libzkt_hostcheck_kara.so" if kara else "libzkt_hostcheck.so")
     src = os.path.join(ROOT, "zk-toolkit_amd", "csrc")
     newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src))
     if not os.path.exists(so) or os.path.getmtime(so) < newest:
-        subprocess.check_call(["hipcc", "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared",
-                               "-o", so, os.path.join(src, "hostcheck.cpp")], timeout=600)
+        subprocess.check_call(["hipcc", "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared"] + (["-DZKT_FQ2_KARATSUBA"] if kara else []) +
+                              ["-o", so, os.path.join(src, "hostcheck.cpp")], timeout=600)
     return ctypes.CDLL(so)
+
+
+def test_fq2_products_agree_on_lazy_representatives(H):
+    """fp2_mul_kara (three product scans, fp.h) against the four-scan product and against python, operands at canonical + {0,1,2}p."""
+    rng = SplitMix64(77)
+    vals = [0, 1, Q - 1, Q - 2, (Q + 1) // 2, 2**380, 2**381 - 1 - (2**381 - 1) // Q * Q] + [rng.below(Q) for _ in range(40)]
+    for t in range(400):
+        a = (vals[rng.below(len(vals))], vals[rng.below(len(vals))]); b = (vals[rng.below(len(vals))], vals[rng.below(len(vals))])
+        lifts = t % 256 if t < 256 else rng.below(256)
+        got = np.zeros((1, 12), dtype=np.uint64)
+        enc = lambda z: ints_to_arr([z[1], z[0]], 6).reshape(1, 12)          # ABI order {u1, u0}
+        assert H.zkt_hostcheck_fq2_mul_lifted(p32(enc(a)), p32(enc(b)), lifts, p32(got)) == 0, (t, lifts)
+        c1, c0 = arr_to_ints(got.reshape(2, 6))
+        assert (c0, c1) == ((a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q), (t, lifts)
 
 
 @pytest.mark.parametrize("field,mod,w,pre", [(0, Q, 6, "fq"), (1, R, 4, "fr"), (2, SECP_P, 4, "sp"), (3, SECP_N, 4, "sn")])

@@ -321,6 +321,41 @@ template <class C, bool SUB> ZKT_HD Fp<C> fp_mul2_impl(const Fp<C>& a, const Fp<
   return r;
 }
 
+// (a0 + a1 u)(b0 + b1 u), u^2 = -1, as THREE product scans under two Montgomery reductions (Karatsuba on the unreduced columns):
+//   P0 = a0 b0,  P1' = a1 (8p - b1),  P2 = (a0 + a1)(b0 + b1)      re = P0 + P1',   im = P2 - P0 + P1'  (= a0 b1 + a1 b0 + 8p a1)
+// 588 + 392 MADs instead of the 784 + 392 of two fp_mul2_impl; the price is ~250 cheap adds, which a single wave per SIMD issues in
+// the shadow of its multiply-adds (profiles/r02_valu_ubench.txt: v_mad_u64_u32 holds a wave 9.5 cycles, the others ~3).
+// Column-wise P2_k >= P0_k (every limb is non-negative), so no column ever goes negative.  Bounds for inputs < 4p with limbs < 2^28:
+// sums < 2^29 per limb, P2_k < 14 * 2^58, P1'_k < 14 * 2^57, reduction < 14 * 2^56: a column stays below 2^62.7;
+// re < 48 p^2, im < 64 p^2, so both outputs are < p (1 + 64 p / R) < 1.03 p.
+template <class C> ZKT_HD void fp2_mul_kara(const Fp<C>& a0, const Fp<C>& a1, const Fp<C>& b0, const Fp<C>& b1, Fp<C>& re, Fp<C>& im) {
+  static_assert(C::W == 28, "lazy-limb fields only");
+  constexpr int N = C::N; constexpr uint32_t M = (1u << 28) - 1;
+  uint32_t sa[N], sb[N], nd[N], mr[N], mi[N]; uint64_t accr = 0, acci = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) { sa[i] = a0.v[i] + a1.v[i]; sb[i] = b0.v[i] + b1.v[i]; nd[i] = C::subk(i) - b1.v[i]; }
+#pragma unroll
+  for (int k = 0; k < 2 * N; ++k) {
+    uint64_t p0 = 0, p1 = 0;
+#pragma unroll
+    for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); ++i) {
+      p0 = mad64(a0.v[i], b0.v[k - i], p0); p1 = mad64(a1.v[i], nd[k - i], p1); acci = mad64(sa[i], sb[k - i], acci);
+    }
+    accr += p0 + p1; acci += p1 - p0;            // the difference may wrap; the sum with the P2 column already in acci is non-negative
+    if (k < N) {
+#pragma unroll
+      for (int j = 0; j < k; ++j) { accr = mad64(mr[j], C::mod(k - j), accr); acci = mad64(mi[j], C::mod(k - j), acci); }
+      mr[k] = ((uint32_t)accr * C::INV) & M; mi[k] = ((uint32_t)acci * C::INV) & M;
+      accr = mad64(mr[k], C::mod(0), accr); acci = mad64(mi[k], C::mod(0), acci);
+    } else {
+#pragma unroll
+      for (int j = k - N + 1; j < N; ++j) { accr = mad64(mr[j], C::mod(k - j), accr); acci = mad64(mi[j], C::mod(k - j), acci); }
+      re.v[k - N] = (uint32_t)accr & M; im.v[k - N] = (uint32_t)acci & M;
+    }
+    accr >>= 28; acci >>= 28;
+  }
+}
+
 // Call policy.  One inlined multiply is ~1000 instructions (8 KB); curve and
 // pairing kernels contain hundreds of them, far beyond the 64 KB instruction
 // cache, so by default the multiply is ONE function per field and kernel image,

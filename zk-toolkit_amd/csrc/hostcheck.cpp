@@ -26,6 +26,21 @@ int zkt_hostcheck_fp(int field, int op, const uint32_t* a, const uint32_t* b, ui
   switch (field) { case 0: run(FqC{}); break; case 1: run(FrC{}); break; case 2: run(SpC{}); break; default: run(SnC{}); }
   return 0;
 }
+// Both Fq2 products (four-scan lazy form and three-scan Karatsuba form, tower.h / fp.h) on non-canonical representatives: every operand
+// coordinate is moved to canonical + j*p (j < 3, selected by two bits of `lifts` each).  Writes the canonical product; returns the number
+// of disagreements between the two forms or with the lazy-limb invariants (0 expected).
+int zkt_hostcheck_fq2_mul_lifted(const uint32_t* a, const uint32_t* b, unsigned lifts, uint32_t* o) {
+  Fq2 x = ld_fq2(a), y = ld_fq2(b);
+  x.c0 = fq_lift(x.c0, (lifts & 3) % 3); x.c1 = fq_lift(x.c1, ((lifts >> 2) & 3) % 3);
+  y.c0 = fq_lift(y.c0, ((lifts >> 4) & 3) % 3); y.c1 = fq_lift(y.c1, ((lifts >> 6) & 3) % 3);
+  const Fq2 four{fp_mulsub(x.c0, y.c0, x.c1, y.c1), fp_muladd(x.c0, y.c1, x.c1, y.c0)};
+  Fq2 three; fp2_mul_kara(x.c0, x.c1, y.c0, y.c1, three.c0, three.c1);
+  int bad = 0;
+  if (!fq_lazy_ok(three.c0) || !fq_lazy_ok(three.c1)) ++bad;
+  if (!fp_eq(four.c0, three.c0) || !fp_eq(four.c1, three.c1)) ++bad;
+  st_fq2(o, three);
+  return bad;
+}
 // op: 0 add 1 sub 2 mul 3 inv 4 neg 5 mul_xi/mul_v 6 sqr 7 frob1 8 frob2 9 conj
 int zkt_hostcheck_tower(int deg, int op, const uint32_t* a, const uint32_t* b, uint32_t* o) {
   if (deg == 2) {

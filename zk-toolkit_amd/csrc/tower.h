@@ -38,8 +38,14 @@ ZKT_HD Fq2 fq2_conj(const Fq2& a) { return Fq2{a.c0, fp_neg(a.c1)}; }
 // fq2.rs:134-146: the 4-product schoolbook, here with lazy reduction — each coordinate is a sum of two products under ONE
 // Montgomery reduction (fp_mulsub / fp_muladd): 784 + 392 MADs like Karatsuba's three multiplications, but none of its five
 // additions and subtractions.
+// -DZKT_FQ2_KARATSUBA: three product scans instead of four (fp2_mul_kara, fp.h) — fewer multiply-adds, more additions: pays where one
+// wave per SIMD runs (the pairing kernels), not where two waves share the issue port.
 ZKT_FQ2 Fq2 fq2_mul(const Fq2& a, const Fq2& b) {
+#if defined(ZKT_FQ2_KARATSUBA)
+  Fq2 r; fp2_mul_kara(a.c0, a.c1, b.c0, b.c1, r.c0, r.c1); return r;
+#else
   return Fq2{fp_mulsub(a.c0, b.c0, a.c1, b.c1), fp_muladd(a.c0, b.c1, a.c1, b.c0)};
+#endif
 }
 ZKT_FQ2 Fq2 fq2_sqr(const Fq2& a) {                                      // fq2.rs:34-36
   Fq t = fp_mul(a.c0, a.c1);

@@ -45,6 +45,7 @@ k_accumulate_g2_pair(const uint32_t* __restrict__ table, const uint32_t* __restr
   Xyzz<F> acc = xyzz_inf<F>();
   uint32_t ent = beg < end ? entries[beg] : 0, ent_next = beg + 1 < end ? entries[beg + 1] : 0;
   const uint32_t* p = table + (size_t)(ent & 0x7fffffffu) * (2 * CW);
+#if !defined(ZKT_G2PAIR_NO_PREFETCH)
   Fq2 nx = ld_half(p), ny = ld_half(p + CW);                        // software-pipelined gather, as in the G1 kernel
   for (uint32_t e = beg; e < end; ++e) {
     Fq2 x = nx, y = ny;
@@ -58,6 +59,18 @@ k_accumulate_g2_pair(const uint32_t* __restrict__ table, const uint32_t* __restr
     if (negate) y = F::neg(y);
     acc = xyzz_add_aff<F>(acc, x, y);
   }
+#else         // -DZKT_G2PAIR_NO_PREFETCH: no point held in registers across the add.  Measured (2^20-term G2 MSM, pipelined): 9.58 ms default, 9.87 ms this way at one wave
+              // per SIMD, 9.51 ms with amdgpu_waves_per_eu(2,2) on top (118 dwords spilled) — no gain, not the default
+  for (uint32_t e = beg; e < end; ++e) {
+    Fq2 x = ld_half(p), y = ld_half(p + CW);
+    const bool negate = ent >> 31;
+    ent = ent_next;
+    ent_next = e + 2 < end ? entries[e + 2] : 0;
+    p = table + (size_t)(ent & 0x7fffffffu) * (2 * CW);
+    if (negate) y = F::neg(y);
+    acc = xyzz_add_aff<F>(acc, x, y);
+  }
+#endif
   const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
   uint32_t* out = nt == 1 ? sums + b * XYW : partial + (size_t)(t0 + tk.y) * XYW;
   st_half(out, acc.X); st_half(out + CW, acc.Y); st_half(out + 2 * CW, acc.ZZ); st_half(out + 3 * CW, acc.ZZZ);
