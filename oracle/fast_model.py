@@ -117,8 +117,9 @@ L_NAF = _naf(R - 1)[::-1][1:]                        # most significant first, l
 assert sum(d << (len(L_NAF) - 1 - i) for i, d in enumerate(L_NAF)) + (1 << len(L_NAF)) == R - 1
 
 
-def miller_fast(P, Qp):
-    """f_{r-1,P}(untwist(Q)) up to Fq6 factors.  P=(x,y) in Fq, Qp=((x0,x1),(y0,y1)) c0/c1 order."""
+def _miller(P, Qp, digits):
+    """f_{n,P}(untwist(Q)) up to Fq6 factors for the loop scalar n given by its signed digits (most significant first, leading 1 dropped),
+    and the Jacobian point V = n P the loop ends on.  P=(x,y) in Fq, Qp=((x0,x1),(y0,y1)) c0/c1 order."""
     xp, yp = P
     Xq = f2_mul(Qp[0], XI_INV)     # untwisted x sits at w0.v2  (g12_point.rs:47-68: x * v^-1 = (x/xi) v^2)
     Yq = f2_mul(Qp[1], XI_INV)     # untwisted y sits at w1.v1  (y * (v w)^-1 = (y/xi) v w)
@@ -128,7 +129,7 @@ def miller_fast(P, Qp):
     def sparse(a, b, c):           # a + b v^2 + c v w,  a in Fq
         return (((a, 0), F2_0, b), (F2_0, c, F2_0))
 
-    for bit in L_NAF:
+    for bit in digits:
         # tangent at V, scaled by 2YZ^3:  (3X^3-2Y^2) - 3X^2 Z^2 * X' + Z3 Z^2 * Y'
         A = X * X % Q; B = Y * Y % Q; C = B * B % Q; ZZ = Z * Z % Q
         D = 2 * ((X + B) ** 2 - A - C) % Q; E = 3 * A % Q
@@ -145,7 +146,13 @@ def miller_fast(P, Qp):
             a = (Rr * xp - Z3 * yp) % Q
             f = f12_mul(f, sparse(a, f2_muls(Xq, -Rr % Q), f2_muls(Yq, Z3)))
             X, Y, Z = X3, Y3, Z3
-    return f
+    return f, (X, Y, Z)
+
+
+def miller_fast(P, Qp):
+    """f_{r-1,P}(untwist(Q)) up to Fq6 factors: the reference's value for every Q ON the twist once r P = infinity (off the twist the signed-digit
+    chain and the reference's binary chain differ: they are the same function on the curve only)."""
+    return _miller(P, Qp, L_NAF)[0]
 
 
 def exp_x_neg(a):
@@ -254,3 +261,110 @@ def calc_g2_g1_exact(Qp, P):
 
 def weil_exact(P, Qp):
     return f12_mul(calc_g1_g2_exact(P, Qp), f12_inv(calc_g2_g1_exact(Qp, P)))
+
+
+# ---- short Miller loop: 127 steps instead of 255 (round 2) ------------------------------------------------------------------
+# For P in G1 and Q in G2 (order r, on E: y^2 = x^3 + 4 and on the twist E': y^2 = x^3 + 4(1+u)) the twisted-ate value
+#   eta = f_{x^2,P}(Q)^((q^12-1)/r)
+# is a fixed power of the Tate value.  With s = x^2: r = s^2 - s + 1, so s^3 = -1 (mod r) and N = s^6 - 1 = L r with L = -2(s+1) (mod r);
+# f_{N,P} = f_{r,P}^L up to factors the final exponentiation kills, and f_{s^6,P} = prod_i f_{s,P}^(s^(5-i) q^(2i)) because [s] acts on G1 as an
+# automorphism that commutes with the evaluation at the untwisted Q up to q^2-Frobenius.  On G_T, q^2 = s (mod r), so tate^L = eta^(6 s^5) and
+#   tate = eta^(6 s^5 / L) = eta^(2 x^2 - 1) = pi^2(eta)^2 * conj(eta)           (q = x (mod r): the Frobenius IS the power by x on G_T).
+# Nothing here is taken on trust: tests/test_fast_model.py checks tate_short against the faithful oracle and both membership tests against r P = infinity.
+X2 = X_ABS * X_ABS
+X2_BITS = [int(c) for c in bin(X2)[3:]]          # 127 doubling steps, 16 additions (the signed form is one digit longer and no sparser)
+# [x^2] P = (BETA x, -y) for P in G1: -x^2 is a primitive cube root of unity mod r, the eigenvalue of (x, y) -> (BETA x, y)
+_B1 = pow(2, (Q - 1) // 3, Q)
+assert _B1 != 1 and pow(_B1, 3, Q) == 1
+
+
+def _g1_x2_affine(P):
+    X, Y, Z = _miller(P, ((1, 0), (1, 0)), X2_BITS)[1]
+    zi = pow(Z, -1, Q)
+    return (X * zi * zi % Q, Y * zi * zi * zi % Q)
+
+
+_G1 = (0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+       0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1)
+_gx2 = _g1_x2_affine(_G1)
+BETA = next(b for b in (_B1, _B1 * _B1 % Q) if (b * _G1[0] % Q, -_G1[1] % Q) == _gx2)
+
+
+def miller_short(P, Qp):
+    """(f_{x^2,P}(untwist(Q)) up to Fq6 factors, P in G1?).  The loop ends on V = x^2 P; P in G1 <=> V == (BETA xp, -yp):
+    then phi(P) = [-x^2] P, phi^2 + phi + 1 = 0 gives [x^4 - x^2 + 1] P = r P = infinity — and conversely."""
+    f, (X, Y, Z) = _miller(P, Qp, X2_BITS)
+    ZZ = Z * Z % Q
+    ok = Z != 0 and X == BETA * P[0] * ZZ % Q and Y == -P[1] * ZZ * Z % Q
+    return f, ok
+
+
+# psi = twist o Frobenius o untwist on E'(Fq2): (x, y) -> (PSI_X conj(x), PSI_Y conj(y)).  Untwisted x' = (x/xi) v^2 and v^q = v xi^((q-1)/3),
+# w^q = w xi^((q-1)/6), so x'^q = conj(x)/conj(xi) xi^(2(q-1)/3) v^2 and y'^q = conj(y)/conj(xi) xi^((q-1)/2) v w; multiply back by xi.
+_XI = (1, 1)
+_XI_OVER_CONJ = f2_mul(_XI, f2_inv(f2_conj(_XI)))
+PSI_X = f2_mul(_XI_OVER_CONJ, f2_pow(_XI, 2 * (Q - 1) // 3))
+PSI_Y = f2_mul(_XI_OVER_CONJ, f2_pow(_XI, (Q - 1) // 2))
+
+
+def g2_psi(Qp):
+    return (f2_mul(PSI_X, f2_conj(Qp[0])), f2_mul(PSI_Y, f2_conj(Qp[1])))
+
+
+def g2_jac_mul(Qp, n):
+    """[n] Q in Jacobian coordinates over Fq2 (a = 0), complete.  None = infinity."""
+    m, sq, add, sub = f2_mul, f2_sqr, f2_add, f2_sub
+    def k(a, c): return f2_muls(a, c % Q)
+    def dbl(p):
+        if p is None or p[1] == F2_0: return None
+        X, Y, Z = p
+        A = sq(X); B = sq(Y); C = sq(B)
+        D = k(sub(sub(sq(add(X, B)), A), C), 2); E = k(A, 3)
+        X3 = sub(sq(E), k(D, 2))
+        return (X3, sub(m(E, sub(D, X3)), k(C, 8)), k(m(Y, Z), 2))
+    def add_aff(p, q):
+        if p is None: return (q[0], q[1], F2_1)
+        X, Y, Z = p
+        ZZ = sq(Z); H = sub(m(q[0], ZZ), X); Rr = sub(m(m(q[1], ZZ), Z), Y)
+        if H == F2_0: return dbl((q[0], q[1], F2_1)) if Rr == F2_0 else None
+        HH = sq(H); HHH = m(H, HH); V = m(X, HH)
+        X3 = sub(sub(sq(Rr), HHH), k(V, 2))
+        return (X3, sub(m(Rr, sub(V, X3)), m(Y, HHH)), m(Z, H))
+    acc = None
+    for c in bin(n)[2:]:
+        acc = dbl(acc)
+        if c == '1': acc = add_aff(acc, Qp)
+    return acc
+
+
+def g2_mul_xabs(Qp):
+    """[|x|] Q: 63 doublings, 5 additions"""
+    return g2_jac_mul(Qp, X_ABS)
+
+
+def g2_on_curve(Qp):
+    return f2_sqr(Qp[1]) == f2_add(f2_mul(f2_sqr(Qp[0]), Qp[0]), (4, 4))          # y^2 = x^3 + 4(1+u)
+
+
+def g2_in_subgroup(Qp):
+    """Q in G2 <=> Q on E' and psi(Q) = [x] Q (x < 0: psi(Q) = -[|x|] Q).  psi^2 - t psi + q = 0 on E' and t = x + 1, q = x (mod r)."""
+    if not g2_on_curve(Qp): return False
+    a = g2_mul_xabs(Qp)
+    if a is None: return False
+    X, Y, Z = a
+    px, py = g2_psi(Qp)
+    ZZ = f2_sqr(Z)
+    return Z != F2_0 and X == f2_mul(px, ZZ) and Y == f2_neg(f2_mul(py, f2_mul(ZZ, Z)))
+
+
+def g1_on_curve(P):
+    return P[1] * P[1] % Q == (P[0] ** 3 + 4) % Q
+
+
+def tate_short(P, Qp):
+    """tate(P, Q) through the 127-step loop; None when the preconditions do not hold (the kernels then take the long loop / the exact path)."""
+    if not (g1_on_curve(P) and g2_in_subgroup(Qp)): return None
+    f, ok = miller_short(P, Qp)
+    if not ok: return None
+    eta = final_exp_fast(f)
+    return f12_mul(f12_sqr(f12_frob(eta, 2)), f12_conj(eta))

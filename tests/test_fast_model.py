@@ -45,3 +45,51 @@ def test_exact_miller_values_and_weil_match_oracle():
         want = fq12_from_arr(o)
         for i in range(2):
             assert tuple(fm.to_ref_order(fn(*_pq(ps[i], qs[i])))) == want[i], (which, i)
+
+
+# ---- the 127-step loop (twisted-ate form) and the membership tests that guard it --------------------------------------------
+def _g2_affine(j):
+    X, Y, Z = j
+    zi = fm.f2_inv(Z); zi2 = fm.f2_sqr(zi)
+    return (fm.f2_mul(X, zi2), fm.f2_mul(Y, fm.f2_mul(zi2, zi)))
+
+
+def test_short_loop_tate_matches_oracle():
+    rng = SplitMix64(24)
+    ps = [g1_gen()] + [g1_mul(g1_gen(), rng.below(R)) for _ in range(3)]
+    qs = [g2_gen()] + [g2_mul(g2_gen(), rng.below(R)) for _ in range(3)]
+    rc, o, _ = pair(3, np.concatenate(ps), np.concatenate(qs))
+    assert rc == 0
+    want = fq12_from_arr(o)
+    for i in range(4):
+        got = fm.tate_short(*_pq(ps[i], qs[i]))
+        assert got is not None and tuple(fm.to_ref_order(got)) == want[i]
+    assert (2 * fm.X2 - 1) % R != 0 and (fm.X2 * fm.X2 - fm.X2 + 1) == R                  # the correction exponent is a unit mod r = x^4 - x^2 + 1
+
+
+def test_short_loop_g1_membership_is_r_torsion():
+    """V = x^2 P == (BETA x, -y)  <=>  r P = infinity, on curve points inside and outside G1 (cofactor parts, small orders)"""
+    rng = SplitMix64(25)
+    q = _pq(g1_gen(), g2_gen())[1]
+    inside = [g1_from_arr(g1_mul(g1_gen(), rng.below(R)))[0] for _ in range(3)]
+    outside = [p for _, p in degenerate_g1_points()] + [py_g1_curve_point(s) for s in range(40, 46)]
+    for p in inside + outside:
+        assert fm.g1_on_curve(p)
+        assert fm.miller_short(p, q)[1] == (py_g1_mul(p, R) is None), p
+    assert all(fm.miller_short(p, q)[1] for p in inside) and not any(fm.miller_short(p, q)[1] for p in outside[-6:])
+
+
+def test_short_loop_g2_membership_is_r_torsion():
+    """psi(Q) == [x] Q  <=>  r Q = infinity on E'(Fq2); off-curve points are refused"""
+    rng = SplitMix64(26)
+    for _ in range(3):
+        t = py_twist_point(rng)
+        assert fm.g2_on_curve(t)
+        assert fm.g2_jac_mul(t, R) is not None and not fm.g2_in_subgroup(t)                # a random twist point is outside G2 ...
+        g = _g2_affine(fm.g2_jac_mul(t, G2_COFACTOR))
+        assert fm.g2_jac_mul(g, R) is None and fm.g2_in_subgroup(g)                        # ... its cofactor multiple is inside
+        assert fm.tate_short(g1_from_arr(g1_gen())[0], t) is None
+    q = _pq(g1_gen(), g2_mul(g2_gen(), rng.below(R)))[1]
+    assert fm.g2_in_subgroup(q)
+    off = (q[0], fm.f2_add(q[1], (1, 0)))
+    assert not fm.g2_on_curve(off) and not fm.g2_in_subgroup(off)

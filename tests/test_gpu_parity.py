@@ -504,3 +504,30 @@ def test_calls_from_several_threads(L):
     L.zkt_g1_bases_free(h)
     assert not errors, errors
     assert not any(t.is_alive() for t in ts)
+
+
+def test_pairing_g2_argument_outside_the_subgroup(L):
+    """The 127-step loop needs Q in G2 and both points on their curves; Q on the twist outside G2 falls back to the 255-step loop, a point off its
+    curve to the reference's own chain — element by element inside an honest batch, values identical to the oracle's reference algorithm."""
+    rng = SplitMix64(4712)
+    g1 = np.zeros((1, G1W), np.uint64); O.zkto_g1_generator(ptr(g1))
+    g2 = np.zeros((1, G2W), np.uint64); O.zkto_g2_generator(ptr(g2))
+    n = 70
+    P = np.zeros((n, G1W), np.uint64); Qs = np.zeros((n, G2W), np.uint64)
+    zk.check(L.zkt_g1_mul_batch(ptr(np.repeat(g1, n, axis=0)), ptr(ints_to_arr([rng.below(R - 1) + 1 for _ in range(n)], 4)), 4, ptr(P), n))
+    zk.check(L.zkt_g2_mul_batch(ptr(np.repeat(g2, n, axis=0)), ptr(ints_to_arr([rng.below(R - 1) + 1 for _ in range(n)], 4)), 4, ptr(Qs), n))
+    outside = {5: to_abi_g2(py_twist_point(rng)), 37: to_abi_g2(py_twist_point(rng)), 64: to_abi_g2(py_twist_point(rng))}     # on E', outside G2
+    for i, pt in outside.items(): Qs[i] = g2_arr([pt])[0]
+    (x1, x0), (y1, y0) = g2_from_arr(Qs[11:12])[0]
+    Qs[11] = g2_arr([((x1, x0), (y1, (y0 + 1) % Q))])[0]                                                                       # off the twist
+    px, py_ = g1_from_arr(P[50:51])[0]
+    p_off = g1_arr([(px, (py_ + 1) % Q)])
+    off_p_has_value = O.zkto_pairing_batch(3, ptr(p_off), ptr(Qs[50:51].copy()), ptr(np.zeros((1, FQ12), np.uint64)), 1, 1, None) == 0
+    if off_p_has_value: P[50] = p_off[0]                                                                                        # off the curve of G1
+    got, want = np.zeros((n, FQ12), np.uint64), np.zeros((n, FQ12), np.uint64)
+    zk.check(L.zkt_tate_batch(ptr(P), ptr(Qs), ptr(got), n))
+    assert O.zkto_pairing_batch(3, ptr(P), ptr(Qs), ptr(want), n, 16, None) == 0
+    assert (got == want).all()
+    oc, sg = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    zk.check(L.zkt_g2_is_on_curve_batch(ptr(Qs), oc.ctypes.data, n)); zk.check(L.zkt_g2_in_subgroup_batch(ptr(Qs), sg.ctypes.data, n))
+    assert [i for i in range(n) if not oc[i]] == [11] and [i for i in range(n) if not sg[i]] == [5, 11, 37, 64]

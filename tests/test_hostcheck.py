@@ -232,6 +232,32 @@ def test_pairing_with_g1_argument_outside_the_subgroup(H):
         assert (hrc == 2) if rc != 0 else (hrc == 0 and (got[0] == want[0]).all()), label
 
 
+def test_short_loop_guards_and_fallbacks(H):
+    """The 127-step loop (pairing.h) runs only for P on E with r P = infinity and Q in G2; everything else falls back to the 255-step loop (any Q)
+    or the reference's chain (P outside G1).  Guards against the python model / plain scalar multiplication, values against the oracle."""
+    rng = SplitMix64(91)
+    H.zkt_hostcheck_short_loop_guards.argtypes = [_u32p, _u32p]
+    p_ok = g1_mul(g1_gen(), rng.below(R)); q_ok = g2_mul(g2_gen(), rng.below(R))
+    assert H.zkt_hostcheck_short_loop_guards(p32(p_ok), p32(q_ok)) == 15
+    for label, pt in degenerate_g1_points():                                  # on the curve, outside G1
+        assert H.zkt_hostcheck_short_loop_guards(p32(g1_arr([pt])), p32(q_ok)) == 13, label
+    px, py_ = g1_from_arr(p_ok)[0]
+    p_off = g1_arr([(px, (py_ + 1) % Q)])
+    assert H.zkt_hostcheck_short_loop_guards(p32(p_off), p32(q_ok)) & 1 == 0          # off the curve
+    (x1, x0), (y1, y0) = g2_from_arr(q_ok)[0]
+    cases = [(g2_arr([to_abi_g2(py_twist_point(rng))]), 11, 50) for _ in range(2)]          # on E', outside G2: the 255-step loop
+    cases.append((g2_arr([((x1, x0), (y1, (y0 + 1) % Q))]), 3, 100))                          # off the twist: the reference's chain
+    for q, guards, route in cases:
+        assert H.zkt_hostcheck_short_loop_guards(p32(p_ok), p32(q)) == guards
+        rc, want, _ = pair(3, p_ok, q, threads=1)
+        got = np.zeros((1, 72), dtype=np.uint64)
+        assert rc == 0 and H.zkt_hostcheck_tate(p32(p_ok), p32(q), p32(got)) == route and (got[0] == want[0]).all(), route
+    rc, want, _ = pair(3, p_off, q_ok, threads=1)                             # P off its curve: the reference's chain, value or panic
+    got = np.zeros((1, 72), dtype=np.uint64)
+    hrc = H.zkt_hostcheck_tate(p32(p_off), p32(q_ok), p32(got))
+    assert (hrc == 2) if rc != 0 else (hrc == 100 and (got[0] == want[0]).all())
+
+
 def test_exact_miller_and_weil_vs_oracle(H):         # pairing.rs:54-55,75-84 raw values
     rng = SplitMix64(81)
     p = g1_mul(g1_gen(), rng.below(R)); q = g2_mul(g2_gen(), rng.below(R))

@@ -206,3 +206,43 @@ def degenerate_g1_points():
     mixed = py_g1_add(py_g1_mul(G1_GEN, 12345), cof)  # r-component and cofactor component
     return [("generic curve point", gen), ("cofactor subgroup, large order", cof), ("order | 121", small), ("order 3: (0, 2)", (0, 2)),
             ("G1 point + cofactor point", mixed)]
+
+
+# ---- points of the twist E'(Fq2): y^2 = x^3 + 4(1+u), outside G2 -----------------------------------------------------------
+def py_f2_sqrt(a):
+    """square root in Fq2 = Fq[u]/(u^2+1) of a = (c0, c1), q = 3 mod 4; None if a is not a square"""
+    a0, a1 = a
+    if a1 == 0:
+        s = pow(a0, (Q + 1) // 4, Q)
+        if s * s % Q == a0: return (s, 0)
+        s = pow(-a0 % Q, (Q + 1) // 4, Q)
+        return (0, s) if s * s % Q == -a0 % Q else None
+    n = (a0 * a0 + a1 * a1) % Q
+    s = pow(n, (Q + 1) // 4, Q)
+    if s * s % Q != n: return None
+    for sg in (s, -s % Q):
+        h = (a0 + sg) * pow(2, -1, Q) % Q
+        x0 = pow(h, (Q + 1) // 4, Q)
+        if x0 and x0 * x0 % Q == h:
+            return (x0, a1 * pow(2 * x0, -1, Q) % Q)
+    return None
+
+
+def py_twist_point(rng):
+    """a point ((x0,x1),(y0,y1)) (c0/c1 order) of E'(Fq2), generic order: almost surely outside G2 (the cofactor has 508 bits)"""
+    f2m = lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)
+    while True:
+        x = (rng.below(Q), rng.below(Q))
+        x3 = f2m(f2m(x, x), x)
+        y = py_f2_sqrt(((x3[0] + 4) % Q, (x3[1] + 4) % Q))
+        if y is not None: return (x, y)
+
+
+def to_abi_g2(pt):
+    """((x0,x1),(y0,y1)) -> ((x1,x0),(y1,y0)), the order g2_arr takes"""
+    (x0, x1), (y0, y1) = pt
+    return ((x1, x0), (y1, y0))
+
+
+BLS_X = -0xD201000000010000
+G2_COFACTOR = (BLS_X**8 - 4 * BLS_X**7 + 5 * BLS_X**6 - 4 * BLS_X**4 + 6 * BLS_X**3 - 4 * BLS_X**2 - 4 * BLS_X + 13) // 9      # #E'(Fq2) = h2 * r

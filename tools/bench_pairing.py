@@ -21,6 +21,7 @@ zk.check(L.zkt_g1_mul_batch_dev(vp(keep[0]), vp(keep[1]), 4, vp(d_p), m, sp))
 zk.check(L.zkt_g2_mul_batch_dev(vp(keep[2]), vp(keep[3]), 4, vp(d_q), m, sp))
 torch.cuda.synchronize()
 d_e = torch.empty((m, 72), dtype=torch.int64, device=dev)
+if os.environ.get("ZKT_BENCH_PTRS"): print("ptrs g1 %x +%x  g2 %x +%x  out %x +%x" % (d_p.data_ptr(), d_p.numel() * 8, d_q.data_ptr(), d_q.numel() * 8, d_e.data_ptr(), d_e.numel() * 8), flush=True)
 zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), m, sp)); torch.cuda.synchronize()
 ts = []
 for _ in range(3):

@@ -109,15 +109,32 @@ int zkt_hostcheck_miller_exact(int which, const uint32_t* g1, const uint32_t* g2
 int zkt_hostcheck_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* o) {
   Aff<FqOps> p = PtIO<FqOps>::ld(g1); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2);
   if (p.inf || q.inf) return 2;
-  // the two passes of launch_tate (zkt_tate.hip): fast loop for P of order r, the reference's own chain otherwise
-  bool in_g1, bad;
-  Fq12 f = miller_g1_g2(p.x, p.y, q.x, q.y, in_g1);
-  if (!in_g1) {
-    f = miller_g1_g2_exact(p.x, p.y, q.x, q.y, bad);
-    if (bad) return 2;
-    if (fq12_is_zero(f)) { for (int k = 0; k < 144; ++k) o[k] = 0; return 0; }
+  // the three passes of launch_tate (zkt_tate.hip): 127-step loop for P in G1 and Q in G2, 255-step loop for Q on E' outside G2, the reference's own chain otherwise
+  Fq12 f; bool in_g1 = false, bad;
+  const int route = tate_short(p.x, p.y, q.x, q.y, f);
+  if (route == TATE_ROUTE_SHORT) { st_fq12(o, f); return 0; }
+  if (route == TATE_ROUTE_LONG) {
+    f = miller_g1_g2(p.x, p.y, q.x, q.y, in_g1);
+    if (in_g1) { st_fq12(o, final_exponentiation(f)); return 50; }          // 50: value produced by the 255-step loop
   }
+  f = miller_g1_g2_exact(p.x, p.y, q.x, q.y, bad);
+  if (bad) return 2;
+  if (fq12_is_zero(f)) { for (int k = 0; k < 144; ++k) o[k] = 0; return 100; }
   st_fq12(o, final_exponentiation(f));
-  return in_g1 ? 0 : 100;                 // 100: value produced by the exact path
+  return 100;                             // 100: value produced by the exact path
+}
+// debugging aid: the raw value of the 255-step loop and its final exponentiation
+int zkt_hostcheck_debug_long(const uint32_t* g1, const uint32_t* g2, uint32_t* of, uint32_t* ofe) {
+  Aff<FqOps> p = PtIO<FqOps>::ld(g1); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2);
+  bool in_g1; Fq12 f = miller_g1_g2(p.x, p.y, q.x, q.y, in_g1);
+  st_fq12(of, f); st_fq12(ofe, final_exponentiation(f));
+  return in_g1;
+}
+// the membership tests that guard the 127-step loop: bit 0 = P on E, bit 1 = r P == infinity (from the loop), bit 2 = Q in G2, bit 3 = Q on E'
+int zkt_hostcheck_short_loop_guards(const uint32_t* g1, const uint32_t* g2) {
+  Aff<FqOps> p = PtIO<FqOps>::ld(g1); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2);
+  if (p.inf || q.inf) return -1;
+  bool ok; (void)miller_g1_g2_short(p.x, p.y, q.x, q.y, ok);
+  return (g1_on_curve(p.x, p.y) ? 1 : 0) | (ok ? 2 : 0) | (g2_on_curve(q.x, q.y) && g2_in_subgroup(q.x, q.y) ? 4 : 0) | (g2_on_curve(q.x, q.y) ? 8 : 0);
 }
 }

@@ -68,8 +68,9 @@ ZKT_FN bool miller_pt_is_neg(const MillerPt& V, const Fq& xp, const Fq& yp) {
 }
 
 // f_{r-1,P}(untwist(Q)) up to Fq6 factors.  P, Q affine, Montgomery domain, neither at infinity.
-// in_g1 <- r P == infinity.  For such P no multiple met on the way is infinity and the value equals the reference's for EVERY Q
-// (the untwisted X of any Fq2 abscissa lies in Fq6, so the dropped vertical lines die in the final exponentiation).  For P outside
+// in_g1 <- r P == infinity.  For such P no multiple met on the way is infinity and the value equals the reference's for EVERY Q ON THE TWIST
+// (the untwisted X of any Fq2 abscissa lies in Fq6, so the dropped vertical lines die in the final exponentiation; but the signed-digit chain
+// and the reference's binary chain are the same function on the curve only — a Q off E' must take miller_g1_g2_exact, see g2_on_curve).  For P outside
 // G1 the reference's behaviour depends on the order of P (it panics when a binary prefix multiple of P is infinity,
 // rational_function.rs:36); the callers then take the exact path (miller_g1_g2_exact) or fail closed.
 ZKT_FN Fq12 miller_g1_g2(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq, bool& in_g1) {
@@ -96,6 +97,75 @@ ZKT_FN Fq12 miller_g1_g2(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& y
     }
   }
   in_g1 = miller_pt_is_neg(V, xp, yp);
+  return f;
+}
+
+// ---- the 127-step loop (twisted-ate form) -------------------------------------------------------------------------------------
+// For P in G1 and Q in G2 the value eta = f_{x^2,P}(Q)^((q^12-1)/r) is a fixed power of the Tate value: with s = x^2, r = s^2 - s + 1, so
+// s^3 = -1 (mod r) and s^6 - 1 = L r with L = -2(s+1); f_{s^6,P} = prod_i f_{s,P}^(s^(5-i) q^(2i)) and q^2 = s on G_T give tate^L = eta^(6 s^5), i.e.
+//   tate = eta^(2 x^2 - 1) = pi^2(eta)^2 * conj(eta)          (q = x (mod r): on G_T the Frobenius IS the power by x)
+// — half the Miller loop for one cyclotomic squaring and one product.  oracle/fast_model.py (tate_short) is the python model;
+// tests/test_fast_model.py checks it against the faithful oracle and checks both membership tests below against r P = infinity, r Q = infinity.
+// The identity needs P in G1 and Q in G2, so both are TESTED here; Q on the twist but outside G2 takes the 255-step loop (valid for every Q ON E'),
+// P outside G1 or a point off its curve takes the reference's own chain — the callers mark such elements and re-run them.
+ZKT_HD Fq g1_beta_const() { Fq b;
+#pragma unroll
+  for (int i = 0; i < FqC::N; ++i) b.v[i] = g1_beta_limb(i);
+  return b; }
+ZKT_HD Fq fq_four() { return fp_dbl(fp_dbl(fp_one<FqC>())); }
+// P on E: y^2 = x^3 + 4 (the reference never checks; off-curve points keep their old route)
+ZKT_FN bool g1_on_curve(const Fq& x, const Fq& y) { return fp_eq(fp_sqr(y), fp_add(fp_mul(fp_sqr(x), x), fq_four())); }
+// Q on E': y^2 = x^3 + 4(1+u).  Off the twist even the 255-step loop is not the reference's value: two addition chains for the same multiple of P
+// give functions that agree on the curve only, and the untwisted Q is then not on it — such elements take the reference's own chain.
+ZKT_FN bool g2_on_curve(const Fq2& xq, const Fq2& yq) {
+  const Fq four = fq_four();
+  const Fq2 b{four, four};
+  return fq2_eq(fq2_sqr(yq), fq2_add(fq2_mul(fq2_sqr(xq), xq), b));
+}
+// Q in G2  <=>  Q on E' (the caller's check) and psi(Q) = [x] Q, psi = twist o Frobenius o untwist (x < 0: psi(Q) = -[|x|] Q).
+// psi^2 - t psi + q = 0 on E', t = x + 1 and q = x (mod r); r is prime to the cofactor of E'(Fq2), so the r-torsion of E'(Fq2) is G2.
+ZKT_FN bool g2_in_subgroup(const Fq2& xq, const Fq2& yq) {
+  const Aff<Fq2Ops> q{xq, yq, false};
+  Jac<Fq2Ops> a = jac_from_aff(q);
+  for (int i = 62; i >= 0; --i) {                              // |x| = 0xd201000000010000: 63 doublings, 5 additions
+    a = jac_dbl(a);
+    if ((BLS_X_ABS >> i) & 1) a = jac_add_aff(a, q);
+  }
+  if (jac_is_inf(a)) return false;
+  const Fq2 px = fq2_mul(fq2_const([](int i) { return g2_psi_x_limb(0, i); }, [](int i) { return g2_psi_x_limb(1, i); }), fq2_conj(xq));
+  const Fq2 py = fq2_mul(fq2_const([](int i) { return g2_psi_y_limb(0, i); }, [](int i) { return g2_psi_y_limb(1, i); }), fq2_conj(yq));
+  const Fq2 ZZ = fq2_sqr(a.Z);
+  return fq2_eq(a.X, fq2_mul(px, ZZ)) && fq2_eq(a.Y, fq2_neg(fq2_mul(py, fq2_mul(ZZ, a.Z))));
+}
+// V == (BETA xp, -yp) for a Jacobian V?  After the loop over x^2, V = x^2 P; -x^2 is the eigenvalue of phi(x, y) = (BETA x, y) on G1, so this is
+// phi(P) = [-x^2] P, and phi^2 + phi + 1 = 0 turns it into [x^4 - x^2 + 1] P = r P = infinity (and conversely) — six multiplications, once per pairing.
+ZKT_FN bool miller_pt_is_x2(const MillerPt& V, const Fq& xp, const Fq& yp) {
+  if (fp_is_zero(V.Z)) return false;
+  const Fq ZZ = fp_sqr(V.Z);
+  return fp_eq(fp_mul(fp_mul(g1_beta_const(), xp), ZZ), V.X) && fp_eq(fp_mul(fp_mul(yp, ZZ), V.Z), fp_neg(V.Y));
+}
+// f_{x^2,P}(untwist(Q)) up to Fq6 factors; ok <- P in G1 (P on the curve is the caller's check)
+ZKT_FN Fq12 miller_g1_g2_short(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq, bool& ok) {
+  const Fq2 xi_inv = xi_inv_const();
+  const Fq2 Xq = fq2_mul(xq, xi_inv), Yq = fq2_mul(yq, xi_inv);
+  MillerPt V{xp, yp, fp_one<FqC>()};
+  MillerLine l;
+  Fq12 f = fq12_one(), ft;
+  for (int i = 0; i < MILLER_X2_NBITS; ++i) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w = (j == (i >> 5)) ? miller_x2_bits_word(j) : w;
+    const bool bit = (w >> (i & 31)) & 1;                                       // wave-uniform (compile-time table)
+    miller_dbl_step(V, Xq, Yq, l);
+    ft = fq12_sqr(f);
+    f = fq12_mul_line(ft, l.a, l.b, l.c);
+    if (bit) {
+      miller_add_step(V, xp, yp, Xq, Yq, l);
+      ft = fq12_mul_line(f, l.a, l.b, l.c);
+      f = ft;
+    }
+  }
+  ok = miller_pt_is_x2(V, xp, yp);
   return f;
 }
 
@@ -166,7 +236,12 @@ ZKT_FN Fq12 fq12_pow_e1(const Fq12& a) {
 }
 
 // f^((q^12-1)/r), exact.  Four named Fq12 buffers (g, a, b, t) are reused; a destination never aliases a source.
-ZKT_FN Fq12 final_exponentiation(const Fq12& f) {
+// SHORT: the argument is the value of the 127-step loop (miller_g1_g2_short) and the result is raised to 2 x^2 - 1 on the way out, which makes it the
+// Tate value: eta^(2x^2-1) = pi^2(eta)^2 conj(eta), one Frobenius, one cyclotomic squaring, one product (derivation at miller_g1_g2_short).
+// The correction lives HERE and not in the caller on purpose: the very same four calls placed in tate_short (after this function had returned)
+// faulted on MI355X with ROCm 7.2 (memory access fault inside the scratch aperture, also with pi applied twice instead of pi^2), while inside this
+// function they run — kept where the toolchain is known to produce working code, and covered by tests/test_gpu_parity.py on every run.
+template <bool SHORT> ZKT_FN Fq12 final_exponentiation_t(const Fq12& f) {
   Fq12 g, a, b, t;
   t = fq12_inv(f);
   a = fq12_conj(f);
@@ -184,7 +259,30 @@ ZKT_FN Fq12 final_exponentiation(const Fq12& f) {
   b = fq12_mul(b, t) ;                     // (aliasing a source here costs one temporary; kept for clarity)
   t = fq12_conj(a);
   a = fq12_mul(b, t);                      // ^(x^2+q^2-1)
-  return fq12_mul(a, g);
+  if constexpr (!SHORT) return fq12_mul(a, g);
+  else {
+    t = fq12_mul(a, g);                    // eta
+    b = fq12_frob<2>(t);                   // eta^(x^2): on G_T the q^2-Frobenius is the power by x^2
+    a = fq12_cyclotomic_sqr(b);
+    b = fq12_conj(t);
+    return fq12_mul(a, b);
+  }
+}
+ZKT_HD Fq12 final_exponentiation(const Fq12& f) { return final_exponentiation_t<false>(f); }
+
+// One Tate pairing through the 127-step loop, with every precondition tested.  Returns TATE_ROUTE_SHORT and the value in r, or the route the element
+// must take instead: TATE_ROUTE_LONG (Q on E' but outside G2: miller_g1_g2 + final_exponentiation) or TATE_ROUTE_EXACT (a point off its curve, or
+// r P != infinity: miller_g1_g2_exact).  tate = eta^(2 x^2 - 1) for eta = final_exponentiation(f_{x^2,P}(Q)): final_exponentiation_t<true>.
+// Kept as ONE function so that the kernels that use it stay small: load, call, store.
+enum { TATE_ROUTE_SHORT = 0, TATE_ROUTE_LONG = 1, TATE_ROUTE_EXACT = 2 };
+ZKT_FN int tate_short(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq, Fq12& r) {
+  if (!g1_on_curve(xp, yp) || !g2_on_curve(xq, yq)) return TATE_ROUTE_EXACT;
+  if (!g2_in_subgroup(xq, yq)) return TATE_ROUTE_LONG;
+  bool in_g1;
+  Fq12 f = miller_g1_g2_short(xp, yp, xq, yq, in_g1);
+  if (!in_g1) return TATE_ROUTE_EXACT;
+  r = final_exponentiation_t<true>(f);
+  return TATE_ROUTE_SHORT;
 }
 
 // ---- raw Miller values and the Weil pairing, bit-exact (row a14) ------------------------------------

@@ -13,12 +13,14 @@
 
 namespace zkt {
 
-// word 11 of an output element is the top word of a canonical Fq (<= 0x1a0111ea): this value marks "not computed yet"
+// word 11 of an output element is the top word of a canonical Fq (<= 0x1a0111ea): these values mark "not computed yet"
 static constexpr int TATE_MARK_WORD = 11;
-static constexpr uint32_t TATE_MARK = 0xffffffffu;
+static constexpr uint32_t TATE_MARK_LONG = 0xffffffffu;       // left to k_tate_long_marked: the preconditions of the 127-step loop do not hold
+static constexpr uint32_t TATE_MARK_EXACT = 0xfffffffeu;      // left to k_tate_exact_marked: r P != infinity
 #ifndef ZKT_TATE_ATTR
 #define ZKT_TATE_ATTR
 #endif
+// First pass, the only one honest inputs see: P on E and in G1, Q in G2 -> 127-step loop, final exponentiation, tate = eta^(2x^2-1) (pairing.h).
 __global__ void __launch_bounds__(64) ZKT_TATE_ATTR k_tate(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
                                              uint32_t* __restrict__ out, size_t n, unsigned long long* err) {
   size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -29,19 +31,41 @@ __global__ void __launch_bounds__(64) ZKT_TATE_ATTR k_tate(const uint32_t* __res
     atomicMin(err, (unsigned long long)i);
     return;
   }
+  Fq12 r;
+  const int route = tate_short(p.x, p.y, q.x, q.y, r);
+  if (route == TATE_ROUTE_SHORT) st_fq12(out + i * 144, r);
+  else out[i * 144 + TATE_MARK_WORD] = route == TATE_ROUTE_LONG ? TATE_MARK_LONG : TATE_MARK_EXACT;
+}
+// Second pass, for the elements the first one marked: the 255-step loop over r - 1, which needs nothing of Q and only r P = infinity of P
+// (checked for free where it ends).  Honest inputs never get here: every lane of every wave leaves after one load.
+__global__ void __launch_bounds__(64) ZKT_TATE_ATTR k_tate_long_marked(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
+                                                                        uint32_t* __restrict__ out, size_t n, unsigned long long* err) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n || out[i * 144 + TATE_MARK_WORD] != TATE_MARK_LONG) return;
+  Aff<FqOps> p = PtIO<FqOps>::ld(g1 + i * ABI_G1_WORDS);
+  Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2 + i * ABI_G2_WORDS);
   bool in_g1;
   Fq12 f = miller_g1_g2(p.x, p.y, q.x, q.y, in_g1);
-  if (!in_g1) { out[i * 144 + TATE_MARK_WORD] = TATE_MARK; return; }        // r P != infinity: left to k_tate_exact_marked
+  if (!in_g1) { out[i * 144 + TATE_MARK_WORD] = TATE_MARK_EXACT; return; }  // r P != infinity: left to k_tate_exact_marked
   st_fq12(out + i * 144, final_exponentiation(f));
 }
-// Second pass over the batch, for the elements k_tate marked: P outside the order-r subgroup.  There the reference's result depends on
+// After the small-batch kernels (zkt_dpairing.hip: 255-step loop for every element): elements with a point off its curve are re-marked for the
+// reference's chain — two addition chains agree on the curve only.
+__global__ void __launch_bounds__(64) k_tate_mark_offcurve(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Aff<FqOps> p = PtIO<FqOps>::ld(g1 + i * ABI_G1_WORDS);
+  Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2 + i * ABI_G2_WORDS);
+  if (p.inf || q.inf) return;
+  if (!g1_on_curve(p.x, p.y) || !g2_on_curve(q.x, q.y)) out[i * 144 + TATE_MARK_WORD] = TATE_MARK_EXACT;
+}
+// Third pass, for the elements marked EXACT: P outside the order-r subgroup (or a point off its curve).  There the reference's result depends on
 // the order of P — it panics when a multiple of P met by its binary chain is infinity (rational_function.rs:36) — so these lanes follow
-// the reference's chain step by step (miller_g1_g2_exact) and report its panics as the batch's error index.  Honest inputs never get
-// here: every lane of every wave leaves after one load.
-__global__ void __launch_bounds__(64) k_tate_exact_marked(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
+// the reference's chain step by step (miller_g1_g2_exact) and report its panics as the batch's error index.
+__global__ void __launch_bounds__(64) ZKT_TATE_ATTR k_tate_exact_marked(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
                                                           uint32_t* __restrict__ out, size_t n, unsigned long long* err) {
   size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= n || out[i * 144 + TATE_MARK_WORD] != TATE_MARK) return;
+  if (i >= n || out[i * 144 + TATE_MARK_WORD] != TATE_MARK_EXACT) return;
   Aff<FqOps> p = PtIO<FqOps>::ld(g1 + i * ABI_G1_WORDS);
   Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2 + i * ABI_G2_WORDS);
   bool bad;
@@ -56,10 +80,13 @@ hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, si
   // small batches: one pairing per 12 lanes (zkt_dpairing.hip) — ~10x lower latency per pairing, lower peak throughput.  ZKT_DTATE_MAX overrides the switch-over.
   static const size_t dmax = [] { const char* e = getenv("ZKT_DTATE_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)16384; }();      // measured: 16,384 pairings 52 ms here, 60 ms on k_tate; 32,768 would be slower
   if (n <= dmax) {
-    hipError_t e = launch_dtate(g1, g2, out, n, err, TATE_MARK_WORD, TATE_MARK, s);
+    hipError_t e = launch_dtate(g1, g2, out, n, err, TATE_MARK_WORD, TATE_MARK_EXACT, s);
     if (e != hipSuccess) return e;
-  } else
-  hipLaunchKernelGGL(k_tate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
+    hipLaunchKernelGGL(k_tate_mark_offcurve, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n);
+  } else {
+    hipLaunchKernelGGL(k_tate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
+    hipLaunchKernelGGL(k_tate_long_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
+  }
   hipLaunchKernelGGL(k_tate_exact_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
   return hipGetLastError();
 }
