@@ -531,3 +531,7 @@ def test_pairing_g2_argument_outside_the_subgroup(L):
     oc, sg = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
     zk.check(L.zkt_g2_is_on_curve_batch(ptr(Qs), oc.ctypes.data, n)); zk.check(L.zkt_g2_in_subgroup_batch(ptr(Qs), sg.ctypes.data, n))
     assert [i for i in range(n) if not oc[i]] == [11] and [i for i in range(n) if not sg[i]] == [5, 11, 37, 64]
+    # the fused product check takes the same routes: e(P,Q) e(-P,Q) == 1 holds for P in G1 and ANY Q on the twist (255-step kernel behind the 127-step one)
+    ok = np.zeros(n, np.uint32)
+    zk.check(L.zkt_pairing_product_check_batch(ptr(np.repeat(P, 2, axis=0)), ptr(np.repeat(Qs, 2, axis=0)), (ctypes.c_uint8 * 2)(0, 1), 2, n, ok.ctypes.data))
+    assert all(int(ok[i]) == 1 for i in range(n) if i not in (11, 50)) and (not off_p_has_value or int(ok[50]) == 0)

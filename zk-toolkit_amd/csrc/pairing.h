@@ -202,6 +202,45 @@ ZKT_FN Fq12 miller_g1_g2_multi(const Fq* xp, const Fq* yp, const Fq2* xq, const 
   return f;
 }
 
+// The same product over the 127-step loop: prod_k f_{x^2,P_k}(untwist(Q_k)).  After the final exponentiation this is (prod_k tate_k)^(1/(2x^2-1)):
+// equal to one exactly when the Tate product is (2x^2-1 is a unit mod r), and final_exponentiation_t<true> turns it into the Tate product itself.
+// Needs every Q_k in G2 and every P_k on E (the callers test both); all_in_g1 <- every P_k in G1, from the points the loops end on.
+template <int K>
+ZKT_FN Fq12 miller_g1_g2_multi_short(const Fq* xp, const Fq* yp, const Fq2* xq, const Fq2* yq, bool& all_in_g1) {
+  const Fq2 xi_inv = xi_inv_const();
+  Fq2 Xq[K], Yq[K]; MillerPt V[K];
+  for (int k = 0; k < K; ++k) { Xq[k] = fq2_mul(xq[k], xi_inv); Yq[k] = fq2_mul(yq[k], xi_inv); V[k] = MillerPt{xp[k], yp[k], fp_one<FqC>()}; }
+  MillerLine l;
+  Fq12 f = fq12_one(), ft;
+  for (int i = 0; i < MILLER_X2_NBITS; ++i) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w = (j == (i >> 5)) ? miller_x2_bits_word(j) : w;
+    const bool bit = (w >> (i & 31)) & 1;
+    ft = fq12_sqr(f); f = ft;
+    for (int k = 0; k < K; ++k) {
+      miller_dbl_step(V[k], Xq[k], Yq[k], l);
+      ft = fq12_mul_line(f, l.a, l.b, l.c); f = ft;
+    }
+    if (bit) {
+      for (int k = 0; k < K; ++k) {
+        miller_add_step(V[k], xp[k], yp[k], Xq[k], Yq[k], l);
+        ft = fq12_mul_line(f, l.a, l.b, l.c); f = ft;
+      }
+    }
+  }
+  all_in_g1 = true;
+  for (int k = 0; k < K; ++k) all_in_g1 = all_in_g1 && miller_pt_is_x2(V[k], xp[k], yp[k]);
+  return f;
+}
+// every P_k on E, every Q_k on E' and in G2: what the 127-step product needs before it starts
+template <int K>
+ZKT_FN bool pairing_args_fit_short_loop(const Fq* xp, const Fq* yp, const Fq2* xq, const Fq2* yq) {
+  for (int k = 0; k < K; ++k)
+    if (!g1_on_curve(xp[k], yp[k]) || !g2_on_curve(xq[k], yq[k]) || !g2_in_subgroup(xq[k], yq[k])) return false;
+  return true;
+}
+
 // a^|x| , |x| = 0xd201000000010000 (bits 63,62,60,57,48,16)
 // (a in the cyclotomic subgroup: Granger-Scott squarings)
 ZKT_FN Fq12 fq12_pow_xabs(const Fq12& a) {

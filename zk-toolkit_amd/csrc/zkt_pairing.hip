@@ -30,12 +30,17 @@ hipError_t launch_miller_exact(int which, const uint32_t* g1, const uint32_t* g2
 // Groth16 verification, one proof per lane (verifier.rs:30-54 / SURVEY §8 f-2):
 //   e(A,B) == alpha_beta * e(S,gamma) * e(C,delta)   <=>   tate-product(A,B; -S,gamma; -C,delta) == alpha_beta
 // (e(-P,Q) = e(P,Q)^-1 exactly).  S_i = sum_j stmt[i][j] * uvw_stmt[j] is formed here too.  ok[i] = 1 / 0.
+// ok[i] = OK_REDO: the preconditions of the 127-step loop (pairing.h) do not hold for element i; the 255-step kernel, launched behind with
+// only_redo = 1, decides it.  Honest batches never see that second pass (one load per lane).
+static constexpr uint32_t OK_REDO = 2;
+template <bool SHORT>
 __global__ void __launch_bounds__(64) k_groth16_verify(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, const uint32_t* __restrict__ C,
                                                        const uint32_t* __restrict__ uvw_stmt, const uint32_t* __restrict__ stmt, int n_stmt,
                                                        const uint32_t* __restrict__ gamma, const uint32_t* __restrict__ delta,
-                                                       const uint32_t* __restrict__ alpha_beta, uint32_t* __restrict__ ok, size_t n, unsigned long long* err) {
+                                                       const uint32_t* __restrict__ alpha_beta, uint32_t* __restrict__ ok, size_t n, unsigned long long* err, int only_redo) {
   size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
+  if (only_redo && ok[i] != OK_REDO) return;
   Jac<FqOps> acc = jac_inf<FqOps>();
   for (int j = 0; j < n_stmt; ++j) {                                   // verifier.rs:41-45
     Aff<FqOps> u = PtIO<FqOps>::ld(uvw_stmt + (size_t)j * ABI_G1_WORDS);
@@ -48,7 +53,13 @@ __global__ void __launch_bounds__(64) k_groth16_verify(const uint32_t* __restric
   Fq xp[3] = {a.x, S.x, c.x}, yp[3] = {a.y, fp_neg(S.y), fp_neg(c.y)};
   Fq2 xq[3] = {b.x, g.x, d.x}, yq[3] = {b.y, g.y, d.y};
   bool in_g1;
-  Fq12 e = final_exponentiation(miller_g1_g2_multi<3>(xp, yp, xq, yq, in_g1));
+  Fq12 e;
+  if constexpr (SHORT) {
+    if (!pairing_args_fit_short_loop<3>(xp, yp, xq, yq)) { ok[i] = OK_REDO; return; }
+    e = final_exponentiation_t<true>(miller_g1_g2_multi_short<3>(xp, yp, xq, yq, in_g1));      // the Tate product itself: comparable with alpha_beta
+  } else {
+    e = final_exponentiation(miller_g1_g2_multi<3>(xp, yp, xq, yq, in_g1));
+  }
   if (!in_g1) { ok[i] = 0; return; }       // a G1 argument outside the order-r subgroup: e(-P,Q) = e(P,Q)^-1 is not available — fail closed
   uint32_t got[144]; st_fq12(got, e);
   uint32_t diff = 0;
@@ -85,17 +96,19 @@ hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uin
                                  const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* ok, size_t n,
                                  unsigned long long* err, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_groth16_verify, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err);
+  hipLaunchKernelGGL(k_groth16_verify<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 0);
+  hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1);
   return hipGetLastError();
 }
 
 // Equality of pairing products as the reference's callers test it (lhs == rhs on GTPoints: signature.rs:34-39,
 // pinocchio/verifier.rs:43-84): e(P1,Q1) == e(P2,Q2) e(P3,Q3)  <=>  tate-product(P1,Q1; -P2,Q2; -P3,Q3) == 1, since
 // e(-P,Q) = e(P,Q)^-1 exactly.  One element per lane; an argument at infinity is the reference's panic (rational_function.rs:36,59).
-template <int K>
-__global__ void __launch_bounds__(64) k_pairing_product_check(PairArgs a, uint32_t* __restrict__ ok, size_t n, unsigned long long* err) {
+template <int K, bool SHORT>
+__global__ void __launch_bounds__(64) k_pairing_product_check(PairArgs a, uint32_t* __restrict__ ok, size_t n, unsigned long long* err, int only_redo) {
   size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
+  if (only_redo && ok[i] != OK_REDO) return;
   Fq xp[K], yp[K]; Fq2 xq[K], yq[K];
   bool inf = false;
   for (int k = 0; k < K; ++k) {
@@ -106,7 +119,13 @@ __global__ void __launch_bounds__(64) k_pairing_product_check(PairArgs a, uint32
   }
   if (inf) { atomicMin(err, (unsigned long long)i); ok[i] = 0; return; }
   bool in_g1;
-  Fq12 e = final_exponentiation(miller_g1_g2_multi<K>(xp, yp, xq, yq, in_g1));
+  Fq12 e;
+  if constexpr (SHORT) {                   // (prod tate)^(1/(2x^2-1)) is one exactly when the Tate product is: no correction needed for "== 1"
+    if (!pairing_args_fit_short_loop<K>(xp, yp, xq, yq)) { ok[i] = OK_REDO; return; }
+    e = final_exponentiation(miller_g1_g2_multi_short<K>(xp, yp, xq, yq, in_g1));
+  } else {
+    e = final_exponentiation(miller_g1_g2_multi<K>(xp, yp, xq, yq, in_g1));
+  }
   if (!in_g1) { ok[i] = 0; return; }       // fail closed, as in k_groth16_verify
   uint32_t got[144]; st_fq12(got, e);
   uint32_t diff = got[132] ^ 1u;                       // canonical one: w0.v0.u0 = 1 (the last Fq of the {w1,w0} layout), all else 0
@@ -119,13 +138,16 @@ hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, 
   if (n == 0) return hipSuccess;
   if (n * (size_t)K <= dproduct_limit()) return launch_dproduct(a, K, nullptr, ok, n, err, s);
   dim3 g((unsigned)((n + 63) / 64)), t(64);
+#define ZKT_PRODUCT_CHECK(KK) hipLaunchKernelGGL((k_pairing_product_check<KK, true>), g, t, 0, s, a, ok, n, err, 0); \
+                              hipLaunchKernelGGL((k_pairing_product_check<KK, false>), g, t, 0, s, a, ok, n, err, 1)
   switch (K) {
-    case 1: hipLaunchKernelGGL(k_pairing_product_check<1>, g, t, 0, s, a, ok, n, err); break;
-    case 2: hipLaunchKernelGGL(k_pairing_product_check<2>, g, t, 0, s, a, ok, n, err); break;
-    case 3: hipLaunchKernelGGL(k_pairing_product_check<3>, g, t, 0, s, a, ok, n, err); break;
-    case 4: hipLaunchKernelGGL(k_pairing_product_check<4>, g, t, 0, s, a, ok, n, err); break;
+    case 1: ZKT_PRODUCT_CHECK(1); break;
+    case 2: ZKT_PRODUCT_CHECK(2); break;
+    case 3: ZKT_PRODUCT_CHECK(3); break;
+    case 4: ZKT_PRODUCT_CHECK(4); break;
     default: return hipErrorInvalidValue;
   }
+#undef ZKT_PRODUCT_CHECK
   return hipGetLastError();
 }
 
