@@ -478,7 +478,8 @@ __device__ __attribute__((noinline)) Fq d_pow_e1(const Ctx& c, const Fq& a) {
   return r;
 }
 // f^((q^12-1)/r), exact: the sequence of final_exponentiation (pairing.h)
-__device__ __attribute__((noinline)) Fq d_final_exp(const Ctx& c, const Fq& f) {
+// SHORT: f comes from the 127-step loop and the result is raised to 2 x^2 - 1 on the way out (final_exponentiation_t<true>, pairing.h)
+template <bool SHORT> __device__ __attribute__((noinline)) Fq d_final_exp(const Ctx& c, const Fq& f) {
   Fq t = d_inv(c, f);
   Fq a = d_conj(c, f);
   Fq g = d_mul(c, a, t);                         // ^(q^6-1)
@@ -494,11 +495,18 @@ __device__ __attribute__((noinline)) Fq d_final_exp(const Ctx& c, const Fq& f) {
   b = d_mul(c, b, t);
   t = d_conj(c, a);
   a = d_mul(c, b, t);                            // ^(x^2+q^2-1)
-  return d_mul(c, a, g);
+  if constexpr (!SHORT) return d_mul(c, a, g);
+  else {
+    t = d_mul(c, a, g);                          // eta
+    b = d_cyc_sqr(c, d_frob2(c, t));             // eta^(2 x^2)
+    return d_mul(c, b, d_conj(c, t));
+  }
 }
 
-// f_{r-1,P}(untwist(Q)) up to Fq6 factors for the group's pair, as miller_g1_g2 (pairing.h); in_g1 <- r P == infinity
-__device__ __attribute__((noinline)) Fq d_miller(const Ctx& c, const Aff<FqOps>& p, const Aff<Fq2Ops>& q, bool& in_g1) {
+// f_{r-1,P}(untwist(Q)) up to Fq6 factors for the group's pair, as miller_g1_g2 (pairing.h); in_g1 <- r P == infinity.
+// SHORT: f_{x^2,P} over the 127 bits of x^2 as miller_g1_g2_short — the callers have Q's membership of G2 and the curve equations checked by
+// k_short_loop_guards beside this kernel, and redo what fails them.
+template <bool SHORT> __device__ __attribute__((noinline)) Fq d_miller(const Ctx& c, const Aff<FqOps>& p, const Aff<Fq2Ops>& q, bool& in_g1) {
   {   // slot file: every lane computes the same values, the group's first lane stores them
     const Fq2 xi_inv = xi_inv_const();
     const Fq2 Xq = fq2_mul(q.x, xi_inv), Yq = fq2_mul(q.y, xi_inv);
@@ -511,25 +519,31 @@ __device__ __attribute__((noinline)) Fq d_miller(const Ctx& c, const Aff<FqOps>&
   }
   Fq f = d_one(c);
 #pragma unroll 1
-  for (int i = 0; i < MILLER_NAF_DIGITS; ++i) {
+  for (int i = 0; i < (SHORT ? MILLER_X2_NBITS : MILLER_NAF_DIGITS); ++i) {
     uint32_t nz = 0, ng = 0;
+    if constexpr (SHORT) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { nz = (j == (i >> 5)) ? miller_naf_nz_word(j) : nz; ng = (j == (i >> 5)) ? miller_naf_neg_word(j) : ng; }
+      for (int j = 0; j < 4; ++j) nz = (j == (i >> 5)) ? miller_x2_bits_word(j) : nz;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { nz = (j == (i >> 5)) ? miller_naf_nz_word(j) : nz; ng = (j == (i >> 5)) ? miller_naf_neg_word(j) : ng; }
+    }
     const bool bit = (nz >> (i & 31)) & 1, neg = (ng >> (i & 31)) & 1;
     f = d_sqr(c, f);
     point_dbl(c);
     f = d_mul_line(c, f);
     if (bit) { point_add(c, neg); f = d_mul_line(c, f); }
   }
-  // r P == infinity?  V = (r-1) P must equal -P
+  // r P == infinity?  V = (r-1) P must equal -P;  after the short loop V = x^2 P must equal (BETA xp, -yp)  (miller_pt_is_x2, pairing.h)
   const Fq X = slotv(c, P_X), Y = slotv(c, P_Y), Z = slotv(c, P_Z);
   const Fq ZZ = fp_sqr(Z);
-  in_g1 = !fp_is_zero(Z) && fp_eq(fp_mul(p.x, ZZ), X) && fp_eq(fp_mul(fp_mul(p.y, ZZ), Z), fp_neg(Y));
+  const Fq xw = SHORT ? fp_mul(g1_beta_const(), p.x) : p.x;
+  in_g1 = !fp_is_zero(Z) && fp_eq(fp_mul(xw, ZZ), X) && fp_eq(fp_mul(fp_mul(p.y, ZZ), Z), fp_neg(Y));
   return f;
 }
 
 // one Tate pairing per group.  Marks elements whose P is outside G1 for k_tate_exact_marked, exactly as k_tate does.
-__global__ void __launch_bounds__(64) k_dtate(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t* __restrict__ out, size_t n,
+template <bool SHORT> __global__ void __launch_bounds__(64) k_dtate(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t* __restrict__ out, size_t n,
                                               unsigned long long* err, uint32_t mark_word, uint32_t mark) {
   __shared__ uint32_t lds[LDS_WORDS];
   const Ctx c = make_ctx(lds);
@@ -545,8 +559,8 @@ __global__ void __launch_bounds__(64) k_dtate(const uint32_t* __restrict__ g1, c
     p.x = fp_one<FqC>(); p.y = fp_one<FqC>(); q.x = fq2_one(); q.y = fq2_one();
   }
   bool in_g1;
-  const Fq f = d_miller(c, p, q, in_g1);
-  const Fq r = d_final_exp(c, f);
+  const Fq f = d_miller<SHORT>(c, p, q, in_g1);
+  const Fq r = d_final_exp<SHORT>(c, f);
   if (!live || inf) return;
   if (!in_g1) { if (c.r.g == 0) out[e * 144 + mark_word] = mark; return; }
   st_fp<FqC>(out + e * 144 + abi_word(c.r.m, c.r.part), r);
@@ -555,7 +569,7 @@ __global__ void __launch_bounds__(64) k_dtate(const uint32_t* __restrict__ g1, c
 // prod_k tate(+-P_k, Q_k) == target (or == 1) per element, K <= 4 pairs: the K Miller loops run side by side in K groups of one wave,
 // the group results meet in the first group's LDS image, ONE final exponentiation follows.  Same contract as k_pairing_product_check /
 // k_groth16_verify (zkt_pairing.hip): infinity -> error index, a G1 argument outside the order-r subgroup -> ok = 0.
-template <int K>
+template <int K, bool SHORT>
 __global__ void __launch_bounds__(64) k_dproduct(PairArgs a, const uint32_t* __restrict__ target, uint32_t* __restrict__ ok, size_t n, unsigned long long* err) {
   __shared__ uint32_t lds[LDS_WORDS];
   const Ctx c = make_ctx(lds);
@@ -574,7 +588,7 @@ __global__ void __launch_bounds__(64) k_dproduct(PairArgs a, const uint32_t* __r
   if (inf) { p.x = fp_one<FqC>(); p.y = fp_one<FqC>(); q.x = fq2_one(); q.y = fq2_one(); }
   if (a.neg[pair]) p.y = fp_neg(p.y);
   bool in_g1;
-  Fq f = d_miller(c, p, q, in_g1);
+  Fq f = d_miller<SHORT>(c, p, q, in_g1);
   // element-wide flags: every lane of the element's K groups must agree
   const int start = eb * K * GL;
   const unsigned long long emask = (K * GL >= 64 ? ~0ull : ((1ull << (K * GL)) - 1ull)) << start;
@@ -587,7 +601,8 @@ __global__ void __launch_bounds__(64) k_dproduct(PairArgs a, const uint32_t* __r
     const Fq prod = dot_mul(c.img(0), lead + 1 * IMG_SLOTS * SW, c.r.m, c.r.part);
     f = (pair == 0) ? prod : f;                                   // groups k > 0 keep their own value until it has been handed over
   }
-  const Fq r = d_final_exp(c, f);
+  // SHORT: (prod tate)^(1/(2x^2-1)) is one exactly when the Tate product is; against a target the corrected exponentiation gives the product itself
+  const Fq r = (SHORT && target) ? d_final_exp<true>(c, f) : d_final_exp<false>(c, f);
   uint32_t w[12]; fp_to_words(r, w);
   uint32_t diff = 0;
   const int off = abi_word(c.r.m, c.r.part);
@@ -609,21 +624,25 @@ hipError_t launch_dfq12_op(int op, const uint32_t* a, const uint32_t* b, uint32_
   return hipGetLastError();
 }
 
-hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s) {
+hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, bool short_loop, hipStream_t s) {
   if (n == 0) return hipSuccess;
   auto blocks = [&](int epb) { return dim3((unsigned)((n + epb - 1) / epb)); };
+#define ZKT_DPRODUCT(KK, EPB) if (short_loop) hipLaunchKernelGGL((dp::k_dproduct<KK, true>), blocks(EPB), dim3(64), 0, s, a, target, ok, n, err); \
+                             else hipLaunchKernelGGL((dp::k_dproduct<KK, false>), blocks(EPB), dim3(64), 0, s, a, target, ok, n, err)
   switch (K) {
-    case 1: hipLaunchKernelGGL(dp::k_dproduct<1>, blocks(5), dim3(64), 0, s, a, target, ok, n, err); break;
-    case 2: hipLaunchKernelGGL(dp::k_dproduct<2>, blocks(2), dim3(64), 0, s, a, target, ok, n, err); break;
-    case 3: hipLaunchKernelGGL(dp::k_dproduct<3>, blocks(1), dim3(64), 0, s, a, target, ok, n, err); break;
-    case 4: hipLaunchKernelGGL(dp::k_dproduct<4>, blocks(1), dim3(64), 0, s, a, target, ok, n, err); break;
+    case 1: ZKT_DPRODUCT(1, 5); break;
+    case 2: ZKT_DPRODUCT(2, 2); break;
+    case 3: ZKT_DPRODUCT(3, 1); break;
+    case 4: ZKT_DPRODUCT(4, 1); break;
     default: return hipErrorInvalidValue;
   }
+#undef ZKT_DPRODUCT
   return hipGetLastError();
 }
-hipError_t launch_dtate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, uint32_t mark_word, uint32_t mark, hipStream_t s) {
+hipError_t launch_dtate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, uint32_t mark_word, uint32_t mark, bool short_loop, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(dp::k_dtate, dim3((unsigned)((n + dp::GPW - 1) / dp::GPW)), dim3(64), 0, s, g1, g2, out, n, err, mark_word, mark);
+  if (short_loop) hipLaunchKernelGGL(dp::k_dtate<true>, dim3((unsigned)((n + dp::GPW - 1) / dp::GPW)), dim3(64), 0, s, g1, g2, out, n, err, mark_word, mark);
+  else hipLaunchKernelGGL(dp::k_dtate<false>, dim3((unsigned)((n + dp::GPW - 1) / dp::GPW)), dim3(64), 0, s, g1, g2, out, n, err, mark_word, mark);
   return hipGetLastError();
 }
 

@@ -50,9 +50,14 @@ hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, 
 // lane-distributed pairing (zkt_dpairing.hip): diagnostic Fq12 ops on the distributed form
 hipError_t launch_dfq12_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n, hipStream_t s);
 // one pairing per 12 lanes; elements whose P is outside G1 get out[i*144 + mark_word] = mark (see zkt_tate.hip)
-hipError_t launch_dtate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, uint32_t mark_word, uint32_t mark, hipStream_t s);
+hipError_t launch_dtate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, uint32_t mark_word, uint32_t mark, bool short_loop, hipStream_t s);
 // prod_k tate(+-P_k, Q_k) == target (NULL: == 1) with the K Miller loops in K lane groups of one wave (small batches)
-hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s);
+hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, bool short_loop, hipStream_t s);
+// The 127-step loop of the small-batch kernels runs on trust; its preconditions (points on their curves, Q in G2) are checked by a one-lane-per-element
+// kernel on a side stream meanwhile.  guard_fork makes `side` wait for everything queued on `s`; guard_join makes `s` wait for the side stream.
+hipError_t guard_fork(hipStream_t s, hipStream_t* side);
+hipError_t guard_join(hipStream_t s, hipStream_t side);
+hipError_t launch_short_loop_guards(const PairArgs& a, int K, uint32_t* flags, size_t n, hipStream_t s);      // flags[i] = 1: every pair of element i fits the 127-step loop
 hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s);
 
 // ---- MSM (zkt_msm.hip), generic over the group (G_G1, G_G2, G_SECP) ------------------------------------------

@@ -1,6 +1,7 @@
 // Pairing kernels other than the plain batched Tate pairing (zkt_tate.hip): raw Miller values / Weil (row a14), the fused
 // Groth16 verification (f-2) and pairing-product equalities (f-4).  The algorithm and why it is bit-identical to the reference are in pairing.h.
 #include <cstdlib>
+#include <mutex>
 #include "abi.h"
 #include "zkt_internal.h"
 
@@ -27,12 +28,65 @@ hipError_t launch_miller_exact(int which, const uint32_t* g1, const uint32_t* g2
   return hipGetLastError();
 }
 
+// ---- preconditions of the 127-step loop for the small-batch kernels -----------------------------------------------------------------
+// The lane-distributed kernels (zkt_dpairing.hip) run the 127-step loop on trust; whether every pair of an element fits it (points on their
+// curves, Q in G2: pairing_args_fit_short_loop) is decided by this one-lane-per-element kernel on a side stream at the same time — the G2
+// test alone is 1.8 ms on a single lane, about a third of the pairing it guards.  Elements that fail are redone by the 255-step kernels.
+__global__ void __launch_bounds__(64) k_short_loop_guards(PairArgs a, int K, uint32_t* __restrict__ flags, size_t n) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t fits = 1;
+  for (int k = 0; k < K && fits; ++k) {
+    Aff<FqOps> p = PtIO<FqOps>::ld(a.g1[k] + i * a.s1[k]);
+    Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(a.g2[k] + i * a.s2[k]);
+    if (p.inf || q.inf) continue;                                  // the reference's panic: reported by the main kernel, nothing to redo
+    fits = pairing_args_fit_short_loop<1>(&p.x, &p.y, &q.x, &q.y) ? 1u : 0u;
+  }
+  flags[i] = fits;
+}
+hipError_t launch_short_loop_guards(const PairArgs& a, int K, uint32_t* flags, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_short_loop_guards, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a, K, flags, n);
+  return hipGetLastError();
+}
+namespace {
+struct GuardStreams {
+  std::mutex mu; hipStream_t side = nullptr; hipEvent_t ev[32] = {}; unsigned next = 0;
+  hipError_t event(hipEvent_t* e) {                                // a small ring: a wait captures the event's record at the time of the call
+    std::lock_guard<std::mutex> lk(mu);
+    hipError_t rc;
+    if (!side && (rc = hipStreamCreateWithFlags(&side, hipStreamNonBlocking)) != hipSuccess) return rc;
+    hipEvent_t& x = ev[next++ % 32];
+    if (!x && (rc = hipEventCreateWithFlags(&x, hipEventDisableTiming)) != hipSuccess) return rc;
+    *e = x; return hipSuccess;
+  }
+} g_guard;
+}  // namespace
+hipError_t guard_fork(hipStream_t s, hipStream_t* side) {
+  hipEvent_t e; hipError_t rc;
+  if ((rc = g_guard.event(&e)) != hipSuccess) return rc;
+  *side = g_guard.side;
+  if ((rc = hipEventRecord(e, s)) != hipSuccess) return rc;
+  return hipStreamWaitEvent(*side, e, 0);
+}
+hipError_t guard_join(hipStream_t s, hipStream_t side) {
+  hipEvent_t e; hipError_t rc;
+  if ((rc = g_guard.event(&e)) != hipSuccess) return rc;
+  if ((rc = hipEventRecord(e, side)) != hipSuccess) return rc;
+  return hipStreamWaitEvent(s, e, 0);
+}
+// ok[i] <- OK_REDO where the guards say the element does not fit the 127-step loop
+static constexpr uint32_t OK_REDO = 2;
+__global__ void __launch_bounds__(256) k_product_resolve(const uint32_t* __restrict__ flags, uint32_t* __restrict__ ok, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n && !flags[i]) ok[i] = OK_REDO;
+}
+
 // Groth16 verification, one proof per lane (verifier.rs:30-54 / SURVEY §8 f-2):
 //   e(A,B) == alpha_beta * e(S,gamma) * e(C,delta)   <=>   tate-product(A,B; -S,gamma; -C,delta) == alpha_beta
 // (e(-P,Q) = e(P,Q)^-1 exactly).  S_i = sum_j stmt[i][j] * uvw_stmt[j] is formed here too.  ok[i] = 1 / 0.
 // ok[i] = OK_REDO: the preconditions of the 127-step loop (pairing.h) do not hold for element i; the 255-step kernel, launched behind with
 // only_redo = 1, decides it.  Honest batches never see that second pass (one load per lane).
-static constexpr uint32_t OK_REDO = 2;
 template <bool SHORT>
 __global__ void __launch_bounds__(64) k_groth16_verify(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, const uint32_t* __restrict__ C,
                                                        const uint32_t* __restrict__ uvw_stmt, const uint32_t* __restrict__ stmt, int n_stmt,
@@ -90,7 +144,17 @@ hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, con
   a.g1[0] = A; a.s1[0] = ABI_G1_WORDS; a.g2[0] = B; a.s2[0] = ABI_G2_WORDS; a.neg[0] = 0;
   a.g1[1] = S; a.s1[1] = ABI_G1_WORDS; a.g2[1] = gamma; a.s2[1] = 0; a.neg[1] = 1;
   a.g1[2] = C; a.s1[2] = ABI_G1_WORDS; a.g2[2] = delta; a.s2[2] = 0; a.neg[2] = 1;
-  return launch_dproduct(a, 3, alpha_beta, ok, n, err, s);
+  // 127-step loops on the lane-distributed kernels, their preconditions checked beside them; what fails is redone by the 255-step kernel
+  uint32_t* flags = nullptr; hipStream_t side;
+  if ((e = hipMallocAsync((void**)&flags, n * sizeof(uint32_t), s)) != hipSuccess) return e;
+  if ((e = guard_fork(s, &side)) != hipSuccess) return e;
+  if ((e = launch_short_loop_guards(a, 3, flags, n, side)) != hipSuccess) return e;
+  if ((e = launch_dproduct(a, 3, alpha_beta, ok, n, err, true, s)) != hipSuccess) return e;
+  if ((e = guard_join(s, side)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_product_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)flags, ok, n);
+  if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1);
+  return hipGetLastError();
 }
 hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
                                  const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* ok, size_t n,
@@ -136,9 +200,20 @@ __global__ void __launch_bounds__(64) k_pairing_product_check(PairArgs a, uint32
 size_t dproduct_limit() { static const size_t v = [] { const char* e = getenv("ZKT_DPRODUCT_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)16384; }(); return v; }
 hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  if (n * (size_t)K <= dproduct_limit()) return launch_dproduct(a, K, nullptr, ok, n, err, s);
   dim3 g((unsigned)((n + 63) / 64)), t(64);
-#define ZKT_PRODUCT_CHECK(KK) hipLaunchKernelGGL((k_pairing_product_check<KK, true>), g, t, 0, s, a, ok, n, err, 0); \
+  const bool small = n * (size_t)K <= dproduct_limit();
+  if (K < 1 || K > 4) return hipErrorInvalidValue;
+  if (small) {                             // 127-step loops on the lane-distributed kernels, their preconditions checked beside them
+    uint32_t* flags = nullptr; hipStream_t side; hipError_t e;
+    if ((e = hipMallocAsync((void**)&flags, n * sizeof(uint32_t), s)) != hipSuccess) return e;
+    if ((e = guard_fork(s, &side)) != hipSuccess) return e;
+    if ((e = launch_short_loop_guards(a, K, flags, n, side)) != hipSuccess) return e;
+    if ((e = launch_dproduct(a, K, nullptr, ok, n, err, true, s)) != hipSuccess) return e;
+    if ((e = guard_join(s, side)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_product_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)flags, ok, n);
+    if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
+  }
+#define ZKT_PRODUCT_CHECK(KK) if (!small) hipLaunchKernelGGL((k_pairing_product_check<KK, true>), g, t, 0, s, a, ok, n, err, 0); \
                               hipLaunchKernelGGL((k_pairing_product_check<KK, false>), g, t, 0, s, a, ok, n, err, 1)
   switch (K) {
     case 1: ZKT_PRODUCT_CHECK(1); break;

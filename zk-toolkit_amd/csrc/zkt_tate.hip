@@ -49,15 +49,16 @@ __global__ void __launch_bounds__(64) ZKT_TATE_ATTR k_tate_long_marked(const uin
   if (!in_g1) { out[i * 144 + TATE_MARK_WORD] = TATE_MARK_EXACT; return; }  // r P != infinity: left to k_tate_exact_marked
   st_fq12(out + i * 144, final_exponentiation(f));
 }
-// After the small-batch kernels (zkt_dpairing.hip: 255-step loop for every element): elements with a point off its curve are re-marked for the
-// reference's chain — two addition chains agree on the curve only.
-__global__ void __launch_bounds__(64) k_tate_mark_offcurve(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t* __restrict__ out, size_t n) {
+// After the small-batch kernels (zkt_dpairing.hip: the 127-step loop for every element, on trust): elements the guard kernel (zkt_pairing.hip,
+// run beside them) found unfit are re-marked — a point off its curve for the reference's chain, Q on E' outside G2 for the 255-step loop.
+__global__ void __launch_bounds__(64) k_tate_resolve(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2,
+                                                     uint32_t* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || flags[i]) return;
   Aff<FqOps> p = PtIO<FqOps>::ld(g1 + i * ABI_G1_WORDS);
   Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2 + i * ABI_G2_WORDS);
   if (p.inf || q.inf) return;
-  if (!g1_on_curve(p.x, p.y) || !g2_on_curve(q.x, q.y)) out[i * 144 + TATE_MARK_WORD] = TATE_MARK_EXACT;
+  out[i * 144 + TATE_MARK_WORD] = (g1_on_curve(p.x, p.y) && g2_on_curve(q.x, q.y)) ? TATE_MARK_LONG : TATE_MARK_EXACT;
 }
 // Third pass, for the elements marked EXACT: P outside the order-r subgroup (or a point off its curve).  There the reference's result depends on
 // the order of P — it panics when a multiple of P met by its binary chain is infinity (rational_function.rs:36) — so these lanes follow
@@ -80,9 +81,16 @@ hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, si
   // small batches: one pairing per 12 lanes (zkt_dpairing.hip) — ~10x lower latency per pairing, lower peak throughput.  ZKT_DTATE_MAX overrides the switch-over.
   static const size_t dmax = [] { const char* e = getenv("ZKT_DTATE_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)16384; }();      // measured: 16,384 pairings 52 ms here, 60 ms on k_tate; 32,768 would be slower
   if (n <= dmax) {
-    hipError_t e = launch_dtate(g1, g2, out, n, err, TATE_MARK_WORD, TATE_MARK_EXACT, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_tate_mark_offcurve, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n);
+    PairArgs a{}; a.g1[0] = g1; a.s1[0] = ABI_G1_WORDS; a.g2[0] = g2; a.s2[0] = ABI_G2_WORDS;
+    uint32_t* flags = nullptr; hipStream_t side; hipError_t e;
+    if ((e = hipMallocAsync((void**)&flags, n * sizeof(uint32_t), s)) != hipSuccess) return e;
+    if ((e = guard_fork(s, &side)) != hipSuccess) return e;
+    if ((e = launch_short_loop_guards(a, 1, flags, n, side)) != hipSuccess) return e;
+    if ((e = launch_dtate(g1, g2, out, n, err, TATE_MARK_WORD, TATE_MARK_EXACT, true, s)) != hipSuccess) return e;
+    if ((e = guard_join(s, side)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_tate_resolve, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)flags, g1, g2, out, n);
+    if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_tate_long_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
   } else {
     hipLaunchKernelGGL(k_tate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
     hipLaunchKernelGGL(k_tate_long_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
