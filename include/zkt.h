@@ -165,9 +165,11 @@ int zkt_g2_msm(const zkt_g2_affine* bases, const uint64_t* scalars, size_t n, zk
 int zkt_secp_msm(const zkt_secp_affine* bases, const uint64_t* scalars, size_t n, zkt_secp_affine* out);
 
 /* a10–a13: Pairing::tate pairing.rs:86-100 — out[i] = Fq12 of tate(g1[i], g2[i]).
- * Domain: bit-identical to the reference for every affine P, Q.  For P of order r (every point the reference constructs) the fast loop is used;
- * r P != infinity is detected for free at the end of that loop and such elements are recomputed on the reference's own chain, including its
- * panics: ZKT_ERR_INFINITY (+ index) when an argument or a multiple of P met by that chain is the point at infinity (rational_function.rs:36,59). */
+ * Domain: bit-identical to the reference for every pair of coordinates.  For P in G1 and Q in G2 (every point the reference constructs) the value
+ * comes from a 127-step Miller loop, tate = eta^(2x^2-1) for the twisted-ate value eta (csrc/pairing.h); both memberships and both curve equations
+ * are tested exactly, per element.  Q on the twist outside G2 takes the 255-step loop over r - 1; P outside G1 or a point off its curve is
+ * recomputed on the reference's own chain, including its panics: ZKT_ERR_INFINITY (+ index) when an argument or a multiple of P met by that
+ * chain is the point at infinity (rational_function.rs:36,59). */
 int zkt_tate_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out_fq12, size_t n);
 /* a12, a14: raw Miller values and the Weil pairing, bit-exact (the reference uses them in its tests only):
  * Pairing::calc_g1_g2 pairing.rs:54, calc_g2_g1 pairing.rs:55, weil = calc_g1_g2(P,Q) * calc_g2_g1(Q,P)^-1 pairing.rs:75-84 */
