@@ -9,5 +9,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats --
 echo stats rc=$?
 python3 tools/bench_protocols.py > gpurun_out/r02_protocols.json 2> gpurun_out/r02_protocols.err
 echo protocols rc=$?
-ZKT_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --groth16-log2n 16 --groth16-proofs 3 --pairings 0 --no-cpu > gpurun_out/r02_bench_rehearsal_2ranks_1gpu.json 2> gpurun_out/r02_rehearsal.err
+ZKT_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --groth16-log2n 16 --groth16-proofs 3 --pairings 4096 --no-cpu > gpurun_out/r02_bench_rehearsal_2ranks_1gpu.json 2> gpurun_out/r02_rehearsal.err
 echo rehearsal rc=$?
