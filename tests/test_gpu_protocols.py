@@ -194,6 +194,15 @@ def test_groth16_verify_batch_mixed(L):              # f-2: fused 3-pairing veri
     assert ok.tolist() == [1, 1, 0, 1, 0, 1]
     for i in range(k):                                  # the oracle's verifier (three separate tate calls) agrees
         assert O.zkto_groth16_verify(ctypes.byref(crs), ptr(As[i:i + 1].copy()), ptr(Bs[i:i + 1].copy()), ptr(Cs[i:i + 1].copy()), ptr(stmts[i:i + 1].copy()), l + 1) == int(ok[i])
+    # G2 arguments outside the subgroup: the fast kernels need B, gamma, delta in G2 (127-step loop) and redo such proofs on the 255-step kernels —
+    # a proof whose B is a twist point outside G2, then a verifying key whose gamma is one: verdicts as the oracle's three-tate verifier gives them
+    rng2 = SplitMix64(72)
+    Bs[1] = g2_arr([to_abi_g2(py_twist_point(rng2))])[0]
+    for swap_gamma in (False, True):
+        if swap_gamma: buf["g2_gamma"][0] = g2_arr([to_abi_g2(py_twist_point(rng2))])[0]
+        zk.check(L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(stmts), l + 1, k, ok.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+        want = [O.zkto_groth16_verify(ctypes.byref(crs), ptr(As[i:i + 1].copy()), ptr(Bs[i:i + 1].copy()), ptr(Cs[i:i + 1].copy()), ptr(stmts[i:i + 1].copy()), l + 1) for i in range(k)]
+        assert ok.tolist() == want and ok[1] == 0
 
 
 @pytest.mark.parametrize("name,W,order,gen_fn,n", [("g2", G2W, R, "zkto_g2_generator", 1 << 13), ("secp", 9, SECP_N, "zkto_secp_generator", 1 << 14)])

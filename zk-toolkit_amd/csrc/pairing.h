@@ -233,11 +233,14 @@ ZKT_FN Fq12 miller_g1_g2_multi_short(const Fq* xp, const Fq* yp, const Fq2* xq, 
   for (int k = 0; k < K; ++k) all_in_g1 = all_in_g1 && miller_pt_is_x2(V[k], xp[k], yp[k]);
   return f;
 }
-// every P_k on E, every Q_k on E' and in G2: what the 127-step product needs before it starts
+// every P_k on E, every Q_k on E' and in G2: what the 127-step product needs before it starts.  Bit k of q_known_good: Q_k was tested by the caller already
+// (a point shared by the whole batch — the verifying key's gamma, delta — is tested once per launch, not once per lane).
 template <int K>
-ZKT_FN bool pairing_args_fit_short_loop(const Fq* xp, const Fq* yp, const Fq2* xq, const Fq2* yq) {
-  for (int k = 0; k < K; ++k)
-    if (!g1_on_curve(xp[k], yp[k]) || !g2_on_curve(xq[k], yq[k]) || !g2_in_subgroup(xq[k], yq[k])) return false;
+ZKT_FN bool pairing_args_fit_short_loop(const Fq* xp, const Fq* yp, const Fq2* xq, const Fq2* yq, unsigned q_known_good = 0) {
+  for (int k = 0; k < K; ++k) {
+    if (!g1_on_curve(xp[k], yp[k])) return false;
+    if (!((q_known_good >> k) & 1) && (!g2_on_curve(xq[k], yq[k]) || !g2_in_subgroup(xq[k], yq[k]))) return false;
+  }
   return true;
 }
 

@@ -85,13 +85,26 @@ __global__ void __launch_bounds__(256) k_product_resolve(const uint32_t* __restr
 // Groth16 verification, one proof per lane (verifier.rs:30-54 / SURVEY §8 f-2):
 //   e(A,B) == alpha_beta * e(S,gamma) * e(C,delta)   <=>   tate-product(A,B; -S,gamma; -C,delta) == alpha_beta
 // (e(-P,Q) = e(P,Q)^-1 exactly).  S_i = sum_j stmt[i][j] * uvw_stmt[j] is formed here too.  ok[i] = 1 / 0.
+// G2 points shared by a whole batch (stride 0: gamma and delta of a verifying key): curve equation and subgroup membership once per launch.
+// good[0] bit j <- points[j] is in G2.  One wave; lanes beyond `count` idle.
+__global__ void __launch_bounds__(64) k_shared_g2_guards(const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1, uint32_t* __restrict__ good) {
+  const int j = threadIdx.x;
+  bool ok = false;
+  if (j < 2) {
+    Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(j == 0 ? p0 : p1);
+    ok = !q.inf && g2_on_curve(q.x, q.y) && g2_in_subgroup(q.x, q.y);
+  }
+  const unsigned long long b = __ballot(ok);
+  if (j == 0) good[0] = (uint32_t)(b & 3u);
+}
 // ok[i] = OK_REDO: the preconditions of the 127-step loop (pairing.h) do not hold for element i; the 255-step kernel, launched behind with
 // only_redo = 1, decides it.  Honest batches never see that second pass (one load per lane).
 template <bool SHORT>
 __global__ void __launch_bounds__(64) k_groth16_verify(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, const uint32_t* __restrict__ C,
                                                        const uint32_t* __restrict__ uvw_stmt, const uint32_t* __restrict__ stmt, int n_stmt,
                                                        const uint32_t* __restrict__ gamma, const uint32_t* __restrict__ delta,
-                                                       const uint32_t* __restrict__ alpha_beta, uint32_t* __restrict__ ok, size_t n, unsigned long long* err, int only_redo) {
+                                                       const uint32_t* __restrict__ alpha_beta, uint32_t* __restrict__ ok, size_t n, unsigned long long* err, int only_redo,
+                                                       const uint32_t* __restrict__ shared_good) {
   size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   if (only_redo && ok[i] != OK_REDO) return;
@@ -109,7 +122,7 @@ __global__ void __launch_bounds__(64) k_groth16_verify(const uint32_t* __restric
   bool in_g1;
   Fq12 e;
   if constexpr (SHORT) {
-    if (!pairing_args_fit_short_loop<3>(xp, yp, xq, yq)) { ok[i] = OK_REDO; return; }
+    if (!pairing_args_fit_short_loop<3>(xp, yp, xq, yq, shared_good ? (shared_good[0] & 3u) << 1 : 0u)) { ok[i] = OK_REDO; return; }      // gamma, delta: pairs 1, 2
     e = final_exponentiation_t<true>(miller_g1_g2_multi_short<3>(xp, yp, xq, yq, in_g1));      // the Tate product itself: comparable with alpha_beta
   } else {
     e = final_exponentiation(miller_g1_g2_multi<3>(xp, yp, xq, yq, in_g1));
@@ -153,15 +166,19 @@ hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, con
   if ((e = guard_join(s, side)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_product_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)flags, ok, n);
   if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1);
+  hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr);
   return hipGetLastError();
 }
 hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
                                  const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* ok, size_t n,
                                  unsigned long long* err, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_groth16_verify<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 0);
-  hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1);
+  uint32_t* good = nullptr; hipError_t e;                   // gamma and delta are the same for every proof: their G2 membership is decided by one wave, not by every lane
+  if ((e = hipMallocAsync((void**)&good, sizeof(uint32_t), s)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_shared_g2_guards, dim3(1), dim3(64), 0, s, gamma, delta, good);
+  hipLaunchKernelGGL(k_groth16_verify<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 0, (const uint32_t*)good);
+  if ((e = hipFreeAsync(good, s)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr);
   return hipGetLastError();
 }
 
