@@ -123,13 +123,6 @@ int zkt_hostcheck_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* o) {
   st_fq12(o, final_exponentiation(f));
   return 100;                             // 100: value produced by the exact path
 }
-// debugging aid: the raw value of the 255-step loop and its final exponentiation
-int zkt_hostcheck_debug_long(const uint32_t* g1, const uint32_t* g2, uint32_t* of, uint32_t* ofe) {
-  Aff<FqOps> p = PtIO<FqOps>::ld(g1); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2);
-  bool in_g1; Fq12 f = miller_g1_g2(p.x, p.y, q.x, q.y, in_g1);
-  st_fq12(of, f); st_fq12(ofe, final_exponentiation(f));
-  return in_g1;
-}
 // the membership tests that guard the 127-step loop: bit 0 = P on E, bit 1 = r P == infinity (from the loop), bit 2 = Q in G2, bit 3 = Q on E'
 int zkt_hostcheck_short_loop_guards(const uint32_t* g1, const uint32_t* g2) {
   Aff<FqOps> p = PtIO<FqOps>::ld(g1); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2);
