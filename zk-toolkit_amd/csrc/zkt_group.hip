@@ -119,6 +119,52 @@ hipError_t launch_group_mul_segs(int grp, const MulSegs& segs, int kw, hipStream
   return hipGetLastError();
 }
 
+// ---- fixed-base products (zkt_internal.h) ------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(64) k_fixed_table(FixedTables ft) {
+  const int w = threadIdx.x;
+  constexpr int W = PtIO<F>::WORDS;
+  const uint32_t* point = ft.point[blockIdx.x]; uint32_t* table = ft.table[blockIdx.x];
+  Jac<F> j = jac_from_aff(PtIO<F>::ld(point));
+  for (int d = 0; d < 4 * w; ++d) j = jac_dbl(j);               // lane 63: 252 doublings — the latency of the launch, paid once per point
+  PtIO<F>::st(table + (size_t)w * W, jac_to_aff(j));
+}
+template <class F>
+__global__ void __launch_bounds__(64) k_fixed_muls(FixedMuls f) {
+  typedef typename F::E E;
+  constexpr int W = PtIO<F>::WORDS, EW = sizeof(E) / 4, JW = 3 * EW;
+  __shared__ uint32_t lds[32 * JW];
+  const FixedMul m = f.m[blockIdx.x];
+  const int w = threadIdx.x;
+  const uint32_t d = (m.k[w >> 3] >> ((w & 7) * 4)) & 15u;      // w-th 4-bit digit of the scalar (8 canonical 32-bit words)
+  const Aff<F> t = PtIO<F>::ld(m.table + (size_t)w * W);
+  Jac<F> acc = jac_inf<F>();
+  for (int b = 3; b >= 0; --b) { acc = jac_dbl(acc); if ((d >> b) & 1) acc = jac_add_aff(acc, t); }
+  auto stj = [](uint32_t* p, const Jac<F>& a) { const uint32_t *x = (const uint32_t*)&a.X, *y = (const uint32_t*)&a.Y, *z = (const uint32_t*)&a.Z;
+    for (int i = 0; i < EW; ++i) { p[i] = x[i]; p[EW + i] = y[i]; p[2 * EW + i] = z[i]; } };
+  auto ldj = [](const uint32_t* p) { Jac<F> a; uint32_t *x = (uint32_t*)&a.X, *y = (uint32_t*)&a.Y, *z = (uint32_t*)&a.Z;
+    for (int i = 0; i < EW; ++i) { x[i] = p[i]; y[i] = p[EW + i]; z[i] = p[2 * EW + i]; } return a; };
+  for (int h = 32; h >= 1; h >>= 1) {
+    if (w >= h && w < 2 * h) stj(lds + (w - h) * JW, acc);
+    __syncthreads();
+    if (w < h) acc = jac_add<F>(acc, ldj(lds + w * JW));
+    __syncthreads();
+  }
+  if (w == 0) PtIO<F>::st(m.out, jac_to_aff(acc));
+}
+hipError_t launch_fixed_tables(int grp, const FixedTables& t, hipStream_t s) {
+  if (grp != G_SECP || t.n < 0 || t.n > 4) return hipErrorInvalidValue;      // instantiated where it is used: the secp256k1 generators of Bulletproofs
+  if (t.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_fixed_table<SpOps>, dim3((unsigned)t.n), dim3(64), 0, s, t);
+  return hipGetLastError();
+}
+hipError_t launch_fixed_muls(int grp, const FixedMuls& f, hipStream_t s) {
+  if (grp != G_SECP || f.n < 0 || f.n > 16) return hipErrorInvalidValue;
+  if (f.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_fixed_muls<SpOps>, dim3((unsigned)f.n), dim3(64), 0, s, f);
+  return hipGetLastError();
+}
+
 // ---- sum of n affine points ------------------------------------------------------------------------------------------------
 // the G2 / secp256k1 sums behind eval_with_g2_hidings (polynomial.rs:283-293) and (AffinePoints * PrimeFieldElems).sum()
 // (secp256k1/affine_points.rs:25-31,123-144).  Two launches: every lane adds a strided share into a Jacobian accumulator (mixed

@@ -35,6 +35,14 @@ hipError_t launch_group_sum_inplace(int grp, uint32_t* pts, size_t n, hipStream_
 struct MulSeg { const uint32_t* pts; const uint32_t* k; uint32_t* out; uint32_t count, pt_stride, k_stride; };
 struct MulSegs { MulSeg s[16]; int n; };
 hipError_t launch_group_mul_segs(int grp, const MulSegs& segs, int scalar_words, hipStream_t s);
+// Fixed-base products: table[w] = 16^w P (64 affine points, one launch of one wave per point, ~4 ms once) and then k P = sum_w digit_w(k) table[w]
+// by ONE WAVE per product — lane w takes the w-th 4-bit digit of the 256-bit scalar, a tree adds the 64 partial products (~0.2 ms instead of the
+// ~4-5 ms of a 255-step double-and-add in one lane).  The Bulletproofs range proof multiplies the same g, h, u a dozen times per proof.
+struct FixedMul { const uint32_t* table; const uint32_t* k; uint32_t* out; };
+struct FixedMuls { FixedMul m[16]; int n; };
+struct FixedTables { const uint32_t* point[4]; uint32_t* table[4]; int n; };       // up to four points per launch, one wave each, side by side
+hipError_t launch_fixed_tables(int grp, const FixedTables& t, hipStream_t s);
+hipError_t launch_fixed_muls(int grp, const FixedMuls& f, hipStream_t s);
 hipError_t launch_miller_exact(int which, const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s);
 hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
                                  const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* ok, size_t n,

@@ -458,12 +458,15 @@ struct zkt_bp_ipa_ctx {
   std::recursive_mutex mu;                 // a context serves one call at a time: concurrent callers queue here (the range proof re-enters for its inner-product argument)
   std::vector<hipStream_t> side;           // one stream per product batch, so the batches overlap each other and the MSMs
   hipEvent_t ev = nullptr;
+  // fixed-base tables (launch_fixed_table) of the range proof's g, h and of u: 3 x 64 points; g and h arrive per call and are cached by value
+  Dev dfix{3 * 64 * SPB};
+  zkt_secp_affine fix_g{}, fix_h{}; bool fix_g_ok = false, fix_h_ok = false, fix_u_ok = false;
   static size_t log2z(size_t n) { size_t l = 0; for (size_t t = n; t > 1; t >>= 1) ++l; return l; }
   explicit zkt_bp_ipa_ctx(size_t n)
       : N(n), NB(2 * n + 1), levels(log2z(n)), lv1(levels ? levels : 1), dbase(NB * SPB), da(N * FRB), db(N * FRB), da2(N * FRB), db2(N * FRB), dwG(N * FRB), dwH(N * FRB),
         dsc((size_t)IPA_SLOTS * NB * FRB), dPp(SPB), dx(lv1 * FRB), dch(4 * FRB), dsq(lv1 * 2 * FRB), dc(2 * FRB), dlr(lv1 * 2 * SPB), dm(lv1 * 2 * SPB), dt(SPB), dcomb(NB * FRB),
         dAL(2 * N * FRB), dBL(2 * N * FRB), dchall(lv1 * 4 * FRB), dpart(lv1 * 2 * FRB) {}
-  bool ok() const { return dbase.p && da.p && db.p && da2.p && db2.p && dwG.p && dwH.p && dsc.p && dPp.p && dx.p && dch.p && dsq.p && dc.p && dlr.p && dm.p && dt.p && dcomb.p && dAL.p && dBL.p && dchall.p && dpart.p; }
+  bool ok() const { return dfix.p && dbase.p && da.p && db.p && da2.p && db2.p && dwG.p && dwH.p && dsc.p && dPp.p && dx.p && dch.p && dsq.p && dc.p && dlr.p && dm.p && dt.p && dcomb.p && dAL.p && dBL.p && dchall.p && dpart.p; }
   ~zkt_bp_ipa_ctx() {
     for (hipStream_t x : side) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
     if (ev) hipEventDestroy(ev);
@@ -657,7 +660,7 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   const int PW = 18;
   unsigned long long* noerr = nullptr;
   // scalar-field vectors on the device (canonical residues), simple arena of n-vectors and scalars
-  const int NV = 32, NS = 64;
+  const int NV = 32, NS = 96;
   Dev vec((size_t)NV * n * FRB), sc((size_t)NS * FRB), derr(8);
   if (!vec.p || !sc.p || !derr.p) return -ZKT_ERR_DEVICE;
   noerr = (unsigned long long*)derr.p;
@@ -759,23 +762,46 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   msm_sub(2, vscl(one_n, sneg(z)), vhad(vadd(vscl(y_n, z), twoz2), yinv_n));
   msm_sub(3, vscl(d_sL, x), vscl(d_sR, x));                                           // x * ((gg*sL).sum() + (hh*sR).sum()): the generator part of S x (:124)
   if (!use_ipa) msm_sub(4, l, vhad(r, yinv_n));                                       // (gg*l).sum() + (hh'*r).sum()  (:142)
+  // ... and every one of them is on a FIXED point but one: g, h, u get 64-entry tables of their 16^w multiples (built when the context first sees
+  // the point, ~4 ms once) and a product is one wave adding 64 partial products (~0.2 ms).  The exception is V z^2 (:115): V is the caller's.  For
+  // the V this proof is about — V = g v + h gamma, v = <aL, 2^n> — it equals g (v z^2) + h (gamma z^2), which folds into the other two terms of
+  // that side; E = g v + h gamma is computed beside and compared with V on the host, and any other V takes the 255-step product below.
+  uint32_t *Tg = c->dfix.w(), *Th = Tg + 64 * PW, *Tu = Th + 64 * PW;
+  auto same_point = [](const zkt_secp_affine& a, const zkt_secp_affine& b) { return memcmp(a.x, b.x, 32) == 0 && memcmp(a.y, b.y, 32) == 0 && a.is_infinity == b.is_infinity; };
   {
-    MulSegs m{}; int k = 0;
-    m.s[k++] = seg(Gp, t_hat, Q(8));   m.s[k++] = seg(Hp, tau_x, Q(9));               // lhs of :116
-    m.s[k++] = seg(Vp, z2, Q(10));     m.s[k++] = seg(Gp, k_g, Q(11));  m.s[k++] = seg(Hp, k_h, Q(14));
-    m.s[k++] = seg(Hp, mu, Q(12));                                                    // h mu = h alpha + x (h rho)
-    if (use_ipa) m.s[k++] = seg(Up, lr, Q(17));
+    FixedTables ft{}; int k = 0;
+    const bool need_g = !c->fix_g_ok || !same_point(c->fix_g, *g), need_h = !c->fix_h_ok || !same_point(c->fix_h, *h), need_u = use_ipa && !c->fix_u_ok;
+    if (need_g) { ft.point[k] = Gp; ft.table[k++] = Tg; }
+    if (need_h) { ft.point[k] = Hp; ft.table[k++] = Th; }
+    if (need_u) { ft.point[k] = Up; ft.table[k++] = Tu; }
+    ft.n = k;
+    okl = okl && launch_fixed_tables(G_SECP, ft, s) == hipSuccess;
+    if (need_g) { c->fix_g = *g; c->fix_g_ok = okl; }
+    if (need_h) { c->fix_h = *h; c->fix_h_ok = okl; }
+    if (need_u) c->fix_u_ok = okl;
+  }
+  uint32_t* v_val = vdot(d_aL, two_n);                                                // v = <aL, 2^n> (:75: the value the bits are of)
+  uint32_t *kg_v = sadd(k_g, smul(v_val, z2)), *kh_v = sadd(k_h, smul(d_gamma, z2));
+  {
+    FixedMuls m{}; int k = 0;
+    auto fx = [&](const uint32_t* T, const uint32_t* kk, uint32_t* out) { m.m[k++] = FixedMul{T, kk, out}; };
+    fx(Tg, t_hat, Q(8));   fx(Th, tau_x, Q(9));                                        // lhs of :116
+    fx(Tg, kg_v, Q(11));   fx(Th, kh_v, Q(14));                                        // rhs of :115 with V z^2 folded in
+    fx(Tg, v_val, Q(27));  fx(Th, d_gamma, Q(28));                                     // E = g v + h gamma, to be compared with V
+    fx(Th, mu, Q(12));                                                                 // h mu = h alpha + x (h rho)
+    if (use_ipa) fx(Tu, lr, Q(17));
     if (out_pts) {
-      m.s[k++] = seg(Hp, alpha, Q(0)); m.s[k++] = seg(Hp, rho, Q(1));
-      m.s[k++] = seg(Gp, t1, Q(4));    m.s[k++] = seg(Hp, tau1, Q(5));  m.s[k++] = seg(Gp, t2, Q(6));  m.s[k++] = seg(Hp, tau2, Q(7));
+      fx(Th, alpha, Q(0)); fx(Th, rho, Q(1));
+      fx(Tg, t1, Q(4));    fx(Th, tau1, Q(5));  fx(Tg, t2, Q(6));  fx(Th, tau2, Q(7));
     }
     m.n = k;
-    run(m);
+    okl = okl && launch_fixed_muls(G_SECP, m, s) == hipSuccess;
   }
   msm_col(0, Q(2)); msm_col(1, Q(3)); msm_col(2, Q(22)); msm_col(3, Q(16));
   if (!use_ipa) msm_col(4, Q(25));
   padd(Q(8), Q(9), Q(13));                                                            // lhs of :116
-  padd(padd(Q(10), Q(11), Q(18)), Q(14), Q(20));                                      // rhs of :115
+  padd(Q(11), Q(14), Q(20));                                                          // rhs of :115 (for V = g v + h gamma)
+  padd(Q(27), Q(28), Q(29));                                                          // E
   padd(padd(Q(2), Q(16), Q(19)), Q(22), Q(21));                                       // P h^-mu: the three generator sums of A, S x and :126-127
   padd(Q(21), Q(12), Pk);                                                             // P (:124-128) = h mu + those
   if (out_pts) {
@@ -783,10 +809,18 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
     padd(Q(1), Q(3), Sk);                                                             // S (:82)
     padd(Q(4), Q(5), T1k); padd(Q(6), Q(7), T2k);                                     // T1 (:99), T2 (:100)
   }
-  zkt_secp_affine hl, hr;
-  if ((rc = down(&hl, Q(13), SPB, s)) || (rc = down(&hr, Q(20), SPB, s))) return -rc;
+  zkt_secp_affine hl, hr, hE;
+  if ((rc = down(&hl, Q(13), SPB, s)) || (rc = down(&hr, Q(20), SPB, s)) || (rc = down(&hE, Q(29), SPB, s))) return -rc;
   if (out_pts && (rc = down(out_pts, R, 5 * SPB, s))) return -rc;
   if (hipStreamSynchronize(s) != hipSuccess || !okl || vi > NV || si > NS) return -ZKT_ERR_DEVICE;
+  if (!same_point(hE, *V)) {                                                          // some other V: its own product, as the reference takes it (:115)
+    MulSegs mv{}; mv.s[0] = seg(Vp, z2, Q(10)); mv.n = 1; run(mv);
+    FixedMuls m{}; m.m[0] = FixedMul{Tg, k_g, Q(11)}; m.m[1] = FixedMul{Th, k_h, Q(14)}; m.n = 2;
+    okl = okl && launch_fixed_muls(G_SECP, m, s) == hipSuccess;
+    padd(padd(Q(10), Q(11), Q(18)), Q(14), Q(20));
+    if ((rc = down(&hr, Q(20), SPB, s))) return -rc;
+    if (hipStreamSynchronize(s) != hipSuccess || !okl) return -ZKT_ERR_DEVICE;
+  }
   if (memcmp(&hl, &hr, SPB) != 0) return 0;                                           // :116-118
   if (use_ipa) {
     uint32_t* Pp = padd(Q(21), Q(17), Q(24));                                         // :138  P h^-mu u^<l,r>
