@@ -198,4 +198,37 @@ hipError_t launch_fq12_pow(const uint32_t* a, const uint32_t* e, int nl, uint32_
   return hipGetLastError();
 }
 
+// one lane runs a short program of dependent scalar operations (zkt_internal.h: ScalarOps); canonical residues in and out, as k_fp_op
+template <class C>
+__global__ void __launch_bounds__(64) k_scalar_ops(ScalarOps ops, unsigned long long* err) {
+  static_assert(C::W == 32, "canonical 32-bit-limb fields");
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Fp<C> r2; for (int j = 0; j < C::N; ++j) r2.v[j] = C::r2(j);
+  for (int k = 0; k < ops.n; ++k) {
+    const ScalarOp o = ops.o[k];
+    Fp<C> x = fp_canon32(ld_raw<C>(o.a)), r;
+    switch (o.op) {
+      case OP_ADD: r = fp_add(x, fp_canon32(ld_raw<C>(o.b))); break;
+      case OP_SUB: r = fp_sub(x, fp_canon32(ld_raw<C>(o.b))); break;
+      case OP_MUL: r = fp_mul(fp_mul(x, fp_canon32(ld_raw<C>(o.b))), r2); break;
+      case OP_NEG: r = fp_neg(x); break;
+      default:                                                             // OP_INV: safe_inv, Err on zero (prime_field_elem.rs:379-382)
+        if (fp_is_zero(x)) { atomicMin(err, 0ull); r = x; }
+        else { Fp<C> one = fp_zero<C>(); one.v[0] = 1; r = fp_mul(fp_inv(fp_mul(x, r2)), one); }
+    }
+    st_raw<C>(o.out, r);
+    __threadfence();                                                       // the next operation may read what this one wrote
+  }
+}
+hipError_t launch_scalar_ops(int field, const ScalarOps& ops, unsigned long long* err, hipStream_t s) {
+  if (ops.n < 0 || ops.n > 48) return hipErrorInvalidValue;
+  if (ops.n == 0) return hipSuccess;
+  switch (field) {
+    case F_FR: hipLaunchKernelGGL(k_scalar_ops<FrC>, dim3(1), dim3(64), 0, s, ops, err); break;
+    case F_SN: hipLaunchKernelGGL(k_scalar_ops<SnC>, dim3(1), dim3(64), 0, s, ops, err); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 }  // namespace zkt

@@ -165,6 +165,22 @@ hipError_t launch_fixed_muls(int grp, const FixedMuls& f, hipStream_t s) {
   return hipGetLastError();
 }
 
+// out[j] = in[j][0] + ... + in[j][cnt-1] (zkt_internal.h: PointSums), one lane per output
+template <class F>
+__global__ void __launch_bounds__(64) k_point_sums(PointSums p) {
+  const int j = threadIdx.x;
+  if (j >= p.n) return;
+  Jac<F> acc = jac_inf<F>();
+  for (int k = 0; k < p.cnt[j]; ++k) acc = jac_add_aff(acc, PtIO<F>::ld(p.in[j][k]));
+  PtIO<F>::st(p.out[j], jac_to_aff(acc));
+}
+hipError_t launch_point_sums(int grp, const PointSums& p, hipStream_t s) {
+  if (grp != G_SECP || p.n < 0 || p.n > 12) return hipErrorInvalidValue;
+  if (p.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_point_sums<SpOps>, dim3(1), dim3(64), 0, s, p);
+  return hipGetLastError();
+}
+
 // ---- sum of n affine points ------------------------------------------------------------------------------------------------
 // the G2 / secp256k1 sums behind eval_with_g2_hidings (polynomial.rs:283-293) and (AffinePoints * PrimeFieldElems).sum()
 // (secp256k1/affine_points.rs:25-31,123-144).  Two launches: every lane adds a strided share into a Jacobian accumulator (mixed

@@ -35,6 +35,15 @@ hipError_t launch_group_sum_inplace(int grp, uint32_t* pts, size_t n, hipStream_
 struct MulSeg { const uint32_t* pts; const uint32_t* k; uint32_t* out; uint32_t count, pt_stride, k_stride; };
 struct MulSegs { MulSeg s[16]; int n; };
 hipError_t launch_group_mul_segs(int grp, const MulSegs& segs, int scalar_words, hipStream_t s);
+// A short straight-line program over scalar-field elements (canonical 8-word residues in device memory), run by ONE lane in ONE launch: the scalar
+// algebra between the vector kernels of a protocol is a chain of dependent one-element operations, and a launch per operation costs ~50 us each.
+struct ScalarOp { int op; const uint32_t* a; const uint32_t* b; uint32_t* out; };      // op: OP_ADD / OP_SUB / OP_MUL / OP_NEG / OP_INV (b unused for the last two)
+struct ScalarOps { ScalarOp o[48]; int n; };
+hipError_t launch_scalar_ops(int field, const ScalarOps& ops, unsigned long long* err, hipStream_t s);
+// out[j] = sum of up to 4 affine points in[j][*] (complete addition, one lane per output, one normalisation each): the tail of a protocol adds a handful
+// of single points in a fixed pattern, and a launch per addition (each with its own inversion) is ~150 us
+struct PointSums { const uint32_t* in[12][4]; int cnt[12]; uint32_t* out[12]; int n; };
+hipError_t launch_point_sums(int grp, const PointSums& p, hipStream_t s);
 // Fixed-base products: table[w] = 16^w P (64 affine points, one launch of one wave per point, ~4 ms once) and then k P = sum_w digit_w(k) table[w]
 // by ONE WAVE per product — lane w takes the w-th 4-bit digit of the 256-bit scalar, a tree adds the 64 partial products (~0.2 ms instead of the
 // ~4-5 ms of a 255-step double-and-add in one lane).  The Bulletproofs range proof multiplies the same g, h, u a dozen times per proof.

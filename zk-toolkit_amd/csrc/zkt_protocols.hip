@@ -8,6 +8,7 @@
 #include <mutex>
 #include <cstring>
 #include <cstdio>
+#include <functional>
 #include <memory>
 #include "abi.h"
 #include "zkt_internal.h"
@@ -671,8 +672,9 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   auto vadd = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = newv(); op(OP_ADD, a, b, o, n); return o; };
   auto vsub = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = newv(); op(OP_SUB, a, b, o, n); return o; };
   auto vhad = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = newv(); op(OP_MUL, a, b, o, n); return o; };
-  auto vscl = [&](const uint32_t* a, const uint32_t* k) { uint32_t* o = newv(); hipLaunchKernelGGL(k_scale<SnC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, k, n, o); return o; };
-  auto vpow = [&](const uint32_t* b) { uint32_t* o = newv(); hipLaunchKernelGGL(k_powseq<SnC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, b, n, o); return o; };
+  std::function<void()> flush_scalars = [] {};          // set below, once the queue of one-element operations exists: whoever reads a scalar runs it first
+  auto vscl = [&](const uint32_t* a, const uint32_t* k) { flush_scalars(); uint32_t* o = newv(); hipLaunchKernelGGL(k_scale<SnC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, k, n, o); return o; };
+  auto vpow = [&](const uint32_t* b) { flush_scalars(); uint32_t* o = newv(); hipLaunchKernelGGL(k_powseq<SnC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, b, n, o); return o; };
   auto vsum = [&](const uint32_t* a) { uint32_t* o = news(); hipLaunchKernelGGL(k_sum<SnC>, dim3(1), dim3(256), 0, s, a, n, o); return o; };
   Dev dparts(64 * FRB);
   if (!dparts.p) return -ZKT_ERR_DEVICE;
@@ -682,11 +684,17 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
     hipLaunchKernelGGL(k_dot_parts<SnC>, dim3(64), dim3(256), 0, s, a, b, n, dparts.w());          // stream order keeps the shared parts buffer safe
     hipLaunchKernelGGL(k_sum<SnC>, dim3(1), dim3(256), 0, s, (const uint32_t*)dparts.w(), (size_t)64, o);
     return o; };
-  auto sadd = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = news(); op(OP_ADD, a, b, o, 1); return o; };
-  auto ssub = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = news(); op(OP_SUB, a, b, o, 1); return o; };
-  auto smul = [&](const uint32_t* a, const uint32_t* b) { uint32_t* o = news(); op(OP_MUL, a, b, o, 1); return o; };
-  auto sneg = [&](const uint32_t* a) { uint32_t* o = news(); op(OP_NEG, a, nullptr, o, 1); return o; };
-  auto sinv = [&](const uint32_t* a) { uint32_t* o = news(); op(OP_INV, a, nullptr, o, 1); return o; };
+  // one-element operations are queued and run as ONE launch (launch_scalar_ops) when something is about to read their results: a launch per
+  // operation is ~50 us of a chain of ~35
+  ScalarOps pend{}; bool sok = true;
+  auto sflush = [&]() { if (pend.n) { sok = sok && launch_scalar_ops(F_SN, pend, noerr, s) == hipSuccess; pend.n = 0; } };
+  auto sop = [&](int o, const uint32_t* a, const uint32_t* b) { uint32_t* out = news(); if (pend.n == 48) sflush(); pend.o[pend.n++] = ScalarOp{o, a, b, out}; return out; };
+  auto sadd = [&](const uint32_t* a, const uint32_t* b) { return sop(OP_ADD, a, b); };
+  auto ssub = [&](const uint32_t* a, const uint32_t* b) { return sop(OP_SUB, a, b); };
+  auto smul = [&](const uint32_t* a, const uint32_t* b) { return sop(OP_MUL, a, b); };
+  auto sneg = [&](const uint32_t* a) { return sop(OP_NEG, a, nullptr); };
+  auto sinv = [&](const uint32_t* a) { return sop(OP_INV, a, nullptr); };
+  flush_scalars = sflush;
   auto sput = [&](const uint64_t* hsrc) { uint32_t* o = news(); hipMemcpyAsync(o, hsrc, FRB, hipMemcpyHostToDevice, s); return o; };
   auto vput = [&](const uint64_t* hsrc) { uint32_t* o = newv(); hipMemcpyAsync(o, hsrc, n * FRB, hipMemcpyHostToDevice, s); return o; };
   unsigned long long ne = NO_ERR; hipMemcpyAsync(derr.p, &ne, 8, hipMemcpyHostToDevice, s);
@@ -795,26 +803,34 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
       fx(Tg, t1, Q(4));    fx(Th, tau1, Q(5));  fx(Tg, t2, Q(6));  fx(Th, tau2, Q(7));
     }
     m.n = k;
+    sflush();
     okl = okl && launch_fixed_muls(G_SECP, m, s) == hipSuccess;
   }
   msm_col(0, Q(2)); msm_col(1, Q(3)); msm_col(2, Q(22)); msm_col(3, Q(16));
   if (!use_ipa) msm_col(4, Q(25));
-  padd(Q(8), Q(9), Q(13));                                                            // lhs of :116
-  padd(Q(11), Q(14), Q(20));                                                          // rhs of :115 (for V = g v + h gamma)
-  padd(Q(27), Q(28), Q(29));                                                          // E
-  padd(padd(Q(2), Q(16), Q(19)), Q(22), Q(21));                                       // P h^-mu: the three generator sums of A, S x and :126-127
-  padd(Q(21), Q(12), Pk);                                                             // P (:124-128) = h mu + those
-  if (out_pts) {
-    padd(Q(0), Q(2), Ak);                                                             // A (:77)
-    padd(Q(1), Q(3), Sk);                                                             // S (:82)
-    padd(Q(4), Q(5), T1k); padd(Q(6), Q(7), T2k);                                     // T1 (:99), T2 (:100)
+  {                                                                                   // every remaining sum of single points in ONE launch, one lane per sum
+    PointSums ps{}; int k = 0;
+    auto sum = [&](uint32_t* out, std::initializer_list<const uint32_t*> in) { int j = 0; for (const uint32_t* q : in) ps.in[k][j++] = q; ps.cnt[k] = j; ps.out[k++] = out; };
+    sum(Q(13), {Q(8), Q(9)});                                                         // lhs of :116
+    sum(Q(20), {Q(11), Q(14)});                                                       // rhs of :115 (for V = g v + h gamma)
+    sum(Q(29), {Q(27), Q(28)});                                                       // E
+    sum(Q(21), {Q(2), Q(16), Q(22)});                                                 // P h^-mu: the three generator sums of A, S x and :126-127
+    sum(Pk, {Q(2), Q(16), Q(22), Q(12)});                                             // P (:124-128) = h mu + those
+    if (out_pts) {
+      sum(Ak, {Q(0), Q(2)});                                                          // A (:77)
+      sum(Sk, {Q(1), Q(3)});                                                          // S (:82)
+      sum(T1k, {Q(4), Q(5)}); sum(T2k, {Q(6), Q(7)});                                 // T1 (:99), T2 (:100)
+    }
+    ps.n = k;
+    okl = okl && launch_point_sums(G_SECP, ps, s) == hipSuccess;
   }
   zkt_secp_affine hl, hr, hE;
   if ((rc = down(&hl, Q(13), SPB, s)) || (rc = down(&hr, Q(20), SPB, s)) || (rc = down(&hE, Q(29), SPB, s))) return -rc;
   if (out_pts && (rc = down(out_pts, R, 5 * SPB, s))) return -rc;
-  if (hipStreamSynchronize(s) != hipSuccess || !okl || vi > NV || si > NS) return -ZKT_ERR_DEVICE;
+  sflush();
+  if (hipStreamSynchronize(s) != hipSuccess || !okl || !sok || vi > NV || si > NS) return -ZKT_ERR_DEVICE;
   if (!same_point(hE, *V)) {                                                          // some other V: its own product, as the reference takes it (:115)
-    MulSegs mv{}; mv.s[0] = seg(Vp, z2, Q(10)); mv.n = 1; run(mv);
+    MulSegs mv{}; mv.s[0] = seg(Vp, z2, Q(10)); mv.n = 1; sflush(); run(mv);
     FixedMuls m{}; m.m[0] = FixedMul{Tg, k_g, Q(11)}; m.m[1] = FixedMul{Th, k_h, Q(14)}; m.n = 2;
     okl = okl && launch_fixed_muls(G_SECP, m, s) == hipSuccess;
     padd(padd(Q(10), Q(11), Q(18)), Q(14), Q(20));
