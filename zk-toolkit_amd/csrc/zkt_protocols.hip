@@ -459,6 +459,7 @@ struct zkt_bp_ipa_ctx {
   std::recursive_mutex mu;                 // a context serves one call at a time: concurrent callers queue here (the range proof re-enters for its inner-product argument)
   std::vector<hipStream_t> side;           // one stream per product batch, so the batches overlap each other and the MSMs
   hipEvent_t ev = nullptr;
+  hipStream_t main = nullptr;              // the range proof's own stream: on the legacy NULL stream every one of its ~150 small launches pays the implicit barriers (~45 us each)
   // fixed-base tables (launch_fixed_table) of the range proof's g, h and of u: 3 x 64 points; g and h arrive per call and are cached by value
   Dev dfix{3 * 64 * SPB};
   zkt_secp_affine fix_g{}, fix_h{}; bool fix_g_ok = false, fix_h_ok = false, fix_u_ok = false;
@@ -470,6 +471,7 @@ struct zkt_bp_ipa_ctx {
   bool ok() const { return dfix.p && dbase.p && da.p && db.p && da2.p && db2.p && dwG.p && dwH.p && dsc.p && dPp.p && dx.p && dch.p && dsq.p && dc.p && dlr.p && dm.p && dt.p && dcomb.p && dAL.p && dBL.p && dchall.p && dpart.p; }
   ~zkt_bp_ipa_ctx() {
     for (hipStream_t x : side) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
+    if (main) { hipStreamSynchronize(main); hipStreamDestroy(main); }
     if (ev) hipEventDestroy(ev);
     if (set) zkt_secp_bases_free(set);
   }
@@ -488,6 +490,7 @@ int zkt_bp_ipa_ctx_create(size_t n, const zkt_secp_affine* gg, const zkt_secp_af
   c->side.assign((c->levels + zkt_bp_ipa_ctx::IPA_BATCH - 1) / zkt_bp_ipa_ctx::IPA_BATCH, nullptr);
   for (hipStream_t& x : c->side) PCHK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
   PCHK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+  PCHK(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking));
   int rc = zkt_secp_bases_from_device((const zkt_secp_affine*)c->dbase.p, c->NB, s, &c->set);
   if (rc) return rc;
   *out = c.release();
@@ -657,7 +660,8 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
                             int use_ipa, const uint64_t* rnd, const uint64_t* xs, zkt_secp_affine* out_pts) {
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   const size_t n = c->N;
-  hipStream_t s = nullptr;
+  hipStream_t s = c->main;
+  if (hipDeviceSynchronize() != hipSuccess) return -ZKT_ERR_DEVICE;      // whatever the caller queued (the context's table build runs on the NULL stream) is done before the own stream starts
   const int PW = 18;
   unsigned long long* noerr = nullptr;
   // scalar-field vectors on the device (canonical residues), simple arena of n-vectors and scalars
@@ -743,10 +747,16 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   msm_sub(1, d_sL, d_sR);                                                             // (gg*sL).sum() + (hh*sR).sum()   of S (:82)
   uint32_t* y_n = vpow(y);                                                            // :87
   uint32_t* z2 = smul(z, z);
+  uint32_t* yinv_n = vpow(sinv(y));                                                   // hh' = hh * y^-i (:109), as coefficients
+  uint32_t* twoz2 = vscl(two_n, z2);
+  // the challenges are the caller's (injected), so the two generator sums that depend on them only through cheap vector kernels are submitted NOW
+  // and run beside A's and S's: four MSMs in flight while the dot-product chain below proceeds
+  uint32_t *sLx = vscl(d_sL, x), *sRx = vscl(d_sR, x);
+  msm_sub(2, vscl(one_n, sneg(z)), vhad(vadd(vscl(y_n, z), twoz2), yinv_n));          // gg * (-z 1^n) + hh' * (z y^n + z^2 2^n)  of P (:126-127)
+  msm_sub(3, sLx, sRx);                                                               // x * ((gg*sL).sum() + (hh*sR).sum()): the generator part of S x (:124)
   uint32_t* onez = vscl(one_n, z);
   uint32_t* l0 = vsub(d_aL, onez);                                                    // :88
   uint32_t* aRz = vadd(aR, onez);
-  uint32_t* twoz2 = vscl(two_n, z2);
   uint32_t* r0 = vadd(vhad(y_n, aRz), twoz2);                                         // :90
   uint32_t* r1 = vhad(y_n, d_sR);                                                     // :91
   uint32_t *t0 = vdot(l0, r0), *t1 = sadd(vdot(d_sL, r0), vdot(l0, r1)), *t2 = vdot(d_sL, r1);   // :93-95
@@ -754,11 +764,10 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   uint32_t* t_hat = sadd(sadd(t0, smul(t1, x)), smul(t2, x2));                        // :104
   uint32_t* tau_x = sadd(sadd(smul(tau2, x2), smul(tau1, x)), smul(z2, d_gamma));     // :105
   uint32_t* mu = sadd(alpha, smul(rho, x));                                           // :106
-  uint32_t* yinv_n = vpow(sinv(y));                                                   // hh' = hh * y^-i (:109), as coefficients
   uint32_t* z3 = smul(z2, z);
   uint32_t* delta_yz = ssub(smul(ssub(z, z2), vsum(y_n)), smul(z3, vsum(two_n)));     // :112 (one_n o v = v)
-  uint32_t* l = vadd(l0, vscl(d_sL, x));                                              // :121
-  uint32_t* r = vadd(vhad(y_n, vadd(aRz, vscl(d_sR, x))), twoz2);                     // :122
+  uint32_t* l = vadd(l0, sLx);                                                        // :121
+  uint32_t* r = vadd(vhad(y_n, vadd(aRz, sRx)), twoz2);                               // :122
   uint32_t* lr = vdot(l, r);
   // Every single-point product is a ~4 ms dependent chain however few points a launch covers, so ALL of them go out in ONE launch: the products the
   // reference takes of T1, T2 and S (:115, :124) are rewritten on the fixed points — T1 x = g (t1 x) + h (tau1 x), S x = h (rho x) + sum over the
@@ -766,9 +775,6 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   uint32_t *t1x = smul(t1, x), *t2x2 = smul(t2, x2);
   uint32_t* k_g = sadd(sadd(delta_yz, t1x), t2x2);                                    // rhs of :115 = V z^2 + g (delta + t1 x + t2 x^2) + h (tau1 x + tau2 x^2)
   uint32_t* k_h = sadd(smul(tau1, x), smul(tau2, x2));
-  // gg * (-z 1^n) + hh' * (z y^n + z^2 2^n)  of P (:126-127)
-  msm_sub(2, vscl(one_n, sneg(z)), vhad(vadd(vscl(y_n, z), twoz2), yinv_n));
-  msm_sub(3, vscl(d_sL, x), vscl(d_sR, x));                                           // x * ((gg*sL).sum() + (hh*sR).sum()): the generator part of S x (:124)
   if (!use_ipa) msm_sub(4, l, vhad(r, yinv_n));                                       // (gg*l).sum() + (hh'*r).sum()  (:142)
   // ... and every one of them is on a FIXED point but one: g, h, u get 64-entry tables of their 16^w multiples (built when the context first sees
   // the point, ~4 ms once) and a product is one wave adding 64 partial products (~0.2 ms).  The exception is V z^2 (:115): V is the caller's.  For
@@ -840,7 +846,7 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   if (memcmp(&hl, &hr, SPB) != 0) return 0;                                           // :116-118
   if (use_ipa) {
     uint32_t* Pp = padd(Q(21), Q(17), Q(24));                                         // :138  P h^-mu u^<l,r>
-    if (!okl) return -ZKT_ERR_DEVICE;
+    if (!okl || hipStreamSynchronize(s) != hipSuccess) return -ZKT_ERR_DEVICE;      // the argument runs on the NULL stream, which does not wait for a non-blocking one
     return ipa_run(c, (const zkt_secp_affine*)Pp, (const uint64_t*)l, (const uint64_t*)r, xs, nullptr, yinv_n);   // :139, over gg, hh' = y^-i hh, u
   }
   uint32_t* rhs = padd(Q(12), Q(25), Q(26));                                          // :142
