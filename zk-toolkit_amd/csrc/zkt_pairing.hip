@@ -104,16 +104,20 @@ __global__ void __launch_bounds__(64) k_groth16_verify(const uint32_t* __restric
                                                        const uint32_t* __restrict__ uvw_stmt, const uint32_t* __restrict__ stmt, int n_stmt,
                                                        const uint32_t* __restrict__ gamma, const uint32_t* __restrict__ delta,
                                                        const uint32_t* __restrict__ alpha_beta, uint32_t* __restrict__ ok, size_t n, unsigned long long* err, int only_redo,
-                                                       const uint32_t* __restrict__ shared_good) {
+                                                       const uint32_t* __restrict__ shared_good, const uint32_t* __restrict__ S_pre) {
   size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   if (only_redo && ok[i] != OK_REDO) return;
-  Jac<FqOps> acc = jac_inf<FqOps>();
-  for (int j = 0; j < n_stmt; ++j) {                                   // verifier.rs:41-45
-    Aff<FqOps> u = PtIO<FqOps>::ld(uvw_stmt + (size_t)j * ABI_G1_WORDS);
-    acc = jac_add(acc, scalar_mul_aff<FqOps>(u, stmt + ((size_t)i * n_stmt + j) * 8, 8));
+  Aff<FqOps> S;
+  if (S_pre) S = PtIO<FqOps>::ld(S_pre + i * ABI_G1_WORDS);            // the statement sums came from one batched scalar multiplication (launch_groth16_verify)
+  else {
+    Jac<FqOps> acc = jac_inf<FqOps>();
+    for (int j = 0; j < n_stmt; ++j) {                                 // verifier.rs:41-45
+      Aff<FqOps> u = PtIO<FqOps>::ld(uvw_stmt + (size_t)j * ABI_G1_WORDS);
+      acc = jac_add(acc, scalar_mul_aff<FqOps>(u, stmt + ((size_t)i * n_stmt + j) * 8, 8));
+    }
+    S = jac_to_aff(acc);
   }
-  Aff<FqOps> S = jac_to_aff(acc);
   Aff<FqOps> a = PtIO<FqOps>::ld(A + i * ABI_G1_WORDS), c = PtIO<FqOps>::ld(C + i * ABI_G1_WORDS);
   Aff<Fq2Ops> b = PtIO<Fq2Ops>::ld(B + i * ABI_G2_WORDS), g = PtIO<Fq2Ops>::ld(gamma), d = PtIO<Fq2Ops>::ld(delta);
   if (a.inf || b.inf || c.inf || S.inf || g.inf || d.inf) { atomicMin(err, (unsigned long long)i); ok[i] = 0; return; }   // tate() with infinity panics
@@ -166,7 +170,7 @@ hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, con
   if ((e = guard_join(s, side)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_product_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)flags, ok, n);
   if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr);
+  hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr, (const uint32_t*)S);
   return hipGetLastError();
 }
 hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
@@ -176,9 +180,22 @@ hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uin
   uint32_t* good = nullptr; hipError_t e;                   // gamma and delta are the same for every proof: their G2 membership is decided by one wave, not by every lane
   if ((e = hipMallocAsync((void**)&good, sizeof(uint32_t), s)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_shared_g2_guards, dim3(1), dim3(64), 0, s, gamma, delta, good);
-  hipLaunchKernelGGL(k_groth16_verify<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 0, (const uint32_t*)good);
+  // The statement sums S_i = sum_j stmt[i][j] uvw_j as ONE batched scalar multiplication, one lane per term, on a kernel that runs four waves per SIMD —
+  // inside the verification kernel (one wave per SIMD, 512 registers) the same multiply-adds issue at less than half the rate.
+  uint32_t *tmp = nullptr, *S = nullptr;
+  if (n_stmt >= 1 && n_stmt <= 12) {
+    if ((e = hipMallocAsync((void**)&tmp, (size_t)n_stmt * n * ABI_G1_WORDS * 4, s)) != hipSuccess) return e;
+    if ((e = hipMallocAsync((void**)&S, n * ABI_G1_WORDS * 4, s)) != hipSuccess) return e;
+    MulSegs segs; segs.n = n_stmt;
+    for (int j = 0; j < n_stmt; ++j) segs.s[j] = MulSeg{uvw_stmt + (size_t)j * ABI_G1_WORDS, stmt + (size_t)j * 8, tmp + (size_t)j * n * ABI_G1_WORDS, (uint32_t)n, 0u, (uint32_t)(n_stmt * 8)};
+    if ((e = launch_group_mul_segs(G_G1, segs, 8, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_stmt_sums, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)tmp, n_stmt, S, n);
+  }
+  hipLaunchKernelGGL(k_groth16_verify<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 0, (const uint32_t*)good, (const uint32_t*)S);
+  hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr, (const uint32_t*)S);
   if ((e = hipFreeAsync(good, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr);
+  if (tmp && (e = hipFreeAsync(tmp, s)) != hipSuccess) return e;
+  if (S && (e = hipFreeAsync(S, s)) != hipSuccess) return e;
   return hipGetLastError();
 }
 
