@@ -298,7 +298,10 @@ def main():
                 stmt = wires[:gl + 1].copy()
                 t0 = time.perf_counter()
                 ok = L.zkt_groth16_verify(ctypes.byref(vk1), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(stmt), gl + 1)
-                g16["verify_ms"] = (time.perf_counter() - t0) * 1e3; g16["verifies"] = bool(ok == 1)
+                g16["verify_first_call_ms"] = (time.perf_counter() - t0) * 1e3; g16["verifies"] = bool(ok == 1)
+                t0 = time.perf_counter()                 # second call: the small-batch kernels, their side stream and the allocator pool exist now
+                ok2 = L.zkt_groth16_verify(ctypes.byref(vk1), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(stmt), gl + 1)
+                g16["verify_ms"] = (time.perf_counter() - t0) * 1e3; g16["verifies"] = g16["verifies"] and bool(ok2 == 1)
         except Exception as e:      # never lose the headline line to the secondary leg; every collective above is preceded by an all-ranks agreement
             g16 = {"error": repr(e), "stage": stage}
 
