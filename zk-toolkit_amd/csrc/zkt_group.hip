@@ -129,12 +129,19 @@ __global__ void __launch_bounds__(64) k_fixed_table(FixedTables ft) {
   for (int d = 0; d < 4 * w; ++d) j = jac_dbl(j);               // lane 63: 252 doublings — the latency of the launch, paid once per point
   PtIO<F>::st(table + (size_t)w * W, jac_to_aff(j));
 }
+template <class F> __device__ inline void fixed_mul_wave(const FixedMul& m);
 template <class F>
-__global__ void __launch_bounds__(64) k_fixed_muls(FixedMuls f) {
+__global__ void __launch_bounds__(64) k_fixed_muls(FixedMuls f) { fixed_mul_wave<F>(f.m[blockIdx.x]); }
+template <class F>
+__global__ void __launch_bounds__(64) k_fixed_muls_batch(const uint32_t* __restrict__ tables, const uint32_t* __restrict__ k, uint32_t* __restrict__ out, size_t n, int n_pts) {
+  constexpr int W = PtIO<F>::WORDS;
+  const size_t i = blockIdx.x / (unsigned)n_pts; const int j = blockIdx.x % (unsigned)n_pts;
+  fixed_mul_wave<F>(FixedMul{tables + (size_t)j * 64 * W, k + (i * n_pts + j) * 8, out + ((size_t)j * n + i) * W});
+}
+template <class F> __device__ inline void fixed_mul_wave(const FixedMul& m) {
   typedef typename F::E E;
   constexpr int W = PtIO<F>::WORDS, EW = sizeof(E) / 4, JW = 3 * EW;
   __shared__ uint32_t lds[32 * JW];
-  const FixedMul m = f.m[blockIdx.x];
   const int w = threadIdx.x;
   const uint32_t d = (m.k[w >> 3] >> ((w & 7) * 4)) & 15u;      // w-th 4-bit digit of the scalar (8 canonical 32-bit words)
   const Aff<F> t = PtIO<F>::ld(m.table + (size_t)w * W);
@@ -153,9 +160,19 @@ __global__ void __launch_bounds__(64) k_fixed_muls(FixedMuls f) {
   if (w == 0) PtIO<F>::st(m.out, jac_to_aff(acc));
 }
 hipError_t launch_fixed_tables(int grp, const FixedTables& t, hipStream_t s) {
-  if (grp != G_SECP || t.n < 0 || t.n > 4) return hipErrorInvalidValue;      // instantiated where it is used: the secp256k1 generators of Bulletproofs
+  if (t.n < 0 || t.n > 12) return hipErrorInvalidValue;
   if (t.n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_fixed_table<SpOps>, dim3((unsigned)t.n), dim3(64), 0, s, t);
+  switch (grp) {                                                            // instantiated where it is used: Bulletproofs' secp256k1 generators, a Groth16 key's statement points
+    case G_SECP: hipLaunchKernelGGL(k_fixed_table<SpOps>, dim3((unsigned)t.n), dim3(64), 0, s, t); break;
+    case G_G1: hipLaunchKernelGGL(k_fixed_table<FqOps>, dim3((unsigned)t.n), dim3(64), 0, s, t); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_fixed_muls_batch(int grp, const uint32_t* tables, const uint32_t* k, uint32_t* out, size_t n, int n_pts, hipStream_t s) {
+  if (grp != G_G1 || n_pts < 1 || n * (size_t)n_pts >= (size_t(1) << 31)) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_fixed_muls_batch<FqOps>, dim3((unsigned)(n * n_pts)), dim3(64), 0, s, tables, k, out, n, n_pts);
   return hipGetLastError();
 }
 hipError_t launch_fixed_muls(int grp, const FixedMuls& f, hipStream_t s) {

@@ -49,15 +49,18 @@ hipError_t launch_point_sums(int grp, const PointSums& p, hipStream_t s);
 // ~4-5 ms of a 255-step double-and-add in one lane).  The Bulletproofs range proof multiplies the same g, h, u a dozen times per proof.
 struct FixedMul { const uint32_t* table; const uint32_t* k; uint32_t* out; };
 struct FixedMuls { FixedMul m[16]; int n; };
-struct FixedTables { const uint32_t* point[4]; uint32_t* table[4]; int n; };       // up to four points per launch, one wave each, side by side
+struct FixedTables { const uint32_t* point[12]; uint32_t* table[12]; int n; };     // up to twelve points per launch, one wave each, side by side
 hipError_t launch_fixed_tables(int grp, const FixedTables& t, hipStream_t s);
 hipError_t launch_fixed_muls(int grp, const FixedMuls& f, hipStream_t s);
+// the same product for a whole batch: out[(j * n + i)] = k[(i * n_pts + j)] * P_j from tables[j] (64 points each), one wave per product, grid = n * n_pts
+hipError_t launch_fixed_muls_batch(int grp, const uint32_t* tables, const uint32_t* k, uint32_t* out, size_t n, int n_pts, hipStream_t s);
 hipError_t launch_miller_exact(int which, const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s);
 hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
                                  const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* ok, size_t n,
                                  unsigned long long* err, hipStream_t s);
 size_t dproduct_limit();      // elements x pairs up to which the verification entry points use the lane-distributed kernels
-hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
+// stmt_tables (optional): fixed-base tables of the n_stmt statement points (launch_fixed_tables), which replace the statement's 255-step scalar multiplications
+hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt_tables, const uint32_t* stmt, int n_stmt,
                                        const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* tmp, uint32_t* S, uint32_t* ok, size_t n,
                                        unsigned long long* err, hipStream_t s);
 // prod_k tate(+-P_k, Q_k) == 1 per element, K <= 4 pairs sharing one Miller squaring chain and one final exponentiation.

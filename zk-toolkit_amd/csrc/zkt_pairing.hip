@@ -147,14 +147,18 @@ __global__ void __launch_bounds__(64) k_stmt_sums(const uint32_t* __restrict__ t
   PtIO<FqOps>::st(out + i * ABI_G1_WORDS, jac_to_aff(acc));
 }
 // e(A,B) == alpha_beta e(S,gamma) e(C,delta) per proof on the lane-distributed kernels; tmp: n_stmt * n G1 points, S: n G1 points (device)
-hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
+hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt_tables, const uint32_t* stmt, int n_stmt,
                                        const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* tmp, uint32_t* S, uint32_t* ok, size_t n,
                                        unsigned long long* err, hipStream_t s) {
   if (n == 0) return hipSuccess;
   if (n_stmt < 1 || n_stmt > 12) return hipErrorInvalidValue;
-  MulSegs segs; segs.n = n_stmt;
-  for (int j = 0; j < n_stmt; ++j) segs.s[j] = MulSeg{uvw_stmt + (size_t)j * ABI_G1_WORDS, stmt + (size_t)j * 8, tmp + (size_t)j * n * ABI_G1_WORDS, (uint32_t)n, 0u, (uint32_t)(n_stmt * 8)};
-  hipError_t e = launch_group_mul_segs(G_G1, segs, 8, s);
+  hipError_t e;
+  if (stmt_tables) e = launch_fixed_muls_batch(G_G1, stmt_tables, stmt, tmp, n, n_stmt, s);      // one wave per term from the key's fixed-base tables: ~0.3 ms instead of a 4 ms chain
+  else {
+    MulSegs segs; segs.n = n_stmt;
+    for (int j = 0; j < n_stmt; ++j) segs.s[j] = MulSeg{uvw_stmt + (size_t)j * ABI_G1_WORDS, stmt + (size_t)j * 8, tmp + (size_t)j * n * ABI_G1_WORDS, (uint32_t)n, 0u, (uint32_t)(n_stmt * 8)};
+    e = launch_group_mul_segs(G_G1, segs, 8, s);
+  }
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_stmt_sums, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)tmp, n_stmt, S, n);
   PairArgs a{};
