@@ -425,7 +425,7 @@ def main():
             result["pairing"] = {"metric": "Tate pairings/sec", "value": m / dt, "batch": m, "kernel_ms": L.zkt_last_kernel_ms(),
                                  "hbm_achieved_GBs": PAIRING_BYTES * m / dt / 1e9, "hbm_frac": PAIRING_BYTES * m / dt / 1e9 / HBM_PEAK_GBS,
                                  "single_pairing_latency_ms": round(lat1 * 1e3, 3),
-                                 "small_batch_note": "n <= 16,384 runs one pairing per 12 lanes (lane-distributed kernel): ~8 ms for 1..2048 pairings; larger batches one pairing per lane"}
+                                 "small_batch_note": "n <= 24,576 runs one pairing per 12 lanes (lane-distributed kernel): ~5 ms for 1..2048 pairings; larger batches one pairing per lane"}
             if pinstr and sq:
                 peak = sq["valu_peak"]["int_mad_lane_ops_per_s_T"]
                 result["pairing"]["valu"] = {"achieved": pinstr * m / dt / 1e12, "peak": peak, "unit": "T lane-instr/s", "frac": pinstr * m / dt / 1e12 / peak,

@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(64) k_pairing_product_check(PairArgs a, uint32
   ok[i] = diff == 0;
 }
 // small batches go to the lane-distributed kernels (zkt_dpairing.hip): ~10 ms per element instead of ~100 ms, lower peak throughput
-size_t dproduct_limit() { static const size_t v = [] { const char* e = getenv("ZKT_DPRODUCT_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)16384; }(); return v; }
+size_t dproduct_limit() { static const size_t v = [] { const char* e = getenv("ZKT_DPRODUCT_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)24576; }(); return v; }
 hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s) {
   if (n == 0) return hipSuccess;
   dim3 g((unsigned)((n + 63) / 64)), t(64);
