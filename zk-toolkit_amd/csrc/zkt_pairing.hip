@@ -168,10 +168,8 @@ hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, con
   // 127-step loops on the lane-distributed kernels, their preconditions checked beside them; what fails is redone by the 255-step kernel
   uint32_t* flags = nullptr; hipStream_t side;
   if ((e = hipMallocAsync((void**)&flags, n * sizeof(uint32_t), s)) != hipSuccess) return e;
-  if ((e = guard_fork(s, &side)) != hipSuccess) return e;
-  if ((e = launch_short_loop_guards(a, 3, flags, n, side)) != hipSuccess) return e;
-  if ((e = launch_dproduct(a, 3, alpha_beta, ok, n, err, true, s)) != hipSuccess) return e;
-  if ((e = guard_join(s, side)) != hipSuccess) return e;
+  if ((e = guard_fork(s, &side)) != hipSuccess || (e = launch_short_loop_guards(a, 3, flags, n, side)) != hipSuccess ||
+      (e = launch_dproduct(a, 3, alpha_beta, ok, n, err, true, s)) != hipSuccess || (e = guard_join(s, side)) != hipSuccess) { (void)hipFreeAsync(flags, s); return e; }
   hipLaunchKernelGGL(k_product_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)flags, ok, n);
   if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr, (const uint32_t*)S);
@@ -188,11 +186,11 @@ hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uin
   // inside the verification kernel (one wave per SIMD, 512 registers) the same multiply-adds issue at less than half the rate.
   uint32_t *tmp = nullptr, *S = nullptr;
   if (n_stmt >= 1 && n_stmt <= 12) {
-    if ((e = hipMallocAsync((void**)&tmp, (size_t)n_stmt * n * ABI_G1_WORDS * 4, s)) != hipSuccess) return e;
-    if ((e = hipMallocAsync((void**)&S, n * ABI_G1_WORDS * 4, s)) != hipSuccess) return e;
+    if ((e = hipMallocAsync((void**)&tmp, (size_t)n_stmt * n * ABI_G1_WORDS * 4, s)) != hipSuccess) { (void)hipFreeAsync(good, s); return e; }
+    if ((e = hipMallocAsync((void**)&S, n * ABI_G1_WORDS * 4, s)) != hipSuccess) { (void)hipFreeAsync(good, s); (void)hipFreeAsync(tmp, s); return e; }
     MulSegs segs; segs.n = n_stmt;
     for (int j = 0; j < n_stmt; ++j) segs.s[j] = MulSeg{uvw_stmt + (size_t)j * ABI_G1_WORDS, stmt + (size_t)j * 8, tmp + (size_t)j * n * ABI_G1_WORDS, (uint32_t)n, 0u, (uint32_t)(n_stmt * 8)};
-    if ((e = launch_group_mul_segs(G_G1, segs, 8, s)) != hipSuccess) return e;
+    if ((e = launch_group_mul_segs(G_G1, segs, 8, s)) != hipSuccess) { (void)hipFreeAsync(good, s); (void)hipFreeAsync(tmp, s); (void)hipFreeAsync(S, s); return e; }
     hipLaunchKernelGGL(k_stmt_sums, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)tmp, n_stmt, S, n);
   }
   hipLaunchKernelGGL(k_groth16_verify<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 0, (const uint32_t*)good, (const uint32_t*)S);
@@ -244,10 +242,8 @@ hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, 
   if (small) {                             // 127-step loops on the lane-distributed kernels, their preconditions checked beside them
     uint32_t* flags = nullptr; hipStream_t side; hipError_t e;
     if ((e = hipMallocAsync((void**)&flags, n * sizeof(uint32_t), s)) != hipSuccess) return e;
-    if ((e = guard_fork(s, &side)) != hipSuccess) return e;
-    if ((e = launch_short_loop_guards(a, K, flags, n, side)) != hipSuccess) return e;
-    if ((e = launch_dproduct(a, K, nullptr, ok, n, err, true, s)) != hipSuccess) return e;
-    if ((e = guard_join(s, side)) != hipSuccess) return e;
+    if ((e = guard_fork(s, &side)) != hipSuccess || (e = launch_short_loop_guards(a, K, flags, n, side)) != hipSuccess ||
+        (e = launch_dproduct(a, K, nullptr, ok, n, err, true, s)) != hipSuccess || (e = guard_join(s, side)) != hipSuccess) { (void)hipFreeAsync(flags, s); return e; }
     hipLaunchKernelGGL(k_product_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)flags, ok, n);
     if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
   }

@@ -84,10 +84,8 @@ hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, si
     PairArgs a{}; a.g1[0] = g1; a.s1[0] = ABI_G1_WORDS; a.g2[0] = g2; a.s2[0] = ABI_G2_WORDS;
     uint32_t* flags = nullptr; hipStream_t side; hipError_t e;
     if ((e = hipMallocAsync((void**)&flags, n * sizeof(uint32_t), s)) != hipSuccess) return e;
-    if ((e = guard_fork(s, &side)) != hipSuccess) return e;
-    if ((e = launch_short_loop_guards(a, 1, flags, n, side)) != hipSuccess) return e;
-    if ((e = launch_dtate(g1, g2, out, n, err, TATE_MARK_WORD, TATE_MARK_EXACT, true, s)) != hipSuccess) return e;
-    if ((e = guard_join(s, side)) != hipSuccess) return e;
+    if ((e = guard_fork(s, &side)) != hipSuccess || (e = launch_short_loop_guards(a, 1, flags, n, side)) != hipSuccess ||
+        (e = launch_dtate(g1, g2, out, n, err, TATE_MARK_WORD, TATE_MARK_EXACT, true, s)) != hipSuccess || (e = guard_join(s, side)) != hipSuccess) { (void)hipFreeAsync(flags, s); return e; }
     hipLaunchKernelGGL(k_tate_resolve, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)flags, g1, g2, out, n);
     if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_tate_long_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
