@@ -320,25 +320,27 @@ extern void zkt_internal_set_error_index(size_t i);
 // keys seen: a verifier checks many proofs against ONE key, and with the tables the statement sum of a proof is one short launch instead of a 255-step
 // scalar multiplication per wire (4 of the 9 ms of a single verification).  Keyed by the points' bytes; device memory is released with the entry.
 namespace {
-struct StmtTables { std::vector<uint8_t> key; void* tables = nullptr; uint64_t stamp = 0; };
+struct StmtTables { std::vector<uint8_t> key; std::shared_ptr<void> tables; uint64_t stamp = 0; };
 std::mutex g_stmt_mu; StmtTables g_stmt[4]; uint64_t g_stmt_clock = 0;
-// returns device tables for the n_stmt points at host pointer `pts` (device copy dU), or nullptr when they could not be provided (caller falls back)
-const uint32_t* stmt_tables_for(const zkt_g1_affine* pts, size_t n_stmt, const uint32_t* dU, hipStream_t s) {
+// Device tables for the n_stmt points at host pointer `pts` (device copy dU), or null when they could not be provided (the caller falls back).
+// The caller keeps the returned reference until its launches have completed: an entry evicted meanwhile is released only when its last user lets go.
+std::shared_ptr<void> stmt_tables_for(const zkt_g1_affine* pts, size_t n_stmt, const uint32_t* dU, hipStream_t s) {
   if (n_stmt < 1 || n_stmt > 12) return nullptr;
   const size_t kb = n_stmt * G1B;
   std::lock_guard<std::mutex> lk(g_stmt_mu);
   StmtTables* victim = &g_stmt[0];
   for (StmtTables& e : g_stmt) {
-    if (e.tables && e.key.size() == kb && memcmp(e.key.data(), pts, kb) == 0) { e.stamp = ++g_stmt_clock; return (const uint32_t*)e.tables; }
+    if (e.tables && e.key.size() == kb && memcmp(e.key.data(), pts, kb) == 0) { e.stamp = ++g_stmt_clock; return e.tables; }
     if (e.stamp < victim->stamp) victim = &e;
   }
-  if (victim->tables) { hipFree(victim->tables); victim->tables = nullptr; }          // hipFree waits for the device: nobody is still reading the old entry
-  if (hipMalloc(&victim->tables, n_stmt * 64 * G1B) != hipSuccess) { victim->tables = nullptr; return nullptr; }
+  void* mem = nullptr;
+  if (hipMalloc(&mem, n_stmt * 64 * G1B) != hipSuccess) return nullptr;
+  std::shared_ptr<void> t(mem, [](void* q) { if (q) hipFree(q); });
   FixedTables ft{}; ft.n = (int)n_stmt;
-  for (size_t j = 0; j < n_stmt; ++j) { ft.point[j] = dU + j * (G1B / 4); ft.table[j] = (uint32_t*)victim->tables + j * 64 * (G1B / 4); }
-  if (launch_fixed_tables(G_G1, ft, s) != hipSuccess) { hipFree(victim->tables); victim->tables = nullptr; return nullptr; }
-  victim->key.assign((const uint8_t*)pts, (const uint8_t*)pts + kb); victim->stamp = ++g_stmt_clock;
-  return (const uint32_t*)victim->tables;
+  for (size_t j = 0; j < n_stmt; ++j) { ft.point[j] = dU + j * (G1B / 4); ft.table[j] = (uint32_t*)mem + j * 64 * (G1B / 4); }
+  if (launch_fixed_tables(G_G1, ft, s) != hipSuccess) return nullptr;
+  victim->tables = t; victim->key.assign((const uint8_t*)pts, (const uint8_t*)pts + kb); victim->stamp = ++g_stmt_clock;
+  return t;
 }
 }  // namespace
 extern "C" {
@@ -443,8 +445,8 @@ int zkt_groth16_verify_batch(const zkt_groth16_crs* c, const zkt_g1_affine* A, c
   if (n_stmt >= 1 && n_stmt <= 12 && n_proofs * 3 <= dproduct_limit()) {      // few proofs: one proof per three lane groups (zkt_dpairing.hip), ~15 ms instead of ~105 ms
     Dev dtmp(n_stmt * n_proofs * G1B), dS(n_proofs * G1B);
     if (!dtmp.p || !dS.p) return ZKT_ERR_DEVICE;
-    const uint32_t* tabs = stmt_tables_for(c->g1_uvw_stmt, n_stmt, dU.w(), s);
-    PCHK(launch_groth16_verify_small(dA.w(), dB.w(), dC.w(), dU.w(), tabs, dW.w(), (int)n_stmt, dg.w(), dd.w(), dab.w(), dtmp.w(), dS.w(), dok.w(), n_proofs, (unsigned long long*)derr.p, s));
+    const std::shared_ptr<void> tabs = stmt_tables_for(c->g1_uvw_stmt, n_stmt, dU.w(), s);     // held until the synchronisation below
+    PCHK(launch_groth16_verify_small(dA.w(), dB.w(), dC.w(), dU.w(), (const uint32_t*)tabs.get(), dW.w(), (int)n_stmt, dg.w(), dd.w(), dab.w(), dtmp.w(), dS.w(), dok.w(), n_proofs, (unsigned long long*)derr.p, s));
     unsigned long long e2 = NO_ERR;
     if ((rc = down(ok, dok.p, n_proofs * 4, s)) || (rc = down(&e2, derr.p, 8, s))) return rc;
     PCHK(hipStreamSynchronize(s));
