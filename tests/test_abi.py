@@ -48,3 +48,11 @@ def test_header_is_plain_c99(tmp_path):
     import subprocess
     src = os.path.join(ROOT, "tests", "c", "abi_consumer.c")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", src])
+
+
+def test_generated_constants_are_in_sync(tmp_path):
+    """csrc/zkt_constants.h is generated (tools/gen_constants.py from oracle/fast_model.py): the committed header must be what the generator writes"""
+    import subprocess, sys
+    out = tmp_path / "zkt_constants.h"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_constants.py"), str(out)], timeout=300)
+    assert out.read_text() == open(os.path.join(ROOT, "zk-toolkit_amd", "csrc", "zkt_constants.h")).read()

@@ -26,7 +26,7 @@ def H(request):
     kara = request.param == "kara"
     so = os.path.join(ROOT, "zk-toolkit_amd", "libzkt_hostcheck_kara.so" if kara else "libzkt_hostcheck.so")
     src = os.path.join(ROOT, "zk-toolkit_amd", "csrc")
-    newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src))
+    newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src) if f.endswith(".h") or f == "hostcheck.cpp")      # what the host build includes (Makefile: $(HDRS))
     if not os.path.exists(so) or os.path.getmtime(so) < newest:
         subprocess.check_call(["hipcc", "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared"] + (["-DZKT_FQ2_KARATSUBA"] if kara else []) +
                               ["-o", so, os.path.join(src, "hostcheck.cpp")], timeout=600)
