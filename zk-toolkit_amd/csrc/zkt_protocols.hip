@@ -278,6 +278,76 @@ __global__ void __launch_bounds__(256) k_sum(const uint32_t* __restrict__ a, siz
   if (t == 0) st_raw<C>(out, acc);
 }
 
+// ---- the range proof's vector algebra in ONE launch (bulletproofs.rs:72-127) -------------------------------------------------------
+// Every challenge is the caller's (injected), so nothing a lane computes for index i waits for anything but the proof's scalars:
+//   aR = aL - 1, l0 = aL - z, aRz = aR + z, r0 = y^i aRz + z^2 2^i, r1 = y^i sR, l = l0 + sL x, r = y^i (aRz + sR x) + z^2 2^i
+// and the scalar vectors of the five generator sums go straight into the MSM slots' buffers ([gg part | hh part], zkt_bp_ipa_ctx::dsc):
+//   slot 0: aL | aR      slot 1: sL | sR      slot 2: -z | (z y^i + z^2 2^i) y^-i      slot 3: sL x | sR x      slot 4 (no argument): l | r y^-i
+// The seven sums the scalar stage needs — t0 = <l0,r0>, t1 = <sL,r0> + <l0,r1>, t2 = <sL,r1>, <l,r>, v = <aL,2^n>, sum y^i, sum 2^i — leave as
+// per-block parts (k_rp_sums folds them).  The step-by-step form (one launch per vector operation, ~50 us each, ~40 of them) is kept behind
+// ZKT_RP_FUSED=0; both produce the same residues.
+struct RpScalars { const uint32_t *y, *yinv, *z, *z2, *x; };
+struct RpOut { uint32_t *s0, *s1, *s2, *s3, *s4, *l, *r, *yinv_n, *parts; };
+template <class C>
+__global__ void __launch_bounds__(256) k_rp_fused(const uint32_t* __restrict__ aL, const uint32_t* __restrict__ sL, const uint32_t* __restrict__ sR, RpScalars k, size_t n, RpOut o) {
+  static_assert(C::W == 32, "canonical 32-bit-limb scalar field");
+  __shared__ uint32_t lds[256 * C::N];
+  const int t = threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * 256 + t;
+  const bool live = i < n;
+  Fp<C> r2, one_raw = fp_zero<C>(); one_raw.v[0] = 1;
+  for (int j = 0; j < C::N; ++j) r2.v[j] = C::r2(j);
+  auto M = [&](const uint32_t* p) { return fp_mul(fp_canon32(ld_raw<C>(p)), r2); };       // canonical words -> Montgomery
+  auto out = [&](uint32_t* p, const Fp<C>& v) { st_raw<C>(p, fp_mul(v, one_raw)); };        // Montgomery -> canonical words
+  auto pw = [&](Fp<C> b, size_t e) { Fp<C> r = fp_one<C>(); for (; e; e >>= 1) { if (e & 1) r = fp_mul(r, b); b = fp_sqr(b); } return r; };
+  const Fp<C> y = M(k.y), yinv = M(k.yinv), z = M(k.z), z2 = M(k.z2), x = M(k.x), one = fp_one<C>();
+  Fp<C> sums[7];
+  for (int q = 0; q < 7; ++q) sums[q] = fp_zero<C>();
+  if (live) {
+    const Fp<C> a = M(aL + i * C::N), sl = M(sL + i * C::N), sr = M(sR + i * C::N);
+    const Fp<C> yi = pw(y, i), yni = pw(yinv, i), twi = pw(fp_add(one, one), i);
+    const Fp<C> aR = fp_sub(a, one), l0 = fp_sub(a, z), aRz = fp_add(aR, z), z2two = fp_mul(z2, twi);
+    const Fp<C> r0 = fp_add(fp_mul(yi, aRz), z2two), r1 = fp_mul(yi, sr);
+    const Fp<C> slx = fp_mul(sl, x), srx = fp_mul(sr, x);
+    const Fp<C> l = fp_add(l0, slx), r = fp_add(fp_mul(yi, fp_add(aRz, srx)), z2two);
+    sums[0] = fp_mul(l0, r0); sums[1] = fp_add(fp_mul(sl, r0), fp_mul(l0, r1)); sums[2] = fp_mul(sl, r1); sums[3] = fp_mul(l, r);
+    sums[4] = fp_mul(a, twi); sums[5] = yi; sums[6] = twi;
+    const size_t w = C::N;
+    out(o.s0 + i * w, a); out(o.s0 + (n + i) * w, aR);
+    out(o.s1 + i * w, sl); out(o.s1 + (n + i) * w, sr);
+    out(o.s2 + i * w, fp_neg(z)); out(o.s2 + (n + i) * w, fp_mul(fp_add(fp_mul(z, yi), z2two), yni));
+    out(o.s3 + i * w, slx); out(o.s3 + (n + i) * w, srx);
+    if (o.s4) { out(o.s4 + i * w, l); out(o.s4 + (n + i) * w, fp_mul(r, yni)); }
+    out(o.l + i * w, l); out(o.r + i * w, r); out(o.yinv_n + i * w, yni);
+  }
+  if (i == 0) for (int q = 0; q < C::N; ++q) {                       // the scalar of the u entry (index 2n) of every slot: 0
+    o.s0[2 * n * C::N + q] = 0; o.s1[2 * n * C::N + q] = 0; o.s2[2 * n * C::N + q] = 0; o.s3[2 * n * C::N + q] = 0; if (o.s4) o.s4[2 * n * C::N + q] = 0;
+  }
+  for (int q = 0; q < 7; ++q) {                                        // block sums, one after the other through the same 8 KB
+    st_raw<C>(lds + t * C::N, sums[q]); __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+      if (t < d) { Fp<C> u = fp_add(ld_raw<C>(lds + t * C::N), ld_raw<C>(lds + (t + d) * C::N)); st_raw<C>(lds + t * C::N, u); }
+      __syncthreads();
+    }
+    if (t == 0) st_raw<C>(o.parts + ((size_t)q * gridDim.x + blockIdx.x) * C::N, ld_raw<C>(lds));     // still in the Montgomery domain: k_rp_sums leaves it
+    __syncthreads();
+  }
+}
+// sums[q] = sum over the blocks of parts[q][*], out of the Montgomery domain (7 canonical scalars, 8 words apart)
+template <class C>
+__global__ void __launch_bounds__(256) k_rp_sums(const uint32_t* __restrict__ parts, size_t nblk, uint32_t* __restrict__ sums) {
+  __shared__ uint32_t lds[256 * C::N];
+  const int t = threadIdx.x, q = blockIdx.x;
+  Fp<C> acc = fp_zero<C>(), one_raw = fp_zero<C>(); one_raw.v[0] = 1;
+  for (size_t b = t; b < nblk; b += 256) acc = fp_add(acc, ld_raw<C>(parts + ((size_t)q * nblk + b) * C::N));
+  st_raw<C>(lds + t * C::N, acc); __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (t < d) { acc = fp_add(acc, ld_raw<C>(lds + (t + d) * C::N)); st_raw<C>(lds + t * C::N, acc); }
+    __syncthreads();
+  }
+  if (t == 0) st_raw<C>(sums + (size_t)q * C::N, fp_mul(acc, one_raw));
+}
+
 // G2Point::hash_to_g2point scalar stage (g2_point.rs:84-88): BigUint::from_bytes_be(buf) reduced into the subgroup field, canonical
 __global__ void __launch_bounds__(256) k_bytes_mod_r(const uint8_t* __restrict__ msgs, const unsigned long long* __restrict__ off, size_t n, uint32_t* __restrict__ out) {
   typedef FrC C;
@@ -769,41 +839,67 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   uint32_t *d_aL = vput(aL), *d_sL = vput(rnd + 28), *d_sR = vput(rnd + 28 + 4 * n);
   uint32_t *alpha = sput(rnd), *rho = sput(rnd + 4), *y = sput(rnd + 8), *z = sput(rnd + 12), *tau1 = sput(rnd + 16), *tau2 = sput(rnd + 20), *x = sput(rnd + 24);
   uint32_t *d_gamma = sput(gamma), *one = sput(one64), *two = sput(two64);
-  uint32_t *one_n = vpow(one), *two_n = vpow(two);                                   // :72-73
-  uint32_t* aR = vsub(d_aL, one_n);                                                   // :75
-  msm_sub(0, d_aL, aR);                                                               // (gg*aL).sum() + (hh*aR).sum()   of A (:77)
-  msm_sub(1, d_sL, d_sR);                                                             // (gg*sL).sum() + (hh*sR).sum()   of S (:82)
-  uint32_t* y_n = vpow(y);                                                            // :87
-  uint32_t* z2 = smul(z, z);
-  uint32_t* yinv_n = vpow(sinv(y));                                                   // hh' = hh * y^-i (:109), as coefficients
-  uint32_t* twoz2 = vscl(two_n, z2);
-  // the challenges are the caller's (injected), so the two generator sums that depend on them only through cheap vector kernels are submitted NOW
-  // and run beside A's and S's: four MSMs in flight while the dot-product chain below proceeds
-  uint32_t *sLx = vscl(d_sL, x), *sRx = vscl(d_sR, x);
-  msm_sub(2, vscl(one_n, sneg(z)), vhad(vadd(vscl(y_n, z), twoz2), yinv_n));          // gg * (-z 1^n) + hh' * (z y^n + z^2 2^n)  of P (:126-127)
-  msm_sub(3, sLx, sRx);                                                               // x * ((gg*sL).sum() + (hh*sR).sum()): the generator part of S x (:124)
-  uint32_t* onez = vscl(one_n, z);
-  uint32_t* l0 = vsub(d_aL, onez);                                                    // :88
-  uint32_t* aRz = vadd(aR, onez);
-  uint32_t* r0 = vadd(vhad(y_n, aRz), twoz2);                                         // :90
-  uint32_t* r1 = vhad(y_n, d_sR);                                                     // :91
-  uint32_t *t0 = vdot(l0, r0), *t1 = sadd(vdot(d_sL, r0), vdot(l0, r1)), *t2 = vdot(d_sL, r1);   // :93-95
-  uint32_t* x2 = smul(x, x);
-  uint32_t* t_hat = sadd(sadd(t0, smul(t1, x)), smul(t2, x2));                        // :104
-  uint32_t* tau_x = sadd(sadd(smul(tau2, x2), smul(tau1, x)), smul(z2, d_gamma));     // :105
-  uint32_t* mu = sadd(alpha, smul(rho, x));                                           // :106
-  uint32_t* z3 = smul(z2, z);
-  uint32_t* delta_yz = ssub(smul(ssub(z, z2), vsum(y_n)), smul(z3, vsum(two_n)));     // :112 (one_n o v = v)
-  uint32_t* l = vadd(l0, sLx);                                                        // :121
-  uint32_t* r = vadd(vhad(y_n, vadd(aRz, sRx)), twoz2);                               // :122
-  uint32_t* lr = vdot(l, r);
-  // Every single-point product is a ~4 ms dependent chain however few points a launch covers, so ALL of them go out in ONE launch: the products the
-  // reference takes of T1, T2 and S (:115, :124) are rewritten on the fixed points — T1 x = g (t1 x) + h (tau1 x), S x = h (rho x) + sum over the
-  // generators with scalars sL x, sR x (one more MSM) — the same group elements, so A, S, T1, T2, P keep their bits.
-  uint32_t *t1x = smul(t1, x), *t2x2 = smul(t2, x2);
-  uint32_t* k_g = sadd(sadd(delta_yz, t1x), t2x2);                                    // rhs of :115 = V z^2 + g (delta + t1 x + t2 x^2) + h (tau1 x + tau2 x^2)
-  uint32_t* k_h = sadd(smul(tau1, x), smul(tau2, x2));
-  if (!use_ipa) msm_sub(4, l, vhad(r, yinv_n));                                       // (gg*l).sum() + (hh'*r).sum()  (:142)
+  uint32_t *z2, *yinv_n, *t1, *t2, *t_hat, *tau_x, *mu, *l, *r, *lr, *k_g, *k_h, *two_n = nullptr, *v_val = nullptr;
+  static const bool fused = [] { const char* e = getenv("ZKT_RP_FUSED"); return !e || atoi(e) != 0; }();
+  Dev dparts7(7 * ((n + 255) / 256) * FRB);
+  if (!dparts7.p) return -ZKT_ERR_DEVICE;
+  if (fused) {                                                                        // the whole vector stage in one launch (k_rp_fused)
+    z2 = smul(z, z);
+    uint32_t *yinv = sinv(y), *x2 = smul(x, x), *z3 = smul(z2, z);
+    sflush();
+    auto slot = [&](int k) { return c->dsc.w() + (size_t)k * NB * 8; };
+    l = newv(); r = newv(); yinv_n = newv();
+    uint32_t* sums = news(); for (int q = 1; q < 7; ++q) (void)news();                 // seven consecutive scalars
+    const size_t nblk = (n + 255) / 256;
+    hipLaunchKernelGGL(k_rp_fused<SnC>, dim3((unsigned)nblk), dim3(256), 0, s, (const uint32_t*)d_aL, (const uint32_t*)d_sL, (const uint32_t*)d_sR,
+                       RpScalars{y, yinv, z, z2, x}, n, RpOut{slot(0), slot(1), slot(2), slot(3), use_ipa ? nullptr : slot(4), l, r, yinv_n, dparts7.w()});
+    hipLaunchKernelGGL(k_rp_sums<SnC>, dim3(7), dim3(256), 0, s, (const uint32_t*)dparts7.w(), nblk, sums);
+    for (int k = 0; k < (use_ipa ? 4 : 5); ++k) { okl = okl && zkt_secp_msm_submit(c->set, (const uint64_t*)slot(k), NB, s, k) == ZKT_OK; if (okl) n_sub = k + 1; }
+    uint32_t *t0 = sums, *sum_y = sums + 5 * 8, *sum_2 = sums + 6 * 8;
+    t1 = sums + 8; t2 = sums + 16; lr = sums + 24; v_val = sums + 32;
+    t_hat = sadd(sadd(t0, smul(t1, x)), smul(t2, x2));                                // :104
+    tau_x = sadd(sadd(smul(tau2, x2), smul(tau1, x)), smul(z2, d_gamma));             // :105
+    mu = sadd(alpha, smul(rho, x));                                                   // :106
+    uint32_t* delta_yz = ssub(smul(ssub(z, z2), sum_y), smul(z3, sum_2));             // :112
+    k_g = sadd(sadd(delta_yz, smul(t1, x)), smul(t2, x2));
+    k_h = sadd(smul(tau1, x), smul(tau2, x2));
+  } else {
+    uint32_t* one_n = vpow(one); two_n = vpow(two);                                   // :72-73
+    uint32_t* aR = vsub(d_aL, one_n);                                                   // :75
+    msm_sub(0, d_aL, aR);                                                               // (gg*aL).sum() + (hh*aR).sum()   of A (:77)
+    msm_sub(1, d_sL, d_sR);                                                             // (gg*sL).sum() + (hh*sR).sum()   of S (:82)
+    uint32_t* y_n = vpow(y);                                                            // :87
+    z2 = smul(z, z);
+    yinv_n = vpow(sinv(y));                                                   // hh' = hh * y^-i (:109), as coefficients
+    uint32_t* twoz2 = vscl(two_n, z2);
+    // the challenges are the caller's (injected), so the two generator sums that depend on them only through cheap vector kernels are submitted NOW
+    // and run beside A's and S's: four MSMs in flight while the dot-product chain below proceeds
+    uint32_t *sLx = vscl(d_sL, x), *sRx = vscl(d_sR, x);
+    msm_sub(2, vscl(one_n, sneg(z)), vhad(vadd(vscl(y_n, z), twoz2), yinv_n));          // gg * (-z 1^n) + hh' * (z y^n + z^2 2^n)  of P (:126-127)
+    msm_sub(3, sLx, sRx);                                                               // x * ((gg*sL).sum() + (hh*sR).sum()): the generator part of S x (:124)
+    uint32_t* onez = vscl(one_n, z);
+    uint32_t* l0 = vsub(d_aL, onez);                                                    // :88
+    uint32_t* aRz = vadd(aR, onez);
+    uint32_t* r0 = vadd(vhad(y_n, aRz), twoz2);                                         // :90
+    uint32_t* r1 = vhad(y_n, d_sR);                                                     // :91
+    uint32_t* t0 = vdot(l0, r0); t1 = sadd(vdot(d_sL, r0), vdot(l0, r1)); t2 = vdot(d_sL, r1);   // :93-95
+    uint32_t* x2 = smul(x, x);
+    t_hat = sadd(sadd(t0, smul(t1, x)), smul(t2, x2));                        // :104
+    tau_x = sadd(sadd(smul(tau2, x2), smul(tau1, x)), smul(z2, d_gamma));     // :105
+    mu = sadd(alpha, smul(rho, x));                                           // :106
+    uint32_t* z3 = smul(z2, z);
+    uint32_t* delta_yz = ssub(smul(ssub(z, z2), vsum(y_n)), smul(z3, vsum(two_n)));     // :112 (one_n o v = v)
+    l = vadd(l0, sLx);                                                        // :121
+    r = vadd(vhad(y_n, vadd(aRz, sRx)), twoz2);                               // :122
+    lr = vdot(l, r);
+    // Every single-point product is a ~4 ms dependent chain however few points a launch covers, so ALL of them go out in ONE launch: the products the
+    // reference takes of T1, T2 and S (:115, :124) are rewritten on the fixed points — T1 x = g (t1 x) + h (tau1 x), S x = h (rho x) + sum over the
+    // generators with scalars sL x, sR x (one more MSM) — the same group elements, so A, S, T1, T2, P keep their bits.
+    uint32_t *t1x = smul(t1, x), *t2x2 = smul(t2, x2);
+    k_g = sadd(sadd(delta_yz, t1x), t2x2);                                    // rhs of :115 = V z^2 + g (delta + t1 x + t2 x^2) + h (tau1 x + tau2 x^2)
+    k_h = sadd(smul(tau1, x), smul(tau2, x2));
+    if (!use_ipa) msm_sub(4, l, vhad(r, yinv_n));                                       // (gg*l).sum() + (hh'*r).sum()  (:142)
+  }
   // ... and every one of them is on a FIXED point but one: g, h, u get 64-entry tables of their 16^w multiples (built when the context first sees
   // the point, ~4 ms once) and a product is one wave adding 64 partial products (~0.2 ms).  The exception is V z^2 (:115): V is the caller's.  For
   // the V this proof is about — V = g v + h gamma, v = <aL, 2^n> — it equals g (v z^2) + h (gamma z^2), which folds into the other two terms of
@@ -822,7 +918,7 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
     if (need_h) { c->fix_h = *h; c->fix_h_ok = okl; }
     if (need_u) c->fix_u_ok = okl;
   }
-  uint32_t* v_val = vdot(d_aL, two_n);                                                // v = <aL, 2^n> (:75: the value the bits are of)
+  if (!v_val) v_val = vdot(d_aL, two_n);                                              // v = <aL, 2^n> (:75: the value the bits are of)
   uint32_t *kg_v = sadd(k_g, smul(v_val, z2)), *kh_v = sadd(k_h, smul(d_gamma, z2));
   {
     FixedMuls m{}; int k = 0;
