@@ -596,6 +596,37 @@ int zkt_bp_ipa_ctx_create(size_t n, const zkt_secp_affine* gg, const zkt_secp_af
 }
 void zkt_bp_ipa_ctx_free(zkt_bp_ipa_ctx* c) { delete c; }
 
+// The verdict-only argument in two halves, so that a caller can have it run beside its own work (the range proof does: everything up to the
+// MSM needs a, b and the challenges only — P enters at the very end).  submit: scalar stage + the one MSM on `slot` (scalars in that slot's buffer);
+// finish: collect, compare with P (host or device pointer).  Challenges must be invertible (checked by the callers).
+static int ipa_verdict_submit(zkt_bp_ipa_ctx* c, const uint64_t* a, const uint64_t* b, const uint64_t* xs, const uint32_t* wH0, hipStream_t s, int slot) {
+  const size_t N = c->N, NB = c->NB, levels = c->levels;
+  uint32_t *AL = c->dAL.w(), *BL = c->dBL.w(), *CH = c->dchall.w();
+  if (hipMemcpyAsync(AL, a, N * FRB, hipMemcpyDefault, s) != hipSuccess || hipMemcpyAsync(BL, b, N * FRB, hipMemcpyDefault, s) != hipSuccess) return ZKT_ERR_DEVICE;
+  int rc2;
+  if ((rc2 = up(c->dx, xs, levels * FRB, s))) return rc2;
+  hipLaunchKernelGGL(k_ipa_challenges_all, dim3((unsigned)((levels + 63) / 64)), dim3(64), 0, s, (const uint32_t*)c->dx.w(), (int)levels, CH);
+  size_t lv = 0;
+  for (; lv < levels && (N >> lv) > 2048; ++lv) {
+    const size_t np = (N >> lv) / 2, o = 2 * N - ((2 * N) >> lv), o2 = 2 * N - ((2 * N) >> (lv + 1));
+    hipLaunchKernelGGL(k_ipa_fold_ab, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const uint32_t*)(AL + o * 8), (const uint32_t*)(BL + o * 8), (const uint32_t*)(CH + lv * 32), np,
+                       AL + o2 * 8, BL + o2 * 8);
+  }
+  if (lv < levels) hipLaunchKernelGGL(k_ipa_fold_tail, dim3(1), dim3(1024), 0, s, AL, BL, (const uint32_t*)CH, N, (int)lv, (int)levels);
+  uint32_t* sF = c->dsc.w() + (size_t)slot * NB * 8;            // the slot's scalar buffer
+  hipLaunchKernelGGL(k_ipa_verdict_scalars, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (const uint32_t*)AL, (const uint32_t*)BL, (const uint32_t*)CH, wH0, N, (int)levels, sF);
+  hipLaunchKernelGGL(k_ipa_u_dots, dim3((unsigned)(2 * levels)), dim3(256), 0, s, (const uint32_t*)AL, (const uint32_t*)BL, (const uint32_t*)CH, N, c->dpart.w());
+  hipLaunchKernelGGL(k_ipa_u_scalar, dim3(1), dim3(64), 0, s, (const uint32_t*)AL, (const uint32_t*)BL, (const uint32_t*)c->dpart.w(), N, (int)levels, sF);
+  if (hipGetLastError() != hipSuccess) return ZKT_ERR_DEVICE;
+  return zkt_secp_msm_submit(c->set, (const uint64_t*)sF, NB, s, slot);
+}
+static int ipa_verdict_finish(zkt_bp_ipa_ctx* c, int slot, const zkt_secp_affine* P, hipStream_t s) {      // 1 / 0, negative = -status
+  zkt_secp_affine rhs, lhs;
+  int rc2;
+  if ((rc2 = zkt_secp_msm_collect(c->set, slot, &rhs, nullptr))) return -rc2;
+  if (hipMemcpyAsync(&lhs, P, SPB, hipMemcpyDefault, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -ZKT_ERR_DEVICE;
+  return memcmp(&rhs, &lhs, SPB) == 0 ? 1 : 0;
+}
 // one argument over the context's generators; a context serves one call at a time.  Returns 1 / 0 like the reference's bool, negative = -status.
 static int ipa_run(zkt_bp_ipa_ctx* c, const zkt_secp_affine* P, const uint64_t* a, const uint64_t* b, const uint64_t* xs, zkt_secp_affine* out_trace, const uint32_t* wH0) {
   if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
@@ -611,30 +642,9 @@ static int ipa_run(zkt_bp_ipa_ctx* c, const zkt_secp_affine* P, const uint64_t* 
     if (zero) return -ZKT_ERR_INV_ZERO;
   }
   if (!out_trace && levels >= 1) {           // verdict only: one MSM (see k_ipa_challenges_all)
-    uint32_t *AL = c->dAL.w(), *BL = c->dBL.w(), *CH = c->dchall.w();
-    if (hipMemcpyAsync(AL, a, N * FRB, hipMemcpyDefault, s) != hipSuccess || hipMemcpyAsync(BL, b, N * FRB, hipMemcpyDefault, s) != hipSuccess ||
-        hipMemcpyAsync(c->dPp.p, P, SPB, hipMemcpyDefault, s) != hipSuccess) return -ZKT_ERR_DEVICE;
-    int rc2;
-    if ((rc2 = up(c->dx, xs, levels * FRB, s))) return -rc2;
-    hipLaunchKernelGGL(k_ipa_challenges_all, dim3((unsigned)((levels + 63) / 64)), dim3(64), 0, s, (const uint32_t*)c->dx.w(), (int)levels, CH);
-    size_t lv = 0;
-    for (; lv < levels && (N >> lv) > 2048; ++lv) {
-      const size_t np = (N >> lv) / 2, o = 2 * N - ((2 * N) >> lv), o2 = 2 * N - ((2 * N) >> (lv + 1));
-      hipLaunchKernelGGL(k_ipa_fold_ab, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const uint32_t*)(AL + o * 8), (const uint32_t*)(BL + o * 8), (const uint32_t*)(CH + lv * 32), np,
-                         AL + o2 * 8, BL + o2 * 8);
-    }
-    if (lv < levels) hipLaunchKernelGGL(k_ipa_fold_tail, dim3(1), dim3(1024), 0, s, AL, BL, (const uint32_t*)CH, N, (int)lv, (int)levels);
-    uint32_t* sF = c->dsc.w();                                    // slot 0's scalar buffer
-    hipLaunchKernelGGL(k_ipa_verdict_scalars, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (const uint32_t*)AL, (const uint32_t*)BL, (const uint32_t*)CH, wH0, N, (int)levels, sF);
-    hipLaunchKernelGGL(k_ipa_u_dots, dim3((unsigned)(2 * levels)), dim3(256), 0, s, (const uint32_t*)AL, (const uint32_t*)BL, (const uint32_t*)CH, N, c->dpart.w());
-    hipLaunchKernelGGL(k_ipa_u_scalar, dim3(1), dim3(64), 0, s, (const uint32_t*)AL, (const uint32_t*)BL, (const uint32_t*)c->dpart.w(), N, (int)levels, sF);
-    if (hipGetLastError() != hipSuccess) return -ZKT_ERR_DEVICE;
-    zkt_secp_affine rhs, lhs;
-    if ((rc2 = zkt_secp_msm_submit(c->set, (const uint64_t*)sF, NB, s, 0))) return -rc2;
-    if ((rc2 = zkt_secp_msm_collect(c->set, 0, &rhs, nullptr))) return -rc2;
-    if ((rc2 = down(&lhs, c->dPp.p, SPB, s))) return -rc2;
-    if (hipStreamSynchronize(s) != hipSuccess) return -ZKT_ERR_DEVICE;
-    return memcmp(&rhs, &lhs, SPB) == 0 ? 1 : 0;
+    int rc2 = ipa_verdict_submit(c, a, b, xs, wH0, s, 0);
+    if (rc2) return -rc2;
+    return ipa_verdict_finish(c, 0, P, s);
   }
   Dev &da = c->da, &db = c->db, &da2 = c->da2, &db2 = c->db2, &dwG = c->dwG, &dwH = c->dwH, &dsc = c->dsc, &dPp = c->dPp, &dx = c->dx, &dch = c->dch, &dsq = c->dsq, &dc = c->dc,
       &dlr = c->dlr, &dm = c->dm, &dt = c->dt;
@@ -830,7 +840,10 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   };
   zkt_secp_affine hres[5];
   int n_col = 0;
-  struct Drain { zkt_bp_ipa_ctx* c; int *col, *sub; ~Drain() { for (; *col < *sub; ++*col) zkt_secp_msm_collect(c->set, *col, nullptr, nullptr); } } drain{c, &n_col, &n_sub};
+  bool ipa_started = false;                                                           // the inner-product argument's own MSM, in flight on IPA_SLOT beside the proof's
+  constexpr int IPA_SLOT = 5;
+  struct Drain { zkt_bp_ipa_ctx* c; int *col, *sub; bool* ipa; int ipa_slot;
+    ~Drain() { for (; *col < *sub; ++*col) zkt_secp_msm_collect(c->set, *col, nullptr, nullptr); if (*ipa) zkt_secp_msm_collect(c->set, ipa_slot, nullptr, nullptr); } } drain{c, &n_col, &n_sub, &ipa_started, IPA_SLOT};
   auto msm_col = [&](int slot, uint32_t* dev_out) {                                               // slots are collected in order
     okl = okl && slot == n_col && zkt_secp_msm_collect(c->set, slot, &hres[slot], nullptr) == ZKT_OK; n_col = slot + 1;
     okl = okl && hipMemcpyAsync(dev_out, &hres[slot], SPB, hipMemcpyHostToDevice, s) == hipSuccess;
@@ -855,6 +868,14 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
                        RpScalars{y, yinv, z, z2, x}, n, RpOut{slot(0), slot(1), slot(2), slot(3), use_ipa ? nullptr : slot(4), l, r, yinv_n, dparts7.w()});
     hipLaunchKernelGGL(k_rp_sums<SnC>, dim3(7), dim3(256), 0, s, (const uint32_t*)dparts7.w(), nblk, sums);
     for (int k = 0; k < (use_ipa ? 4 : 5); ++k) { okl = okl && zkt_secp_msm_submit(c->set, (const uint64_t*)slot(k), NB, s, k) == ZKT_OK; if (okl) n_sub = k + 1; }
+    // The argument's scalar stage and its one MSM need l, r and the challenges only — its P enters at the very end — so it starts NOW and runs beside the
+    // proof's own generator sums.  The reference reaches it only after :116-118 hold; a proof that fails there is rejected below whatever the argument says,
+    // and a zero challenge (its error) keeps the sequential order.
+    if (use_ipa && c->levels >= 1 && xs) {
+      bool nz = true;
+      for (size_t lv = 0; lv < c->levels && nz; ++lv) nz = (xs[lv * 4] | xs[lv * 4 + 1] | xs[lv * 4 + 2] | xs[lv * 4 + 3]) != 0;
+      if (nz && okl) { okl = ipa_verdict_submit(c, (const uint64_t*)l, (const uint64_t*)r, xs, yinv_n, s, IPA_SLOT) == ZKT_OK; ipa_started = okl; }      // (a side stream for its ~1 ms of small kernels measured no better: 6.5 against 6.2 ms)
+    }
     uint32_t *t0 = sums, *sum_y = sums + 5 * 8, *sum_2 = sums + 6 * 8;
     t1 = sums + 8; t2 = sums + 16; lr = sums + 24; v_val = sums + 32;
     t_hat = sadd(sadd(t0, smul(t1, x)), smul(t2, x2));                                // :104
@@ -946,6 +967,7 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
     sum(Q(29), {Q(27), Q(28)});                                                       // E
     sum(Q(21), {Q(2), Q(16), Q(22)});                                                 // P h^-mu: the three generator sums of A, S x and :126-127
     sum(Pk, {Q(2), Q(16), Q(22), Q(12)});                                             // P (:124-128) = h mu + those
+    if (use_ipa) sum(Q(24), {Q(2), Q(16), Q(22), Q(17)});                             // :138  P h^-mu u^<l,r>: the argument's P
     if (out_pts) {
       sum(Ak, {Q(0), Q(2)});                                                          // A (:77)
       sum(Sk, {Q(1), Q(3)});                                                          // S (:82)
@@ -969,8 +991,10 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   }
   if (memcmp(&hl, &hr, SPB) != 0) return 0;                                           // :116-118
   if (use_ipa) {
-    uint32_t* Pp = padd(Q(21), Q(17), Q(24));                                         // :138  P h^-mu u^<l,r>
-    if (!okl || hipStreamSynchronize(s) != hipSuccess) return -ZKT_ERR_DEVICE;      // the argument runs on the NULL stream, which does not wait for a non-blocking one
+    uint32_t* Pp = Q(24);                                                             // :138, summed with the others above
+    if (!okl) return -ZKT_ERR_DEVICE;
+    if (ipa_started) { ipa_started = false; return ipa_verdict_finish(c, IPA_SLOT, (const zkt_secp_affine*)Pp, s); }      // :139, already in flight
+    if (hipStreamSynchronize(s) != hipSuccess) return -ZKT_ERR_DEVICE;                // the argument runs on the NULL stream, which does not wait for a non-blocking one
     return ipa_run(c, (const zkt_secp_affine*)Pp, (const uint64_t*)l, (const uint64_t*)r, xs, nullptr, yinv_n);   // :139, over gg, hh' = y^-i hh, u
   }
   uint32_t* rhs = padd(Q(12), Q(25), Q(26));                                          // :142
