@@ -214,7 +214,9 @@ int zkt_init(int device) {
   g.ready = true;
   return ZKT_OK;
 }
+extern "C" void zkt_internal_clear_caches();       // zkt_protocols.hip
 void zkt_shutdown(void) {
+  zkt_internal_clear_caches();                        // before g.mu is taken: releasing a cached context frees base sets, which lock it themselves
   std::lock_guard<std::mutex> lk(g.mu);
   if (!g.ready) return;
   (void)hipSetDevice(g.device);

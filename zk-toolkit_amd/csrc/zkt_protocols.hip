@@ -574,6 +574,43 @@ struct zkt_bp_ipa_ctx {
     if (set) zkt_secp_bases_free(set);
   }
 };
+// The reference's one-shot calls (inner_product_argument, range_proof: bulletproofs.rs:19-55, 58-147) take the generators every time; a caller proves
+// many statements over ONE generator set.  The last context built by a one-shot call (window-multiple table of 2n+1 points, work buffers, fixed-base
+// tables: ~20 ms to set up at 65,536 generators) is kept and reused when the next call brings the same generators, byte for byte (host pointers only;
+// ZKT_BP_CTX_CACHE=0 turns this off; zkt_shutdown releases it).
+namespace {
+struct BpCtxCache { std::mutex mu; std::vector<uint8_t> key; std::shared_ptr<zkt_bp_ipa_ctx> ctx; } g_bpc;
+bool bp_host_ptr(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return true; }      // unregistered host memory
+  return a.type != hipMemoryTypeDevice;
+}
+std::shared_ptr<zkt_bp_ipa_ctx> bp_ctx_for(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u, int* rc) {
+  static const bool enabled = [] { const char* e = getenv("ZKT_BP_CTX_CACHE"); return !e || atoi(e) != 0; }();
+  const bool cacheable = enabled && bp_host_ptr(gg) && bp_host_ptr(hh) && bp_host_ptr(u);
+  const size_t nb = n * SPB;
+  std::unique_lock<std::mutex> lk(g_bpc.mu, std::defer_lock);
+  if (cacheable) {
+    lk.lock();
+    if (g_bpc.ctx && g_bpc.ctx->N == n && g_bpc.key.size() == 2 * nb + SPB && memcmp(g_bpc.key.data(), gg, nb) == 0 && memcmp(g_bpc.key.data() + nb, hh, nb) == 0 &&
+        memcmp(g_bpc.key.data() + 2 * nb, u, SPB) == 0) { *rc = ZKT_OK; return g_bpc.ctx; }
+  }
+  zkt_bp_ipa_ctx* c = nullptr;
+  *rc = zkt_bp_ipa_ctx_create(n, gg, hh, u, &c);
+  if (*rc) return nullptr;
+  std::shared_ptr<zkt_bp_ipa_ctx> sp(c, [](zkt_bp_ipa_ctx* q) { zkt_bp_ipa_ctx_free(q); });
+  if (cacheable) {
+    g_bpc.key.resize(2 * nb + SPB);
+    memcpy(g_bpc.key.data(), gg, nb); memcpy(g_bpc.key.data() + nb, hh, nb); memcpy(g_bpc.key.data() + 2 * nb, u, SPB);
+    g_bpc.ctx = sp;
+  }
+  return sp;
+}
+}  // namespace
+extern "C" void zkt_internal_clear_caches() {             // zkt_shutdown: device memory held by the per-key caches of this file
+  { std::lock_guard<std::mutex> lk(g_bpc.mu); g_bpc.ctx.reset(); g_bpc.key.clear(); }
+  { std::lock_guard<std::mutex> lk(g_stmt_mu); for (StmtTables& e : g_stmt) { e.tables.reset(); e.key.clear(); e.stamp = 0; } }
+}
 extern "C" {
 int zkt_bp_ipa_ctx_create(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u, zkt_bp_ipa_ctx** out) {
   if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
@@ -730,12 +767,10 @@ int zkt_bp_inner_product_argument_ctx(zkt_bp_ipa_ctx* c, const zkt_secp_affine* 
 int zkt_bp_inner_product_argument(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u, const zkt_secp_affine* P,
                                   const uint64_t* a, const uint64_t* b, const uint64_t* xs, zkt_secp_affine* out_trace) {
   if (n == 0 || (n & (n - 1)) || !gg || !hh || !u || !P || !a || !b || (n > 1 && !xs)) return -ZKT_ERR_SHAPE;
-  zkt_bp_ipa_ctx* c = nullptr;
-  int rc = zkt_bp_ipa_ctx_create(n, gg, hh, u, &c);
+  int rc;
+  const std::shared_ptr<zkt_bp_ipa_ctx> c = bp_ctx_for(n, gg, hh, u, &rc);
   if (rc) return -rc;
-  rc = zkt_bp_inner_product_argument_ctx(c, P, a, b, xs, out_trace);
-  zkt_bp_ipa_ctx_free(c);
-  return rc;
+  return zkt_bp_inner_product_argument_ctx(c.get(), P, a, b, xs, out_trace);
 }
 
 
@@ -750,12 +785,10 @@ int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, c
   if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
   if (n == 0 || (n & (n - 1)) || !V || !aL || !gamma || !g || !h || !gg || !hh || !rnd || (use_ipa && (!u || (n > 1 && !xs)))) return -ZKT_ERR_SHAPE;
   zkt_secp_affine inf_pt; memset(&inf_pt, 0, sizeof inf_pt); inf_pt.is_infinity = 1;
-  zkt_bp_ipa_ctx* c = nullptr;
-  int rc = zkt_bp_ipa_ctx_create(n, gg, hh, use_ipa ? u : &inf_pt, &c);
+  int rc;
+  const std::shared_ptr<zkt_bp_ipa_ctx> c = bp_ctx_for(n, gg, hh, use_ipa ? u : &inf_pt, &rc);
   if (rc) return -rc;
-  rc = range_proof_core(c, V, aL, gamma, g, h, use_ipa, rnd, xs, out_pts);
-  zkt_bp_ipa_ctx_free(c);
-  return rc;
+  return range_proof_core(c.get(), V, aL, gamma, g, h, use_ipa, rnd, xs, out_pts);
 }
 // the same proof over a context's resident generators gg, hh, u (zkt_bp_ipa_ctx_create): no table build, no generator upload per proof
 int zkt_bp_range_proof_ctx(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const uint64_t* aL, const uint64_t* gamma, const zkt_secp_affine* g, const zkt_secp_affine* h,
