@@ -54,7 +54,7 @@ typedef struct { uint64_t x[4], y[4]; uint32_t is_infinity, _pad; } zkt_secp_aff
 
 /* lifecycle — mcl_initializer.rs:4-15 (init once, panic on failure) */
 int zkt_init(int device);                 /* device = HIP ordinal, -1 = current */
-void zkt_shutdown(void);
+void zkt_shutdown(void);                  /* also releases what the library keeps between calls: the last one-shot Bulletproofs context, the statement tables of the last four Groth16 keys */
 int zkt_version(void);
 const char* zkt_strerror(int status);
 size_t zkt_last_error_index(void);        /* thread-local; valid after a non-OK return */
@@ -272,7 +272,9 @@ int zkt_bp_inner_product_argument_ctx(zkt_bp_ipa_ctx* ctx, const zkt_secp_affine
 
 /* a18: Bulletproofs::range_proof bulletproofs.rs:58-147 (n = bit length, a power of two; aL = the value's bits).  rnd =
  * alpha, rho, y, z, tau1, tau2, x, sL[n], sR[n] (the values the reference draws at :76,:79-81,:84-85,:97-98,:102);
- * u = the random point of :137 and xs the inner-product challenges (only with use_ipa).  out_pts (optional) = A,S,T1,T2,P. */
+ * u = the random point of :137 and xs the inner-product challenges (only with use_ipa).  out_pts (optional) = A,S,T1,T2,P.
+ * The context built for gg, hh, u (window-multiple table, work buffers: ~20 ms at 65,536 generators) is kept after the call and reused by the next
+ * one-shot call that brings the same generators byte for byte (host pointers; ZKT_BP_CTX_CACHE=0 disables); zkt_bp_inner_product_argument likewise. */
 int zkt_bp_range_proof(size_t n, const zkt_secp_affine* V, const uint64_t* aL, const uint64_t* gamma, const zkt_secp_affine* g,
                        const zkt_secp_affine* h, const zkt_secp_affine* gg, const zkt_secp_affine* hh, int use_ipa,
                        const uint64_t* rnd, const zkt_secp_affine* u, const uint64_t* xs, zkt_secp_affine* out_pts);
