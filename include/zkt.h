@@ -54,7 +54,7 @@ typedef struct { uint64_t x[4], y[4]; uint32_t is_infinity, _pad; } zkt_secp_aff
 
 /* lifecycle — mcl_initializer.rs:4-15 (init once, panic on failure) */
 int zkt_init(int device);                 /* device = HIP ordinal, -1 = current */
-void zkt_shutdown(void);                  /* also releases what the library keeps between calls: the last one-shot Bulletproofs context, the statement tables of the last four Groth16 keys */
+void zkt_shutdown(void);                  /* also releases what the library keeps between calls: the last one-shot Bulletproofs context, the statement tables of the last four Groth16 keys, the io-point tables of the last two Pinocchio keys */
 int zkt_version(void);
 const char* zkt_strerror(int status);
 size_t zkt_last_error_index(void);        /* thread-local; valid after a non-OK return */
@@ -250,7 +250,9 @@ int zkt_pinocchio_setup(zkt_pinocchio_crs* crs, const uint64_t* vi, const uint64
 int zkt_pinocchio_prove(const zkt_pinocchio_crs* crs, const uint64_t* wires, const uint64_t* h, size_t h_len,
                         const uint64_t* delta_v, const uint64_t* delta_y, zkt_pinocchio_proof* proof);
 /* 1 accept, 0 reject, negative = -status (a pairing argument at infinity panics in the reference); the five equalities are
- * evaluated in the reference's order */
+ * decided in the reference's order (a rejection by an earlier one wins over a panic of a later one).  Up to 12 io wires: fixed-base
+ * tables of the key's io points are built on first sight of a key (~40 ms) and kept for the last two keys, a verification then takes
+ * ~6 ms; calls are serialised inside the library. */
 int zkt_pinocchio_verify(const zkt_pinocchio_crs* crs, const zkt_pinocchio_proof* proof, const uint64_t* io_wires);
 
 /* a18: Bulletproofs::inner_product_argument bulletproofs.rs:19-55 over secp256k1; n a power of two; a, b are 4-limb

@@ -51,3 +51,45 @@ def test_pinocchio_vs_oracle(L, case):
     # ... but a rejection by an earlier check wins over the later panic (verifier.rs returns before evaluating it)
     for buf in (opb, gpb): buf["alpha_v_mid_s"][:] = buf["v_mid_s"]
     assert both(opf, gpf, io) == (0, 0)
+
+
+def _instance(L, constraints, seed):
+    A, B, C, wit, l = chain_circuit(constraints)
+    n, n_io = len(A), l + 1
+    V, W, Y, h, max_degree = pinocchio_instance(A, B, C, wit)
+    rng = SplitMix64(seed)
+    rnd = ints_to_arr([rng.below(R - 1) + 1 for _ in range(8)], 4)
+    dv, dy = ints_to_arr([rng.below(R - 1) + 1], 4), ints_to_arr([rng.below(R - 1) + 1], 4)
+    wires, H = ints_to_arr(wit, 4), ints_to_arr(h, 4)
+    crs, cbuf = alloc_pinocchio(n, n_io, len(wit) - n_io, max_degree)
+    zk.check(L.zkt_pinocchio_setup(ctypes.byref(crs), ptr(V), ptr(W), ptr(Y), ptr(rnd)))
+    pf, pbuf = alloc_pinocchio_proof()
+    zk.check(L.zkt_pinocchio_prove(ctypes.byref(crs), ptr(wires), ptr(H), len(h), ptr(dv), ptr(dy), ctypes.byref(pf)))
+    return crs, cbuf, pf, pbuf, wires[:n_io].copy()
+
+
+def test_pinocchio_verify_with_several_keys(L):
+    """The verifier keeps fixed-base tables of the last two keys' io points (zkt_pinocchio.hip): alternate between three keys so that entries are
+    reused, evicted and rebuilt, and compare every decision with the oracle's verifier on the same key, proof and statement."""
+    inst = [_instance(L, 4, 501), _instance(L, 4, 502), _instance(L, 6, 503)]
+    def both(k, io):
+        crs, _, pf, _, _ = inst[k]
+        return O.zkto_pinocchio_verify(ctypes.byref(crs), ctypes.byref(pf), ptr(io)), L.zkt_pinocchio_verify(ctypes.byref(crs), ctypes.byref(pf), ptr(io))
+    for k in (0, 1, 0, 1, 2, 0, 2, 1):
+        io = inst[k][4]
+        assert both(k, io) == (1, 1)
+        bad = io.copy(); bad[1, 1] ^= np.uint64(5)
+        assert both(k, bad) == (0, 0)
+    # a proof checked against another key of the same shape
+    crs1, pf0, io0 = inst[1][0], inst[0][2], inst[0][4]
+    assert O.zkto_pinocchio_verify(ctypes.byref(crs1), ctypes.byref(pf0), ptr(io0)) == 0
+    assert L.zkt_pinocchio_verify(ctypes.byref(crs1), ctypes.byref(pf0), ptr(io0)) == 0
+    # statement wires of zero: every product is the point at infinity and the sums are the proof's own points
+    zero = np.zeros_like(inst[0][4])
+    assert both(0, zero) == (0, 0)
+    # only the last equality has an argument at infinity (h_s): the first four pass, the reference panics in the fifth
+    inst[2][3]["h_s"][:] = 0; inst[2][3]["h_s"][0, 24] = 1
+    assert both(2, inst[2][4]) == (-2, -ZKT_ERR_INFINITY)
+    # ... and a statement that is larger than the group order is used as the integer it is, on both sides
+    big = inst[1][4].copy(); big[1] = np.array(int_to_limbs(int(limbs_to_int(inst[1][4][1])) + R, 4), np.uint64)
+    assert both(1, big) == (1, 1)

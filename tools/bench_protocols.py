@@ -146,8 +146,14 @@ t0 = time.perf_counter(); zk.check(L.zkt_pinocchio_setup(ctypes.byref(crs), ptr(
 pf, pbuf = alloc_pinocchio_proof()
 wires, Hq = ints_to_arr(wit, 4), ints_to_arr(hq, 4)
 t0 = time.perf_counter(); zk.check(L.zkt_pinocchio_prove(ctypes.byref(crs), ptr(wires), ptr(Hq), len(hq), ptr(fr(777)), ptr(fr(888)), ctypes.byref(pf))); t_p = time.perf_counter() - t0
-t0 = time.perf_counter(); okp = L.zkt_pinocchio_verify(ctypes.byref(crs), ctypes.byref(pf), ptr(wires[:n_io].copy())); t_v = time.perf_counter() - t0
+io_p = wires[:n_io].copy()
+t0 = time.perf_counter(); okp = L.zkt_pinocchio_verify(ctypes.byref(crs), ctypes.byref(pf), ptr(io_p)); t_v0 = time.perf_counter() - t0
 assert okp == 1
-res["pinocchio"] = {"constraints": nn, "setup_s": t_s, "prove_s": t_p, "verify_s": t_v, "accepts": True,
-                    "note": "host-pointer one-shot MSM entry points; latency of a single small proof, not a throughput figure"}
+t_v = []
+for _ in range(5):
+    t0 = time.perf_counter(); okp = L.zkt_pinocchio_verify(ctypes.byref(crs), ctypes.byref(pf), ptr(io_p)); t_v.append(time.perf_counter() - t0)
+    assert okp == 1
+res["pinocchio"] = {"constraints": nn, "setup_s": t_s, "prove_s": t_p, "verify_first_call_s": t_v0, "verify_s": sorted(t_v)[len(t_v) // 2], "accepts": True,
+                    "note": "latency of a single small proof, not a throughput figure; prove goes through the host-pointer one-shot MSM entry points; "
+                            "verify_first_call_s includes building the fixed-base tables of the key's io points, verify_s is the median of five more calls on that key"}
 print(json.dumps(res, indent=1))

@@ -162,17 +162,19 @@ template <class F> __device__ inline void fixed_mul_wave(const FixedMul& m) {
 hipError_t launch_fixed_tables(int grp, const FixedTables& t, hipStream_t s) {
   if (t.n < 0 || t.n > 12) return hipErrorInvalidValue;
   if (t.n == 0) return hipSuccess;
-  switch (grp) {                                                            // instantiated where it is used: Bulletproofs' secp256k1 generators, a Groth16 key's statement points
+  switch (grp) {                                                            // Bulletproofs' secp256k1 generators, a Groth16 key's statement points, a Pinocchio key's io points (G1 and G2)
     case G_SECP: hipLaunchKernelGGL(k_fixed_table<SpOps>, dim3((unsigned)t.n), dim3(64), 0, s, t); break;
     case G_G1: hipLaunchKernelGGL(k_fixed_table<FqOps>, dim3((unsigned)t.n), dim3(64), 0, s, t); break;
+    case G_G2: hipLaunchKernelGGL(k_fixed_table<Fq2Ops>, dim3((unsigned)t.n), dim3(64), 0, s, t); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 hipError_t launch_fixed_muls_batch(int grp, const uint32_t* tables, const uint32_t* k, uint32_t* out, size_t n, int n_pts, hipStream_t s) {
-  if (grp != G_G1 || n_pts < 1 || n * (size_t)n_pts >= (size_t(1) << 31)) return hipErrorInvalidValue;
+  if ((grp != G_G1 && grp != G_G2) || n_pts < 1 || n * (size_t)n_pts >= (size_t(1) << 31)) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_fixed_muls_batch<FqOps>, dim3((unsigned)(n * n_pts)), dim3(64), 0, s, tables, k, out, n, n_pts);
+  if (grp == G_G1) hipLaunchKernelGGL(k_fixed_muls_batch<FqOps>, dim3((unsigned)(n * n_pts)), dim3(64), 0, s, tables, k, out, n, n_pts);
+  else hipLaunchKernelGGL(k_fixed_muls_batch<Fq2Ops>, dim3((unsigned)(n * n_pts)), dim3(64), 0, s, tables, k, out, n, n_pts);
   return hipGetLastError();
 }
 hipError_t launch_fixed_muls(int grp, const FixedMuls& f, hipStream_t s) {

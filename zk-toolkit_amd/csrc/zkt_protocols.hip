@@ -607,7 +607,9 @@ std::shared_ptr<zkt_bp_ipa_ctx> bp_ctx_for(size_t n, const zkt_secp_affine* gg, 
   return sp;
 }
 }  // namespace
-extern "C" void zkt_internal_clear_caches() {             // zkt_shutdown: device memory held by the per-key caches of this file
+extern "C" void zkt_pinocchio_clear_caches();             // zkt_pinocchio.hip
+extern "C" void zkt_internal_clear_caches() {             // zkt_shutdown: device memory held by the per-key caches
+  zkt_pinocchio_clear_caches();
   { std::lock_guard<std::mutex> lk(g_bpc.mu); g_bpc.ctx.reset(); g_bpc.key.clear(); }
   { std::lock_guard<std::mutex> lk(g_stmt_mu); for (StmtTables& e : g_stmt) { e.tables.reset(); e.key.clear(); e.stamp = 0; } }
 }
