@@ -51,28 +51,31 @@ hipError_t launch_short_loop_guards(const PairArgs& a, int K, uint32_t* flags, s
 }
 namespace {
 struct GuardStreams {
-  std::mutex mu; hipStream_t side[2] = {}; hipEvent_t ev[32] = {}; unsigned next = 0, next_side = 0;
-  hipError_t event(hipEvent_t* e, hipStream_t* fork_to) {          // a small ring: a wait captures the event's record at the time of the call
+  // ONE side stream for the whole library, on purpose: the runtime sizes a queue's scratch for every wave slot of the device (8192) times the largest
+  // per-lane frame it has seen, and keeps it — 2.6 GB for a queue that ran k_short_loop_guards, 5-9 GB for one that ran a pairing kernel.  The
+  // process's scratch pool is ~30 GB; spreading pairing-family kernels over more queues exhausts it and the runtime aborts the process
+  // (HSA_STATUS_ERROR_OUT_OF_RESOURCES in its queue-error callback), which is how a second side stream and two verifier streams ended the GPU suite.
+  std::mutex mu; hipStream_t side = nullptr; hipEvent_t ev[32] = {}; unsigned next = 0;
+  hipError_t event(hipEvent_t* e) {                                // a small ring: a wait captures the event's record at the time of the call
     std::lock_guard<std::mutex> lk(mu);
     hipError_t rc;
-    for (hipStream_t& x : side) if (!x && (rc = hipStreamCreateWithFlags(&x, hipStreamNonBlocking)) != hipSuccess) return rc;
+    if (!side && (rc = hipStreamCreateWithFlags(&side, hipStreamNonBlocking)) != hipSuccess) return rc;
     hipEvent_t& x = ev[next++ % 32];
     if (!x && (rc = hipEventCreateWithFlags(&x, hipEventDisableTiming)) != hipSuccess) return rc;
-    *e = x;
-    if (fork_to) *fork_to = side[next_side++ & 1];                 // two side streams in turn: the guards of two checks issued from different streams run side by side
-    return hipSuccess;
+    *e = x; return hipSuccess;
   }
 } g_guard;
 }  // namespace
 hipError_t guard_fork(hipStream_t s, hipStream_t* side) {
   hipEvent_t e; hipError_t rc;
-  if ((rc = g_guard.event(&e, side)) != hipSuccess) return rc;
+  if ((rc = g_guard.event(&e)) != hipSuccess) return rc;
+  *side = g_guard.side;
   if ((rc = hipEventRecord(e, s)) != hipSuccess) return rc;
   return hipStreamWaitEvent(*side, e, 0);
 }
 hipError_t guard_join(hipStream_t s, hipStream_t side) {
   hipEvent_t e; hipError_t rc;
-  if ((rc = g_guard.event(&e, nullptr)) != hipSuccess) return rc;
+  if ((rc = g_guard.event(&e)) != hipSuccess) return rc;
   if ((rc = hipEventRecord(e, side)) != hipSuccess) return rc;
   return hipStreamWaitEvent(s, e, 0);
 }

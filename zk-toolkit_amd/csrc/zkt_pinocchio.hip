@@ -98,24 +98,18 @@ extern void zkt_internal_set_error_index(size_t i);
 
 // ---- verification with the key's io points as fixed-base tables ------------------------------------------------------------------
 // A verifier checks many proofs against ONE key.  The statement sums sum_i io_i * {vk_io, yk_io, wk_io}[i] (verifier.rs:70-76) through the one-shot
-// MSM entry points cost 2.6 + 2.8 + 7.1 ms for a handful of wires — a 255-step doubling chain each, however few points — and the five equalities ran
-// as two launches one after the other (5 + 5 ms).  Here the key's io points get fixed-base tables once (launch_fixed_tables, kept for the last two keys,
-// keyed by the points' bytes), a statement sum is one wave per wire, the additions are one lane each, and the 2-pair and 3-pair checks run side by
-// side on two streams: ~25 ms -> ~7 ms per verification, same decisions in the same order.
+// MSM entry points cost 2.6 + 2.8 + 7.1 ms for a handful of wires — a 255-step doubling chain each, however few points.  Here the key's io points get
+// fixed-base tables once (launch_fixed_tables, kept for the last two keys, keyed by the points' bytes), a statement sum is one wave per wire and the
+// additions are one lane each: ~25 ms -> ~11 ms per verification, same decisions in the same order.  Everything runs on the stream the other protocol
+// calls use: the two product checks on two streams of their own took another 5 ms off, but every queue that runs a pairing kernel keeps 5-9 GB of
+// scratch (see GuardStreams, zkt_pairing.hip) and two more such queues exhausted the process's scratch pool.
 namespace {
 constexpr size_t PIN_FAST_IO = 12;                  // launch_fixed_tables takes twelve points per launch
 struct PinTables { std::vector<uint8_t> key; std::shared_ptr<void> mem; uint64_t stamp = 0; };
 struct PinState {
-  std::mutex mu;                                    // one verification at a time on the two streams below
-  hipStream_t a = nullptr, b = nullptr; hipEvent_t ev = nullptr;
+  std::mutex mu;                                    // the table cache; a verification holds it from look-up to completion, so an entry is never released under a running launch
   PinTables tab[2]; uint64_t clock = 0;
 } g_pin;
-int pin_streams_ready() {
-  if (!g_pin.a) QCHK(hipStreamCreateWithFlags(&g_pin.a, hipStreamNonBlocking));
-  if (!g_pin.b) QCHK(hipStreamCreateWithFlags(&g_pin.b, hipStreamNonBlocking));
-  if (!g_pin.ev) QCHK(hipEventCreateWithFlags(&g_pin.ev, hipEventDisableTiming));
-  return ZKT_OK;
-}
 // tables of [vk_io | yk_io] (G1, 2 n_io points) followed by wk_io (G2, n_io points); dio1 / dio2 = the same points already in HBM.  Caller holds g_pin.mu.
 std::shared_ptr<void> pin_tables_for(const zkt_pinocchio_crs* c, const uint32_t* dio1, const uint32_t* dio2, hipStream_t s) {
   const size_t nio = c->n_io, k1 = nio * G1B, k2 = nio * G2B;
@@ -156,8 +150,7 @@ int pin_decide(int rc4, size_t inf4, const uint32_t* ok4, int rc1, uint32_t ok1)
 }
 int pin_verify_fast(const zkt_pinocchio_crs* c, const zkt_pinocchio_proof* pf, const uint64_t* io_wires) {
   std::lock_guard<std::mutex> lk(g_pin.mu);
-  int rc = pin_streams_ready(); if (rc) return -rc;
-  hipStream_t sa = g_pin.a, sb = g_pin.b;
+  hipStream_t sa = nullptr, sb = nullptr;           // one stream: the 2-pair checks, then the statement sums and the 3-pair check
   const size_t nio = c->n_io;
   const int W1 = (int)(G1B / 4), W2 = (int)(G2B / 4);
   // the four two-pair equalities lhs == rhs as tate(lhs) * tate(-rhs) == 1 (:43-66); slot 1 = v_mid_s + w_mid_s + y_mid_s (:44) is filled on the device
@@ -168,13 +161,11 @@ int pin_verify_fast(const zkt_pinocchio_crs* c, const zkt_pinocchio_proof* pf, c
   Dev d1(sizeof g1s), d2(sizeof g2s), dm1(sizeof m1), dm2(sizeof m2), dio1(2 * nio * G1B), dio2(nio * G2B), dk(nio * FRB), dp1(2 * nio * G1B), dp2(nio * G2B),
       dsum1(2 * G1B), dsum2(G2B), dok(5 * 4), derr(16);
   if (!d1.p || !d2.p || !dm1.p || !dm2.p || !dio1.p || !dio2.p || !dk.p || !dp1.p || !dp2.p || !dsum1.p || !dsum2.p || !dok.p || !derr.p) return -ZKT_ERR_DEVICE;
-#define VCHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(sa); (void)hipStreamSynchronize(sb); return -ZKT_ERR_DEVICE; } } while (0)
+#define VCHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(sa); return -ZKT_ERR_DEVICE; } } while (0)
   const unsigned long long noerr[2] = {~0ull, ~0ull};
-  // stream a: 2-pair checks.  stream b: statement sums, then the 3-pair check.
   VCHK(hipMemcpyAsync(d1.p, g1s, sizeof g1s, hipMemcpyHostToDevice, sa)); VCHK(hipMemcpyAsync(d2.p, g2s, sizeof g2s, hipMemcpyHostToDevice, sa));
   VCHK(hipMemcpyAsync(dm1.p, m1, sizeof m1, hipMemcpyHostToDevice, sa)); VCHK(hipMemcpyAsync(dm2.p, m2, sizeof m2, hipMemcpyHostToDevice, sa));
   VCHK(hipMemcpyAsync(derr.p, noerr, 16, hipMemcpyHostToDevice, sa));
-  VCHK(hipEventRecord(g_pin.ev, sa)); VCHK(hipStreamWaitEvent(sb, g_pin.ev, 0));
   {
     PinSums ps{}; ps.n = 1;                                       // vwy = (v_mid_s + w_mid_s) + y_mid_s
     ps.s[0] = PinSum{{d1.w() + 1 * W1, dm1.w(), d1.w() + 7 * W1}, 3, nullptr, 0, d1.w() + 1 * W1};
@@ -188,7 +179,7 @@ int pin_verify_fast(const zkt_pinocchio_crs* c, const zkt_pinocchio_proof* pf, c
     VCHK(hipMemcpyAsync(dio1.p, c->vk_io, nio * G1B, hipMemcpyHostToDevice, sb)); VCHK(hipMemcpyAsync(dio1.w() + nio * W1, c->yk_io, nio * G1B, hipMemcpyHostToDevice, sb));
     VCHK(hipMemcpyAsync(dio2.p, c->wk_io, nio * G2B, hipMemcpyHostToDevice, sb)); VCHK(hipMemcpyAsync(dk.p, io_wires, nio * FRB, hipMemcpyHostToDevice, sb));
     tabs = pin_tables_for(c, dio1.w(), dio2.w(), sb);
-    if (!tabs) { (void)hipStreamSynchronize(sa); (void)hipStreamSynchronize(sb); return -ZKT_ERR_DEVICE; }
+    if (!tabs) { (void)hipStreamSynchronize(sa); return -ZKT_ERR_DEVICE; }
     const uint32_t* t1 = (const uint32_t*)tabs.get(); const uint32_t* t2 = t1 + 2 * nio * 64 * W1;
     // products io_i * point_i: out[j] for table j with scalar k[j] (n = 1 "proof", n_pts tables)
     VCHK(launch_fixed_muls_batch(G_G1, t1, dk.w(), dp1.w(), 1, (int)nio, sb));
@@ -211,7 +202,6 @@ int pin_verify_fast(const zkt_pinocchio_crs* c, const zkt_pinocchio_proof* pf, c
   }
   uint32_t ok[5] = {0, 0, 0, 0, 0}; unsigned long long e[2] = {~0ull, ~0ull};
   VCHK(hipStreamSynchronize(sa));
-  VCHK(hipStreamSynchronize(sb));
   VCHK(hipMemcpy(ok, dok.p, sizeof ok, hipMemcpyDeviceToHost)); VCHK(hipMemcpy(e, derr.p, sizeof e, hipMemcpyDeviceToHost));
 #undef VCHK
   return pin_decide(e[0] != ~0ull ? ZKT_ERR_INFINITY : ZKT_OK, (size_t)e[0], ok, e[1] != ~0ull ? ZKT_ERR_INFINITY : ZKT_OK, ok[4]);
@@ -219,8 +209,6 @@ int pin_verify_fast(const zkt_pinocchio_crs* c, const zkt_pinocchio_proof* pf, c
 }  // namespace
 extern "C" void zkt_pinocchio_clear_caches() {      // zkt_shutdown (through zkt_internal_clear_caches)
   std::lock_guard<std::mutex> lk(g_pin.mu);
-  if (g_pin.a) (void)hipStreamSynchronize(g_pin.a);
-  if (g_pin.b) (void)hipStreamSynchronize(g_pin.b);
   for (PinTables& t : g_pin.tab) { t.mem.reset(); t.key.clear(); t.stamp = 0; }
 }
 
