@@ -52,7 +52,7 @@ hipError_t launch_short_loop_guards(const PairArgs& a, int K, uint32_t* flags, s
 namespace {
 struct GuardStreams {
   // ONE side stream for the whole library, on purpose: the runtime sizes a queue's scratch for every wave slot of the device (8192) times the largest
-  // per-lane frame it has seen, and keeps it — 2.6 GB for a queue that ran k_short_loop_guards, 5-9 GB for one that ran a pairing kernel.  The
+  // per-lane frame it has seen (capped at 6 GiB), and keeps it — 2.4 GiB for a queue that ran k_short_loop_guards, 5-6 GiB for one that ran a pairing kernel.  The
   // process's scratch pool is ~30 GB; spreading pairing-family kernels over more queues exhausts it and the runtime aborts the process
   // (HSA_STATUS_ERROR_OUT_OF_RESOURCES in its queue-error callback), which is how a second side stream and two verifier streams ended the GPU suite.
   std::mutex mu; hipStream_t side = nullptr; hipEvent_t ev[32] = {}; unsigned next = 0;

@@ -101,7 +101,7 @@ extern void zkt_internal_set_error_index(size_t i);
 // MSM entry points cost 2.6 + 2.8 + 7.1 ms for a handful of wires — a 255-step doubling chain each, however few points.  Here the key's io points get
 // fixed-base tables once (launch_fixed_tables, kept for the last two keys, keyed by the points' bytes), a statement sum is one wave per wire and the
 // additions are one lane each: ~25 ms -> ~11 ms per verification, same decisions in the same order.  Everything runs on the stream the other protocol
-// calls use: the two product checks on two streams of their own took another 5 ms off, but every queue that runs a pairing kernel keeps 5-9 GB of
+// calls use: the two product checks on two streams of their own took another 5 ms off, but every queue that runs a pairing kernel keeps 5-6 GiB of
 // scratch (see GuardStreams, zkt_pairing.hip) and two more such queues exhausted the process's scratch pool.
 namespace {
 constexpr size_t PIN_FAST_IO = 12;                  // launch_fixed_tables takes twelve points per launch
