@@ -252,7 +252,7 @@ int zkt_pinocchio_prove(const zkt_pinocchio_crs* crs, const uint64_t* wires, con
 /* 1 accept, 0 reject, negative = -status (a pairing argument at infinity panics in the reference); the five equalities are
  * decided in the reference's order (a rejection by an earlier one wins over a panic of a later one).  Up to 12 io wires: fixed-base
  * tables of the key's io points are built on first sight of a key (~30 ms) and kept for the last two keys, a verification then takes
- * ~11 ms; calls are serialised inside the library. */
+ * ~6.5 ms; calls are serialised inside the library. */
 int zkt_pinocchio_verify(const zkt_pinocchio_crs* crs, const zkt_pinocchio_proof* proof, const uint64_t* io_wires);
 
 /* a18: Bulletproofs::inner_product_argument bulletproofs.rs:19-55 over secp256k1; n a power of two; a, b are 4-limb

@@ -93,3 +93,23 @@ def test_pinocchio_verify_with_several_keys(L):
     # ... and a statement that is larger than the group order is used as the integer it is, on both sides
     big = inst[1][4].copy(); big[1] = np.array(int_to_limbs(int(limbs_to_int(inst[1][4][1])) + R, 4), np.uint64)
     assert both(1, big) == (1, 1)
+
+
+def test_pinocchio_verify_points_outside_g2(L):
+    """The fused five-equality launch runs the 127-step Miller loop, which needs every G2 argument in G2; a proof carrying a point of the twist outside G2
+    (or off the twist) must come out as the reference's own evaluation decides — the verifier falls back to the table-free path for that proof."""
+    crs, cbuf, pf, pbuf, io = _instance(L, 5, 777)
+    both = lambda: (O.zkto_pinocchio_verify(ctypes.byref(crs), ctypes.byref(pf), ptr(io)), L.zkt_pinocchio_verify(ctypes.byref(crs), ctypes.byref(pf), ptr(io)))
+    assert both() == (1, 1)
+    rng = SplitMix64(99)
+    keep = {k: pbuf[k].copy() for k in ("h_s", "g2_w_mid_s")}
+    pbuf["h_s"][:] = g2_arr([to_abi_g2(py_twist_point(rng))])                                 # on E', outside G2: only the divisibility check sees it
+    o, g = both(); assert o == g and o in (0, 1)
+    pbuf["h_s"][:] = keep["h_s"]
+    pbuf["g2_w_mid_s"][:] = g2_arr([to_abi_g2(py_twist_point(rng))])                          # used by the alpha_w check and, through w_s, by the last one
+    o, g = both(); assert o == g and o in (0, 1)
+    (x1, x0), (y1, y0) = g2_from_arr(keep["g2_w_mid_s"])[0]
+    pbuf["g2_w_mid_s"][:] = g2_arr([((x1, x0), (y1, (y0 + 1) % Q))])                           # off the twist: the reference adds and pairs it all the same, or panics
+    o, g = both(); assert (o, g) in ((0, 0), (1, 1)) or (o < 0 and g < 0)
+    pbuf["g2_w_mid_s"][:] = keep["g2_w_mid_s"]
+    assert both() == (1, 1)

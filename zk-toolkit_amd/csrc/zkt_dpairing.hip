@@ -570,7 +570,8 @@ template <bool SHORT> __global__ void __launch_bounds__(64) k_dtate(const uint32
 // the group results meet in the first group's LDS image, ONE final exponentiation follows.  Same contract as k_pairing_product_check /
 // k_groth16_verify (zkt_pairing.hip): infinity -> error index, a G1 argument outside the order-r subgroup -> ok = 0.
 template <int K, bool SHORT>
-__global__ void __launch_bounds__(64) k_dproduct(PairArgs a, const uint32_t* __restrict__ target, uint32_t* __restrict__ ok, size_t n, unsigned long long* err) {
+__global__ void __launch_bounds__(64) k_dproduct(PairArgs a, const uint32_t* __restrict__ target, uint32_t* __restrict__ ok, size_t n, unsigned long long* err,
+                                                 const uint8_t* __restrict__ kcount) {
   __shared__ uint32_t lds[LDS_WORDS];
   const Ctx c = make_ctx(lds);
   constexpr int EPB = GPW / K;                                    // elements per wave
@@ -589,6 +590,9 @@ __global__ void __launch_bounds__(64) k_dproduct(PairArgs a, const uint32_t* __r
   if (a.neg[pair]) p.y = fp_neg(p.y);
   bool in_g1;
   Fq f = d_miller<SHORT>(c, p, q, in_g1);
+  // kcount (optional): element e multiplies only its first kcount[e] pairs.  The caller fills the unused slots with a copy of pair 0, so everything up to
+  // here ran on valid points; the spare group hands over one and raises no flag (Pinocchio's 2-pair and 3-pair equalities in ONE launch of K = 3).
+  if (kcount && pair >= (int)kcount[e]) { f = d_one(c); in_g1 = true; inf = false; }
   // element-wide flags: every lane of the element's K groups must agree
   const int start = eb * K * GL;
   const unsigned long long emask = (K * GL >= 64 ? ~0ull : ((1ull << (K * GL)) - 1ull)) << start;
@@ -624,11 +628,11 @@ hipError_t launch_dfq12_op(int op, const uint32_t* a, const uint32_t* b, uint32_
   return hipGetLastError();
 }
 
-hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, bool short_loop, hipStream_t s) {
+hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, bool short_loop, hipStream_t s, const uint8_t* kcount) {
   if (n == 0) return hipSuccess;
   auto blocks = [&](int epb) { return dim3((unsigned)((n + epb - 1) / epb)); };
-#define ZKT_DPRODUCT(KK, EPB) if (short_loop) hipLaunchKernelGGL((dp::k_dproduct<KK, true>), blocks(EPB), dim3(64), 0, s, a, target, ok, n, err); \
-                             else hipLaunchKernelGGL((dp::k_dproduct<KK, false>), blocks(EPB), dim3(64), 0, s, a, target, ok, n, err)
+#define ZKT_DPRODUCT(KK, EPB) if (short_loop) hipLaunchKernelGGL((dp::k_dproduct<KK, true>), blocks(EPB), dim3(64), 0, s, a, target, ok, n, err, kcount); \
+                             else hipLaunchKernelGGL((dp::k_dproduct<KK, false>), blocks(EPB), dim3(64), 0, s, a, target, ok, n, err, kcount)
   switch (K) {
     case 1: ZKT_DPRODUCT(1, 5); break;
     case 2: ZKT_DPRODUCT(2, 2); break;

@@ -72,7 +72,12 @@ hipError_t launch_dfq12_op(int op, const uint32_t* a, const uint32_t* b, uint32_
 // one pairing per 12 lanes; elements whose P is outside G1 get out[i*144 + mark_word] = mark (see zkt_tate.hip)
 hipError_t launch_dtate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, uint32_t mark_word, uint32_t mark, bool short_loop, hipStream_t s);
 // prod_k tate(+-P_k, Q_k) == target (NULL: == 1) with the K Miller loops in K lane groups of one wave (small batches)
-hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, bool short_loop, hipStream_t s);
+// kcount (optional, device): element i multiplies only its first kcount[i] <= K pairs; its unused slots must hold a copy of its pair 0
+hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, bool short_loop, hipStream_t s, const uint8_t* kcount = nullptr);
+// Small batches of products with DIFFERENT pair counts in one launch (K = the largest): the 127-step kernels with their guards beside them, as
+// launch_pairing_product_check does for n*K <= the small-batch limit, but WITHOUT the 255-step / exact re-evaluation: ok[i] = 2 means "element i does not fit
+// the short loop, evaluate it another way".  n * K must be within the small-batch limit.
+hipError_t launch_pairing_product_check_counts(const PairArgs& a, int K, const uint8_t* kcount, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s);
 // The 127-step loop of the small-batch kernels runs on trust; its preconditions (points on their curves, Q in G2) are checked by a one-lane-per-element
 // kernel on a side stream meanwhile.  guard_fork makes `side` wait for everything queued on `s`; guard_join makes `s` wait for the side stream.
 hipError_t guard_fork(hipStream_t s, hipStream_t* side);

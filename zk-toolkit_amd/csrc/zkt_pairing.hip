@@ -238,6 +238,17 @@ __global__ void __launch_bounds__(64) k_pairing_product_check(PairArgs a, uint32
 }
 // small batches go to the lane-distributed kernels (zkt_dpairing.hip): ~10 ms per element instead of ~100 ms, lower peak throughput
 size_t dproduct_limit() { static const size_t v = [] { const char* e = getenv("ZKT_DPRODUCT_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)24576; }(); return v; }
+hipError_t launch_pairing_product_check_counts(const PairArgs& a, int K, const uint8_t* kcount, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  if (K < 1 || K > 4 || !kcount || n * (size_t)K > dproduct_limit()) return hipErrorInvalidValue;
+  uint32_t* flags = nullptr; hipStream_t side; hipError_t e;
+  if ((e = hipMallocAsync((void**)&flags, n * sizeof(uint32_t), s)) != hipSuccess) return e;
+  if ((e = guard_fork(s, &side)) != hipSuccess || (e = launch_short_loop_guards(a, K, flags, n, side)) != hipSuccess ||          // the unused slots repeat pair 0: same verdict
+      (e = launch_dproduct(a, K, nullptr, ok, n, err, true, s, kcount)) != hipSuccess || (e = guard_join(s, side)) != hipSuccess) { (void)hipFreeAsync(flags, s); return e; }
+  hipLaunchKernelGGL(k_product_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)flags, ok, n);
+  if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
+  return hipGetLastError();
+}
 hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s) {
   if (n == 0) return hipSuccess;
   dim3 g((unsigned)((n + 63) / 64)), t(64);

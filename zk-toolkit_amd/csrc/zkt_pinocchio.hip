@@ -100,9 +100,10 @@ extern void zkt_internal_set_error_index(size_t i);
 // A verifier checks many proofs against ONE key.  The statement sums sum_i io_i * {vk_io, yk_io, wk_io}[i] (verifier.rs:70-76) through the one-shot
 // MSM entry points cost 2.6 + 2.8 + 7.1 ms for a handful of wires — a 255-step doubling chain each, however few points.  Here the key's io points get
 // fixed-base tables once (launch_fixed_tables, kept for the last two keys, keyed by the points' bytes), a statement sum is one wave per wire and the
-// additions are one lane each: ~25 ms -> ~11 ms per verification, same decisions in the same order.  Everything runs on the stream the other protocol
-// calls use: the two product checks on two streams of their own took another 5 ms off, but every queue that runs a pairing kernel keeps 5-6 GiB of
-// scratch (see GuardStreams, zkt_pairing.hip) and two more such queues exhausted the process's scratch pool.
+// additions are one lane each, and the five equalities are ONE launch of the lane-distributed product kernel (K = 3 with a pair count per element):
+// ~25 ms -> ~6.5 ms per verification, same decisions in the same order.  Everything runs on the stream the other protocol calls use: every queue that runs
+// a pairing kernel keeps 5-6 GiB of scratch (see GuardStreams, zkt_pairing.hip), and two verifier streams of their own exhausted the process's scratch pool.
+// An element that does not fit the short Miller loop (a point off its curve or outside G2) sends the whole verification to the table-free path below.
 namespace {
 constexpr size_t PIN_FAST_IO = 12;                  // launch_fixed_tables takes twelve points per launch
 struct PinTables { std::vector<uint8_t> key; std::shared_ptr<void> mem; uint64_t stamp = 0; };
@@ -148,63 +149,71 @@ int pin_decide(int rc4, size_t inf4, const uint32_t* ok4, int rc1, uint32_t ok1)
   if (rc1 != ZKT_OK) return -rc1;
   return ok1 ? 1 : 0;
 }
+constexpr int PIN_FALL_BACK = -1000000;             // pin_verify_fast: an element does not fit the short Miller loop (a point off its curve or outside G2) — evaluate the reference way
 int pin_verify_fast(const zkt_pinocchio_crs* c, const zkt_pinocchio_proof* pf, const uint64_t* io_wires) {
   std::lock_guard<std::mutex> lk(g_pin.mu);
-  hipStream_t sa = nullptr, sb = nullptr;           // one stream: the 2-pair checks, then the statement sums and the 3-pair check
+  hipStream_t s = nullptr;                          // the stream every protocol call uses (scratch budget: DESIGN.md §4)
   const size_t nio = c->n_io;
   const int W1 = (int)(G1B / 4), W2 = (int)(G2B / 4);
-  // the four two-pair equalities lhs == rhs as tate(lhs) * tate(-rhs) == 1 (:43-66); slot 1 = v_mid_s + w_mid_s + y_mid_s (:44) is filled on the device
-  zkt_g1_affine g1s[8] = {*pf->beta_vwy_mid_s, *pf->v_mid_s, *pf->alpha_v_mid_s, *pf->v_mid_s, *pf->alpha_w_mid_s, *c->alpha_w, *pf->alpha_y_mid_s, *pf->y_mid_s};
-  zkt_g2_affine g2s[8] = {*c->gamma, *c->beta_gamma, *c->one_g2, *c->alpha_v, *c->one_g2, *pf->g2_w_mid_s, *c->one_g2, *c->alpha_y};
-  zkt_g1_affine m1[2] = {*pf->g1_w_mid_s, *c->t};               // operands that are not already in g1s / g2s
-  zkt_g2_affine m2[1] = {*pf->h_s};
-  Dev d1(sizeof g1s), d2(sizeof g2s), dm1(sizeof m1), dm2(sizeof m2), dio1(2 * nio * G1B), dio2(nio * G2B), dk(nio * FRB), dp1(2 * nio * G1B), dp2(nio * G2B),
-      dsum1(2 * G1B), dsum2(G2B), dok(5 * 4), derr(16);
-  if (!d1.p || !d2.p || !dm1.p || !dm2.p || !dio1.p || !dio2.p || !dk.p || !dp1.p || !dp2.p || !dsum1.p || !dsum2.p || !dok.p || !derr.p) return -ZKT_ERR_DEVICE;
-#define VCHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(sa); return -ZKT_ERR_DEVICE; } } while (0)
-  const unsigned long long noerr[2] = {~0ull, ~0ull};
-  VCHK(hipMemcpyAsync(d1.p, g1s, sizeof g1s, hipMemcpyHostToDevice, sa)); VCHK(hipMemcpyAsync(d2.p, g2s, sizeof g2s, hipMemcpyHostToDevice, sa));
-  VCHK(hipMemcpyAsync(dm1.p, m1, sizeof m1, hipMemcpyHostToDevice, sa)); VCHK(hipMemcpyAsync(dm2.p, m2, sizeof m2, hipMemcpyHostToDevice, sa));
-  VCHK(hipMemcpyAsync(derr.p, noerr, 16, hipMemcpyHostToDevice, sa));
-  {
-    PinSums ps{}; ps.n = 1;                                       // vwy = (v_mid_s + w_mid_s) + y_mid_s
-    ps.s[0] = PinSum{{d1.w() + 1 * W1, dm1.w(), d1.w() + 7 * W1}, 3, nullptr, 0, d1.w() + 1 * W1};
-    hipLaunchKernelGGL(k_pin_sums<FqOps>, dim3(1), dim3(64), 0, sa, ps);
-    PairArgs a{};
-    for (int j = 0; j < 2; ++j) { a.g1[j] = d1.w() + j * W1; a.g2[j] = d2.w() + j * W2; a.s1[j] = 2 * W1; a.s2[j] = 2 * W2; a.neg[j] = j; }
-    VCHK(launch_pairing_product_check(a, 2, dok.w(), 4, (unsigned long long*)derr.p, sa));
-  }
+  // Five equalities lhs == rhs as products == 1 (verifier.rs:43-84), packed as 5 elements x 3 pair slots for ONE launch: the four 2-pair checks repeat
+  // their pair 0 in slot 2 (kcount = 2), the divisibility check uses all three.  Slots marked * are filled on the device.
+  //   0: (beta_vwy_mid_s, gamma)   (*v_mid_s + w_mid_s + y_mid_s, beta_gamma)        :43-48
+  //   1: (alpha_v_mid_s, one_g2)   (v_mid_s, alpha_v)                                :50-55
+  //   2: (alpha_w_mid_s, one_g2)   (alpha_w, g2_w_mid_s)                             :56-61
+  //   3: (alpha_y_mid_s, one_g2)   (y_mid_s, alpha_y)                                :62-66
+  //   4: (*v_s, *w_s)              (t, h_s)                 (*y_s, one_g2)           :69-84
+  zkt_g1_affine g1p[15] = {*pf->beta_vwy_mid_s, *pf->g1_w_mid_s /* operand of the sum that replaces it */, *pf->beta_vwy_mid_s,
+                           *pf->alpha_v_mid_s, *pf->v_mid_s, *pf->alpha_v_mid_s,
+                           *pf->alpha_w_mid_s, *c->alpha_w, *pf->alpha_w_mid_s,
+                           *pf->alpha_y_mid_s, *pf->y_mid_s, *pf->alpha_y_mid_s,
+                           *pf->v_mid_s, *c->t, *pf->y_mid_s};
+  zkt_g2_affine g2p[15] = {*c->gamma, *c->beta_gamma, *c->gamma,
+                           *c->one_g2, *c->alpha_v, *c->one_g2,
+                           *c->one_g2, *pf->g2_w_mid_s, *c->one_g2,
+                           *c->one_g2, *c->alpha_y, *c->one_g2,
+                           *pf->g2_w_mid_s, *pf->h_s, *c->one_g2};
+  const uint8_t kcount[8] = {2, 2, 2, 2, 3, 0, 0, 0};
+  Dev d1(sizeof g1p), d2(sizeof g2p), dio1(2 * nio * G1B), dio2(nio * G2B), dk(nio * FRB), dp1(2 * nio * G1B), dp2(nio * G2B), dok(5 * 4), derr(8), dcnt(8);
+  if (!d1.p || !d2.p || !dio1.p || !dio2.p || !dk.p || !dp1.p || !dp2.p || !dok.p || !derr.p || !dcnt.p) return -ZKT_ERR_DEVICE;
+#define VCHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); return -ZKT_ERR_DEVICE; } } while (0)
+  const unsigned long long noerr = ~0ull;
+  VCHK(hipMemcpyAsync(d1.p, g1p, sizeof g1p, hipMemcpyHostToDevice, s)); VCHK(hipMemcpyAsync(d2.p, g2p, sizeof g2p, hipMemcpyHostToDevice, s));
+  VCHK(hipMemcpyAsync(derr.p, &noerr, 8, hipMemcpyHostToDevice, s)); VCHK(hipMemcpyAsync(dcnt.p, kcount, 8, hipMemcpyHostToDevice, s));
   std::shared_ptr<void> tabs;
   if (nio) {
-    VCHK(hipMemcpyAsync(dio1.p, c->vk_io, nio * G1B, hipMemcpyHostToDevice, sb)); VCHK(hipMemcpyAsync(dio1.w() + nio * W1, c->yk_io, nio * G1B, hipMemcpyHostToDevice, sb));
-    VCHK(hipMemcpyAsync(dio2.p, c->wk_io, nio * G2B, hipMemcpyHostToDevice, sb)); VCHK(hipMemcpyAsync(dk.p, io_wires, nio * FRB, hipMemcpyHostToDevice, sb));
-    tabs = pin_tables_for(c, dio1.w(), dio2.w(), sb);
-    if (!tabs) { (void)hipStreamSynchronize(sa); return -ZKT_ERR_DEVICE; }
+    VCHK(hipMemcpyAsync(dio1.p, c->vk_io, nio * G1B, hipMemcpyHostToDevice, s)); VCHK(hipMemcpyAsync(dio1.w() + nio * W1, c->yk_io, nio * G1B, hipMemcpyHostToDevice, s));
+    VCHK(hipMemcpyAsync(dio2.p, c->wk_io, nio * G2B, hipMemcpyHostToDevice, s)); VCHK(hipMemcpyAsync(dk.p, io_wires, nio * FRB, hipMemcpyHostToDevice, s));
+    tabs = pin_tables_for(c, dio1.w(), dio2.w(), s);
+    if (!tabs) { (void)hipStreamSynchronize(s); return -ZKT_ERR_DEVICE; }
     const uint32_t* t1 = (const uint32_t*)tabs.get(); const uint32_t* t2 = t1 + 2 * nio * 64 * W1;
     // products io_i * point_i: out[j] for table j with scalar k[j] (n = 1 "proof", n_pts tables)
-    VCHK(launch_fixed_muls_batch(G_G1, t1, dk.w(), dp1.w(), 1, (int)nio, sb));
-    VCHK(launch_fixed_muls_batch(G_G1, t1 + nio * 64 * W1, dk.w(), dp1.w() + nio * W1, 1, (int)nio, sb));
-    VCHK(launch_fixed_muls_batch(G_G2, t2, dk.w(), dp2.w(), 1, (int)nio, sb));
+    VCHK(launch_fixed_muls_batch(G_G1, t1, dk.w(), dp1.w(), 1, (int)nio, s));
+    VCHK(launch_fixed_muls_batch(G_G1, t1 + nio * 64 * W1, dk.w(), dp1.w() + nio * W1, 1, (int)nio, s));
+    VCHK(launch_fixed_muls_batch(G_G2, t2, dk.w(), dp2.w(), 1, (int)nio, s));
   }
   {
-    PinSums p1{}; p1.n = 2;                                       // v_s = v_mid_s + v_io, y_s = y_mid_s + y_io (:70-76)
-    p1.s[0] = PinSum{{d1.w() + 3 * W1, nullptr, nullptr}, 1, dp1.w(), (int)nio, dsum1.w()};
-    p1.s[1] = PinSum{{d1.w() + 7 * W1, nullptr, nullptr}, 1, dp1.w() + nio * W1, (int)nio, dsum1.w() + W1};
-    hipLaunchKernelGGL(k_pin_sums<FqOps>, dim3(1), dim3(64), 0, sb, p1);
-    PinSums p2{}; p2.n = 1;                                       // w_s = g2_w_mid_s + w_io
-    p2.s[0] = PinSum{{d2.w() + 5 * W2, nullptr, nullptr}, 1, dp2.w(), (int)nio, dsum2.w()};
-    hipLaunchKernelGGL(k_pin_sums<Fq2Ops>, dim3(1), dim3(64), 0, sb, p2);
-    PairArgs a{};                                                 // e(v_s, w_s) == e(t, h_s) * e(y_s, one_g2) (:78-84)
-    a.g1[0] = dsum1.w(); a.g1[1] = dm1.w() + W1; a.g1[2] = dsum1.w() + W1;
-    a.g2[0] = dsum2.w(); a.g2[1] = dm2.w(); a.g2[2] = d2.w() + 2 * W2;
-    a.neg[0] = 0; a.neg[1] = 1; a.neg[2] = 1;
-    VCHK(launch_pairing_product_check(a, 3, dok.w() + 4, 1, (unsigned long long*)derr.p + 1, sb));
+    uint32_t* G1 = d1.w(); uint32_t* G2 = d2.w();
+    PinSums p1{}; p1.n = 3;
+    p1.s[0] = PinSum{{G1 + 4 * W1, G1 + 1 * W1, G1 + 10 * W1}, 3, nullptr, 0, G1 + 1 * W1};                    // (v_mid_s + w_mid_s) + y_mid_s (:44), in place of w_mid_s
+    p1.s[1] = PinSum{{G1 + 4 * W1, nullptr, nullptr}, 1, dp1.w(), (int)nio, G1 + 12 * W1};                      // v_s = v_mid_s + v_io (:70-72)
+    p1.s[2] = PinSum{{G1 + 10 * W1, nullptr, nullptr}, 1, dp1.w() + nio * W1, (int)nio, G1 + 14 * W1};          // y_s = y_mid_s + y_io (:75-76)
+    hipLaunchKernelGGL(k_pin_sums<FqOps>, dim3(1), dim3(64), 0, s, p1);
+    PinSums p2{}; p2.n = 1;
+    p2.s[0] = PinSum{{G2 + 7 * W2, nullptr, nullptr}, 1, dp2.w(), (int)nio, G2 + 12 * W2};                      // w_s = g2_w_mid_s + w_io (:73-74)
+    hipLaunchKernelGGL(k_pin_sums<Fq2Ops>, dim3(1), dim3(64), 0, s, p2);
+    PairArgs a{};
+    for (int j = 0; j < 3; ++j) { a.g1[j] = G1 + j * W1; a.g2[j] = G2 + j * W2; a.s1[j] = 3 * W1; a.s2[j] = 3 * W2; a.neg[j] = j ? 1 : 0; }
+    const hipError_t le = launch_pairing_product_check_counts(a, 3, (const uint8_t*)dcnt.p, dok.w(), 5, (unsigned long long*)derr.p, s);
+    if (le == hipErrorInvalidValue) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); return PIN_FALL_BACK; }      // small-batch kernels switched off (ZKT_DPRODUCT_MAX)
+    VCHK(le);
   }
-  uint32_t ok[5] = {0, 0, 0, 0, 0}; unsigned long long e[2] = {~0ull, ~0ull};
-  VCHK(hipStreamSynchronize(sa));
-  VCHK(hipMemcpy(ok, dok.p, sizeof ok, hipMemcpyDeviceToHost)); VCHK(hipMemcpy(e, derr.p, sizeof e, hipMemcpyDeviceToHost));
+  uint32_t ok[5] = {0, 0, 0, 0, 0}; unsigned long long e = ~0ull;
+  VCHK(hipMemcpyAsync(ok, dok.p, sizeof ok, hipMemcpyDeviceToHost, s)); VCHK(hipMemcpyAsync(&e, derr.p, sizeof e, hipMemcpyDeviceToHost, s));
+  VCHK(hipStreamSynchronize(s));
 #undef VCHK
-  return pin_decide(e[0] != ~0ull ? ZKT_ERR_INFINITY : ZKT_OK, (size_t)e[0], ok, e[1] != ~0ull ? ZKT_ERR_INFINITY : ZKT_OK, ok[4]);
+  for (uint32_t v : ok) if (v > 1) return PIN_FALL_BACK;
+  // one error word for the five elements: the smallest index with an argument at infinity.  If it is among the first four, the decision is taken there or before.
+  return pin_decide(e < 4 ? ZKT_ERR_INFINITY : ZKT_OK, (size_t)e, ok, e == 4 ? ZKT_ERR_INFINITY : ZKT_OK, ok[4]);
 }
 }  // namespace
 extern "C" void zkt_pinocchio_clear_caches() {      // zkt_shutdown (through zkt_internal_clear_caches)
@@ -298,7 +307,7 @@ int zkt_pinocchio_verify(const zkt_pinocchio_crs* c, const zkt_pinocchio_proof* 
   if (zkt_internal_ready() != ZKT_OK) return -ZKT_ERR_DEVICE;
   if (!c || !pf || (c->n_io && !io_wires)) return -ZKT_ERR_SHAPE;
   static const bool fast = [] { const char* e = getenv("ZKT_PINOCCHIO_FAST_VERIFY"); return !e || atoi(e) != 0; }();
-  if (fast && c->n_io <= PIN_FAST_IO) return pin_verify_fast(c, pf, io_wires);
+  if (fast && c->n_io <= PIN_FAST_IO) { const int v = pin_verify_fast(c, pf, io_wires); if (v != PIN_FALL_BACK) return v; }
   int rc;
   zkt_g1_affine t1, vwy;
   if ((rc = zkt_g1_add_batch(pf->v_mid_s, pf->g1_w_mid_s, &t1, 1)) || (rc = zkt_g1_add_batch(&t1, pf->y_mid_s, &vwy, 1))) return -rc;      // :44
