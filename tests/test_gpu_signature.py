@@ -124,3 +124,19 @@ def test_pairing_product_check(L, k):
     P1[2, 0] = 0; P1[2, 0, 12] = 1
     assert L.zkt_pairing_product_check_batch(ptr(P1), ptr(Q2), neg.ctypes.data, k, n, ok.ctypes.data) == ZKT_ERR_INFINITY
     assert L.zkt_last_error_index() == 2
+
+
+def test_hash_to_g2_digit_patterns(L):
+    """hash_to_g2point multiplies the generator through a comb table of 4-bit digits (zkt_group.hip): scalars with a single digit, all digits 15,
+    digits only in the top words, r - 1, and r itself (which reduces to 0: the point at infinity) against the oracle's double-and-add."""
+    _, g2 = _gens()
+    vals = [1, 15, 16, 1 << 128, 15 << 248, (1 << 252) - 1, R - 1, R - 2, R >> 1, 0x1111111111111111111111111111111111111111111111111111111111111111 % R,
+            0x0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f % R, 0xf0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0 % R]
+    msgs = [v.to_bytes(32, "big") for v in vals] + [R.to_bytes(32, "big"), (2 * R).to_bytes(33, "big")]
+    buf, off = _pack(msgs)
+    n = len(msgs)
+    H = np.zeros((n, G2W), np.uint64)
+    zk.check(L.zkt_bls_hash_to_g2_batch(buf.ctypes.data, off.ctypes.data, n, H.ctypes.data))
+    want = _g2_mul(np.repeat(g2, len(vals), axis=0), vals)
+    assert (H[:len(vals)] == want).all()
+    assert all(int(H[i, 24]) & 0xFFFFFFFF == 1 for i in (n - 2, n - 1))                                 # r and 2r hash to scalar 0

@@ -472,21 +472,21 @@ int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_spars
   ZCHK(gen1.alloc(G1B)); ZCHK(gen2.alloc(G2B)); ZCHK(pU.alloc(rows * G1B)); ZCHK(pA.alloc(nA * G1B)); ZCHK(pB.alloc(nA * G2B)); ZCHK(pC.alloc(nC * G1B));
   ZCHK(small1.alloc(3 * G1B)); ZCHK(small2.alloc(3 * G2B)); ZCHK(gt.alloc(576));
   RCHK(hipMemcpyAsync(gen1.p, G1_GEN, G1B, hipMemcpyHostToDevice, s)); RCHK(hipMemcpyAsync(gen2.p, G2_GEN, G2B, hipMemcpyHostToDevice, s));
-  RCHK(launch_group_mul(G_G1, gen1.w(), dtrap.w(), 8, small1.w(), 1, s, true));               // alpha
-  RCHK(launch_group_mul(G_G1, gen1.w(), dtrap.w() + 8, 8, small1.w() + 26, 1, s, true));      // beta
-  RCHK(launch_group_mul(G_G1, gen1.w(), dtrap.w() + 24, 8, small1.w() + 52, 1, s, true));     // delta
-  RCHK(launch_group_mul(G_G2, gen2.w(), dtrap.w() + 8, 8, small2.w(), 1, s, true));           // beta
-  RCHK(launch_group_mul(G_G2, gen2.w(), dtrap.w() + 16, 8, small2.w() + 50, 1, s, true));     // gamma
-  RCHK(launch_group_mul(G_G2, gen2.w(), dtrap.w() + 24, 8, small2.w() + 100, 1, s, true));    // delta
+  RCHK(launch_generator_mul(G_G1, gen1.w(), dtrap.w(), small1.w(), 1, s));               // alpha
+  RCHK(launch_generator_mul(G_G1, gen1.w(), dtrap.w() + 8, small1.w() + 26, 1, s));      // beta
+  RCHK(launch_generator_mul(G_G1, gen1.w(), dtrap.w() + 24, small1.w() + 52, 1, s));     // delta
+  RCHK(launch_generator_mul(G_G2, gen2.w(), dtrap.w() + 8, small2.w(), 1, s));           // beta
+  RCHK(launch_generator_mul(G_G2, gen2.w(), dtrap.w() + 16, small2.w() + 50, 1, s));     // gamma
+  RCHK(launch_generator_mul(G_G2, gen2.w(), dtrap.w() + 24, small2.w() + 100, 1, s));    // delta
   // uvw: statement part to the verifying key, witness part into the C set
-  RCHK(launch_group_mul(G_G1, gen1.w(), y.w(), 8, pU.w(), rows, s, true));
+  RCHK(launch_generator_mul(G_G1, gen1.w(), y.w(), pU.w(), rows, s));
   RCHK(hipMemcpyAsync(vk->g1_uvw_stmt, pU.p, (l + 1) * G1B, hipMemcpyDeviceToHost, s));
   if (vk->g1_uvw_wit && nw) RCHK(hipMemcpyAsync(vk->g1_uvw_wit, pU.w() + (l + 1) * 26, nw * G1B, hipMemcpyDeviceToHost, s));
   if (nw) RCHK(hipMemcpyAsync(pC.w() + n * 26, pU.w() + (l + 1) * 26, nw * G1B, hipMemcpyDeviceToDevice, s));
-  RCHK(launch_group_mul(G_G1, gen1.w(), Lc.w(), 8, pC.w(), n, s, true));                       // [L_j(x)]_1
+  RCHK(launch_generator_mul(G_G1, gen1.w(), Lc.w(), pC.w(), n, s));                       // [L_j(x)]_1
   RCHK(hipMemcpyAsync(pA.p, pC.p, n * G1B, hipMemcpyDeviceToDevice, s));
-  if (nh) RCHK(launch_group_mul(G_G1, gen1.w(), hbc.w(), 8, pC.w() + (n + nw) * 26, nh, s, true));   // [Lambda_s(x) t(x)/delta]_1
-  RCHK(launch_group_mul(G_G2, gen2.w(), Lc.w(), 8, pB.w(), n, s, true));                       // [L_j(x)]_2
+  if (nh) RCHK(launch_generator_mul(G_G1, gen1.w(), hbc.w(), pC.w() + (n + nw) * 26, nh, s));   // [Lambda_s(x) t(x)/delta]_1
+  RCHK(launch_generator_mul(G_G2, gen2.w(), Lc.w(), pB.w(), n, s));                       // [L_j(x)]_2
   RCHK(hipMemcpyAsync(pA.w() + n * 26, small1.p, G1B, hipMemcpyDeviceToDevice, s));            // A tail: alpha, delta
   RCHK(hipMemcpyAsync(pA.w() + (n + 1) * 26, small1.w() + 52, G1B, hipMemcpyDeviceToDevice, s));
   RCHK(hipMemcpyAsync(pB.w() + n * 50, small2.p, G2B, hipMemcpyDeviceToDevice, s));            // B tail: beta, delta

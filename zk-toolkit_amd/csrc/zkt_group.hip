@@ -4,6 +4,7 @@
 //   Neg                     bls12_381/g1_point.rs:177-195, g2_point.rs:91-107
 // Points arrive and leave as canonical affine structs (include/zkt.h); inside a lane the
 // point is Jacobian over Montgomery residues and is normalised once at the end.
+#include <mutex>
 #include "abi.h"
 #include "zkt_internal.h"
 
@@ -116,6 +117,82 @@ hipError_t launch_group_mul_segs(int grp, const MulSegs& segs, int kw, hipStream
     case G_SECP: hipLaunchKernelGGL(k_group_mul_segs<SpOps>, dim3(nblk(total, 64)), dim3(64), 0, s, segs, kw, total); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+// ---- multiples of a group's generator: a comb table instead of 255 doublings per product ------------------------------------------
+// Every fixed-base multiplication on this path is generator * scalar (CRS::new crs.rs:85-135, pinocchio/crs.rs:86-140, hash_to_g2point
+// g2_point.rs:84-88).  table[w * 15 + d - 1] = d * 16^w * G (w < 64, d = 1..15: 960 affine points in internal coordinates, none at infinity since
+// d * 16^w < r), built once per process and group by one launch of 960 double-and-add lanes.  A product is then at most 64 mixed additions and no doubling
+// — ~660 field multiplications instead of ~2,700 — and the result is the same group element, hence the same canonical affine bytes.
+template <class F> struct RawXY;
+template <class C> struct RawXY<PrimeOps<C>> {
+  static constexpr int CW = C::N;
+  __device__ static Fp<C> ld(const uint32_t* p) { return ld_raw<C>(p); }
+  __device__ static void st(uint32_t* p, const Fp<C>& a) { st_raw<C>(p, a); }
+};
+template <> struct RawXY<Fq2Ops> {
+  static constexpr int CW = 2 * FqC::N;
+  __device__ static Fq2 ld(const uint32_t* p) { Fq2 r; r.c0 = ld_raw<FqC>(p); r.c1 = ld_raw<FqC>(p + FqC::N); return r; }
+  __device__ static void st(uint32_t* p, const Fq2& a) { st_raw<FqC>(p, a.c0); st_raw<FqC>(p + FqC::N, a.c1); }
+};
+static constexpr int COMB_ENTRIES = 64 * 15;
+template <class F>
+__global__ void __launch_bounds__(64) k_generator_table(const uint32_t* __restrict__ gen_abi, uint32_t* __restrict__ table) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= COMB_ENTRIES) return;
+  constexpr int CW = RawXY<F>::CW;
+  const int w = t / 15; const uint32_t d = (uint32_t)(t % 15) + 1u;
+  uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  k[w >> 3] = d << ((w & 7) * 4);                                  // d * 16^w: the digit sits inside one 32-bit word
+  const Aff<F> a = jac_to_aff(scalar_mul_aff<F>(PtIO<F>::ld(gen_abi), k, 8));
+  RawXY<F>::st(table + (size_t)t * 2 * CW, a.x); RawXY<F>::st(table + (size_t)t * 2 * CW + CW, a.y);
+}
+template <class F>
+__global__ void __launch_bounds__(64) k_generator_mul(const uint32_t* __restrict__ table, const uint32_t* __restrict__ scalars, uint32_t* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  constexpr int CW = RawXY<F>::CW, W = PtIO<F>::WORDS;
+  uint32_t k[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) k[j] = scalars[i * 8 + j];
+  Jac<F> acc = jac_inf<F>();
+#pragma unroll 1
+  for (int w = 0; w < 64; ++w) {
+    uint32_t kw = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kw = (j == (w >> 3)) ? k[j] : kw;   // no dynamically indexed register array
+    const uint32_t d = (kw >> ((w & 7) * 4)) & 15u;
+    if (d) {
+      const uint32_t* e = table + ((size_t)w * 15 + d - 1) * 2 * CW;
+      Aff<F> q; q.x = RawXY<F>::ld(e); q.y = RawXY<F>::ld(e + CW); q.inf = false;
+      acc = jac_add_aff(acc, q);
+    }
+  }
+  PtIO<F>::st(out + i * W, jac_to_aff(acc));
+}
+namespace {
+struct GeneratorTable { std::mutex mu; uint32_t* dev = nullptr; };
+GeneratorTable g_gen_table[2];                                     // G_G1, G_G2
+}
+hipError_t launch_generator_mul(int grp, const uint32_t* gen_abi, const uint32_t* k, uint32_t* out, size_t n, hipStream_t s) {
+  if (grp != G_G1 && grp != G_G2) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  GeneratorTable& T = g_gen_table[grp == G_G1 ? 0 : 1];
+  {
+    std::lock_guard<std::mutex> lk(T.mu);
+    if (!T.dev) {                                                  // first use in this process: build on the caller's stream and wait, so that later callers on other streams find it complete
+      const size_t bytes = (size_t)COMB_ENTRIES * 2 * (grp == G_G1 ? RawXY<FqOps>::CW : RawXY<Fq2Ops>::CW) * 4;
+      uint32_t* mem = nullptr; hipError_t e;
+      if ((e = hipMalloc((void**)&mem, bytes)) != hipSuccess) return e;
+      if (grp == G_G1) hipLaunchKernelGGL(k_generator_table<FqOps>, dim3(COMB_ENTRIES / 64), dim3(64), 0, s, gen_abi, mem);
+      else hipLaunchKernelGGL(k_generator_table<Fq2Ops>, dim3(COMB_ENTRIES / 64), dim3(64), 0, s, gen_abi, mem);
+      if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(s)) != hipSuccess) { (void)hipFree(mem); return e; }
+      T.dev = mem;
+    }
+  }
+  if (grp == G_G1) hipLaunchKernelGGL(k_generator_mul<FqOps>, dim3(nblk(n, 64)), dim3(64), 0, s, (const uint32_t*)T.dev, k, out, n);
+  else hipLaunchKernelGGL(k_generator_mul<Fq2Ops>, dim3(nblk(n, 64)), dim3(64), 0, s, (const uint32_t*)T.dev, k, out, n);
   return hipGetLastError();
 }
 

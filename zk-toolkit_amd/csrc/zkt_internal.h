@@ -51,6 +51,9 @@ struct FixedMul { const uint32_t* table; const uint32_t* k; uint32_t* out; };
 struct FixedMuls { FixedMul m[16]; int n; };
 struct FixedTables { const uint32_t* point[12]; uint32_t* table[12]; int n; };     // up to twelve points per launch, one wave each, side by side
 hipError_t launch_fixed_tables(int grp, const FixedTables& t, hipStream_t s);
+// out[i] = k[i] * G for the group's standard generator (G_G1 / G_G2; gen_abi = that generator on the device, read on first use only): a comb table of
+// 960 multiples built once per process, at most 64 mixed additions per product instead of a 255-step double-and-add.  k: 8 words per scalar.
+hipError_t launch_generator_mul(int grp, const uint32_t* gen_abi, const uint32_t* k, uint32_t* out, size_t n, hipStream_t s);
 hipError_t launch_fixed_muls(int grp, const FixedMuls& f, hipStream_t s);
 // the same product for a whole batch: out[(j * n + i)] = k[(i * n_pts + j)] * P_j from tables[j] (64 points each), one wave per product, grid = n * n_pts
 hipError_t launch_fixed_muls_batch(int grp, const uint32_t* tables, const uint32_t* k, uint32_t* out, size_t n, int n_pts, hipStream_t s);

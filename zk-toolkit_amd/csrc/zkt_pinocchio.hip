@@ -246,11 +246,11 @@ int zkt_pinocchio_setup(zkt_pinocchio_crs* c, const uint64_t* vi, const uint64_t
   hipLaunchKernelGGL(k_pin_powseq, dim3((unsigned)((deg + 255) / 256)), dim3(256), 0, s, (const uint32_t*)(drnd.w() + 56), deg, dpow.w());
   QCHK(hipGetLastError());
   // generator * scalar for every element
-  QCHK(launch_group_mul(G_G1, dgen1.w(), dcols.w(), 8, d1.w(), 7 * rows, s, true));
-  QCHK(launch_group_mul(G_G2, dgen2.w(), dcols.w() + rows * 8, 8, d2.w(), rows, s, true));                 // g2_w * w_i(s)
-  QCHK(launch_group_mul(G_G2, dgen2.w(), dpow.w(), 8, d2.w() + rows * 50, deg, s, true));                   // si
-  QCHK(launch_group_mul(G_G1, dgen1.w(), dsing.w(), 8, ds1.w(), 10, s, true));
-  QCHK(launch_group_mul(G_G2, dgen2.w(), dsing.w(), 8, ds2.w(), 10, s, true));
+  QCHK(launch_generator_mul(G_G1, dgen1.w(), dcols.w(), d1.w(), 7 * rows, s));
+  QCHK(launch_generator_mul(G_G2, dgen2.w(), dcols.w() + rows * 8, d2.w(), rows, s));                 // g2_w * w_i(s)
+  QCHK(launch_generator_mul(G_G2, dgen2.w(), dpow.w(), d2.w() + rows * 50, deg, s));                   // si
+  QCHK(launch_generator_mul(G_G1, dgen1.w(), dsing.w(), ds1.w(), 10, s));
+  QCHK(launch_generator_mul(G_G2, dgen2.w(), dsing.w(), ds2.w(), 10, s));
   auto g1col = [&](int col, size_t from) { return d1.w() + ((size_t)col * rows + from) * 26; };
   auto dl = [&](void* h, const void* d, size_t bytes) -> int { if (bytes) QCHK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s)); return ZKT_OK; };
   zkt_g1_affine* mid1[7] = {c->vk_mid, c->g1_wk_mid, c->yk_mid, c->alpha_vk_mid, c->alpha_wk_mid, c->alpha_yk_mid, c->beta_vwy_k_mid};

@@ -437,17 +437,17 @@ int zkt_groth16_setup(zkt_groth16_crs* c, const uint64_t* ui, const uint64_t* vi
                      (const uint32_t*)dtrap.w(), n, l, m, dy.w(), dxp.w(), dxt.w());
   // fixed-base multiplications g * y (crs.rs:85-135): [uvw (m+1) | xi (n) | xt_by_delta (n) | alpha beta delta]
   uint32_t* o1 = dout1.w();
-  PCHK(launch_group_mul(G_G1, dgen1.w(), dy.w(), 8, o1, rows, s, true));
-  PCHK(launch_group_mul(G_G1, dgen1.w(), dxp.w(), 8, o1 + rows * 26, n, s, true));
-  PCHK(launch_group_mul(G_G1, dgen1.w(), dxt.w(), 8, o1 + (rows + n) * 26, n, s, true));
-  PCHK(launch_group_mul(G_G1, dgen1.w(), dtrap.w(), 8, o1 + (rows + 2 * n) * 26, 1, s, true));            // alpha
-  PCHK(launch_group_mul(G_G1, dgen1.w(), dtrap.w() + 8, 8, o1 + (rows + 2 * n + 1) * 26, 1, s, true));    // beta
-  PCHK(launch_group_mul(G_G1, dgen1.w(), dtrap.w() + 24, 8, o1 + (rows + 2 * n + 2) * 26, 1, s, true));   // delta
+  PCHK(launch_generator_mul(G_G1, dgen1.w(), dy.w(), o1, rows, s));
+  PCHK(launch_generator_mul(G_G1, dgen1.w(), dxp.w(), o1 + rows * 26, n, s));
+  PCHK(launch_generator_mul(G_G1, dgen1.w(), dxt.w(), o1 + (rows + n) * 26, n, s));
+  PCHK(launch_generator_mul(G_G1, dgen1.w(), dtrap.w(), o1 + (rows + 2 * n) * 26, 1, s));            // alpha
+  PCHK(launch_generator_mul(G_G1, dgen1.w(), dtrap.w() + 8, o1 + (rows + 2 * n + 1) * 26, 1, s));    // beta
+  PCHK(launch_generator_mul(G_G1, dgen1.w(), dtrap.w() + 24, o1 + (rows + 2 * n + 2) * 26, 1, s));   // delta
   uint32_t* o2 = dout2.w();
-  PCHK(launch_group_mul(G_G2, dgen2.w(), dxp.w(), 8, o2, n, s, true));
-  PCHK(launch_group_mul(G_G2, dgen2.w(), dtrap.w() + 8, 8, o2 + n * 50, 1, s, true));          // beta
-  PCHK(launch_group_mul(G_G2, dgen2.w(), dtrap.w() + 16, 8, o2 + (n + 1) * 50, 1, s, true));   // gamma
-  PCHK(launch_group_mul(G_G2, dgen2.w(), dtrap.w() + 24, 8, o2 + (n + 2) * 50, 1, s, true));   // delta
+  PCHK(launch_generator_mul(G_G2, dgen2.w(), dxp.w(), o2, n, s));
+  PCHK(launch_generator_mul(G_G2, dgen2.w(), dtrap.w() + 8, o2 + n * 50, 1, s));          // beta
+  PCHK(launch_generator_mul(G_G2, dgen2.w(), dtrap.w() + 16, o2 + (n + 1) * 50, 1, s));   // gamma
+  PCHK(launch_generator_mul(G_G2, dgen2.w(), dtrap.w() + 24, o2 + (n + 2) * 50, 1, s));   // delta
   unsigned long long noerr = NO_ERR; if ((rc = up(derr, &noerr, 8, s))) return rc;
   PCHK(launch_tate(o1 + (rows + 2 * n) * 26, o2 + n * 50, dgt.w(), 1, (unsigned long long*)derr.p, s));   // crs.rs:137-139
   if ((rc = down(c->g1_uvw_stmt, o1, (l + 1) * G1B, s)) || (rc = down(c->g1_uvw_wit, o1 + (l + 1) * 26, (m - l) * G1B, s)) ||
@@ -1069,7 +1069,7 @@ static int bls_hash_dev(const uint8_t* msgs, const uint64_t* offsets, size_t n, 
   if ((rc = up(dm, msgs, total, s)) || (rc = up(doff, offsets, (n + 1) * 8, s)) || (rc = up(dgen2, G2_GEN, G2B, s))) return rc;
   if (!dsc.p || !dH.p) return ZKT_ERR_DEVICE;
   hipLaunchKernelGGL(k_bytes_mod_r, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t*)dm.p, (const unsigned long long*)doff.p, n, dsc.w());
-  PCHK(launch_group_mul(G_G2, dgen2.w(), dsc.w(), 8, dH.w(), n, s, true));
+  PCHK(launch_generator_mul(G_G2, dgen2.w(), dsc.w(), dH.w(), n, s));
   PCHK(hipStreamSynchronize(s));
   return ZKT_OK;
 }
