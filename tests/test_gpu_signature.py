@@ -140,3 +140,21 @@ def test_hash_to_g2_digit_patterns(L):
     want = _g2_mul(np.repeat(g2, len(vals), axis=0), vals)
     assert (H[:len(vals)] == want).all()
     assert all(int(H[i, 24]) & 0xFFFFFFFF == 1 for i in (n - 2, n - 1))                                 # r and 2r hash to scalar 0
+
+
+def test_sign_with_unreduced_and_zero_keys(L):
+    """Signer::sign is hash_to_g2point(m) * sk; the engine multiplies the generator once by (h * sk mod r).  Same group element for every 256-bit sk,
+    reduced or not, and for sk = 0 or r (the point at infinity)."""
+    _, g2 = _gens()
+    msgs = [b"chili crab", b"\x00\x01", b"a", b"\xff" * 40, b"", b"zk"]
+    sks = [0, R, R + 5, (1 << 256) - 1, 12345, R - 1]
+    buf, off = _pack(msgs)
+    n = len(msgs)
+    sig = np.zeros((n, G2W), np.uint64)
+    zk.check(L.zkt_bls_sign_batch(buf.ctypes.data, off.ctypes.data, ptr(ints_to_arr(sks, 4)), n, ptr(sig)))
+    H = _g2_mul(np.repeat(g2, n, axis=0), [int.from_bytes(m, "big") % R for m in msgs])
+    want = np.zeros((n, G2W), np.uint64)
+    for i in range(n):
+        want[i] = _g2_mul(H[i:i + 1], [sks[i]])[0]
+    assert (sig == want).all()
+    assert all(int(sig[i, 24]) & 0xFFFFFFFF == 1 for i in (0, 1, 4))

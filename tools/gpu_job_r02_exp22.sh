@@ -1,0 +1,10 @@
+# BLS signing as one generator multiplication by (h * sk mod r) (round 2)
+set -x
+cd /root/repo
+export TMPDIR=/tmp
+timeout -k 10 600 python -m pytest tests/test_gpu_signature.py -m gpu -x -q > gpurun_out/exp22_tests.log 2>&1 || { tail -30 gpurun_out/exp22_tests.log; echo "tests FAILED"; exit 1; }
+tail -2 gpurun_out/exp22_tests.log
+timeout -k 10 600 python3 tools/bench_protocols.py > gpurun_out/exp22_protocols.json 2> gpurun_out/exp22_protocols.err || { tail gpurun_out/exp22_protocols.err; exit 1; }
+python3 -c "
+import json; d=json.load(open('gpurun_out/exp22_protocols.json'))
+print('bls', d['bls']['sign_per_s'], d['bls']['verify_per_s'])"

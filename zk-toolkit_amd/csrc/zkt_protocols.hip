@@ -1062,13 +1062,16 @@ int zkt_pairing_product_check_batch(const zkt_g1_affine* g1, const zkt_g2_affine
 }
 
 // G2Point::hash_to_g2point (g2_point.rs:84-88) for n messages: msgs = the concatenated bytes, offsets[n+1]
-static int bls_hash_dev(const uint8_t* msgs, const uint64_t* offsets, size_t n, Dev& dH, hipStream_t s) {
+// times (optional, n canonical-or-not 256-bit scalars on the device): dH[i] = hash_to_g2point(m_i) * times[i] — the hash point is generator * h, so the
+// product is generator * (h * times mod r): one multiplication of the generator instead of a second, variable-base one (same group element).
+static int bls_hash_dev(const uint8_t* msgs, const uint64_t* offsets, size_t n, Dev& dH, hipStream_t s, const uint32_t* times = nullptr) {
   const size_t total = (size_t)offsets[n];
-  Dev dm(total), doff((n + 1) * 8), dsc(n * FRB), dgen2(G2B);
+  Dev dm(total), doff((n + 1) * 8), dsc(n * FRB), dgen2(G2B), derr(8);
   int rc;
   if ((rc = up(dm, msgs, total, s)) || (rc = up(doff, offsets, (n + 1) * 8, s)) || (rc = up(dgen2, G2_GEN, G2B, s))) return rc;
-  if (!dsc.p || !dH.p) return ZKT_ERR_DEVICE;
+  if (!dsc.p || !dH.p || !derr.p) return ZKT_ERR_DEVICE;
   hipLaunchKernelGGL(k_bytes_mod_r, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t*)dm.p, (const unsigned long long*)doff.p, n, dsc.w());
+  if (times) PCHK(launch_fp_op(F_FR, OP_MUL, dsc.w(), times, dsc.w(), n, (unsigned long long*)derr.p, s));      // inputs are reduced mod r first, as PrimeFieldElem::new does
   PCHK(launch_generator_mul(G_G2, dgen2.w(), dsc.w(), dH.w(), n, s));
   PCHK(hipStreamSynchronize(s));
   return ZKT_OK;
@@ -1088,11 +1091,10 @@ int zkt_bls_sign_batch(const uint8_t* msgs, const uint64_t* offsets, const uint6
   if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
   if (!offsets || !sks || !sigs || (offsets[n] && !msgs)) return ZKT_ERR_SHAPE;
   if (n == 0) return ZKT_OK;
-  hipStream_t s = nullptr; Dev dH(n * G2B), dsk(n * FRB), dsig(n * G2B);
-  int rc = bls_hash_dev(msgs, offsets, n, dH, s); if (rc) return rc;
+  hipStream_t s = nullptr; Dev dsk(n * FRB), dsig(n * G2B);
+  int rc;
   if ((rc = up(dsk, sks, n * FRB, s))) return rc;
-  if (!dsig.p) return ZKT_ERR_DEVICE;
-  PCHK(launch_group_mul(G_G2, dH.w(), dsk.w(), 8, dsig.w(), n, s));
+  if ((rc = bls_hash_dev(msgs, offsets, n, dsig, s, dsk.w()))) return rc;      // (h * sk) G2 = sk * hash_to_g2point(m): the hash point has order r
   if ((rc = down(sigs, dsig.p, n * G2B, s))) return rc;
   PCHK(hipStreamSynchronize(s));
   return ZKT_OK;
