@@ -54,7 +54,7 @@ typedef struct { uint64_t x[4], y[4]; uint32_t is_infinity, _pad; } zkt_secp_aff
 
 /* lifecycle — mcl_initializer.rs:4-15 (init once, panic on failure) */
 int zkt_init(int device);                 /* device = HIP ordinal, -1 = current */
-void zkt_shutdown(void);                  /* also releases what the library keeps between calls: the last one-shot Bulletproofs context, the statement tables of the last four Groth16 keys, the io-point tables of the last two Pinocchio keys */
+void zkt_shutdown(void);                  /* also releases what the library keeps between calls: the last one-shot Bulletproofs context, the statement tables of the last four Groth16 keys, the io-point tables of the last two Pinocchio keys (the comb tables of the two BLS12-381 generators, 320 KB, stay for the life of the process) */
 int zkt_version(void);
 const char* zkt_strerror(int status);
 size_t zkt_last_error_index(void);        /* thread-local; valid after a non-OK return */
