@@ -19,7 +19,14 @@ fn offsets(msgs: &[Vec<u8>]) -> (Vec<u8>, Vec<u64>) {
 impl Signer {
     pub fn new() -> Self { init(); Signer { g1: G1Point::g() } } // :14-22
     /// G1 generator * sk (:24-27)
-    pub fn gen_public_key(&self, sk: &PrivateKey) -> G1Point { &self.g1 * &sk.value }
+    pub fn gen_public_key(&self, sk: &PrivateKey) -> G1Point { self.gen_public_keys(&[sk.value.clone()]).remove(0) }
+    /// n keys, one launch through the generator's comb table
+    pub fn gen_public_keys(&self, sks: &[Fr]) -> Vec<G1Point> {
+        let k = Fr::flatten(sks);
+        let mut out = vec![G1Point::zero_raw(); sks.len()];
+        check(unsafe { ffi::zkt_bls_public_keys_batch(k.as_ptr(), sks.len(), out.as_mut_ptr()) });
+        out.iter().map(G1Point::from_raw).collect()
+    }
     /// hash_to_g2point(m) * sk (:28-31)
     pub fn sign(&self, m: &Vec<u8>, sk: &PrivateKey) -> G2Point { self.sign_batch(&[m.clone()], &[sk.value.clone()]).remove(0) }
     /// tate(g1, sig) == tate(pk, hash_to_g2point(m)) (:34-39)

@@ -224,8 +224,10 @@ int zkt_pairing_product_check_batch(const zkt_g1_affine* g1, const zkt_g2_affine
 /* f-4: BLS signatures, Signer signature.rs:8-40.  Messages are n byte strings, concatenated, offsets[n+1].
  * G2Point::hash_to_g2point g2_point.rs:84-88 (the bytes as a big-endian integer, reduced mod r, times the G2 generator);
  * sign = hash * sk (signature.rs:28-31, computed as generator * (h * sk mod r): the same group element; sk = 4-limb PrivateKey.value, private_key.rs:10-27; gen_public_key is
- * zkt_g1_mul_batch of the generator); verify = tate(g1, sig) == tate(pk, hash) (signature.rs:34-39), one signature per lane. */
+ * zkt_bls_public_keys_batch, or zkt_g1_mul_batch of the generator); verify = tate(g1, sig) == tate(pk, hash) (signature.rs:34-39), one signature per lane. */
 int zkt_bls_hash_to_g2_batch(const uint8_t* msgs, const uint64_t* offsets, size_t n, zkt_g2_affine* out);
+/* Signer::gen_public_key signature.rs:24-27 for n private keys (4 limbs each): pks[i] = G1 generator * sks[i], through the generator's comb table */
+int zkt_bls_public_keys_batch(const uint64_t* sks, size_t n, zkt_g1_affine* pks);
 int zkt_bls_sign_batch(const uint8_t* msgs, const uint64_t* offsets, const uint64_t* sks, size_t n, zkt_g2_affine* sigs);
 int zkt_bls_verify_batch(const uint8_t* msgs, const uint64_t* offsets, const zkt_g2_affine* sigs, const zkt_g1_affine* pks, size_t n, uint32_t* ok);
 

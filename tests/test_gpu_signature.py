@@ -158,3 +158,16 @@ def test_sign_with_unreduced_and_zero_keys(L):
         want[i] = _g2_mul(H[i:i + 1], [sks[i]])[0]
     assert (sig == want).all()
     assert all(int(sig[i, 24]) & 0xFFFFFFFF == 1 for i in (0, 1, 4))
+
+
+def test_public_keys_vs_oracle(L):
+    """Signer::gen_public_key (signature.rs:24-27) for a batch: G1 generator * sk through the comb table against the oracle's double-and-add, including
+    sk = 0 / r (the point at infinity), single digits and unreduced values."""
+    g1, _ = _gens()
+    rng = SplitMix64(808)
+    sks = [0, R, 1, 15, 16, 1 << 252, R - 1, R + 7, (1 << 256) - 1] + [rng.below(R - 1) + 1 for _ in range(60)]
+    n = len(sks)
+    pk = np.zeros((n, G1W), np.uint64)
+    zk.check(L.zkt_bls_public_keys_batch(ptr(ints_to_arr(sks, 4)), n, ptr(pk)))
+    assert (pk == _g1_mul(np.repeat(g1, n, axis=0), sks)).all()
+    assert all(int(pk[i, 12]) & 0xFFFFFFFF == 1 for i in (0, 1))

@@ -65,6 +65,7 @@ def lib():
         L.zkt_pinocchio_prove.argtypes = [vp, vp, vp, sz, vp, vp, vp]
         L.zkt_bls_hash_to_g2_batch.argtypes = [vp, vp, sz, vp]
         L.zkt_bls_sign_batch.argtypes = [vp, vp, vp, sz, vp]
+        L.zkt_bls_public_keys_batch.argtypes = [vp, sz, vp]
         L.zkt_bls_verify_batch.argtypes = [vp, vp, vp, vp, sz, vp]
         for grp in ("g1", "g2", "secp"):
             getattr(L, f"zkt_{grp}_msm_submit").argtypes = [vp, vp, sz, vp, ctypes.c_int]

@@ -1086,6 +1086,20 @@ int zkt_bls_hash_to_g2_batch(const uint8_t* msgs, const uint64_t* offsets, size_
   PCHK(hipStreamSynchronize(s));
   return ZKT_OK;
 }
+// Signer::gen_public_key (signature.rs:24-27): G1 generator * sk
+int zkt_bls_public_keys_batch(const uint64_t* sks, size_t n, zkt_g1_affine* pks) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!sks || !pks) return ZKT_ERR_SHAPE;
+  if (n == 0) return ZKT_OK;
+  hipStream_t s = nullptr; Dev dsk(n * FRB), dgen1(G1B), dpk(n * G1B);
+  int rc;
+  if ((rc = up(dsk, sks, n * FRB, s)) || (rc = up(dgen1, G1_GEN, G1B, s))) return rc;
+  if (!dpk.p) return ZKT_ERR_DEVICE;
+  PCHK(launch_generator_mul(G_G1, dgen1.w(), dsk.w(), dpk.w(), n, s));
+  if ((rc = down(pks, dpk.p, n * G1B, s))) return rc;
+  PCHK(hipStreamSynchronize(s));
+  return ZKT_OK;
+}
 // Signer::sign (signature.rs:28-31): hash_to_g2point(m) * sk
 int zkt_bls_sign_batch(const uint8_t* msgs, const uint64_t* offsets, const uint64_t* sks, size_t n, zkt_g2_affine* sigs) {
   if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
