@@ -54,7 +54,7 @@ typedef struct { uint64_t x[4], y[4]; uint32_t is_infinity, _pad; } zkt_secp_aff
 
 /* lifecycle — mcl_initializer.rs:4-15 (init once, panic on failure) */
 int zkt_init(int device);                 /* device = HIP ordinal, -1 = current */
-void zkt_shutdown(void);                  /* also releases what the library keeps between calls: the last one-shot Bulletproofs context, the statement tables of the last four Groth16 keys, the io-point tables of the last two Pinocchio keys (the comb tables of the two BLS12-381 generators, 320 KB, stay for the life of the process) */
+void zkt_shutdown(void);                  /* releases everything bound to the device of this zkt_init: the communicator of zkt_comm_init (zkt_comm_finalize), the last one-shot Bulletproofs context, the statement tables of the last four Groth16 keys, the io-point tables of the last two Pinocchio keys, the comb tables of the two BLS12-381 generators and the library's side stream.  Handles the caller still owns (zkt_*_bases, contexts, keys) must be freed BEFORE it.  zkt_init may then be called again, on the same or another device */
 int zkt_version(void);
 const char* zkt_strerror(int status);
 size_t zkt_last_error_index(void);        /* thread-local; valid after a non-OK return */

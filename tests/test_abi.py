@@ -42,6 +42,25 @@ def test_gt_eq_is_plain_memory_equality():
     assert L.zkt_gt_eq(ptr(a), ptr(b)) == 0
 
 
+def test_comm_shard_range_rejects_bad_ranks_and_library_needs_no_rccl_at_load_time():
+    """zkt_comm_shard_range is pure host arithmetic: world < 1 or a rank outside [0, world) yields the empty range (it used to divide by zero);
+    and RCCL is opened on first use, so a single-GPU consumer of libzkt_hip.so does not link it."""
+    import subprocess
+    L = zk.lib()
+    lo, hi = ctypes.c_size_t(7), ctypes.c_size_t(7)
+    for rank, world in ((0, 0), (0, -3), (-1, 4), (4, 4), (9, 2)):
+        lo.value = hi.value = 7
+        L.zkt_comm_shard_range(ctypes.c_size_t(1000), rank, world, ctypes.byref(lo), ctypes.byref(hi))
+        assert (lo.value, hi.value) == (0, 0), (rank, world)
+    L.zkt_comm_shard_range(ctypes.c_size_t(10), 2, 3, ctypes.byref(lo), ctypes.byref(hi))
+    assert (lo.value, hi.value) == (7, 10)
+    L.zkt_comm_shard_range(ctypes.c_size_t(10), 0, 3, None, None)             # NULL outputs are allowed
+    needed = subprocess.check_output(["readelf", "-d", zk.LIB_PATH], text=True)
+    assert "librccl" not in needed and "libamdhip64" in needed
+    assert L.zkt_comm_rank() == -1 and L.zkt_comm_world() == 0                 # before zkt_comm_init
+    L.zkt_comm_finalize()                                                       # harmless when not initialised
+
+
 def test_header_is_plain_c99(tmp_path):
     """include/zkt.h is the drop-in boundary a cgo / Rust-FFI binding consumes: it must compile as C (no C++, no torch types),
     and so must the plain-C consumer that the GPU suite runs (tests/c/abi_consumer.c)."""

@@ -216,10 +216,14 @@ int zkt_init(int device) {
 }
 extern "C" void zkt_internal_clear_caches();       // zkt_protocols.hip
 void zkt_shutdown(void) {
+  if (g.ready) (void)hipSetDevice(g.device);
+  zkt_comm_finalize();                                // the communicator and its buffers live on this device
   zkt_internal_clear_caches();                        // before g.mu is taken: releasing a cached context frees base sets, which lock it themselves
   std::lock_guard<std::mutex> lk(g.mu);
   if (!g.ready) return;
   (void)hipSetDevice(g.device);
+  group_release_device_state();                       // generator comb tables
+  pairing_release_device_state();                     // guard side stream + events
   if (g.arena) (void)hipFree(g.arena);
   if (g.d_err) (void)hipFree(g.d_err);
   if (g.d_small) (void)hipFree(g.d_small);

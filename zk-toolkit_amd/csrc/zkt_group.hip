@@ -175,6 +175,10 @@ namespace {
 struct GeneratorTable { std::mutex mu; uint32_t* dev = nullptr; };
 GeneratorTable g_gen_table[2];                                     // G_G1, G_G2
 }
+// zkt_shutdown: the comb tables live on the device zkt_init chose; a later zkt_init may pick another one, so they are rebuilt on first use
+void group_release_device_state() {
+  for (GeneratorTable& T : g_gen_table) { std::lock_guard<std::mutex> lk(T.mu); if (T.dev) { (void)hipFree(T.dev); T.dev = nullptr; } }
+}
 hipError_t launch_generator_mul(int grp, const uint32_t* gen_abi, const uint32_t* k, uint32_t* out, size_t n, hipStream_t s) {
   if (grp != G_G1 && grp != G_G2) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;

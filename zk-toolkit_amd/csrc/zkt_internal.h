@@ -86,6 +86,10 @@ hipError_t launch_pairing_product_check_counts(const PairArgs& a, int K, const u
 hipError_t guard_fork(hipStream_t s, hipStream_t* side);
 hipError_t guard_join(hipStream_t s, hipStream_t side);
 hipError_t launch_short_loop_guards(const PairArgs& a, int K, uint32_t* flags, size_t n, hipStream_t s);      // flags[i] = 1: every pair of element i fits the 127-step loop
+// zkt_shutdown: release what is bound to the device of the current zkt_init (generator comb tables; the guard side stream and its events), so that
+// a later zkt_init on another device starts clean
+void group_release_device_state();
+void pairing_release_device_state();
 hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s);
 
 // ---- MSM (zkt_msm.hip), generic over the group (G_G1, G_G2, G_SECP) ------------------------------------------

@@ -64,8 +64,15 @@ struct GuardStreams {
     if (!x && (rc = hipEventCreateWithFlags(&x, hipEventDisableTiming)) != hipSuccess) return rc;
     *e = x; return hipSuccess;
   }
+  void release() {                                                 // zkt_shutdown: stream and events belong to the device of that zkt_init
+    std::lock_guard<std::mutex> lk(mu);
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); side = nullptr; }
+    for (hipEvent_t& x : ev) if (x) { (void)hipEventDestroy(x); x = nullptr; }
+    next = 0;
+  }
 } g_guard;
 }  // namespace
+void pairing_release_device_state() { g_guard.release(); }
 hipError_t guard_fork(hipStream_t s, hipStream_t* side) {
   hipEvent_t e; hipError_t rc;
   if ((rc = g_guard.event(&e)) != hipSuccess) return rc;
