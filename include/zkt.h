@@ -108,6 +108,18 @@ int zkt_sn_pow_batch(const uint64_t* a, const uint64_t* exps, size_t exp_limbs, 
 int zkt_sn_pow_seq(const uint64_t* base, size_t n, uint64_t* out);
 int zkt_sn_repeat(const uint64_t* base, size_t n, uint64_t* out);
 
+/* a18 (vector forms of the field, used by the Bulletproofs code): PrimeFieldElems::sum prime_field_elems.rs:35-41 (the fold acc + x from zero;
+ * an EMPTY vector is the reference's assert -> ZKT_ERR_SHAPE) and PrimeFieldElems * PrimeFieldElem :152-175 (every element times ONE scalar k;
+ * empty vector -> ZKT_ERR_SHAPE likewise).  The element-wise +, -, * of two vectors (:90-150) are the *_add/sub/mul_batch calls above. */
+int zkt_fq_sum(const uint64_t* a, size_t n, uint64_t* out);
+int zkt_fr_sum(const uint64_t* a, size_t n, uint64_t* out);
+int zkt_sp_sum(const uint64_t* a, size_t n, uint64_t* out);
+int zkt_sn_sum(const uint64_t* a, size_t n, uint64_t* out);
+int zkt_fq_scale_batch(const uint64_t* a, const uint64_t* k, uint64_t* out, size_t n);
+int zkt_fr_scale_batch(const uint64_t* a, const uint64_t* k, uint64_t* out, size_t n);
+int zkt_sp_scale_batch(const uint64_t* a, const uint64_t* k, uint64_t* out, size_t n);
+int zkt_sn_scale_batch(const uint64_t* a, const uint64_t* k, uint64_t* out, size_t n);
+
 /* a4–a6: Fq2 fq2.rs:21-151, Fq6 fq6.rs:22-171, Fq12 fq12.rs:23-172 */
 int zkt_fq2_add_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 int zkt_fq2_sub_batch(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
@@ -154,6 +166,16 @@ int zkt_secp_in_subgroup_batch(const zkt_secp_affine* points, uint32_t* out, siz
 int zkt_g1_mul_batch(const zkt_g1_affine* points, const uint64_t* scalars, int scalar_limbs, zkt_g1_affine* out, size_t n);
 int zkt_g2_mul_batch(const zkt_g2_affine* points, const uint64_t* scalars, int scalar_limbs, zkt_g2_affine* out, size_t n);
 int zkt_secp_mul_batch(const zkt_secp_affine* points, const uint64_t* scalars, int scalar_limbs, zkt_secp_affine* out, size_t n);
+/* a18 (vector forms of the group): AffinePoints::sum secp256k1/affine_points.rs:25-31 — the fold from AffinePoint::zero(), so n = 0 gives the point
+ * at infinity — and AffinePoints * PrimeFieldElem :105-122, every point times ONE scalar k (scalar_limbs u64 limbs, used as-is like a8).  The
+ * element-wise point-vector + point-vector (:84-103) and point-vector * scalar-vector (:124-144) are *_add_batch / *_mul_batch above; the same calls
+ * exist for G1 and G2. */
+int zkt_g1_sum(const zkt_g1_affine* points, size_t n, zkt_g1_affine* out);
+int zkt_g2_sum(const zkt_g2_affine* points, size_t n, zkt_g2_affine* out);
+int zkt_secp_sum(const zkt_secp_affine* points, size_t n, zkt_secp_affine* out);
+int zkt_g1_scale_batch(const zkt_g1_affine* points, const uint64_t* k, int scalar_limbs, zkt_g1_affine* out, size_t n);
+int zkt_g2_scale_batch(const zkt_g2_affine* points, const uint64_t* k, int scalar_limbs, zkt_g2_affine* out, size_t n);
+int zkt_secp_scale_batch(const zkt_secp_affine* points, const uint64_t* k, int scalar_limbs, zkt_secp_affine* out, size_t n);
 /* a9: Polynomial::eval_with_g1_hidings polynomial.rs:271-281 — out = sum_i scalars[i]*bases[i];
  * scalars are 4 limbs (256 bits) each, used as-is */
 int zkt_g1_msm(const zkt_g1_affine* bases, const uint64_t* scalars, size_t n, zkt_g1_affine* out);

@@ -91,6 +91,23 @@ def chain_circuit(n, seed=7):
     return A, B, C, wit, 1
 
 
+def bits_circuit(n, seed=7):
+    """A witness of 0/1 values (what a real circuit's witness is full of): n-1 booleanity constraints b_j * b_j = b_j and one packing
+    constraint (sum_j 2^j b_j) * 1 = out; wires [one, out | b_0 .. b_{n-2}], l = 1.  (A w) and (B w) are 0/1 vectors: the MSM's skew path."""
+    from zkt_testlib import SplitMix64
+    rng = SplitMix64(seed)
+    bs = [rng.below(2) for _ in range(n - 1)]
+    out = sum(b << j for j, b in enumerate(bs)) % R
+    wit = [1, out] + bs
+    cols = n + 1
+    A = [[0] * cols for _ in range(n)]; B = [[0] * cols for _ in range(n)]; C = [[0] * cols for _ in range(n)]
+    for j in range(n - 1):
+        A[j][2 + j] = 1; B[j][2 + j] = 1; C[j][2 + j] = 1
+    for j in range(n - 1): A[n - 1][2 + j] = pow(2, j, R)
+    B[n - 1][0] = 1; C[n - 1][1] = 1
+    return A, B, C, wit, 1
+
+
 class Crs(ctypes.Structure):
     _fields_ = [("n", ctypes.c_size_t), ("l", ctypes.c_size_t), ("m", ctypes.c_size_t)] + \
                [(k, ctypes.POINTER(ctypes.c_uint64)) for k in ("g1_alpha", "g1_beta", "g1_delta", "g1_xi", "g1_uvw_stmt", "g1_uvw_wit", "g1_xt_by_delta",

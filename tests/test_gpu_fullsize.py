@@ -84,6 +84,65 @@ def test_config2_resident_g1_msm_2p20(L):
     assert (got == results["uniform"]).all(), "one-shot 2^20 MSM"
 
 
+def test_config4_resident_g2_msm_2p20(L):
+    """The B sum of a Groth16 proof at 2^20 constraints is a resident G2 MSM of this size (prover.rs:111,119; eval_with_g2_hidings polynomial.rs:283-293):
+    linearity against python integers for uniform / 0-1 / 2^256-1 scalars — the lane-pair accumulate and the Fq2 reduce kernels at the size they run."""
+    import torch
+    n = 1 << 20
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    ks = rand_u64_array(13, (n, 4)); ks[:, 3] >>= np.uint64(2)
+    d_k = torch.from_numpy(ks.view(np.int64)).cuda()
+    d_gen = torch.from_numpy(_gen_rows(_g2_gen(), n).view(np.int64)).cuda()
+    d_bases = torch.empty((n, G2W), dtype=torch.int64, device="cuda")
+    zk.check(L.zkt_g2_mul_batch_dev(vp(d_gen), vp(d_k), 4, vp(d_bases), n, None))
+    torch.cuda.synchronize(); del d_gen
+    h = ctypes.c_void_p()
+    zk.check(L.zkt_g2_bases_from_device(vp(d_bases), n, None, ctypes.byref(h)))
+    K = _ints(ks)
+    (x1, x0), (y1, y0) = G2_GEN
+    gen = ((x0, x1), (y0, y1))
+    uniform = rand_u64_array(14, (n, 4)); uniform[:, 3] >>= np.uint64(1)
+    bits = np.zeros((n, 4), np.uint64); bits[:, 0] = rand_u64_array(15, (n,)) & np.uint64(1)
+    top = np.zeros((n, 4), np.uint64); top[:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for name, sc in (("uniform", uniform), ("bits", bits), ("all-ones-256", top)):
+        d_s = torch.from_numpy(sc.view(np.int64)).cuda()
+        got = np.zeros((1, G2W), np.uint64)
+        zk.check(L.zkt_g2_msm_dev(h, vp(d_s), n, None, ptr(got), None))
+        tot = sum(k * s for k, s in zip(K, _ints(sc))) % R
+        want = g2_arr([to_abi_g2(py_g2_mul(gen, tot))])
+        assert (got == want).all(), f"resident 2^20 G2 MSM, {name} scalars"
+    L.zkt_g2_bases_free(h)
+
+
+def test_config5_resident_secp_msm_2p17_plus_1(L):
+    """Every generator sum of the 65,536-bit range proof is an MSM over [gg | hh | u]: 2^17 + 1 secp256k1 points (bulletproofs.rs:58-147,
+    affine_points.rs:25-31,123-144).  Linearity against python integers at exactly that size, uniform / 0-1 / 2^256-1 scalars, with the
+    point at infinity and a repeated point among the bases."""
+    import torch
+    n = (1 << 17) + 1
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    ks = rand_scalars(23, n, SECP_N)
+    ks[5] = 0; ks[7] = ks[6]                                                      # an infinity and a repeat among the generators
+    gen = secp_arr([SECP_GEN])
+    bases = np.zeros((n, 9), np.uint64)
+    zk.check(L.zkt_secp_mul_batch(ptr(_gen_rows(gen, n)), ptr(ks), 4, ptr(bases), n))
+    assert bases[5, 8] == 1 and (bases[6] == bases[7]).all()
+    h = ctypes.c_void_p()
+    zk.check(L.zkt_secp_bases_upload(ptr(bases), n, ctypes.byref(h)))
+    K = _ints(ks)
+    uniform = rand_u64_array(24, (n, 4))                                          # 256-bit scalars, used as-is: some exceed the group order
+    bits = np.zeros((n, 4), np.uint64); bits[:, 0] = rand_u64_array(25, (n,)) & np.uint64(1)
+    top = np.zeros((n, 4), np.uint64); top[:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for name, sc in (("uniform", uniform), ("bits", bits), ("all-ones-256", top)):
+        d_s = torch.from_numpy(sc.view(np.int64)).cuda()
+        got = np.zeros((1, 9), np.uint64)
+        zk.check(L.zkt_secp_msm_dev(h, vp(d_s), n, None, ptr(got), None))
+        tot = sum(k * s for k, s in zip(K, _ints(sc))) % SECP_N
+        want = secp_arr([py_secp_mul(SECP_GEN, tot)])
+        assert (got == want).all(), f"resident 2^17+1 secp256k1 MSM, {name} scalars"
+    L.zkt_secp_bases_free(h)
+
+
 def test_config3_tate_2p16(L):
     import torch
     n, half = 1 << 16, 1 << 15

@@ -27,9 +27,9 @@ def _r1cs_setup(L, mats, n, l, m, trap):
     return vk, vbuf, pk
 
 
-@pytest.mark.parametrize("case", ["cubic", "chain1", "chain2", "chain3", "chain16", "chain61"])
+@pytest.mark.parametrize("case", ["cubic", "chain1", "chain2", "chain3", "chain16", "chain61", "bits61"])
 def test_r1cs_path_matches_reference_algorithm(L, case):
-    A, B, C, wit, l = example_cubic() if case == "cubic" else chain_circuit(int(case[5:]))
+    A, B, C, wit, l = example_cubic() if case == "cubic" else bits_circuit(int(case[4:])) if case.startswith("bits") else chain_circuit(int(case[5:]))
     n, m = len(A), len(wit) - 1
     ui, vi, wi, h, _ = qap_from_r1cs(A, B, C, wit)
     U, V, W = dense(ui, n), dense(vi, n), dense(wi, n)

@@ -535,3 +535,69 @@ def test_pairing_g2_argument_outside_the_subgroup(L):
     ok = np.zeros(n, np.uint32)
     zk.check(L.zkt_pairing_product_check_batch(ptr(np.repeat(P, 2, axis=0)), ptr(np.repeat(Qs, 2, axis=0)), (ctypes.c_uint8 * 2)(0, 1), 2, n, ok.ctypes.data))
     assert all(int(ok[i]) == 1 for i in range(n) if i not in (11, 50)) and (not off_p_has_value or int(ok[50]) == 0)
+
+
+@pytest.mark.parametrize("pre,mod,w", [("fq", Q, 6), ("fr", R, 4), ("sp", SECP_P, 4), ("sn", SECP_N, 4)])
+def test_field_vector_sum_and_scalar_broadcast(L, pre, mod, w):
+    """row a18's vector forms: PrimeFieldElems::sum (prime_field_elems.rs:35-41) and PrimeFieldElems * PrimeFieldElem (:152-175) against the oracle's
+    element operations (the fold acc + x; x * k per element), for one-block, two-pass and ragged sizes; the reference's empty-vector asserts."""
+    f = FIELD_IDS[pre]
+    sz, vp = ctypes.c_size_t, ctypes.c_void_p
+    getattr(L, f"zkt_{pre}_sum").argtypes = [vp, sz, vp]; getattr(L, f"zkt_{pre}_scale_batch").argtypes = [vp, vp, vp, sz]
+    O.zkto_field_op.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, sz, vp]
+    for n in (1, 2, 255, 257, 1000, 70001):
+        a = _rand_field(900 + n, max(n, 6), mod, w)[:n].copy()
+        if n > 3: a[3] = int_to_limbs((1 << (64 * w)) - 1, w)                      # not below the order: reduced on load like PrimeFieldElem::new
+        got = np.zeros((1, w), np.uint64)
+        zk.check(getattr(L, f"zkt_{pre}_sum")(a.ctypes.data, n, got.ctypes.data))
+        if n <= 1000:                                                               # the oracle's fold, element by element
+            acc = np.zeros((1, w), np.uint64)
+            for i in range(n):
+                nxt = np.zeros((1, w), np.uint64)
+                assert O.zkto_field_op(f, 0, acc.ctypes.data, a[i:i + 1].copy().ctypes.data, nxt.ctypes.data, 1, None) == 0
+                acc = nxt
+            assert (got == acc).all(), (pre, n)
+        assert limbs_to_int(got[0]) == sum(limbs_to_int(r) for r in a) % mod, (pre, n)
+        k = ints_to_arr([SplitMix64(n).below(mod) if n != 2 else (1 << (64 * w)) - 1], w)
+        got, want = np.zeros_like(a), np.zeros_like(a)
+        zk.check(getattr(L, f"zkt_{pre}_scale_batch")(a.ctypes.data, k.ctypes.data, got.ctypes.data, n))
+        assert O.zkto_field_op(f, 2, a.ctypes.data, np.repeat(k, n, axis=0).ctypes.data, want.ctypes.data, n, None) == 0
+        assert (got == want).all(), (pre, n)
+    one = np.zeros((1, w), np.uint64)
+    assert getattr(L, f"zkt_{pre}_sum")(one.ctypes.data, 0, one.ctypes.data) == ZKT_ERR_SHAPE           # assert!(self.0.len() > 0)
+    assert getattr(L, f"zkt_{pre}_scale_batch")(one.ctypes.data, one.ctypes.data, one.ctypes.data, 0) == ZKT_ERR_SHAPE
+
+
+@pytest.mark.parametrize("grp,name,W,order", GROUPS)
+def test_point_vector_sum_and_scalar_broadcast(L, grp, name, W, order):
+    """AffinePoints::sum (secp256k1/affine_points.rs:25-31: the fold from zero) and AffinePoints * PrimeFieldElem (:105-122) against the oracle's affine
+    additions / scalar multiplications — with infinities, repeated points (P + P) and opposite points (P + (-P)) inside the vector."""
+    sz, vp = ctypes.c_size_t, ctypes.c_void_p
+    getattr(L, f"zkt_{name}_sum").argtypes = [vp, sz, vp]; getattr(L, f"zkt_{name}_scale_batch").argtypes = [vp, vp, ctypes.c_int, vp, sz]
+    rng = SplitMix64(7100 + grp)
+    n = 150 if grp != 1 else 90
+    ks = [rng.below(order) for _ in range(n - 6)]
+    ks += [0, ks[0], (order - ks[1]) % order, 1, order - 1, 0]                       # infinity, a repeat of point 0, the opposite of point 1, G, -G, infinity
+    g = np.repeat(_gen(grp), n, axis=0)
+    pts = np.zeros_like(g)
+    assert getattr(O, f"zkto_{name}_mul_batch")(ptr(g), ptr(ints_to_arr(ks, 4)), 4, ptr(pts), n, 8) == 0
+    for cnt in (0, 1, 2, 64, 65, n):
+        got = np.zeros((1, W), np.uint64)
+        zk.check(getattr(L, f"zkt_{name}_sum")(pts.ctypes.data, cnt, got.ctypes.data))
+        acc = np.zeros((1, W), np.uint64); acc[0, W - 1] = 1                         # AffinePoint::zero()
+        for i in range(cnt):
+            nxt = np.zeros((1, W), np.uint64)
+            assert getattr(O, f"zkto_{name}_add_batch")(ptr(acc), ptr(pts[i:i + 1].copy()), ptr(nxt), 1) == 0
+            acc = nxt
+        assert (got == acc).all(), (name, cnt)
+    # the two orders the fold must not depend on: (P0 + P0') first and last — same group element, canonical output
+    perm = pts[::-1].copy(); got2 = np.zeros((1, W), np.uint64)
+    zk.check(getattr(L, f"zkt_{name}_sum")(perm.ctypes.data, n, got2.ctypes.data))
+    assert (got2 == got).all()
+    for k in (rng.below(order), 0, order, (1 << 256) - 1):
+        kk = ints_to_arr([k], 4)
+        got, want = np.zeros_like(pts), np.zeros_like(pts)
+        zk.check(getattr(L, f"zkt_{name}_scale_batch")(pts.ctypes.data, kk.ctypes.data, 4, got.ctypes.data, n))
+        assert getattr(O, f"zkto_{name}_mul_batch")(ptr(pts), ptr(np.repeat(kk, n, axis=0)), 4, ptr(want), n, 8) == 0
+        assert (got == want).all(), (name, k)
+    zk.check(getattr(L, f"zkt_{name}_scale_batch")(pts.ctypes.data, kk.ctypes.data, 4, got.ctypes.data, 0))      # empty vector: allowed (no assert in the reference)

@@ -173,6 +173,67 @@ def py_g1_mul(p, k):
     return r
 
 
+def py_secp_add(p, q):
+    """Affine add on secp256k1 (y^2 = x^3 + 7) over python ints."""
+    if p is None: return q
+    if q is None: return p
+    (x1, y1), (x2, y2) = p, q
+    if x1 == x2 and (y1 + y2) % SECP_P == 0: return None
+    m = (3 * x1 * x1 * pow(2 * y1, -1, SECP_P) if p == q else (y2 - y1) * pow(x2 - x1, -1, SECP_P)) % SECP_P
+    x3 = (m * m - x1 - x2) % SECP_P
+    return (x3, (m * (x1 - x3) - y1) % SECP_P)
+
+
+def py_secp_mul(p, k):
+    r = None
+    while k:
+        if k & 1: r = py_secp_add(r, p)
+        p = py_secp_add(p, p); k >>= 1
+    return r
+
+
+SECP_GEN = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798, 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
+
+
+def secp_arr(points):
+    a = np.zeros((len(points), 9), dtype=np.uint64)
+    for i, p in enumerate(points):
+        if p is None: a[i, 8] = 1
+        else: a[i, :4] = int_to_limbs(p[0], 4); a[i, 4:8] = int_to_limbs(p[1], 4)
+    return a
+
+
+def _f2m(a, b): return ((a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)
+def _f2inv(a):
+    d = pow(a[0] * a[0] + a[1] * a[1], -1, Q)
+    return (a[0] * d % Q, -a[1] * d % Q)
+
+
+def py_g2_add(p, q):
+    """Affine add on the twist y^2 = x^3 + 4(1+u) over Fq2 = Fq[u]/(u^2+1), python ints; points are ((x0,x1),(y0,y1)) in c0/c1 order."""
+    if p is None: return q
+    if q is None: return p
+    (x1, y1), (x2, y2) = p, q
+    if x1 == x2 and ((y1[0] + y2[0]) % Q, (y1[1] + y2[1]) % Q) == (0, 0): return None
+    if p == q:
+        xx = _f2m(x1, x1)
+        m = _f2m((3 * xx[0] % Q, 3 * xx[1] % Q), _f2inv((2 * y1[0] % Q, 2 * y1[1] % Q)))
+    else:
+        m = _f2m(((y2[0] - y1[0]) % Q, (y2[1] - y1[1]) % Q), _f2inv(((x2[0] - x1[0]) % Q, (x2[1] - x1[1]) % Q)))
+    mm = _f2m(m, m)
+    x3 = ((mm[0] - x1[0] - x2[0]) % Q, (mm[1] - x1[1] - x2[1]) % Q)
+    t = _f2m(m, ((x1[0] - x3[0]) % Q, (x1[1] - x3[1]) % Q))
+    return (x3, ((t[0] - y1[0]) % Q, (t[1] - y1[1]) % Q))
+
+
+def py_g2_mul(p, k):
+    r = None
+    while k:
+        if k & 1: r = py_g2_add(r, p)
+        p = py_g2_add(p, p); k >>= 1
+    return r
+
+
 G1_GEN = (0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
           0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1)
 G2_GEN = ((0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E,

@@ -1,0 +1,59 @@
+#!/bin/bash
+# One parameterised GPU job (replaces the one-off tools/gpu_job_rNN_*.sh of earlier rounds).  Run through gpurun:
+#   gpurun --timeout 900 -- 'bash tools/gpu_job.sh <tag> <step> [<step> ...]'
+# Every step writes under gpurun_out/<tag>_*; a failed step ends the job (no further GPU step after a failure or a timeout).
+# Steps:
+#   tests[:expr]      pytest -m gpu (optionally -k expr)
+#   bench             python3 bench.py  -> <tag>_bench.json
+#   bench_stats       rocprofv3 --kernel-trace --stats of bench.py (MSM + pairing legs) -> prof_<tag>_stats/
+#   msm_latency       tools/bench_msm_latency.py under rocprofv3 --kernel-trace -> <tag>_msm_latency_kernel_trace.txt
+#   groth16_stats     tools/bench_groth16.py at 2^20 under rocprofv3 --kernel-trace --stats -> prof_<tag>_g16/ + timeline
+#   protocols         tools/bench_protocols.py -> <tag>_protocols.json
+#   protocols_stats   the same under rocprofv3 --kernel-trace --stats
+#   bp                tools/bench_bp.py (range proof / inner-product argument)
+#   pmc_acc | pmc_hbm | pmc_tate | pmc_tate_hbm   counter passes (their own runs: no trace domains beside --pmc)
+#   rehearsal         two ranks on one card through the callback transport (bench.py --gpus 2, gloo)
+#   py:<script> [..]  python3 <script> -> <tag>_<script>.log
+#   cmd:<shell>       any shell command (quoted)
+set -o pipefail
+cd /root/repo
+export TMPDIR=/tmp
+TAG=$1; shift
+O=gpurun_out
+mkdir -p $O
+fail() { echo "STEP FAILED: $1"; tail -25 "$2" 2>/dev/null; exit 1; }
+for STEP in "$@"; do
+  echo "=== step $STEP ($(date +%H:%M:%S))"
+  case "$STEP" in
+    tests*) K="${STEP#tests}"; K="${K#:}"
+      timeout -k 10 1000 python -m pytest tests -m gpu -x -q --durations=10 ${K:+-k "$K"} > $O/${TAG}_gputests.log 2>&1 || fail tests $O/${TAG}_gputests.log
+      tail -14 $O/${TAG}_gputests.log ;;
+    bench) timeout -k 10 900 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || fail bench $O/${TAG}_bench.err
+      python3 -c "import json,sys; d=json.loads(open('$O/${TAG}_bench.json').read().strip().splitlines()[-1]); print({k:d[k] for k in ('value','ms_per_step')}, d.get('roofline'), d['config'].get('single_msm_latency_ms'), d.get('pairing',{}).get('value'), d.get('groth16',{}).get('value'), d.get('bulletproofs'))" ;;
+    bench_stats) timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_stats -- python3 bench.py --groth16-log2n 0 > $O/${TAG}_bench_msm_pairing.json 2> $O/prof_${TAG}_stats.err || fail bench_stats $O/prof_${TAG}_stats.err ;;
+    msm_latency) timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_${TAG}_lat -- python3 tools/bench_msm_latency.py > $O/${TAG}_msm_latency.log 2>&1 || fail msm_latency $O/${TAG}_msm_latency.log
+      grep "latency" $O/${TAG}_msm_latency.log
+      python3 tools/trace_summary.py $(ls $O/prof_${TAG}_lat/*/*kernel_trace.csv | head -1) > $O/${TAG}_msm_latency_kernel_trace.txt 2>&1 || true
+      cat $O/${TAG}_msm_latency_kernel_trace.txt | cut -c1-150 ;;
+    groth16_stats) timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_g16 -- python3 tools/bench_groth16.py --log-n 20 --proofs 8 > $O/prof_${TAG}_g16.log 2>&1 || fail groth16_stats $O/prof_${TAG}_g16.log
+      grep -v "^[WEI]2026" $O/prof_${TAG}_g16.log | tail -4
+      cp $(ls $O/prof_${TAG}_g16/*/*kernel_stats.csv | head -1) $O/${TAG}_groth16_2p20_kernel_stats.csv
+      python3 tools/trace_timeline.py $(ls $O/prof_${TAG}_g16/*/*kernel_trace.csv | head -1) 3 140 > $O/${TAG}_g16_timeline.txt 2>&1 || true ;;
+    protocols) timeout -k 10 900 python3 tools/bench_protocols.py > $O/${TAG}_protocols.json 2> $O/${TAG}_protocols.err || fail protocols $O/${TAG}_protocols.err
+      cat $O/${TAG}_protocols.json | cut -c1-1500 ;;
+    protocols_stats) timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_protocols -- python3 tools/bench_protocols.py > $O/${TAG}_protocols_b.json 2> $O/prof_${TAG}_protocols.err || fail protocols_stats $O/prof_${TAG}_protocols.err ;;
+    bp) timeout -k 10 600 python3 tools/bench_bp.py > $O/${TAG}_bp.log 2>&1 || fail bp $O/${TAG}_bp.log
+      tail -12 $O/${TAG}_bp.log ;;
+    pmc_acc) timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $O/prof_${TAG}_sq_acc --output-format csv -- python3 bench.py --no-cpu --steps 8 --warmup 2 --pairings 0 --groth16-log2n 0 > $O/prof_${TAG}_sq_acc.log 2>&1 || fail pmc_acc $O/prof_${TAG}_sq_acc.log ;;
+    pmc_hbm) timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE -d $O/prof_${TAG}_hbm --output-format csv -- python3 bench.py --no-cpu --steps 8 --warmup 2 --pairings 0 --groth16-log2n 0 > $O/prof_${TAG}_hbm.log 2>&1 || fail pmc_hbm $O/prof_${TAG}_hbm.log ;;
+    pmc_tate) timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/prof_${TAG}_sq_tate --output-format csv -- python3 tools/bench_pairing.py > $O/prof_${TAG}_sq_tate.log 2>&1 || fail pmc_tate $O/prof_${TAG}_sq_tate.log ;;
+    pmc_tate_hbm) timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE -d $O/prof_${TAG}_hbm_tate --output-format csv -- python3 tools/bench_pairing.py > $O/prof_${TAG}_hbm_tate.log 2>&1 || fail pmc_tate_hbm $O/prof_${TAG}_hbm_tate.log ;;
+    rehearsal) ZKT_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --groth16-log2n 16 --groth16-proofs 3 --pairings 4096 --no-cpu > $O/${TAG}_bench_rehearsal_2ranks_1gpu.json 2> $O/${TAG}_rehearsal.err || fail rehearsal $O/${TAG}_rehearsal.err ;;
+    py:*) S="${STEP#py:}"; N=$(basename ${S%% *} .py)
+      timeout -k 10 900 python3 $S > $O/${TAG}_${N}.log 2>&1 || fail "$STEP" $O/${TAG}_${N}.log
+      grep -v "^[WEI]2026" $O/${TAG}_${N}.log | tail -25 ;;
+    cmd:*) timeout -k 10 900 bash -c "${STEP#cmd:}" || { echo "STEP FAILED: $STEP"; exit 1; } ;;
+    *) echo "unknown step $STEP"; exit 2 ;;
+  esac
+done
+echo all steps ok

@@ -117,6 +117,29 @@ int fp_pow_seq(int field, const uint64_t* base, size_t n, uint64_t* out, bool re
   return staged_raw(base, w, nullptr, 0, out, w * n, ZKT_ERR_SHAPE,
                     [&](uint32_t* da, uint32_t*, uint32_t* dout, hipStream_t s) { return launch_fp_pow_seq(field, da, dout, n, repeat, s); });
 }
+// a18's vector forms: PrimeFieldElems::sum (prime_field_elems.rs:35-41, panics on an empty vector) and PrimeFieldElems * PrimeFieldElem (:152-175)
+int fp_sum(int field, const uint64_t* a, size_t n, uint64_t* out) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (n == 0 || !a || !out) return ZKT_ERR_SHAPE;                    // assert!(self.0.len() > 0)
+  const size_t w = field_bytes(field);
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCHK(hipSetDevice(g.device));
+  int rc = arena_reserve(padded(w * n) + padded(w * (1 + fp_sum_scratch_elems())) + 1024);
+  if (rc) return rc;
+  Carver cv(g.arena);
+  uint32_t* da = cv.take<uint32_t>(w * n); uint32_t* dout = cv.take<uint32_t>(w * (1 + fp_sum_scratch_elems()));
+  HIPCHK(hipMemcpyAsync(da, a, w * n, hipMemcpyHostToDevice, g.stream));
+  HIPCHK(launch_fp_sum(field, da, n, dout, dout + w / 4, g.stream));
+  HIPCHK(hipMemcpyAsync(out, dout, w, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return ZKT_OK;
+}
+int fp_scale(int field, const uint64_t* a, const uint64_t* k, uint64_t* out, size_t n) {
+  if (n == 0) return ZKT_ERR_SHAPE;                                  // assert!(self.len() > 0)
+  const size_t w = field_bytes(field);
+  return staged_raw(a, w * n, k, w, out, w * n, ZKT_ERR_SHAPE,
+                    [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_fp_scale(field, da, db, dout, n, s); });
+}
 int tower_batch(int deg, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
   const size_t w = (size_t)deg * 48;
   const bool binary = op == T_ADD || op == T_SUB || op == T_MUL;
@@ -240,6 +263,8 @@ void zkt_shutdown(void) {
   FP_UN(zkt_##P##_cube_batch, F, OP_CUBE)                                                                        \
   int zkt_##P##_pow_batch(const uint64_t* a, const uint64_t* exps, size_t exp_limbs, int exp_shared, uint64_t* out, size_t n) { \
     return fp_pow_batch(F, a, exps, exp_limbs, exp_shared, out, n); }                                            \
+  int zkt_##P##_sum(const uint64_t* a, size_t n, uint64_t* out) { return fp_sum(F, a, n, out); }                   \
+  int zkt_##P##_scale_batch(const uint64_t* a, const uint64_t* k, uint64_t* out, size_t n) { return fp_scale(F, a, k, out, n); } \
   int zkt_##P##_pow_seq(const uint64_t* base, size_t n, uint64_t* out) { return fp_pow_seq(F, base, n, out, false); }  \
   int zkt_##P##_repeat(const uint64_t* base, size_t n, uint64_t* out) { return fp_pow_seq(F, base, n, out, true); }
 FP_FIELD_API(fq, F_FQ) FP_FIELD_API(fr, F_FR) FP_FIELD_API(sp, F_SP) FP_FIELD_API(sn, F_SN)
@@ -316,6 +341,43 @@ static int group_mul(int grp, const void* pts, const uint64_t* scalars, int limb
   return staged(pts, w, scalars, (size_t)limbs * 8, out, w, n, ZKT_ERR_SHAPE,
                 [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_group_mul(grp, da, db, limbs * 2, dout, n, s); });
 }
+// AffinePoints::sum (secp256k1/affine_points.rs:25-31: the fold from AffinePoint::zero(), so an empty vector sums to infinity) and
+// AffinePoints * PrimeFieldElem (:105-122): every point times ONE scalar
+static int group_sum(int grp, const void* pts, size_t n, void* out) {
+  if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  const size_t w = pt_bytes(grp);
+  if (!out || (n && !pts)) return ZKT_ERR_SHAPE;
+  if (n == 0) { memset(out, 0, w); ((uint32_t*)out)[w / 4 - 2] = 1; return ZKT_OK; }
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCHK(hipSetDevice(g.device));
+  int rc = arena_reserve(padded(w * (n + 1)) + 1024);
+  if (rc) return rc;
+  Carver cv(g.arena);
+  uint32_t* da = cv.take<uint32_t>(w * (n + 1));
+  HIPCHK(hipMemcpyAsync(da, pts, w * n, hipMemcpyHostToDevice, g.stream));
+  if (n == 1) {                                                      // zero + p: goes through the addition so that the coordinates come back reduced
+    std::vector<uint8_t> inf(w, 0); ((uint32_t*)inf.data())[w / 4 - 2] = 1;
+    HIPCHK(hipMemcpyAsync((uint8_t*)da + w, inf.data(), w, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+  }
+  HIPCHK(launch_group_sum_inplace(grp, da, n == 1 ? 2 : n, g.stream));            // result in da[0]
+  HIPCHK(hipMemcpyAsync(out, da, w, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return ZKT_OK;
+}
+static int group_scale(int grp, const void* pts, const uint64_t* k, int limbs, void* out, size_t n) {
+  if (limbs < 1 || limbs > 6) return ZKT_ERR_SHAPE;
+  if (n == 0) return ensure_ready();
+  size_t w = pt_bytes(grp);
+  return staged_raw(pts, w * n, k, (size_t)limbs * 8, out, w * n, ZKT_ERR_SHAPE,
+                    [&](uint32_t* da, uint32_t* db, uint32_t* dout, hipStream_t s) { return launch_group_mul(grp, da, db, limbs * 2, dout, n, s, false, true); });
+}
+int zkt_g1_sum(const zkt_g1_affine* p, size_t n, zkt_g1_affine* o) { return group_sum(G_G1, p, n, o); }
+int zkt_g2_sum(const zkt_g2_affine* p, size_t n, zkt_g2_affine* o) { return group_sum(G_G2, p, n, o); }
+int zkt_secp_sum(const zkt_secp_affine* p, size_t n, zkt_secp_affine* o) { return group_sum(G_SECP, p, n, o); }
+int zkt_g1_scale_batch(const zkt_g1_affine* p, const uint64_t* k, int l, zkt_g1_affine* o, size_t n) { return group_scale(G_G1, p, k, l, o, n); }
+int zkt_g2_scale_batch(const zkt_g2_affine* p, const uint64_t* k, int l, zkt_g2_affine* o, size_t n) { return group_scale(G_G2, p, k, l, o, n); }
+int zkt_secp_scale_batch(const zkt_secp_affine* p, const uint64_t* k, int l, zkt_secp_affine* o, size_t n) { return group_scale(G_SECP, p, k, l, o, n); }
 int zkt_g1_add_batch(const zkt_g1_affine* a, const zkt_g1_affine* b, zkt_g1_affine* o, size_t n) { return group_add(G_G1, a, b, o, n); }
 int zkt_g2_add_batch(const zkt_g2_affine* a, const zkt_g2_affine* b, zkt_g2_affine* o, size_t n) { return group_add(G_G2, a, b, o, n); }
 int zkt_secp_add_batch(const zkt_secp_affine* a, const zkt_secp_affine* b, zkt_secp_affine* o, size_t n) { return group_add(G_SECP, a, b, o, n); }

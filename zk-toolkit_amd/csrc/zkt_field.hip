@@ -118,6 +118,62 @@ hipError_t launch_fp_pow_seq(int field, const uint32_t* base, uint32_t* o, size_
   return hipGetLastError();
 }
 
+// PrimeFieldElems * PrimeFieldElem (prime_field_elems.rs:152-175): out[i] = a[i] * k, one scalar for the whole vector
+template <class C>
+__global__ void __launch_bounds__(TPB) k_fp_scale(const uint32_t* __restrict__ a, const uint32_t* __restrict__ k, uint32_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  constexpr int A = C::ABI_N;
+  st_fp<C>(out + i * A, fp_mul(ld_fp<C>(a + i * A), ld_fp<C>(k)));
+}
+// PrimeFieldElems::sum (prime_field_elems.rs:35-41): the fold acc + x from zero.  Grid-stride partial sums per lane, an LDS tree per block, one
+// canonical partial per block; the second launch (one block) sums the partials.  Addition is exact in any order, so the residue is the reference's.
+static constexpr int SUM_MAX_BLOCKS = 256;
+template <class C>
+__global__ void __launch_bounds__(TPB) k_fp_sum(const uint32_t* __restrict__ a, size_t n, uint32_t* __restrict__ out) {
+  constexpr int A = C::ABI_N;
+  __shared__ uint32_t lds[TPB / 2 * C::N];
+  Fp<C> acc = fp_zero<C>();
+  for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * TPB) acc = fp_add(acc, ld_fp<C>(a + i * A));
+  const int t = threadIdx.x;
+  for (int d = TPB / 2; d >= 1; d >>= 1) {
+    if (t >= d && t < 2 * d) st_raw<C>(lds + (t - d) * C::N, acc);
+    __syncthreads();
+    if (t < d) acc = fp_add(acc, ld_raw<C>(lds + t * C::N));
+    __syncthreads();
+  }
+  if (t == 0) st_fp<C>(out + (size_t)blockIdx.x * A, acc);
+}
+template <class C> static hipError_t sum_c(const uint32_t* a, size_t n, uint32_t* o, uint32_t* parts, hipStream_t s) {
+  const unsigned nb = (unsigned)(nblocks(n) < (unsigned)SUM_MAX_BLOCKS ? nblocks(n) : SUM_MAX_BLOCKS);
+  if (nb <= 1) { hipLaunchKernelGGL(k_fp_sum<C>, dim3(1), dim3(TPB), 0, s, a, n, o); return hipGetLastError(); }
+  hipLaunchKernelGGL(k_fp_sum<C>, dim3(nb), dim3(TPB), 0, s, a, n, parts);
+  hipLaunchKernelGGL(k_fp_sum<C>, dim3(1), dim3(TPB), 0, s, (const uint32_t*)parts, (size_t)nb, o);
+  return hipGetLastError();
+}
+size_t fp_sum_scratch_elems() { return SUM_MAX_BLOCKS; }
+hipError_t launch_fp_sum(int field, const uint32_t* a, size_t n, uint32_t* o, uint32_t* parts, hipStream_t s) {
+  switch (field) {
+    case F_FQ: return sum_c<FqC>(a, n, o, parts, s);
+    case F_FR: return sum_c<FrC>(a, n, o, parts, s);
+    case F_SP: return sum_c<SpC>(a, n, o, parts, s);
+    case F_SN: return sum_c<SnC>(a, n, o, parts, s);
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t launch_fp_scale(int field, const uint32_t* a, const uint32_t* k, uint32_t* o, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  dim3 g(nblocks(n)), t(TPB);
+  switch (field) {
+    case F_FQ: hipLaunchKernelGGL(k_fp_scale<FqC>, g, t, 0, s, a, k, o, n); break;
+    case F_FR: hipLaunchKernelGGL(k_fp_scale<FrC>, g, t, 0, s, a, k, o, n); break;
+    case F_SP: hipLaunchKernelGGL(k_fp_scale<SpC>, g, t, 0, s, a, k, o, n); break;
+    case F_SN: hipLaunchKernelGGL(k_fp_scale<SnC>, g, t, 0, s, a, k, o, n); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 // diagnostic: `count` independent runs of the fp.h self-test program (fq_program.h), one per lane, seeds seed0 + lane
 __global__ void __launch_bounds__(64) k_selftest_fq_program(unsigned long long seed0, int steps, const uint32_t* __restrict__ in4, uint32_t* __restrict__ out4,
                                                             int* __restrict__ bad, size_t count) {

@@ -21,6 +21,10 @@ hipError_t launch_fp_op(int field, int op, const uint32_t* a, const uint32_t* b,
 hipError_t launch_fp_pow(int field, const uint32_t* a, const uint32_t* e, int e_words, bool shared, uint32_t* out, size_t n, hipStream_t s);
 // pow_seq (prime_field_elem.rs:346-361): out[i] = base^i for i < n;  repeat (:363-376): out[i] = base
 hipError_t launch_fp_pow_seq(int field, const uint32_t* base, uint32_t* out, size_t n, bool repeat, hipStream_t s);
+// PrimeFieldElems::sum (prime_field_elems.rs:35-41) and PrimeFieldElems * PrimeFieldElem (:152-175); parts: fp_sum_scratch_elems() elements of scratch
+size_t fp_sum_scratch_elems();
+hipError_t launch_fp_sum(int field, const uint32_t* a, size_t n, uint32_t* out, uint32_t* parts, hipStream_t s);
+hipError_t launch_fp_scale(int field, const uint32_t* a, const uint32_t* k, uint32_t* out, size_t n, hipStream_t s);
 hipError_t launch_selftest_fq_program(unsigned long long seed0, int steps, const uint32_t* in4, uint32_t* out4, int* bad, size_t count, hipStream_t s);
 hipError_t launch_tower_op(int deg, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n,
                            unsigned long long* err, hipStream_t s);
@@ -102,6 +106,7 @@ struct MsmPlan {
   size_t ws_bytes;     // workspace bytes per in-flight MSM
   int direct;          // 1 = table-free one-shot form: `table` is the n bases themselves, every window has its own 2^(c-1) buckets
   size_t half;         // buckets per window, 2^(c-1)
+  uint32_t chunk;      // most entries one accumulate task (lane) adds: buckets with more are cut into equal pieces (8..128, pick_chunk)
 };
 MsmPlan msm_plan(size_t n, int grp);
 // table-free form for one-shot calls (zkt_*_msm with host pointers): no window-multiple table to build — nwin bucket sets, the per-window
@@ -123,4 +128,4 @@ hipError_t launch_msm_jac_sum_to_affine(int grp, const uint32_t* jac_partials, s
 
 // G2 bucket accumulation with two lanes per task (zkt_msm_g2pair.hip, a translation unit with its own namespace): global scope
 hipError_t zkt_launch_accumulate_g2_pair(const uint32_t* table, const uint32_t* entries, const uint32_t* offsets, const void* order, const uint32_t* task_off,
-                                         size_t nbuckets, uint32_t chunk, uint32_t* sums, uint32_t* partial, size_t max_tasks, hipStream_t s);
+                                         size_t nbuckets, uint32_t* sums, uint32_t* partial, size_t max_tasks, hipStream_t s);

@@ -57,6 +57,8 @@ static int coord_words(int grp) { return grp == G_G1 ? FqC::N : grp == G_G2 ? 2 
 // plan
 // ---------------------------------------------------------------------------------
 #if defined(ZKT_MSM_PART_G1)
+static constexpr uint32_t MSM_CHUNK_MAX = 128;
+static uint32_t pick_chunk(size_t entries, int grp);
 MsmPlan msm_plan(size_t n, int grp) {
   MsmPlan p; p.n = n; p.grp = grp;
   const size_t XYW = 4 * (size_t)coord_words(grp);
@@ -66,17 +68,33 @@ MsmPlan msm_plan(size_t n, int grp) {
   if (c > 20) c = 20;
   p.c = c; p.nwin = (256 + 1 + c - 1) / c; p.nbuckets = size_t(1) << (c - 1);
   size_t ent = (size_t)p.nwin * n;
+  p.chunk = pick_chunk(ent, grp);
   size_t b = 0;
   b += (p.nbuckets + 1) * 4 * 3;          // counts, offsets, cursor
   b += 2 * ent * 4 + 256;                  // entries, slots
   b += p.nbuckets * XYW * 4;               // bucket sums
   b += (2048 + 64) * XYW * 4;              // row/col sums, bit classes
   b += (1024 + 3 * 1025) * 4 + 2 * (p.nbuckets + 1) * 4;          // scan scratch, size bins, task counts/offsets
-  b += (p.nbuckets + ent / 128 + 2) * (8 + XYW * 4);              // task list + partial sums of split buckets
+  b += (p.nbuckets + ent / p.chunk + 2) * (8 + XYW * 4);          // task list + partial sums of split buckets
   b += 4096;
   p.ws_bytes = b;
   p.direct = 0; p.half = p.nbuckets;
   return p;
+}
+// Task granularity (entries per lane-task of the accumulate kernel) as a function of the problem: large MSMs keep long chains (128: the
+// partial sums of split buckets cost a full addition each), small ones are cut until the grid fills the chip — at 2^17 terms a chunk of 128
+// left 65,536 one-bucket tasks = ONE wave per SIMD, each lane a serial chain of 32-55 additions at the single-wave multiply-add rate
+// (1.37 ms for an eighth of the work of a 2^20-term MSM, profiles/r02_msm_latency_kernel_trace.txt).
+static uint32_t pick_chunk(size_t entries, int grp) {
+  static const int forced = [] { const char* e = getenv("ZKT_MSM_CHUNK"); return e ? atoi(e) : 0; }();
+  if (forced >= 2 && forced <= (int)MSM_CHUNK_MAX) return (uint32_t)forced;
+  // lanes to fill: 256 CUs x 4 SIMDs x 2 waves x 64 lanes (G1, secp256k1), x 1.5 so that the short tail tasks have something to hide under;
+  // the G2 pair kernel runs one wave per SIMD and two lanes per task
+  const size_t tasks = grp == G_G2 ? (size_t)65536 : (size_t)196608;
+  size_t c = (entries + tasks - 1) / tasks;
+  if (c < 8) c = 8;
+  if (c > MSM_CHUNK_MAX) c = MSM_CHUNK_MAX;
+  return (uint32_t)c;
 }
 MsmPlan msm_plan_direct(size_t n, int grp) {
   MsmPlan p; p.n = n; p.grp = grp;
@@ -87,11 +105,12 @@ MsmPlan msm_plan_direct(size_t n, int grp) {
   if (c > 16) c = 16;
   p.c = c; p.nwin = (256 + 1 + c - 1) / c; p.half = size_t(1) << (c - 1); p.nbuckets = (size_t)p.nwin * p.half; p.direct = 1;
   size_t ent = (size_t)p.nwin * n;
+  p.chunk = pick_chunk(ent, grp);
   size_t b = 0;
   b += (p.nbuckets + 1) * 4 * 3 + 2 * ent * 4 + 256 + p.nbuckets * XYW * 4;
   b += (size_t)p.nwin * (2048 + 64 + 1) * XYW * 4;               // per-window row/col sums, bit classes, window results
   b += (1024 + 3 * 1025) * 4 + 2 * (p.nbuckets + 1) * 4;
-  b += (p.nbuckets + ent / 128 + 2) * (8 + XYW * 4);
+  b += (p.nbuckets + ent / p.chunk + 2) * (8 + XYW * 4);
   b += 8192;
   p.ws_bytes = b;
   return p;
@@ -292,37 +311,39 @@ static void launch_scan(const uint32_t* in, uint32_t* out, size_t m, uint32_t* s
   hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(256), 0, s, in, m, (const uint32_t*)scratch, out);
 }
 
-// Work list.  A bucket is processed in chunks of at most CHUNK entries, one chunk per lane ("task"), so one lane never
-// runs an unbounded list: with random scalars every bucket (~26 entries at 2^20) is a single task, while skewed inputs
-// (many equal scalars: a real witness is full of 0/1) split their hot buckets over many lanes, whose partial sums are
-// merged afterwards.  Tasks are ordered by size (largest first) by a counting sort, so the 64 lanes of a wave run
-// equally long lists.
-static constexpr uint32_t CHUNK = 128;
+// Work list.  A bucket of cnt entries is cut into nt = ceil(cnt / chunk) equal pieces (the first cnt % nt of them one entry longer), one
+// piece per lane ("task"), so one lane never runs an unbounded list: with random scalars at 2^20 terms every bucket (~26 entries) is a single
+// task, while skewed inputs (many equal scalars: a real witness is full of 0/1) and small MSMs (chunk from pick_chunk) spread their buckets
+// over many lanes, whose partial sums are merged afterwards.  Tasks are ordered by size (largest first) by a counting sort, so the 64 lanes
+// of a wave run equally long lists.
+static constexpr uint32_t CHUNK = 128;           // the largest chunk (MsmPlan::chunk <= CHUNK): one size bin per possible task size
 static constexpr int SIZE_BINS = CHUNK + 1;      // bin k holds tasks of size CHUNK - k
-__device__ inline uint32_t ntasks_of(uint32_t c) { return c <= CHUNK ? 1u : (c + CHUNK - 1) / CHUNK; }
-static __global__ void __launch_bounds__(256) k_task_count(const uint32_t* __restrict__ counts, size_t m, uint32_t* __restrict__ ntask, uint32_t* __restrict__ hist) {
+__device__ inline uint32_t ntasks_of(uint32_t c, uint32_t chunk) { return c <= chunk ? 1u : (c + chunk - 1) / chunk; }
+__device__ inline uint32_t task_size_of(uint32_t c, uint32_t nt) { return (c + nt - 1) / nt; }      // the larger of the two piece sizes
+static __global__ void __launch_bounds__(256) k_task_count(const uint32_t* __restrict__ counts, size_t m, uint32_t chunk, uint32_t* __restrict__ ntask, uint32_t* __restrict__ hist) {
   ZKT_SIDE_PRIO;
   __shared__ uint32_t h[SIZE_BINS];
   for (int i = threadIdx.x; i < SIZE_BINS; i += 256) h[i] = 0;
   __syncthreads();
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < m) {
-    uint32_t c = counts[i], nt = ntasks_of(c), last = c - (nt - 1) * CHUNK;
+    uint32_t c = counts[i], nt = ntasks_of(c, chunk);
     ntask[i] = nt;
-    atomicAdd(&h[CHUNK - last], 1u);
-    if (nt > 1) atomicAdd(&h[0], nt - 1);
+    atomicAdd(&h[CHUNK - task_size_of(c, nt)], nt);
   }
   __syncthreads();
   for (int k = threadIdx.x; k < SIZE_BINS; k += 256) if (h[k]) atomicAdd(&hist[k], h[k]);
 }
-static __global__ void __launch_bounds__(256) k_task_scatter(const uint32_t* __restrict__ counts, size_t m, const uint32_t* __restrict__ size_hist,
+static __global__ void __launch_bounds__(256) k_task_scatter(const uint32_t* __restrict__ counts, size_t m, uint32_t chunk, const uint32_t* __restrict__ size_hist,
                                                       uint32_t* __restrict__ bincur, uint2* __restrict__ order) {
   ZKT_SIDE_PRIO;
   // rank inside the block with LDS atomics, then ONE global atomic per (block, non-empty bin): ~50 distinct sizes
   // are shared by 2^19 buckets, so per-element global atomics would serialise.  The exclusive scan of the SIZE_BINS-entry
   // histogram (bin offsets in the size-ordered task list) is recomputed by every block: 129 values, cheaper than three more launches.
   __shared__ uint32_t h[SIZE_BINS], base[SIZE_BINS], binoff[SIZE_BINS + 1], scan[256];
+  __shared__ uint32_t hot_n, hot_b[256], hot_pos[256], hot_nt[256];
   for (int i = threadIdx.x; i < SIZE_BINS; i += 256) h[i] = 0;
+  if (threadIdx.x == 0) hot_n = 0;
   {
     static_assert(SIZE_BINS <= 256, "one histogram bin per thread");
     uint32_t v = threadIdx.x < SIZE_BINS ? size_hist[threadIdx.x] : 0, tot;
@@ -332,16 +353,19 @@ static __global__ void __launch_bounds__(256) k_task_scatter(const uint32_t* __r
   __syncthreads();
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   uint32_t bin = 0, rank = 0, nt = 1;
-  if (i < m) { uint32_t c = counts[i]; nt = ntasks_of(c); bin = CHUNK - (c - (nt - 1) * CHUNK); rank = atomicAdd(&h[bin], 1u); }
+  if (i < m) { uint32_t c = counts[i]; nt = ntasks_of(c, chunk); bin = CHUNK - task_size_of(c, nt); rank = atomicAdd(&h[bin], nt); }
   __syncthreads();
   for (int k = threadIdx.x; k < SIZE_BINS; k += 256) if (h[k]) base[k] = binoff[k] + atomicAdd(&bincur[k], h[k]);
   __syncthreads();
   if (i < m) {
-    order[base[bin] + rank] = make_uint2((uint32_t)i, nt - 1);                       // the last (possibly short) chunk
-    if (nt > 1) {                                                                    // full chunks of a hot bucket (rare)
-      uint32_t b0 = binoff[0] + atomicAdd(&bincur[0], nt - 1);
-      for (uint32_t k = 0; k + 1 < nt; ++k) order[b0 + k] = make_uint2((uint32_t)i, k);
-    }
+    const uint32_t pos = base[bin] + rank;
+    if (nt <= 16) { for (uint32_t k = 0; k < nt; ++k) order[pos + k] = make_uint2((uint32_t)i, k); }
+    else { const uint32_t slot = atomicAdd(&hot_n, 1u); hot_b[slot] = (uint32_t)i; hot_pos[slot] = pos; hot_nt[slot] = nt; }      // a hot bucket: the whole block writes its tasks
+  }
+  __syncthreads();
+  for (uint32_t hb = 0; hb < hot_n; ++hb) {
+    const uint32_t b = hot_b[hb], pos = hot_pos[hb], cnt = hot_nt[hb];
+    for (uint32_t k = threadIdx.x; k < cnt; k += 256) order[pos + k] = make_uint2(b, k);
   }
 }
 
@@ -360,8 +384,13 @@ __global__ void __launch_bounds__(64) ZKT_ACC_ATTR k_accumulate(const uint32_t* 
   if (t >= task_off[nbuckets]) return;
   const uint2 tk = order[t];
   const size_t b = tk.x;
-  uint32_t beg = offsets[b] + tk.y * CHUNK, end = offsets[b + 1];
-  if (end - beg > CHUNK) end = beg + CHUNK;
+  const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
+  const uint32_t off = offsets[b], cnt = offsets[b + 1] - off;
+  uint32_t beg = off, end = off + cnt;
+  if (nt != 1) {                                   // piece tk.y of nt equal pieces: the first cnt % nt pieces hold one entry more
+    const uint32_t q = cnt / nt, r = cnt - q * nt;
+    beg = off + tk.y * q + (tk.y < r ? tk.y : r); end = beg + q + (tk.y < r ? 1u : 0u);
+  }
   constexpr int CW = Coord<F>::CW, XYW = 4 * CW;
   Xyzz<F> acc = xyzz_inf<F>();
   // software-pipelined gather: the next point (and the entry after it) are in flight while this one is added, so the
@@ -397,7 +426,6 @@ __global__ void __launch_bounds__(64) ZKT_ACC_ATTR k_accumulate(const uint32_t* 
       acc = xyzz_add_aff<F>(acc, x, y);
     }
   }
-  const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
   st_xy<F>(nt == 1 ? sums + b * XYW : partial + (size_t)(t0 + tk.y) * XYW, acc);
 }
 
@@ -432,12 +460,19 @@ __global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_merge_partials(const u
   constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
   __shared__ uint32_t lds[RED_TPB / 2 * XYW];
   static_assert(RED_TPB == 64, "one wave per block: the ballot below covers the block");
+  constexpr uint32_t MERGE_LANE_MAX = 8;
   // Every lane looks at one bucket of a 64-bucket tile (one coalesced read) and the wave then merges the split ones among them, one after the other.
   // With uniform scalars no bucket is split and the kernel is one pass over task_off (a bucket per BLOCK iteration made this 0.15-0.2 ms of pure latency).
   for (size_t b0 = (size_t)blockIdx.x * RED_TPB; b0 < nbuckets; b0 += (size_t)gridDim.x * RED_TPB) {
     const size_t mine = b0 + threadIdx.x;
-    const bool split = mine < nbuckets && task_off[mine + 1] - task_off[mine] != 1;
-    unsigned long long todo = __ballot(split);
+    const uint32_t my_t0 = mine < nbuckets ? task_off[mine] : 0u, my_nt = mine < nbuckets ? task_off[mine + 1] - my_t0 : 1u;
+    // a bucket cut into a few pieces (small MSMs: every bucket is) is summed by its own lane, 64 buckets side by side; only hot buckets take the wave
+    if (my_nt > 1 && my_nt <= MERGE_LANE_MAX) {
+      XY acc = ld_xy<F>(partial + (size_t)my_t0 * XYW);
+      for (uint32_t k = 1; k < my_nt; ++k) acc = xyzz_add<F>(acc, ld_xy<F>(partial + (size_t)(my_t0 + k) * XYW));
+      st_xy<F>(sums + mine * XYW, acc);
+    }
+    unsigned long long todo = __ballot(my_nt > MERGE_LANE_MAX);
     while (todo) {                                   // wave-uniform
       const int l = __ffsll((long long)todo) - 1; todo &= todo - 1;
       const size_t b = b0 + l;
@@ -508,7 +543,12 @@ __global__ void __launch_bounds__(64) k_combine(const uint32_t* __restrict__ cls
   XY v = xyzz_inf<F>();
   if (t < nbA) v = ld_xy<F>(clsA + t * XYW);
   if (t >= shift && t - shift < nbB) v = xyzz_add<F>(v, ld_xy<F>(clsB + (t - shift) * XYW));
-  for (int d = 0; d < t && t < 32; ++d) v = xyzz_dbl<F>(v);
+  if (t >= 2 && t < 32 && !xyzz_is_inf(v)) {          // t doublings: in Jacobian coordinates (2M + 5S each against 6M + 3S), converted back for the tree
+    Jac<F> j = xyzz_to_jac<F>(v);
+    for (int d = 0; d < t; ++d) j = jac_dbl(j);
+    if (jac_is_inf(j)) v = xyzz_inf<F>();
+    else { v.X = j.X; v.Y = j.Y; v.ZZ = F::sqr(j.Z); v.ZZZ = F::mul(v.ZZ, j.Z); }
+  } else if (t == 1) v = xyzz_dbl<F>(v);
   for (int d = 16; d >= 1; d >>= 1) {
     if (t >= d && t < 2 * d) st_xy<F>(lds + (t - d) * XYW, v);
     __syncthreads();
@@ -582,7 +622,7 @@ MsmWs carve(const MsmPlan& P, void* workspace) {
   w.scan_tmp = (uint32_t*)ws; ws += 1024 * 4;
   w.ntask = (uint32_t*)ws; ws += (B + 1) * 4;
   w.task_off = (uint32_t*)ws; ws += (B + 1) * 4;
-  w.max_tasks = B + (size_t)P.nwin * P.n / CHUNK + 1;
+  w.max_tasks = B + (size_t)P.nwin * P.n / P.chunk + 1;
   ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   w.order = (uint2*)ws; ws += w.max_tasks * 8;
   w.partial = (uint32_t*)ws; ws += w.max_tasks * XYW * 4;
@@ -605,9 +645,9 @@ hipError_t PART(launch_msm_sort)(const MsmPlan& P, const uint8_t* inf, const uin
   } else {
     if ((e = hipMemsetAsync(w.offsets, 0, (B + 1) * 4, s)) != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_task_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, w.ntask, w.size_hist);
+  hipLaunchKernelGGL(k_task_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, P.chunk, w.ntask, w.size_hist);
   launch_scan(w.ntask, w.task_off, B, w.scan_tmp, s);
-  hipLaunchKernelGGL(k_task_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, (const uint32_t*)w.size_hist, w.size_cur, w.order);
+  hipLaunchKernelGGL(k_task_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, P.chunk, (const uint32_t*)w.size_hist, w.size_cur, w.order);
   return hipGetLastError();
 }
 // stage 2 (VALU bound, the dominant kernel): one bucket per lane
@@ -615,7 +655,7 @@ hipError_t PART(launch_msm_accumulate)(const MsmPlan& P, const uint32_t* table, 
   MsmWs w = carve(P, workspace);
 #if defined(ZKT_MSM_PART_OTHER) && !defined(ZKT_G2_ONE_LANE)
   if (P.grp == G_G2)        // two lanes per task: zkt_msm_g2pair.hip
-    return ::zkt_launch_accumulate_g2_pair(table, (const uint32_t*)w.entries, (const uint32_t*)w.offsets, (const void*)w.order, (const uint32_t*)w.task_off, P.nbuckets, CHUNK,
+    return ::zkt_launch_accumulate_g2_pair(table, (const uint32_t*)w.entries, (const uint32_t*)w.offsets, (const void*)w.order, (const uint32_t*)w.task_off, P.nbuckets,
                                            w.sums, w.partial, w.max_tasks, s);
 #endif
   MSM_DISPATCH(P.grp, hipLaunchKernelGGL(k_accumulate<F>, dim3((unsigned)((w.max_tasks + 63) / 64)), dim3(64), 0, s, table, (const uint32_t*)w.entries,
@@ -630,7 +670,10 @@ hipError_t PART(launch_msm_reduce)(const MsmPlan& P, void* workspace, uint32_t* 
   int lo_bits = 0; while ((size_t(1) << lo_bits) < NLO) ++lo_bits;
   int hi_bits = 0; while ((size_t(1) << hi_bits) < NHI) ++hi_bits;
   const int nbA = lo_bits + 1, nbB = NHI > 1 ? hi_bits : 0;     // weights lo+1 in [1,NLO]; hi in [0,NHI)
-  const int RS = (NHI > 1 && NLO >= 128 && 2 * NHI <= 1024) ? 2 : 1;                 // pieces per row (k_marginals)
+  // pieces per row (k_marginals): a column block sums NHI points, a row piece NLO / RS — cut the rows until both carry chains of the same length
+  // (at 2^16 buckets: 64 x 1024, RS = 16 gives 64-point pieces, one per lane + the tree, instead of 8 per lane), within the 1024-entry row buffer
+  int RS = 1;
+  while (NHI > 1 && (size_t)(2 * RS) * NHI <= 1024 && NLO / (size_t)(2 * RS) >= 64 && NLO / (size_t)(2 * RS) >= NHI) RS *= 2;
   const size_t NROW = (size_t)RS * NHI;
   if (P.direct) {                                          // every window reduced side by side (grid.y), then joined
     const unsigned ny = (unsigned)P.nwin;

@@ -32,7 +32,7 @@ __device__ inline void st_half(uint32_t* p, const Fq2& a) { uint32_t* q = p + (f
 #endif
 __global__ void __launch_bounds__(64) ZKT_G2PAIR_ATTR
 k_accumulate_g2_pair(const uint32_t* __restrict__ table, const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offsets,
-                     const uint2* __restrict__ order, const uint32_t* __restrict__ task_off, size_t nbuckets, uint32_t chunk,
+                     const uint2* __restrict__ order, const uint32_t* __restrict__ task_off, size_t nbuckets,
                      uint32_t* __restrict__ sums, uint32_t* __restrict__ partial) {
   typedef Fq2Ops F;
   constexpr int CW = 2 * FqC::N, XYW = 4 * CW;                      // words of one Fq2 coordinate / one XYZZ point in memory
@@ -40,8 +40,13 @@ k_accumulate_g2_pair(const uint32_t* __restrict__ table, const uint32_t* __restr
   if (t >= task_off[nbuckets]) return;
   const uint2 tk = order[t];
   const size_t b = tk.x;
-  uint32_t beg = offsets[b] + tk.y * chunk, end = offsets[b + 1];
-  if (end - beg > chunk) end = beg + chunk;
+  const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
+  const uint32_t off = offsets[b], cnt = offsets[b + 1] - off;
+  uint32_t beg = off, end = off + cnt;
+  if (nt != 1) {                                   // piece tk.y of nt equal pieces, exactly as k_accumulate (zkt_msm.hip)
+    const uint32_t q = cnt / nt, r = cnt - q * nt;
+    beg = off + tk.y * q + (tk.y < r ? tk.y : r); end = beg + q + (tk.y < r ? 1u : 0u);
+  }
   Xyzz<F> acc = xyzz_inf<F>();
   uint32_t ent = beg < end ? entries[beg] : 0, ent_next = beg + 1 < end ? entries[beg + 1] : 0;
   const uint32_t* p = table + (size_t)(ent & 0x7fffffffu) * (2 * CW);
@@ -71,7 +76,6 @@ k_accumulate_g2_pair(const uint32_t* __restrict__ table, const uint32_t* __restr
     acc = xyzz_add_aff<F>(acc, x, y);
   }
 #endif
-  const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
   uint32_t* out = nt == 1 ? sums + b * XYW : partial + (size_t)(t0 + tk.y) * XYW;
   st_half(out, acc.X); st_half(out + CW, acc.Y); st_half(out + 2 * CW, acc.ZZ); st_half(out + 3 * CW, acc.ZZZ);
 }
@@ -80,9 +84,9 @@ k_accumulate_g2_pair(const uint32_t* __restrict__ table, const uint32_t* __restr
 #undef zkt
 
 hipError_t zkt_launch_accumulate_g2_pair(const uint32_t* table, const uint32_t* entries, const uint32_t* offsets, const void* order, const uint32_t* task_off,
-                                         size_t nbuckets, uint32_t chunk, uint32_t* sums, uint32_t* partial, size_t max_tasks, hipStream_t s) {
+                                         size_t nbuckets, uint32_t* sums, uint32_t* partial, size_t max_tasks, hipStream_t s) {
   if (max_tasks == 0) return hipSuccess;
   hipLaunchKernelGGL(zkt_g2pair::k_accumulate_g2_pair, dim3((unsigned)((2 * max_tasks + 63) / 64)), dim3(64), 0, s, table, entries, offsets, (const uint2*)order, task_off,
-                     nbuckets, chunk, sums, partial);
+                     nbuckets, sums, partial);
   return hipGetLastError();
 }

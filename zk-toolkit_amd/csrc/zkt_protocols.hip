@@ -556,7 +556,7 @@ struct zkt_bp_ipa_ctx {
   zkt_secp_bases* set = nullptr;
   std::recursive_mutex mu;                 // a context serves one call at a time: concurrent callers queue here (the range proof re-enters for its inner-product argument)
   std::vector<hipStream_t> side;           // one stream per product batch, so the batches overlap each other and the MSMs
-  hipEvent_t ev = nullptr;
+  hipEvent_t ev = nullptr, ev_null = nullptr;
   hipStream_t main = nullptr;              // the range proof's own stream: on the legacy NULL stream every one of its ~150 small launches pays the implicit barriers (~45 us each)
   // fixed-base tables (launch_fixed_table) of the range proof's g, h and of u: 3 x 64 points; g and h arrive per call and are cached by value
   Dev dfix{3 * 64 * SPB};
@@ -571,6 +571,7 @@ struct zkt_bp_ipa_ctx {
     for (hipStream_t x : side) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
     if (main) { hipStreamSynchronize(main); hipStreamDestroy(main); }
     if (ev) hipEventDestroy(ev);
+    if (ev_null) hipEventDestroy(ev_null);
     if (set) zkt_secp_bases_free(set);
   }
 };
@@ -627,6 +628,7 @@ int zkt_bp_ipa_ctx_create(size_t n, const zkt_secp_affine* gg, const zkt_secp_af
   c->side.assign((c->levels + zkt_bp_ipa_ctx::IPA_BATCH - 1) / zkt_bp_ipa_ctx::IPA_BATCH, nullptr);
   for (hipStream_t& x : c->side) PCHK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
   PCHK(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+  PCHK(hipEventCreateWithFlags(&c->ev_null, hipEventDisableTiming));
   PCHK(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking));
   int rc = zkt_secp_bases_from_device((const zkt_secp_affine*)c->dbase.p, c->NB, s, &c->set);
   if (rc) return rc;
@@ -804,7 +806,10 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   const size_t n = c->N;
   hipStream_t s = c->main;
-  if (hipDeviceSynchronize() != hipSuccess) return -ZKT_ERR_DEVICE;      // whatever the caller queued (the context's table build runs on the NULL stream) is done before the own stream starts
+  // Order the proof's own (non-blocking) stream behind whatever was queued on the legacy NULL stream — the context's uploads and table build run there, and so
+  // does the inner-product argument of the previous proof.  An event does that without waiting for anyone else's streams (a hipDeviceSynchronize() here stalled
+  // every other thread's MSM pipelines once per proof).
+  if (hipEventRecord(c->ev_null, nullptr) != hipSuccess || hipStreamWaitEvent(s, c->ev_null, 0) != hipSuccess) return -ZKT_ERR_DEVICE;
   const int PW = 18;
   unsigned long long* noerr = nullptr;
   // scalar-field vectors on the device (canonical residues), simple arena of n-vectors and scalars
