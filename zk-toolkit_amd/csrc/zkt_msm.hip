@@ -73,9 +73,10 @@ MsmPlan msm_plan(size_t n, int grp) {
   b += (p.nbuckets + 1) * 4 * 3;          // counts, offsets, cursor
   b += 2 * ent * 4 + 256;                  // entries, slots
   b += p.nbuckets * XYW * 4;               // bucket sums
-  b += (2048 + 64) * XYW * 4;              // row/col sums, bit classes
+  b += (2048 + 64 * 4) * XYW * 4;          // row/col sums, bit classes (WB_SPLIT = 4 parts each)
   b += (1024 + 3 * 1025) * 4 + 2 * (p.nbuckets + 1) * 4;          // scan scratch, size bins, task counts/offsets
   b += (p.nbuckets + ent / p.chunk + 2) * (8 + XYW * 4);          // task list + partial sums of split buckets
+  b += 64 * 64 * XYW * 4 + 1024;                                  // block sums of hot buckets (k_merge_hot), hot list
   b += 4096;
   p.ws_bytes = b;
   p.direct = 0; p.half = p.nbuckets;
@@ -108,9 +109,10 @@ MsmPlan msm_plan_direct(size_t n, int grp) {
   p.chunk = pick_chunk(ent, grp);
   size_t b = 0;
   b += (p.nbuckets + 1) * 4 * 3 + 2 * ent * 4 + 256 + p.nbuckets * XYW * 4;
-  b += (size_t)p.nwin * (2048 + 64 + 1) * XYW * 4;               // per-window row/col sums, bit classes, window results
+  b += (size_t)p.nwin * (2048 + 64 * 4 + 1) * XYW * 4;           // per-window row/col sums, bit classes (4 parts each), window results
   b += (1024 + 3 * 1025) * 4 + 2 * (p.nbuckets + 1) * 4;
   b += (p.nbuckets + ent / p.chunk + 2) * (8 + XYW * 4);
+  b += 64 * 64 * XYW * 4 + 1024;
   b += 8192;
   p.ws_bytes = b;
   return p;
@@ -334,8 +336,12 @@ static __global__ void __launch_bounds__(256) k_task_count(const uint32_t* __res
   __syncthreads();
   for (int k = threadIdx.x; k < SIZE_BINS; k += 256) if (h[k]) atomicAdd(&hist[k], h[k]);
 }
+// Buckets cut into more than HOT_NT pieces (a witness full of one value; the carry window of a plan whose windows end exactly at the scalars' top bit: half of
+// all scalars then meet in bucket 0) are listed in hot[1..], hot[0] counting them: their partial sums are merged by 64 blocks each (k_merge_hot) instead
+// of one wave walking thousands of partials.  More than HOT_CAP of them: the list is ignored and k_merge_partials does them all.
+static constexpr uint32_t HOT_NT = 512, HOT_CAP = 64, HOT_FAN = 64;
 static __global__ void __launch_bounds__(256) k_task_scatter(const uint32_t* __restrict__ counts, size_t m, uint32_t chunk, const uint32_t* __restrict__ size_hist,
-                                                      uint32_t* __restrict__ bincur, uint2* __restrict__ order) {
+                                                      uint32_t* __restrict__ bincur, uint2* __restrict__ order, uint32_t* __restrict__ hot) {
   ZKT_SIDE_PRIO;
   // rank inside the block with LDS atomics, then ONE global atomic per (block, non-empty bin): ~50 distinct sizes
   // are shared by 2^19 buckets, so per-element global atomics would serialise.  The exclusive scan of the SIZE_BINS-entry
@@ -361,6 +367,7 @@ static __global__ void __launch_bounds__(256) k_task_scatter(const uint32_t* __r
     const uint32_t pos = base[bin] + rank;
     if (nt <= 16) { for (uint32_t k = 0; k < nt; ++k) order[pos + k] = make_uint2((uint32_t)i, k); }
     else { const uint32_t slot = atomicAdd(&hot_n, 1u); hot_b[slot] = (uint32_t)i; hot_pos[slot] = pos; hot_nt[slot] = nt; }      // a hot bucket: the whole block writes its tasks
+    if (nt > HOT_NT) { const uint32_t g = atomicAdd(&hot[0], 1u); if (g < HOT_CAP) hot[1 + g] = (uint32_t)i; }
   }
   __syncthreads();
   for (uint32_t hb = 0; hb < hot_n; ++hb) {
@@ -432,135 +439,11 @@ __global__ void __launch_bounds__(64) ZKT_ACC_ATTR k_accumulate(const uint32_t* 
 // ---------------------------------------------------------------------------------
 // bucket reduction  sum_b (b+1) S_b, b = hi*NLO + lo:
 //   = sum_lo (lo+1) C_lo + NLO * sum_hi hi * R_hi,   C_lo = sum_hi S, R_hi = sum_lo S
+// four lanes per point operation: msm_reduce_coop.h
 // ---------------------------------------------------------------------------------
-// block-level tree sum of one XYZZ per lane through LDS (RED_TPB lanes -> lane 0): log2 depth
-static constexpr int RED_TPB = 64;
-// The reduce kernels sum full XYZZ points (12M + 2S inlined): the G1 build used 255 VGPRs + 9 AGPRs, one wave per SIMD by nine registers, so the 1536
-// blocks of k_marginals ran in two rounds at the single-wave issue rate.  Capping them at two waves per SIMD costs a few dwords of scratch.
-#ifndef ZKT_RED_ATTR
-#define ZKT_RED_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
-#endif
-template <class F, int TPB = RED_TPB> __device__ inline Xyzz<F> block_tree_sum(Xyzz<F> v, uint32_t* lds /* TPB/2 * XYW words */) {
-  constexpr int XYW = 4 * Coord<F>::CW;
-  const int lane = threadIdx.x;
-  for (int d = TPB / 2; d >= 1; d >>= 1) {
-    if (lane >= d && lane < 2 * d) st_xy<F>(lds + (lane - d) * XYW, v);
-    __syncthreads();
-    if (lane < d) v = xyzz_add<F>(v, ld_xy<F>(lds + lane * XYW));
-    __syncthreads();
-  }
-  return v;
-}
-// hot buckets (more than one task): sums[b] = sum of the bucket's partials.  Blocks stride over the buckets; the test is
-// block-uniform, so the barrier inside the tree is safe.
-template <class F>
-__global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_merge_partials(const uint32_t* __restrict__ task_off, size_t nbuckets, const uint32_t* __restrict__ partial,
-                                                            uint32_t* __restrict__ sums) {
-  ZKT_SIDE_PRIO;
-  constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
-  __shared__ uint32_t lds[RED_TPB / 2 * XYW];
-  static_assert(RED_TPB == 64, "one wave per block: the ballot below covers the block");
-  constexpr uint32_t MERGE_LANE_MAX = 8;
-  // Every lane looks at one bucket of a 64-bucket tile (one coalesced read) and the wave then merges the split ones among them, one after the other.
-  // With uniform scalars no bucket is split and the kernel is one pass over task_off (a bucket per BLOCK iteration made this 0.15-0.2 ms of pure latency).
-  for (size_t b0 = (size_t)blockIdx.x * RED_TPB; b0 < nbuckets; b0 += (size_t)gridDim.x * RED_TPB) {
-    const size_t mine = b0 + threadIdx.x;
-    const uint32_t my_t0 = mine < nbuckets ? task_off[mine] : 0u, my_nt = mine < nbuckets ? task_off[mine + 1] - my_t0 : 1u;
-    // a bucket cut into a few pieces (small MSMs: every bucket is) is summed by its own lane, 64 buckets side by side; only hot buckets take the wave
-    if (my_nt > 1 && my_nt <= MERGE_LANE_MAX) {
-      XY acc = ld_xy<F>(partial + (size_t)my_t0 * XYW);
-      for (uint32_t k = 1; k < my_nt; ++k) acc = xyzz_add<F>(acc, ld_xy<F>(partial + (size_t)(my_t0 + k) * XYW));
-      st_xy<F>(sums + mine * XYW, acc);
-    }
-    unsigned long long todo = __ballot(my_nt > MERGE_LANE_MAX);
-    while (todo) {                                   // wave-uniform
-      const int l = __ffsll((long long)todo) - 1; todo &= todo - 1;
-      const size_t b = b0 + l;
-      const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
-      XY acc = xyzz_inf<F>();
-      for (uint32_t k = threadIdx.x; k < nt; k += RED_TPB) acc = xyzz_add<F>(acc, ld_xy<F>(partial + (size_t)(t0 + k) * XYW));
-      acc = block_tree_sum<F>(acc, lds);
-      if (threadIdx.x == 0) st_xy<F>(sums + b * XYW, acc);
-    }
-  }
-}
-
-// Both marginals of the NHI x NLO bucket matrix in ONE launch: blocks [0,NLO) produce the column sums C_lo = sum_hi S[hi][lo];
-// blocks [NLO, NLO + RS*NHI) the row sums, every row cut into RS pieces (rowsum[RS*hi + piece]) so that row and column blocks carry chains of
-// the same length — with NLO = 1024, NHI = 512 and RS = 2 all 2048 blocks sum 512 points (8 per lane + the tree) and fill two waves per SIMD.
-template <class F>
-__global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_marginals(const uint32_t* __restrict__ in, size_t NLO, size_t NHI, int RS,
-                                                       uint32_t* __restrict__ colsum, uint32_t* __restrict__ rowsum) {
-  ZKT_SIDE_PRIO;
-  constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
-  __shared__ uint32_t lds[RED_TPB / 2 * XYW];
-  const int lane = threadIdx.x;
-  in += (size_t)blockIdx.y * NLO * NHI * XYW; colsum += (size_t)blockIdx.y * 1024 * XYW; rowsum += (size_t)blockIdx.y * 1024 * XYW;   // grid.y = window (direct form)
-  const bool is_col = blockIdx.x < NLO;
-  const size_t o = is_col ? blockIdx.x : blockIdx.x - NLO;
-  const size_t piece = NLO / RS;
-  const size_t count = is_col ? NHI : piece, stride_j = is_col ? NLO : 1;
-  const size_t first = is_col ? o : (o / RS) * NLO + (o % RS) * piece;
-  XY acc = xyzz_inf<F>();
-  for (size_t j = lane; j < count; j += RED_TPB) acc = xyzz_add<F>(acc, ld_xy<F>(in + (first + j * stride_j) * XYW));
-  acc = block_tree_sum<F>(acc, lds);
-  if (lane == 0) st_xy<F>((is_col ? colsum : rowsum) + o * XYW, acc);
-}
-// Bit classes of both weighted sums in one launch: blocks [0,nbA) slice colsum by the bits of (lo+1),
-// blocks [nbA, nbA+nbB) slice the RS*NHI row pieces by the bits of hi = index / RS.  D[t] for the final combine: t = bit (A) or lo_bits + bit (B).
-// Only nbA + nbB (~20) blocks exist, so they are wide: WB_TPB lanes share a class (4 points per lane + an 8-level tree at 1024 entries).
-static constexpr int WB_TPB = 256;
-template <class F>
-__global__ void __launch_bounds__(WB_TPB) k_weight_bits(const uint32_t* __restrict__ colsum, size_t NLO, int nbA,
-                                                        const uint32_t* __restrict__ rowsum, size_t NROW, int RS, uint32_t* __restrict__ clsA, uint32_t* __restrict__ clsB) {
-  ZKT_SIDE_PRIO;
-  constexpr int XYW = 4 * Coord<F>::CW; typedef Xyzz<F> XY;
-  __shared__ uint32_t lds[WB_TPB / 2 * XYW];
-  const int lane = threadIdx.x;
-  colsum += (size_t)blockIdx.y * 1024 * XYW; rowsum += (size_t)blockIdx.y * 1024 * XYW; clsA += (size_t)blockIdx.y * 32 * XYW; clsB += (size_t)blockIdx.y * 32 * XYW;
-  const bool isA = (int)blockIdx.x < nbA;
-  const int bit = isA ? blockIdx.x : blockIdx.x - nbA;
-  const uint32_t* in = isA ? colsum : rowsum; const size_t m = isA ? NLO : NROW;
-  XY acc = xyzz_inf<F>();
-  for (size_t i = lane; i < m; i += WB_TPB) {
-    const uint32_t wgt = isA ? (uint32_t)i + 1u : (uint32_t)i / (uint32_t)RS;
-    if (wgt >> bit & 1) acc = xyzz_add<F>(acc, ld_xy<F>(in + i * XYW));
-  }
-  acc = block_tree_sum<F, WB_TPB>(acc, lds);
-  if (lane == 0) st_xy<F>((isA ? clsA : clsB) + bit * XYW, acc);
-}
-// total = sum_{b<=shift} 2^b A_b + 2^shift sum_b 2^b B_b = sum_t 2^t D_t with D_t = A_t (t<=shift) (+) B_{t-shift} (t>=shift).
-// One wave: lane t doubles D_t t times (<= 19 doublings instead of a 40-step serial Horner), then an LDS tree;
-// lane 0 writes the Jacobian sum and its affine normalisation.
-template <class F>
-__global__ void __launch_bounds__(64) k_combine(const uint32_t* __restrict__ clsA, int nbA, const uint32_t* __restrict__ clsB, int nbB, int shift,
-                                                uint32_t* __restrict__ out_jac, uint32_t* __restrict__ out_abi) {
-  ZKT_SIDE_PRIO;
-  constexpr int CW = Coord<F>::CW, XYW = 4 * CW; typedef Xyzz<F> XY;
-  __shared__ uint32_t lds[32 * XYW];
-  const int t = threadIdx.x;
-  clsA += (size_t)blockIdx.y * 32 * XYW; clsB += (size_t)blockIdx.y * 32 * XYW; out_jac += (size_t)blockIdx.y * XYW;      // window results are XYW apart
-  XY v = xyzz_inf<F>();
-  if (t < nbA) v = ld_xy<F>(clsA + t * XYW);
-  if (t >= shift && t - shift < nbB) v = xyzz_add<F>(v, ld_xy<F>(clsB + (t - shift) * XYW));
-  if (t >= 2 && t < 32 && !xyzz_is_inf(v)) {          // t doublings: in Jacobian coordinates (2M + 5S each against 6M + 3S), converted back for the tree
-    Jac<F> j = xyzz_to_jac<F>(v);
-    for (int d = 0; d < t; ++d) j = jac_dbl(j);
-    if (jac_is_inf(j)) v = xyzz_inf<F>();
-    else { v.X = j.X; v.Y = j.Y; v.ZZ = F::sqr(j.Z); v.ZZZ = F::mul(v.ZZ, j.Z); }
-  } else if (t == 1) v = xyzz_dbl<F>(v);
-  for (int d = 16; d >= 1; d >>= 1) {
-    if (t >= d && t < 2 * d) st_xy<F>(lds + (t - d) * XYW, v);
-    __syncthreads();
-    if (t < d) v = xyzz_add<F>(v, ld_xy<F>(lds + t * XYW));
-    __syncthreads();
-  }
-  if (t == 0) {
-    Jac<F> j = xyzz_to_jac<F>(v);
-    Coord<F>::st(out_jac, j.X); Coord<F>::st(out_jac + CW, j.Y); Coord<F>::st(out_jac + 2 * CW, j.Z);
-    if (out_abi) PtIO<F>::st(out_abi, xyzz_to_aff<F>(v));
-  }
-}
+}  // namespace zkt
+#include "msm_reduce_coop.h"
+namespace zkt {
 
 // direct form: total = sum_w 2^(c w) W_w.  One wave: lane w doubles its window result c*w times (the longest lane does the
 // c*(nwin-1) <= 256 doublings a serial Horner would), then an LDS tree; lane 0 writes the Jacobian sum and its affine normalisation.
@@ -591,8 +474,8 @@ __global__ void __launch_bounds__(64) k_join_windows(const uint32_t* __restrict_
 
 namespace {
 struct MsmWs {   // workspace carve-up (one per in-flight MSM)
-  uint32_t *zero_begin, *counts, *cursor, *size_hist, *size_off, *size_cur, *zero_end;   // [zero_begin, zero_end) is cleared per MSM
-  uint32_t *offsets, *entries, *slot, *sums, *colsum, *rowsum, *clsA, *clsB, *win_jac, *scan_tmp, *ntask, *task_off, *partial;
+  uint32_t *zero_begin, *counts, *cursor, *size_hist, *size_off, *size_cur, *hot, *zero_end;   // [zero_begin, zero_end) is cleared per MSM
+  uint32_t *offsets, *entries, *slot, *sums, *colsum, *rowsum, *clsA, *clsB, *win_jac, *scan_tmp, *ntask, *task_off, *partial, *hot_part;
   uint2* order; size_t max_tasks;
 };
 MsmWs carve(const MsmPlan& P, void* workspace) {
@@ -605,6 +488,7 @@ MsmWs carve(const MsmPlan& P, void* workspace) {
   w.size_hist = (uint32_t*)ws; ws += (SIZE_BINS + 1) * 4;
   w.size_off = (uint32_t*)ws; ws += (SIZE_BINS + 1) * 4;
   w.size_cur = (uint32_t*)ws; ws += (SIZE_BINS + 1) * 4;
+  w.hot = (uint32_t*)ws; ws += (HOT_CAP + 1) * 4;
   w.zero_end = (uint32_t*)ws;
   w.offsets = (uint32_t*)ws; ws += (B + 1) * 4;
   ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
@@ -616,8 +500,8 @@ MsmWs carve(const MsmPlan& P, void* workspace) {
   const size_t nw = P.direct ? (size_t)P.nwin : 1;                // the direct form reduces every window side by side
   w.colsum = (uint32_t*)ws; ws += nw * 1024 * XYW * 4;
   w.rowsum = (uint32_t*)ws; ws += nw * 1024 * XYW * 4;
-  w.clsA = (uint32_t*)ws; ws += nw * 32 * XYW * 4;
-  w.clsB = (uint32_t*)ws; ws += nw * 32 * XYW * 4;
+  w.clsA = (uint32_t*)ws; ws += nw * 32 * WB_SPLIT * XYW * 4;
+  w.clsB = (uint32_t*)ws; ws += nw * 32 * WB_SPLIT * XYW * 4;
   w.win_jac = (uint32_t*)ws; ws += nw * XYW * 4;
   w.scan_tmp = (uint32_t*)ws; ws += 1024 * 4;
   w.ntask = (uint32_t*)ws; ws += (B + 1) * 4;
@@ -626,6 +510,7 @@ MsmWs carve(const MsmPlan& P, void* workspace) {
   ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   w.order = (uint2*)ws; ws += w.max_tasks * 8;
   w.partial = (uint32_t*)ws; ws += w.max_tasks * XYW * 4;
+  w.hot_part = (uint32_t*)ws; ws += (size_t)HOT_CAP * HOT_FAN * XYW * 4;
   return w;
 }
 }  // namespace
@@ -647,7 +532,7 @@ hipError_t PART(launch_msm_sort)(const MsmPlan& P, const uint8_t* inf, const uin
   }
   hipLaunchKernelGGL(k_task_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, P.chunk, w.ntask, w.size_hist);
   launch_scan(w.ntask, w.task_off, B, w.scan_tmp, s);
-  hipLaunchKernelGGL(k_task_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, P.chunk, (const uint32_t*)w.size_hist, w.size_cur, w.order);
+  hipLaunchKernelGGL(k_task_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, P.chunk, (const uint32_t*)w.size_hist, w.size_cur, w.order, w.hot);
   return hipGetLastError();
 }
 // stage 2 (VALU bound, the dominant kernel): one bucket per lane
@@ -678,18 +563,20 @@ hipError_t PART(launch_msm_reduce)(const MsmPlan& P, void* workspace, uint32_t* 
   if (P.direct) {                                          // every window reduced side by side (grid.y), then joined
     const unsigned ny = (unsigned)P.nwin;
     MSM_DISPATCH(P.grp,
-      hipLaunchKernelGGL(k_merge_partials<F>, dim3((unsigned)((P.nbuckets + 63) / 64 < 2048 ? (P.nbuckets + 63) / 64 : 2048)), dim3(RED_TPB), 0, s, (const uint32_t*)w.task_off, P.nbuckets, (const uint32_t*)w.partial, w.sums);
+      hipLaunchKernelGGL(k_merge_hot<F>, dim3(HOT_FAN, HOT_CAP), dim3(RED_TPB), 0, s, (const uint32_t*)w.task_off, (const uint32_t*)w.partial, (const uint32_t*)w.hot, w.hot_part);
+      hipLaunchKernelGGL(k_merge_partials<F>, dim3((unsigned)((P.nbuckets + RED_NG - 1) / RED_NG < 4096 ? (P.nbuckets + RED_NG - 1) / RED_NG : 4096)), dim3(RED_TPB), 0, s, (const uint32_t*)w.task_off, P.nbuckets, (const uint32_t*)w.partial, (const uint32_t*)w.hot, (const uint32_t*)w.hot_part, w.sums);
       hipLaunchKernelGGL(k_marginals<F>, dim3((unsigned)(NLO + (NHI > 1 ? NROW : 0)), ny), dim3(RED_TPB), 0, s, (const uint32_t*)w.sums, NLO, NHI, RS, w.colsum, w.rowsum);
-      hipLaunchKernelGGL(k_weight_bits<F>, dim3((unsigned)(nbA + nbB), ny), dim3(WB_TPB), 0, s, (const uint32_t*)w.colsum, NLO, nbA, (const uint32_t*)w.rowsum, NROW, RS, w.clsA, w.clsB);
-      hipLaunchKernelGGL(k_combine<F>, dim3(1, ny), dim3(64), 0, s, (const uint32_t*)w.clsA, nbA, (const uint32_t*)w.clsB, nbB, lo_bits, w.win_jac, (uint32_t*)nullptr);
+      hipLaunchKernelGGL(k_weight_bits<F>, dim3((unsigned)(nbA + nbB) * WB_SPLIT, ny), dim3(WB_TPB), 0, s, (const uint32_t*)w.colsum, NLO, nbA, (const uint32_t*)w.rowsum, NHI, RS, w.clsA, w.clsB);
+      hipLaunchKernelGGL(k_combine<F>, dim3(1, ny), dim3(CMB_TPB), 0, s, (const uint32_t*)w.clsA, nbA, (const uint32_t*)w.clsB, nbB, lo_bits, w.win_jac, (uint32_t*)nullptr);
       hipLaunchKernelGGL(k_join_windows<F>, dim3(1), dim3(64), 0, s, (const uint32_t*)w.win_jac, P.nwin, P.c, dev_result_jac, dev_out_abi));
     return hipGetLastError();
   }
   MSM_DISPATCH(P.grp,
-    hipLaunchKernelGGL(k_merge_partials<F>, dim3((unsigned)((B + 63) / 64 < 2048 ? (B + 63) / 64 : 2048)), dim3(RED_TPB), 0, s, (const uint32_t*)w.task_off, B, (const uint32_t*)w.partial, w.sums);
+    hipLaunchKernelGGL(k_merge_hot<F>, dim3(HOT_FAN, HOT_CAP), dim3(RED_TPB), 0, s, (const uint32_t*)w.task_off, (const uint32_t*)w.partial, (const uint32_t*)w.hot, w.hot_part);
+    hipLaunchKernelGGL(k_merge_partials<F>, dim3((unsigned)((B + RED_NG - 1) / RED_NG < 4096 ? (B + RED_NG - 1) / RED_NG : 4096)), dim3(RED_TPB), 0, s, (const uint32_t*)w.task_off, B, (const uint32_t*)w.partial, (const uint32_t*)w.hot, (const uint32_t*)w.hot_part, w.sums);
     hipLaunchKernelGGL(k_marginals<F>, dim3((unsigned)(NLO + (NHI > 1 ? NROW : 0))), dim3(RED_TPB), 0, s, (const uint32_t*)w.sums, NLO, NHI, RS, w.colsum, w.rowsum);
-    hipLaunchKernelGGL(k_weight_bits<F>, dim3((unsigned)(nbA + nbB)), dim3(WB_TPB), 0, s, (const uint32_t*)w.colsum, NLO, nbA, (const uint32_t*)w.rowsum, NROW, RS, w.clsA, w.clsB);
-    hipLaunchKernelGGL(k_combine<F>, dim3(1), dim3(64), 0, s, (const uint32_t*)w.clsA, nbA, (const uint32_t*)w.clsB, nbB, lo_bits, dev_result_jac, dev_out_abi));
+    hipLaunchKernelGGL(k_weight_bits<F>, dim3((unsigned)(nbA + nbB) * WB_SPLIT), dim3(WB_TPB), 0, s, (const uint32_t*)w.colsum, NLO, nbA, (const uint32_t*)w.rowsum, NHI, RS, w.clsA, w.clsB);
+    hipLaunchKernelGGL(k_combine<F>, dim3(1), dim3(CMB_TPB), 0, s, (const uint32_t*)w.clsA, nbA, (const uint32_t*)w.clsB, nbB, lo_bits, dev_result_jac, dev_out_abi));
   return hipGetLastError();
 }
 
