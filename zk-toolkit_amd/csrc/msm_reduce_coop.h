@@ -9,9 +9,9 @@
 // Here a GROUP of four adjacent lanes performs one point operation.  The addition formulas (add-2008-s) have four independent products at
 // three of their four dependency levels, so a group runs an addition as FOUR rounds of ONE field multiplication per lane (a doubling as
 // three) instead of fourteen in sequence.  Operands live in numbered LDS slots of the group; a round is the same code for every lane —
-//     c = (slot[a1] - slot[a2]) * (slot[b1] - slot[b2])  ->  slot[d]
-// with the slot numbers read from a per-lane table (a2 / b2 name a slot holding zero where no difference is wanted), so there is no
-// divergence between the roles.  A lane holds two operands and one product at a time: ~120 VGPRs for Fq2, nothing spills.
+//     c = slot[a] * slot[b]  ->  slot[d]
+// with the slot numbers read from a per-lane table, so the multiplications (nine tenths of the work) run without divergence between the roles;
+// the few differences the formulas need (P = U2 - U1, R = S2 - S1, Q - X3) are made by the one lane that consumes them.  A lane holds two operands and one product at a time: ~120 VGPRs for Fq2, nothing spills.
 // The exceptional cases of the group law (macros.rs:43-63: an operand at infinity, P + P, P + (-P)) are detected by every lane of the group
 // from the same LDS values: infinity operands are a four-lane copy, P + (-P) a four-lane store, P + P the cooperative doubling.
 #pragma once
@@ -21,7 +21,7 @@ namespace zkt {
 template <class F> struct Coop {
   typedef typename F::E E;
   static constexpr int CW = Coord<F>::CW, SW = (CW + 3) & ~3;        // slot words: 16-byte aligned rows
-  enum Slot { AX = 0, AY, AZZ, AZZZ, BX, BY, BZZ, BZZZ, T0, T1, T2, T3, T4, T5, T6, T7, ZERO, NSLOT };
+  enum Slot { AX = 0, AY, AZZ, AZZZ, BX, BY, BZZ, BZZZ, T0, T1, T2, T3, T4, T5, T6, T7, NSLOT };
   static constexpr int GW = NSLOT * SW;                                // LDS words per group
   __device__ static E ld(const uint32_t* g, int slot) { return Coord<F>::ld(g + slot * SW); }
   __device__ static void st(uint32_t* g, int slot, const E& v) { Coord<F>::st(g + slot * SW, v); }
@@ -33,86 +33,80 @@ __device__ inline int pick4(int r, int a, int b, int c, int d) { return r == 0 ?
 template <class F> __device__ inline void coop_set_inf(uint32_t* g, int r) {         // A <- infinity (X = Y = 1, ZZ = ZZZ = 0), lane r writes coordinate r
   Coop<F>::st(g, Coop<F>::AX + r, r < 2 ? F::one() : F::zero());
 }
-template <class F> __device__ inline void coop_init(uint32_t* g, int r) {            // call once per kernel (then coop_sync): the zero slot, A = infinity
-  if (r == 0) Coop<F>::st(g, Coop<F>::ZERO, F::zero());
-  coop_set_inf<F>(g, r);
-}
+template <class F> __device__ inline void coop_init(uint32_t* g, int r) { coop_set_inf<F>(g, r); }      // A = infinity (then coop_sync)
 
-// A <- 2 A (dbl-2008-s-1), three rounds.  Same calling rule as coop_add.
+// flag of lane `src` (0..3) of the caller's group, for every lane of the group
+__device__ inline bool group_flag(bool f, int src) { return __shfl((int)f, (int)(threadIdx.x & ~3u) + src) != 0; }
+
+// A <- 2 A (dbl-2008-s-1), three rounds.  Every lane of the BLOCK must call it (it contains barriers); `active` = this group has a doubling
+// to do (divergence between the groups of a wave is fine: an idle group only keeps the barriers).
 template <class F> __device__ inline void coop_dbl(uint32_t* g, int r, bool active) {
   typedef Coop<F> K; typedef typename F::E E;
   bool inf = false;
   if (active) {
-    inf = F::is_zero(K::ld(g, K::AZZ)) || F::is_zero(K::ld(g, K::AY));          // infinity, or a point of order two (y = 0, macros.rs:61-63)
-    // round 1: V = U^2 with U = 2Y -> T0 (U -> T5);  XX = X^2 -> T1 (M = 3 XX -> T6)
-    const E x = K::ld(g, r == 0 ? K::AY : K::AX);
-    const E a = F::add(x, K::ld(g, r == 0 ? K::AY : K::ZERO));
-    const E c = F::mul(a, a);
-    if (r < 2) K::st(g, K::T0 + r, c);
-    if (r == 0) K::st(g, K::T5, a);
-    const E m = F::add(F::add(c, c), c);
-    if (r == 1) K::st(g, K::T6, m);
-  }
-  const bool ok = active && !inf;
-  coop_sync();
-  if (active) {
-    // round 2: W = U V -> T2, S = X V -> T3, MM = M^2 -> T4, ZZ3 = V ZZ -> AZZ
-    const E c = F::mul(K::ld(g, pick4(r, K::T5, K::AX, K::T6, K::T0)), K::ld(g, pick4(r, K::T0, K::T0, K::T6, K::AZZ)));
-    K::st(g, pick4(r, K::T2, K::T3, K::T4, K::AZZ), c);                 // (an infinite A is rewritten at the end)
+    // round 1: V = U^2 with U = 2Y -> T0 (U -> T5);  XX = X^2 -> T1 (M = 3 XX -> T6);  lanes 2, 3 test ZZ and Y for zero meanwhile
+    if (r < 2) {
+      E x = K::ld(g, r == 0 ? K::AY : K::AX);
+      if (r == 0) { x = F::add(x, x); K::st(g, K::T5, x); }
+      const E c = F::mul(x, x);
+      K::st(g, K::T0 + r, c);
+      if (r == 1) K::st(g, K::T6, F::add(F::add(c, c), c));
+    } else inf = F::is_zero(K::ld(g, r == 2 ? K::AZZ : K::AY));            // infinity, or a point of order two (y = 0, macros.rs:61-63)
+    inf = group_flag(inf, 2) || group_flag(inf, 3);
   }
   coop_sync();
   if (active) {
+    // round 2: W = U V -> T2, S = X V -> T3, MM = M^2 -> T4, ZZ3 = V ZZ -> AZZ (an infinite A is rewritten at the end)
+    K::st(g, pick4(r, K::T2, K::T3, K::T4, K::AZZ), F::mul(K::ld(g, pick4(r, K::T5, K::AX, K::T6, K::T0)), K::ld(g, pick4(r, K::T0, K::T0, K::T6, K::AZZ))));
+  }
+  coop_sync();
+  if (active && r < 3) {
     // round 3: X3 = MM - 2S -> AX;  ZZZ3 = W ZZZ -> AZZZ, WY = W Y -> T7, Y3a = M (S - X3) -> T1
-    const E x3 = F::sub2(K::ld(g, K::T4), K::ld(g, K::ZERO), K::ld(g, K::T3));
-    if (r == 2) K::st(g, K::AX, x3);
-    const E b = F::sub(K::ld(g, pick4(r, K::AZZZ, K::AY, K::T3, K::T3)), K::ld(g, pick4(r, K::ZERO, K::ZERO, K::AX, K::AX)));
-    const E c = F::mul(K::ld(g, pick4(r, K::T2, K::T2, K::T6, K::T6)), b);
-    if (r < 3) K::st(g, pick4(r, K::AZZZ, K::T7, K::T1, K::T1), c);
+    E b = K::ld(g, pick4(r, K::AZZZ, K::AY, K::T3, K::T3));
+    if (r == 2) { const E x3 = F::sub2(K::ld(g, K::T4), F::zero(), b); K::st(g, K::AX, x3); b = F::sub(b, x3); }
+    K::st(g, pick4(r, K::AZZZ, K::T7, K::T1, K::T1), F::mul(K::ld(g, pick4(r, K::T2, K::T2, K::T6, K::T6)), b));
   }
   coop_sync();
   if (active) {
-    if (ok) { if (r == 1) K::st(g, K::AY, F::sub(K::ld(g, K::T1), K::ld(g, K::T7))); }          // Y3 = M (S - X3) - W Y
-    else coop_set_inf<F>(g, r);
+    if (inf) coop_set_inf<F>(g, r);
+    else if (r == 1) K::st(g, K::AY, F::sub(K::ld(g, K::T1), K::ld(g, K::T7)));                // Y3 = M (S - X3) - W Y
   }
   coop_sync();
 }
 
-// A <- A + B for the group's XYZZ points in slots A*, B* (B is clobbered).  Every lane of the BLOCK must call it (it contains barriers);
-// `active` = this group has an addition to do (wave-divergent between groups is fine: an idle group only keeps the barriers).
+// A <- A + B for the group's XYZZ points in slots A*, B* (B is clobbered), four rounds.  Same calling rule.
 template <class F> __device__ inline void coop_add(uint32_t* g, int r, bool active) {
   typedef Coop<F> K; typedef typename F::E E;
-  bool infA = false, infB = false, eqx = false, eqy = false;
+  bool infA = false, infB = false, eqx = false, eqy = false, ok = false;
   if (active) {
-    infA = F::is_zero(K::ld(g, K::AZZ)); infB = F::is_zero(K::ld(g, K::BZZ));
-    // round 1: U1 = X1 ZZ2, U2 = X2 ZZ1, S1 = Y1 ZZZ2, S2 = Y2 ZZZ1
-    const E a = K::ld(g, pick4(r, K::AX, K::BX, K::AY, K::BY)), b = K::ld(g, pick4(r, K::BZZ, K::AZZ, K::BZZZ, K::AZZZ));
-    K::st(g, K::T0 + r, F::mul(a, b));
+    // round 1: U1 = X1 ZZ2 -> T0, U2 = X2 ZZ1 -> T1, S1 = Y1 ZZZ2 -> T2, S2 = Y2 ZZZ1 -> T3; lanes 0 / 1 test ZZ1 / ZZ2 for zero on the way
+    const E b = K::ld(g, pick4(r, K::BZZ, K::AZZ, K::BZZZ, K::AZZZ));
+    const bool z = r < 2 && F::is_zero(b);
+    infB = group_flag(z, 0); infA = group_flag(z, 1);
+    K::st(g, K::T0 + r, F::mul(K::ld(g, pick4(r, K::AX, K::BX, K::AY, K::BY)), b));
   }
   coop_sync();
   if (active) {
-    // round 2: ZZ12 = ZZ1 ZZ2, ZZZ12 = ZZZ1 ZZZ2, PP = P^2, RR = R^2 with P = U2 - U1, R = S2 - S1
-    eqx = F::is_zero(F::sub(K::ld(g, K::T1), K::ld(g, K::T0))); eqy = F::is_zero(F::sub(K::ld(g, K::T3), K::ld(g, K::T2)));
-    const E a = F::sub(K::ld(g, pick4(r, K::AZZ, K::AZZZ, K::T1, K::T3)), K::ld(g, pick4(r, K::ZERO, K::ZERO, K::T0, K::T2)));
-    const E b = F::sub(K::ld(g, pick4(r, K::BZZ, K::BZZZ, K::T1, K::T3)), K::ld(g, pick4(r, K::ZERO, K::ZERO, K::T0, K::T2)));
+    // round 2: ZZ12 = ZZ1 ZZ2 -> T4, ZZZ12 = ZZZ1 ZZZ2 -> T5, PP = P^2 -> T6, RR = R^2 -> T7 with P = U2 - U1 -> T1, R = S2 - S1 -> T3
+    E a = K::ld(g, pick4(r, K::AZZ, K::AZZZ, K::T1, K::T3)), b;
+    bool z = false;
+    if (r >= 2) { a = F::sub(a, K::ld(g, r == 2 ? K::T0 : K::T2)); z = F::is_zero(a); K::st(g, r == 2 ? K::T1 : K::T3, a); b = a; }
+    else b = K::ld(g, r == 0 ? K::BZZ : K::BZZZ);
+    eqx = group_flag(z, 2); eqy = group_flag(z, 3);
     K::st(g, K::T4 + r, F::mul(a, b));
+    ok = !infA && !infB && !eqx;                                         // the generic case: results overwrite A (and the dead B slots) from here on
   }
-  const bool ok = active && !infA && !infB && !eqx;                     // the generic case: results overwrite A (and the dead B slots) from here on
   coop_sync();
-  if (active) {
+  if (ok && r < 3) {
     // round 3: PPP = P PP -> BX, Q = U1 PP -> BY, ZZ3 = ZZ12 PP -> AZZ
-    const E a = F::sub(K::ld(g, pick4(r, K::T1, K::T0, K::T4, K::T4)), K::ld(g, pick4(r, K::T0, K::ZERO, K::ZERO, K::ZERO)));
-    const E c = F::mul(a, K::ld(g, K::T6));
-    if (ok && r < 3) K::st(g, pick4(r, K::BX, K::BY, K::AZZ, K::AZZ), c);
+    K::st(g, pick4(r, K::BX, K::BY, K::AZZ, K::AZZ), F::mul(K::ld(g, pick4(r, K::T1, K::T0, K::T4, K::T4)), K::ld(g, K::T6)));
   }
   coop_sync();
-  if (active) {
+  if (ok && r < 3) {
     // round 4: X3 = RR - PPP - 2Q -> AX;  ZZZ3 = ZZZ12 PPP -> AZZZ, T = S1 PPP -> BZZ, Y3a = R (Q - X3) -> BZZZ
-    const E x3 = F::sub2(K::ld(g, K::T7), K::ld(g, K::BX), K::ld(g, K::BY));
-    if (ok && r == 2) K::st(g, K::AX, x3);
-    const E a = F::sub(K::ld(g, pick4(r, K::T5, K::T2, K::T3, K::T3)), K::ld(g, pick4(r, K::ZERO, K::ZERO, K::T2, K::T2)));
-    const E b = F::sub(K::ld(g, pick4(r, K::BX, K::BX, K::BY, K::BY)), K::ld(g, pick4(r, K::ZERO, K::ZERO, K::AX, K::AX)));
-    const E c = F::mul(a, b);
-    if (ok && r < 3) K::st(g, pick4(r, K::AZZZ, K::BZZ, K::BZZZ, K::BZZZ), c);
+    E b = K::ld(g, pick4(r, K::BX, K::BX, K::BY, K::BY));
+    if (r == 2) { const E x3 = F::sub2(K::ld(g, K::T7), K::ld(g, K::BX), b); K::st(g, K::AX, x3); b = F::sub(b, x3); }
+    K::st(g, pick4(r, K::AZZZ, K::BZZ, K::BZZZ, K::BZZZ), F::mul(K::ld(g, pick4(r, K::T5, K::T2, K::T3, K::T3)), b));
   }
   coop_sync();
   if (active) {
@@ -150,13 +144,32 @@ template <class F, int NG> __device__ inline void coop_block_tree(uint32_t* lds,
 // the reduce kernels
 // ---------------------------------------------------------------------------------
 static constexpr int RED_TPB = 64, RED_NG = RED_TPB / 4;             // one wave = 16 groups per block
+// two waves per SIMD for every reduce kernel: the one-lane bulk phase of the prime-field kernels would take 280 registers (one wave per SIMD, the
+// 2048 marginal blocks of a 2^20-term MSM in two rounds) and the Fq2 kernels 257 — capped at 256 they keep a few dwords in scratch instead
 #ifndef ZKT_RED_ATTR
-#define ZKT_RED_ATTR
+#define ZKT_RED_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
 
-// sum of `count` points in[(first + j * stride) * XYW], j < count, by the NG groups of the block -> A of group 0
-template <class F, int NG> __device__ inline void coop_block_sum(uint32_t* lds, int grp, int r, const uint32_t* __restrict__ in, size_t first, size_t stride, size_t count) {
+// Where the one-lane XYZZ addition fits the register file (the prime-field groups) a LONG list is first summed one point per lane — every lane busy,
+// no exchange — and only the 4 * NG lane sums go through the groups: the cooperative form pays ~15 % in idle lane-rounds and LDS traffic, which is
+// the wrong trade while there is a point for every lane (marginals of a 2^20-term MSM: 512 points per block).  For Fq2 the one-lane addition
+// spills several hundred registers, so G2 stays cooperative throughout.
+template <class F> struct CoopBulk { static constexpr bool serial = false; };
+template <class C> struct CoopBulk<PrimeOps<C>> { static constexpr bool serial = true; };
+template <class F, int NG> struct CoopStage { static constexpr int WORDS = CoopBulk<F>::serial ? 4 * NG * 4 * Coord<F>::CW : 4; };
+
+// sum of `count` points in[(first + j * stride) * XYW], j < count, by the NG groups of the block (4 * NG lanes) -> A of group 0
+template <class F, int NG> __device__ inline void coop_block_sum(uint32_t* lds, uint32_t* stage, int grp, int r, const uint32_t* in, size_t first, size_t stride, size_t count) {
   typedef Coop<F> K; constexpr int XYW = 4 * Coord<F>::CW;
+  if constexpr (CoopBulk<F>::serial) {
+    if (count > (size_t)4 * NG) {                                       // block-uniform
+      Xyzz<F> acc = xyzz_inf<F>();
+      for (size_t j = threadIdx.x; j < count; j += 4 * NG) acc = xyzz_add<F>(acc, ld_xy<F>(in + (first + j * stride) * XYW));
+      st_xy<F>(stage + (size_t)threadIdx.x * XYW, acc);
+      coop_sync();
+      in = stage; first = 0; stride = 1; count = 4 * NG;                // the groups sum the lane sums
+    }
+  }
   uint32_t* g = lds + grp * K::GW;
   coop_init<F>(g, r);
   coop_sync();
@@ -207,13 +220,13 @@ __global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_merge_partials(const u
   ZKT_SIDE_PRIO;
   typedef Coop<F> K; constexpr int XYW = 4 * Coord<F>::CW;
   __shared__ __attribute__((aligned(16))) uint32_t lds[RED_NG * K::GW];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[CoopStage<F, RED_NG>::WORDS];
   static_assert(RED_TPB == 64 && HOT_CAP <= 64, "one wave per block: the ballots below cover the block");
   constexpr uint32_t MERGE_GROUP_MAX = 8;
   const int grp = threadIdx.x >> 2, r = threadIdx.x & 3;
   uint32_t* g = lds + grp * K::GW;
   const uint32_t hc = hot[0];
   const uint32_t my_hot = threadIdx.x < hc && hc <= HOT_CAP ? hot[1 + threadIdx.x] : 0xffffffffu;
-  if (r == 0) K::st(g, K::ZERO, F::zero());
   for (size_t b0 = (size_t)blockIdx.x * RED_NG; b0 < nbuckets; b0 += (size_t)gridDim.x * RED_NG) {
     const size_t mine = b0 + grp;
     const uint32_t my_t0 = mine < nbuckets ? task_off[mine] : 0u, my_nt = mine < nbuckets ? task_off[mine + 1] - my_t0 : 1u;
@@ -241,7 +254,7 @@ __global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_merge_partials(const u
       const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
       const unsigned long long listed = __ballot(my_hot == (uint32_t)b);
       // a listed hot bucket: the HOT_FAN block sums of k_merge_hot; any other: its partials
-      coop_block_sum<F, RED_NG>(lds, grp, r, listed ? hot_part : partial, listed ? (size_t)(__ffsll((long long)listed) - 1) * HOT_FAN : (size_t)t0, 1, listed ? (size_t)HOT_FAN : (size_t)nt);
+      coop_block_sum<F, RED_NG>(lds, stage, grp, r, listed ? hot_part : partial, listed ? (size_t)(__ffsll((long long)listed) - 1) * HOT_FAN : (size_t)t0, 1, listed ? (size_t)HOT_FAN : (size_t)nt);
       if (grp == 0) coop_store<F>(lds, r, sums + b * XYW);
       coop_sync();
     }
@@ -257,6 +270,7 @@ __global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_marginals(const uint32
   ZKT_SIDE_PRIO;
   typedef Coop<F> K; constexpr int XYW = 4 * Coord<F>::CW;
   __shared__ __attribute__((aligned(16))) uint32_t lds[RED_NG * K::GW];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[CoopStage<F, RED_NG>::WORDS];
   const int grp = threadIdx.x >> 2, r = threadIdx.x & 3;
   in += (size_t)blockIdx.y * NLO * NHI * XYW; colsum += (size_t)blockIdx.y * 1024 * XYW; rowsum += (size_t)blockIdx.y * 1024 * XYW;   // grid.y = window (direct form)
   const bool is_col = blockIdx.x < NLO;
@@ -264,7 +278,7 @@ __global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_marginals(const uint32
   const size_t piece = NLO / RS;
   const size_t count = is_col ? NHI : piece, stride_j = is_col ? NLO : 1;
   const size_t first = is_col ? o : (o / RS) * NLO + (o % RS) * piece;
-  coop_block_sum<F, RED_NG>(lds, grp, r, in, first, stride_j, count);
+  coop_block_sum<F, RED_NG>(lds, stage, grp, r, in, first, stride_j, count);
   if (grp == 0) coop_store<F>(lds, r, (is_col ? colsum : rowsum) + o * XYW);
 }
 
@@ -274,7 +288,7 @@ __global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_marginals(const uint32
 static constexpr int WB_TPB = 128, WB_NG = WB_TPB / 4, WB_SPLIT = 4;
 __device__ inline uint32_t insert_one(uint32_t q, int bit) { return ((q >> bit) << (bit + 1)) | (1u << bit) | (q & ((1u << bit) - 1u)); }
 template <class F>
-__global__ void __launch_bounds__(WB_TPB) k_weight_bits(const uint32_t* __restrict__ colsum, size_t NLO, int nbA,
+__global__ void __launch_bounds__(WB_TPB) ZKT_RED_ATTR k_weight_bits(const uint32_t* __restrict__ colsum, size_t NLO, int nbA,
                                                         const uint32_t* __restrict__ rowsum, size_t NHI, int RS, uint32_t* __restrict__ clsA, uint32_t* __restrict__ clsB) {
   ZKT_SIDE_PRIO;
   typedef Coop<F> K; constexpr int XYW = 4 * Coord<F>::CW;
