@@ -151,34 +151,39 @@ static constexpr int RED_TPB = 64, RED_NG = RED_TPB / 4;             // one wave
 #endif
 
 // Where the one-lane XYZZ addition fits the register file (the prime-field groups) a LONG list is first summed one point per lane — every lane busy,
-// no exchange — and only the 4 * NG lane sums go through the groups: the cooperative form pays ~15 % in idle lane-rounds and LDS traffic, which is
+// no exchange — and only the 4 * NG lane sums (each group's own four) go through the groups: the cooperative form pays ~15 % in idle lane-rounds and LDS traffic, which is
 // the wrong trade while there is a point for every lane (marginals of a 2^20-term MSM: 512 points per block).  For Fq2 the one-lane addition
 // spills several hundred registers, so G2 stays cooperative throughout.
 template <class F> struct CoopBulk { static constexpr bool serial = false; };
 template <class C> struct CoopBulk<PrimeOps<C>> { static constexpr bool serial = true; };
-template <class F, int NG> struct CoopStage { static constexpr int WORDS = CoopBulk<F>::serial ? 4 * NG * 4 * Coord<F>::CW : 4; };
 
 // sum of `count` points in[(first + j * stride) * XYW], j < count, by the NG groups of the block (4 * NG lanes) -> A of group 0
-template <class F, int NG> __device__ inline void coop_block_sum(uint32_t* lds, uint32_t* stage, int grp, int r, const uint32_t* in, size_t first, size_t stride, size_t count) {
+template <class F, int NG> __device__ inline void coop_block_sum(uint32_t* lds, int grp, int r, const uint32_t* __restrict__ in, size_t first, size_t stride, size_t count) {
   typedef Coop<F> K; constexpr int XYW = 4 * Coord<F>::CW;
-  if constexpr (CoopBulk<F>::serial) {
-    if (count > (size_t)4 * NG) {                                       // block-uniform
+  uint32_t* g = lds + grp * K::GW;
+  bool bulk = false;
+  if constexpr (CoopBulk<F>::serial) bulk = count > (size_t)4 * NG;     // block-uniform
+  if (bulk) {
+    if constexpr (CoopBulk<F>::serial) {
       Xyzz<F> acc = xyzz_inf<F>();
       for (size_t j = threadIdx.x; j < count; j += 4 * NG) acc = xyzz_add<F>(acc, ld_xy<F>(in + (first + j * stride) * XYW));
-      st_xy<F>(stage + (size_t)threadIdx.x * XYW, acc);
-      coop_sync();
-      in = stage; first = 0; stride = 1; count = 4 * NG;                // the groups sum the lane sums
-    }
-  }
-  uint32_t* g = lds + grp * K::GW;
-  coop_init<F>(g, r);
-  coop_sync();
+      // the four lane sums of a group are that group's first four points: lane 0's goes to A, the others to B one after the other
 #pragma unroll 1
-  for (size_t j0 = 0; j0 < count; j0 += NG) {                          // block-uniform trip count
-    const size_t j = j0 + grp; const bool act = j < count;
-    if (act) coop_load<F>(g, r, K::BX, in + (first + j * stride) * XYW);
+      for (int k = 0; k < 4; ++k) {
+        if (r == k) { const int base = k == 0 ? K::AX : K::BX; K::st(g, base, acc.X); K::st(g, base + 1, acc.Y); K::st(g, base + 2, acc.ZZ); K::st(g, base + 3, acc.ZZZ); }
+        if (k) { coop_sync(); coop_add<F>(g, r, true); }
+      }
+    }
+  } else {
+    coop_init<F>(g, r);
     coop_sync();
-    coop_add<F>(g, r, act);
+#pragma unroll 1
+    for (size_t j0 = 0; j0 < count; j0 += NG) {                        // block-uniform trip count
+      const size_t j = j0 + grp; const bool act = j < count;
+      if (act) coop_load<F>(g, r, K::BX, in + (first + j * stride) * XYW);
+      coop_sync();
+      coop_add<F>(g, r, act);
+    }
   }
   coop_block_tree<F, NG>(lds, grp, r);
 }
@@ -220,7 +225,6 @@ __global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_merge_partials(const u
   ZKT_SIDE_PRIO;
   typedef Coop<F> K; constexpr int XYW = 4 * Coord<F>::CW;
   __shared__ __attribute__((aligned(16))) uint32_t lds[RED_NG * K::GW];
-  __shared__ __attribute__((aligned(16))) uint32_t stage[CoopStage<F, RED_NG>::WORDS];
   static_assert(RED_TPB == 64 && HOT_CAP <= 64, "one wave per block: the ballots below cover the block");
   constexpr uint32_t MERGE_GROUP_MAX = 8;
   const int grp = threadIdx.x >> 2, r = threadIdx.x & 3;
@@ -254,7 +258,7 @@ __global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_merge_partials(const u
       const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
       const unsigned long long listed = __ballot(my_hot == (uint32_t)b);
       // a listed hot bucket: the HOT_FAN block sums of k_merge_hot; any other: its partials
-      coop_block_sum<F, RED_NG>(lds, stage, grp, r, listed ? hot_part : partial, listed ? (size_t)(__ffsll((long long)listed) - 1) * HOT_FAN : (size_t)t0, 1, listed ? (size_t)HOT_FAN : (size_t)nt);
+      coop_block_sum<F, RED_NG>(lds, grp, r, listed ? hot_part : partial, listed ? (size_t)(__ffsll((long long)listed) - 1) * HOT_FAN : (size_t)t0, 1, listed ? (size_t)HOT_FAN : (size_t)nt);
       if (grp == 0) coop_store<F>(lds, r, sums + b * XYW);
       coop_sync();
     }
@@ -270,7 +274,6 @@ __global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_marginals(const uint32
   ZKT_SIDE_PRIO;
   typedef Coop<F> K; constexpr int XYW = 4 * Coord<F>::CW;
   __shared__ __attribute__((aligned(16))) uint32_t lds[RED_NG * K::GW];
-  __shared__ __attribute__((aligned(16))) uint32_t stage[CoopStage<F, RED_NG>::WORDS];
   const int grp = threadIdx.x >> 2, r = threadIdx.x & 3;
   in += (size_t)blockIdx.y * NLO * NHI * XYW; colsum += (size_t)blockIdx.y * 1024 * XYW; rowsum += (size_t)blockIdx.y * 1024 * XYW;   // grid.y = window (direct form)
   const bool is_col = blockIdx.x < NLO;
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_marginals(const uint32
   const size_t piece = NLO / RS;
   const size_t count = is_col ? NHI : piece, stride_j = is_col ? NLO : 1;
   const size_t first = is_col ? o : (o / RS) * NLO + (o % RS) * piece;
-  coop_block_sum<F, RED_NG>(lds, stage, grp, r, in, first, stride_j, count);
+  coop_block_sum<F, RED_NG>(lds, grp, r, in, first, stride_j, count);
   if (grp == 0) coop_store<F>(lds, r, (is_col ? colsum : rowsum) + o * XYW);
 }
 
