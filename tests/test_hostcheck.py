@@ -65,10 +65,20 @@ def test_field_ops(H, field, mod, w, pre):
     es = [rng.below(mod) for _ in range(len(xs) - 3)] + [0, 1, mod - 1]
     assert H.zkt_hostcheck_fp(field, 8, p32(a), p32(ints_to_arr(es, w)), p32(o), len(xs)) == 0
     assert arr_to_ints(o) == [pow(x, e, mod) for x, e in zip(xs, es)]
-    for op in (5, 6):                                  # binary-Euclid inverse and x^(p-2) through fp_pow
+    for op in (5, 6, 9, 10):                           # fp_inv (word-step binary GCD), x^(p-2) through fp_pow, the classic bit-step Euclid, the word-step GCD on canonical words
         o = np.zeros_like(nz)
         assert H.zkt_hostcheck_fp(field, op, p32(nz), None, p32(o), len(nz)) == 0
         assert arr_to_ints(o) == [pow(x, -1, mod) for x in arr_to_ints(nz)], op
+    # the word-step GCD on inputs that stress its approximations: tiny values, values around 2^31 / 2^62 / word boundaries, p - small, (p +- 1) / 2,
+    # all-ones patterns and 3000 random residues (a wrong factor matrix would leave b != 1 and take the fallback: results are compared with python's pow)
+    edge = [1, 2, 3, mod - 1, mod - 2, (mod - 1) // 2, (mod + 1) // 2, 2**31 - 1, 2**31, 2**31 + 1, 2**62 - 1, 2**62, 2**63, 2**64 - 1, 2**64, 2**64 + 1]
+    edge += [2**k for k in range(1, mod.bit_length() - 1, 7)] + [mod - 2**k for k in range(1, mod.bit_length() - 2, 11)] + [(1 << k) - 1 for k in range(2, mod.bit_length() - 1, 13)]
+    edge += [rng.below(mod) for _ in range(3000)] + [rng.below(2**64) + 1 for _ in range(200)] + [mod - 1 - rng.below(2**64) for _ in range(200)]
+    e = ints_to_arr([x % mod for x in edge if x % mod], w); o = np.zeros_like(e)
+    assert H.zkt_hostcheck_fp(field, 10, p32(e), None, p32(o), len(e)) == 0
+    assert arr_to_ints(o) == [pow(x, -1, mod) for x in arr_to_ints(e)]
+    H.zkt_hostcheck_bgcd_fallbacks.restype = ctypes.c_ulong
+    assert H.zkt_hostcheck_bgcd_fallbacks() == 0, "the word-step GCD fell back to the classic loop"
 
 
 def _fq_program_model(seed, steps, regs):

@@ -8,12 +8,15 @@
 using namespace zkt;
 
 extern "C" {
+unsigned long zkt_hostcheck_bgcd_fallbacks() { return bgcd_fallbacks(); }      // 0 expected: the word-step GCD always ends with b = 1
 int zkt_hostcheck_fq_program(uint64_t seed, int steps, const uint32_t* in4, uint32_t* out4) { return fq_program(seed, steps, in4, out4); }
-// op: 0 add 1 sub 2 mul 3 sqr 4 neg 5 inv (binary Euclid) 6 inv as x^(p-2) through fp_pow 7 cube 8 pow (b = exponent, ABI_N words per element)
+// op: 0 add 1 sub 2 mul 3 sqr 4 neg 5 inv (fp_inv: the word-step binary GCD) 6 inv as x^(p-2) through fp_pow 7 cube 8 pow (b = exponent, ABI_N words per element)
+//     9 the classic bit-step binary Euclid on canonical words (bgcd_inverse_classic), 10 the word-step GCD on canonical words (bgcd_inverse)
 int zkt_hostcheck_fp(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n) {
   auto run = [&](auto tag) {
     typedef decltype(tag) C;
     for (size_t i = 0; i < n; ++i) {
+      if (op == 9 || op == 10) { uint32_t w[C::ABI_N]; for (int j = 0; j < C::ABI_N; ++j) w[j] = a[i * C::ABI_N + j]; if (op == 9) bgcd_inverse_classic<C>(w); else bgcd_inverse<C>(w); for (int j = 0; j < C::ABI_N; ++j) o[i * C::ABI_N + j] = w[j]; continue; }
       Fp<C> x = ld_fp<C>(a + i * C::ABI_N), y = b ? ld_fp<C>(b + i * C::ABI_N) : fp_zero<C>(), r;
       switch (op) {
         case 0: r = fp_add(x, y); break; case 1: r = fp_sub(x, y); break; case 2: r = fp_mul(x, y); break;
