@@ -515,27 +515,67 @@ template <class C> ZKT_HD void bgcd_inverse(uint32_t* io) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) minv *= 2u - C::mod32(0) * minv;
   minv = (0u - minv) & 0x7fffffffu;                      // -p^-1 mod 2^31
-  // |x f + y g| as N + 1 words (x, y < 2^(32N), |f|, |g| <= 2^31) and its sign
-  auto lincomb = [&](const uint32_t* x, const uint32_t* y, int64_t f, int64_t g, uint32_t* t) -> bool {
-    const bool sf = f < 0, sg = g < 0;
-    const uint32_t uf = (uint32_t)(sf ? -f : f), ug = (uint32_t)(sg ? -g : g);
-    uint32_t P[N + 1], Q[N + 1]; uint64_t cp = 0, cq = 0;
+  // (x f + y g) / 2^31 for x, y < 2^(32N) and |f| + |g| <= 2^31, streamed limb by limb in two's complement: every partial sum
+  // carry + x_i f + y_i g lies in [-2^63, 2^63), so one signed 64-bit accumulator carries it.  The low 31 bits of the sum are zero by construction
+  // of (f, g); |result| < 2^(32N).  Writes the magnitude, returns the sign.  (No N-word temporaries: with them the function took 270 registers and,
+  // called three levels deep from k_tower_op<12>, trampled its callers' live registers on this compiler.)
+  auto comb_shift = [&](const uint32_t* x, const uint32_t* y, int64_t f, int64_t g, uint32_t* out) -> bool {
+    const uint64_t uf = (uint64_t)f, ug = (uint64_t)g;
+    uint64_t acc = (uint64_t)x[0] * uf + (uint64_t)y[0] * ug;
+    uint32_t prev = (uint32_t)acc; int64_t carry = (int64_t)acc >> 32;
 #pragma unroll
-    for (int i = 0; i < N; ++i) { cp += (uint64_t)x[i] * uf; P[i] = (uint32_t)cp; cp >>= 32; cq += (uint64_t)y[i] * ug; Q[i] = (uint32_t)cq; cq >>= 32; }
-    P[N] = (uint32_t)cp; Q[N] = (uint32_t)cq;
-    if (sf == sg) {
-      uint32_t c = 0;
-#pragma unroll
-      for (int i = 0; i <= N; ++i) t[i] = addc(P[i], Q[i], c);
-      return sf;
+    for (int i = 1; i < N; ++i) {
+      acc = (uint64_t)carry + (uint64_t)x[i] * uf + (uint64_t)y[i] * ug;
+      const uint32_t w = (uint32_t)acc; carry = (int64_t)acc >> 32;
+      out[i - 1] = (prev >> 31) | (w << 1); prev = w;
     }
-    uint32_t bw = 0;
+    out[N - 1] = (prev >> 31) | ((uint32_t)carry << 1);
+    const bool neg = carry < 0;
+    if (neg) { uint32_t c = 1;
 #pragma unroll
-    for (int i = 0; i <= N; ++i) t[i] = subb(P[i], Q[i], bw);          // P - Q; a borrow means Q - P is the magnitude
-    if (bw) { uint32_t c = 1;
+      for (int i = 0; i < N; ++i) out[i] = addc(~out[i], 0u, c); }
+    return neg;
+  };
+  // (x f + y g) / 2^31 mod p for x, y < p: q p is added so that the low 31 bits vanish (q = -(x f + y g) / p mod 2^31), in a second carry chain
+  // beside the signed one; the quotient lies in (-p, 2p) and is brought into [0, p); `flip` negates the result (the row's sign was turned).
+  auto comb_mont = [&](const uint32_t* x, const uint32_t* y, int64_t f, int64_t g, bool flip, uint32_t* out) {
+    const uint64_t uf = (uint64_t)f, ug = (uint64_t)g;
+    uint64_t a1 = (uint64_t)x[0] * uf + (uint64_t)y[0] * ug;
+    const uint32_t q = ((uint32_t)a1 * minv) & 0x7fffffffu;
+    uint64_t a2 = (uint64_t)q * C::mod32(0);
+    uint64_t w = (uint64_t)(uint32_t)a1 + (uint32_t)a2;                // low word of the sum: its low 31 bits are zero
+    uint32_t prev = (uint32_t)w; uint64_t cw = w >> 32;
+    int64_t c1 = (int64_t)a1 >> 32; uint64_t c2 = a2 >> 32;
+    uint32_t r[N];
 #pragma unroll
-      for (int i = 0; i <= N; ++i) t[i] = addc(~t[i], 0u, c); }
-    return sf ? !bw : (bw != 0);                                       // sign of (sf ? -P : P) + (sg ? -Q : Q)
+    for (int i = 1; i < N; ++i) {
+      a1 = (uint64_t)c1 + (uint64_t)x[i] * uf + (uint64_t)y[i] * ug; c1 = (int64_t)a1 >> 32;
+      a2 = c2 + (uint64_t)q * C::mod32(i); c2 = a2 >> 32;
+      w = (uint64_t)(uint32_t)a1 + (uint32_t)a2 + cw; cw = w >> 32;
+      r[i - 1] = (prev >> 31) | ((uint32_t)w << 1); prev = (uint32_t)w;
+    }
+    const int64_t top = c1 + (int64_t)c2 + (int64_t)cw;               // the words above 2^(32N): |top| < 2^32
+    r[N - 1] = (prev >> 31) | ((uint32_t)top << 1);
+    const int64_t hi = top >> 31;                                       // the quotient is hi * 2^(32N) + r, hi in {-1, 0, 1}
+    uint32_t s2[N], bw = 0, c = 0;
+    if (hi < 0) {                                                       // negative: + p
+#pragma unroll
+      for (int i = 0; i < N; ++i) r[i] = addc(r[i], C::mod32(i), c);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) s2[i] = subb(r[i], C::mod32(i), bw);
+      const bool ge = hi > 0 || !bw;
+#pragma unroll
+      for (int i = 0; i < N; ++i) r[i] = ge ? s2[i] : r[i];
+    }
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) nz |= r[i];
+    if (flip && nz) { bw = 0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) r[i] = subb(C::mod32(i), r[i], bw); }
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = r[i];
   };
 #pragma unroll 1
   for (int it = 0; it < ITER; ++it) {
@@ -565,36 +605,11 @@ template <class C> ZKT_HD void bgcd_inverse(uint32_t* io) {
       xa -= xb & odd; f0 -= f1 & (int64_t)odd; g0 -= g1 & (int64_t)odd;
       xa >>= 1; f1 <<= 1; g1 <<= 1;
     }
-    uint32_t ta[N + 1], tb[N + 1];
-    const bool na = lincomb(a, b, f0, g0, ta), nb = lincomb(a, b, f1, g1, tb);
+    uint32_t na[N], nb[N], nu[N], nv[N];
+    const bool sa = comb_shift(a, b, f0, g0, na), sb = comb_shift(a, b, f1, g1, nb);
+    comb_mont(u, v, f0, g0, sa, nu); comb_mont(u, v, f1, g1, sb, nv);                 // cofactors: same rows, negated where a row's result was
 #pragma unroll
-    for (int i = 0; i < N; ++i) { a[i] = (ta[i] >> 31) | (ta[i + 1] << 1); b[i] = (tb[i] >> 31) | (tb[i + 1] << 1); }
-    // cofactors: (u f + v g) / 2^31 mod p, negated where the row was
-    uint32_t tu[N + 1], tv[N + 1];
-    const bool nu = lincomb(u, v, f0, g0, tu) != na, nv = lincomb(u, v, f1, g1, tv) != nb;
-    auto mont31 = [&](uint32_t* t, bool neg, uint32_t* out) {
-      const uint32_t q = (t[0] * minv) & 0x7fffffffu;
-      uint64_t c = 0;
-#pragma unroll
-      for (int i = 0; i < N; ++i) { c += (uint64_t)q * C::mod32(i) + t[i]; t[i] = (uint32_t)c; c >>= 32; }
-      t[N] += (uint32_t)c;
-      uint32_t r[N], s2[N], bw = 0;
-#pragma unroll
-      for (int i = 0; i < N; ++i) { r[i] = (t[i] >> 31) | (t[i + 1] << 1); }
-      const uint32_t top = t[N] >> 31;                                   // value < 2p < 2^(32N+1)
-#pragma unroll
-      for (int i = 0; i < N; ++i) s2[i] = subb(r[i], C::mod32(i), bw);
-      const bool ge = top || !bw;
-      uint32_t nz = 0;
-#pragma unroll
-      for (int i = 0; i < N; ++i) { r[i] = ge ? s2[i] : r[i]; nz |= r[i]; }
-      if (neg && nz) { bw = 0;
-#pragma unroll
-        for (int i = 0; i < N; ++i) r[i] = subb(C::mod32(i), r[i], bw); }
-#pragma unroll
-      for (int i = 0; i < N; ++i) out[i] = r[i];
-    };
-    mont31(tu, nu, u); mont31(tv, nv, v);
+    for (int i = 0; i < N; ++i) { a[i] = na[i]; b[i] = nb[i]; u[i] = nu[i]; v[i] = nv[i]; }
   }
   uint32_t rest = b[0] ^ 1u;
 #pragma unroll
