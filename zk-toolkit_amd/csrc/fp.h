@@ -627,17 +627,30 @@ template <class C> ZKT_HD void bgcd_inverse(uint32_t* io) {
 // In: a*R (Montgomery), non-zero.  Out: a^-1*R.
 // W = 32: the integer inverse of a*R is a^-1*R^-1; one Montgomery product with R^3 lifts it back.
 // W = 28: leave the Montgomery domain (canonical words), invert, re-enter.
+// Which loop: the word-step GCD for the 8-word fields everywhere, and for Fq in the objects built with -DZKT_WORDSTEP_INV_FQ (the MSM objects, where
+// fp_inv is called straight from a kernel).  In the tower / pairing objects Fq keeps the classic loop ON PURPOSE: there fp_inv sits below functions that
+// realign their stack (fq6_inv, fq12_inv, the final exponentiation: 64-byte aligned Fq6 temporaries) and keep their incoming stack pointer in s34, the
+// base-pointer register — and this compiler's inter-procedural register allocation does not keep s34 out of the hands of their callees.  The word-step
+// loop writes s0..s91; fq2_inv, which holds a modulus limb in an SGPR across its call to fp_inv, was thereby pushed to s34, fq6_inv returned with a
+// trampled base pointer and the next callee faulted on its first stack store (rocgdb, round 3).  The classic loop stays below s34.
+template <class C> ZKT_HD void fp_inverse_words(uint32_t* w) {
+#if defined(ZKT_WORDSTEP_INV_FQ)
+  bgcd_inverse<C>(w);
+#else
+  if constexpr (C::W == 28) bgcd_inverse_classic<C>(w); else bgcd_inverse<C>(w);
+#endif
+}
 template <class C> ZKT_FN Fp<C> fp_inv(Fp<C> a) {
   uint32_t w[C::ABI_N];
   if constexpr (C::W == 28) {
     fp_to_words(a, w);
-    bgcd_inverse<C>(w);
+    fp_inverse_words<C>(w);
     return fp_from_words<C>(w);
   } else {
     Fp<C> r, r3;
 #pragma unroll
     for (int i = 0; i < C::N; ++i) w[i] = a.v[i];
-    bgcd_inverse<C>(w);
+    fp_inverse_words<C>(w);
 #pragma unroll
     for (int i = 0; i < C::N; ++i) { r.v[i] = w[i]; r3.v[i] = C::r3(i); }
     return fp_mul(r, r3);
