@@ -10,6 +10,7 @@ type Bin = unsafe extern "C" fn(*const u64, *const u64, *mut u64, usize) -> i32;
 type Un = unsafe extern "C" fn(*const u64, *mut u64, usize) -> i32;
 type Pow = unsafe extern "C" fn(*const u64, *const u64, usize, i32, *mut u64, usize) -> i32;
 type Seq = unsafe extern "C" fn(*const u64, usize, *mut u64) -> i32;
+type Sum = unsafe extern "C" fn(*const u64, usize, *mut u64) -> i32;
 
 /// one of the reference's `PrimeField`s: its order lives in the library, its entry points here
 pub trait FieldSpec: Clone + std::fmt::Debug + PartialEq + Eq {
@@ -17,6 +18,7 @@ pub trait FieldSpec: Clone + std::fmt::Debug + PartialEq + Eq {
     const ADD: Bin; const SUB: Bin; const MUL: Bin;
     const SQR: Un; const CUBE: Un; const NEG: Un; const INV: Un;
     const POW: Pow; const POW_SEQ: Seq; const REPEAT: Seq;
+    const SUM: Sum; const SCALE: Bin;
     fn order() -> BigUint;
 }
 macro_rules! field_spec {
@@ -28,18 +30,19 @@ macro_rules! field_spec {
 }
 // no proc-macro dependencies: the entry-point names are spelled out
 macro_rules! paste_field {
-    ($name:ident, $limbs:expr, fq, $order:expr) => { impl_spec!($name, $limbs, $order, zkt_fq_add_batch, zkt_fq_sub_batch, zkt_fq_mul_batch, zkt_fq_sqr_batch, zkt_fq_cube_batch, zkt_fq_neg_batch, zkt_fq_inv_batch, zkt_fq_pow_batch, zkt_fq_pow_seq, zkt_fq_repeat); };
-    ($name:ident, $limbs:expr, fr, $order:expr) => { impl_spec!($name, $limbs, $order, zkt_fr_add_batch, zkt_fr_sub_batch, zkt_fr_mul_batch, zkt_fr_sqr_batch, zkt_fr_cube_batch, zkt_fr_neg_batch, zkt_fr_inv_batch, zkt_fr_pow_batch, zkt_fr_pow_seq, zkt_fr_repeat); };
-    ($name:ident, $limbs:expr, sp, $order:expr) => { impl_spec!($name, $limbs, $order, zkt_sp_add_batch, zkt_sp_sub_batch, zkt_sp_mul_batch, zkt_sp_sqr_batch, zkt_sp_cube_batch, zkt_sp_neg_batch, zkt_sp_inv_batch, zkt_sp_pow_batch, zkt_sp_pow_seq, zkt_sp_repeat); };
-    ($name:ident, $limbs:expr, sn, $order:expr) => { impl_spec!($name, $limbs, $order, zkt_sn_add_batch, zkt_sn_sub_batch, zkt_sn_mul_batch, zkt_sn_sqr_batch, zkt_sn_cube_batch, zkt_sn_neg_batch, zkt_sn_inv_batch, zkt_sn_pow_batch, zkt_sn_pow_seq, zkt_sn_repeat); };
+    ($name:ident, $limbs:expr, fq, $order:expr) => { impl_spec!($name, $limbs, $order, zkt_fq_add_batch, zkt_fq_sub_batch, zkt_fq_mul_batch, zkt_fq_sqr_batch, zkt_fq_cube_batch, zkt_fq_neg_batch, zkt_fq_inv_batch, zkt_fq_pow_batch, zkt_fq_pow_seq, zkt_fq_repeat, zkt_fq_sum, zkt_fq_scale_batch); };
+    ($name:ident, $limbs:expr, fr, $order:expr) => { impl_spec!($name, $limbs, $order, zkt_fr_add_batch, zkt_fr_sub_batch, zkt_fr_mul_batch, zkt_fr_sqr_batch, zkt_fr_cube_batch, zkt_fr_neg_batch, zkt_fr_inv_batch, zkt_fr_pow_batch, zkt_fr_pow_seq, zkt_fr_repeat, zkt_fr_sum, zkt_fr_scale_batch); };
+    ($name:ident, $limbs:expr, sp, $order:expr) => { impl_spec!($name, $limbs, $order, zkt_sp_add_batch, zkt_sp_sub_batch, zkt_sp_mul_batch, zkt_sp_sqr_batch, zkt_sp_cube_batch, zkt_sp_neg_batch, zkt_sp_inv_batch, zkt_sp_pow_batch, zkt_sp_pow_seq, zkt_sp_repeat, zkt_sp_sum, zkt_sp_scale_batch); };
+    ($name:ident, $limbs:expr, sn, $order:expr) => { impl_spec!($name, $limbs, $order, zkt_sn_add_batch, zkt_sn_sub_batch, zkt_sn_mul_batch, zkt_sn_sqr_batch, zkt_sn_cube_batch, zkt_sn_neg_batch, zkt_sn_inv_batch, zkt_sn_pow_batch, zkt_sn_pow_seq, zkt_sn_repeat, zkt_sn_sum, zkt_sn_scale_batch); };
 }
 macro_rules! impl_spec {
-    ($name:ident, $limbs:expr, $order:expr, $add:ident, $sub:ident, $mul:ident, $sqr:ident, $cube:ident, $neg:ident, $inv:ident, $pow:ident, $seq:ident, $rep:ident) => {
+    ($name:ident, $limbs:expr, $order:expr, $add:ident, $sub:ident, $mul:ident, $sqr:ident, $cube:ident, $neg:ident, $inv:ident, $pow:ident, $seq:ident, $rep:ident, $sum:ident, $scale:ident) => {
         impl FieldSpec for $name {
             const LIMBS: usize = $limbs;
             const ADD: Bin = ffi::$add; const SUB: Bin = ffi::$sub; const MUL: Bin = ffi::$mul;
             const SQR: Un = ffi::$sqr; const CUBE: Un = ffi::$cube; const NEG: Un = ffi::$neg; const INV: Un = ffi::$inv;
             const POW: Pow = ffi::$pow; const POW_SEQ: Seq = ffi::$seq; const REPEAT: Seq = ffi::$rep;
+            const SUM: Sum = ffi::$sum; const SCALE: Bin = ffi::$scale;
             fn order() -> BigUint { BigUint::parse_bytes($order, 16).unwrap() }
         }
     };
@@ -180,4 +183,81 @@ impl<F: FieldSpec> Neg for PrimeFieldElem<F> {
 impl<'a, F: FieldSpec> Neg for &'a PrimeFieldElem<F> {
     type Output = PrimeFieldElem<F>;
     fn neg(self) -> PrimeFieldElem<F> { self.negate() }
+}
+
+/// `PrimeField` (building_block/field/prime_field.rs:14-100): the field as a value, as the reference passes it around.  The order lives in the
+/// library; what a caller needs from the value are `elem` and the entropy draws of `rand_elem` (prime_field.rs:73-85: ceil(bits / 8) random
+/// big-endian bytes reduced mod the order, redrawn while zero if `exclude_zero`).  Entropy: the OS source (`/dev/urandom`), as `RandomNumber`
+/// (building_block/random_number.rs:8-13) seeds from it.
+#[derive(Clone, Debug, PartialEq, Eq)]
+pub struct PrimeField<F: FieldSpec> { _f: PhantomData<F> }
+impl<F: FieldSpec> PrimeField<F> {
+    pub fn new() -> Self { PrimeField { _f: PhantomData } }
+    pub fn order(&self) -> BigUint { F::order() }
+    pub fn elem(&self, x: &impl ToBigUint) -> PrimeFieldElem<F> { PrimeFieldElem::new(x) } // prime_field.rs:44-46
+    pub fn rand_elem(&self, exclude_zero: bool) -> PrimeFieldElem<F> {
+        use std::io::Read;
+        let buf_size = ((F::order().bits() as f64) / 8f64).ceil() as usize;
+        let mut buf = vec![0u8; buf_size];
+        loop {
+            std::fs::File::open("/dev/urandom").and_then(|mut f| f.read_exact(&mut buf)).expect("OS entropy");
+            let x = PrimeFieldElem::<F>::new(&BigUint::from_bytes_be(&buf));
+            if !exclude_zero || !x.is_zero() { return x; }
+        }
+    }
+    pub fn rand_elems(&self, n: &usize, exclude_zero: bool) -> PrimeFieldElems<F> { // prime_field.rs:87-90
+        PrimeFieldElems((0..*n).map(|_| self.rand_elem(exclude_zero)).collect())
+    }
+}
+
+/// `PrimeFieldElems` (building_block/field/prime_field_elems.rs:13-175): a vector of field elements with element-wise `+ - *`, `* scalar`
+/// and `sum` — each ONE batched call into the library.
+#[derive(Clone, Debug, PartialEq, Eq)]
+pub struct PrimeFieldElems<F: FieldSpec>(pub Vec<PrimeFieldElem<F>>);
+impl<F: FieldSpec> PrimeFieldElems<F> {
+    pub fn new(xs: &[PrimeFieldElem<F>]) -> Self { PrimeFieldElems(xs.to_vec()) } // :30-32
+    pub fn len(&self) -> usize { self.0.len() }
+    pub fn is_empty(&self) -> bool { self.0.is_empty() }
+    /// :35-41 — panics on an empty vector, as the reference's assert does
+    pub fn sum(&self) -> PrimeFieldElem<F> {
+        assert!(self.0.len() > 0);
+        let fa = PrimeFieldElem::<F>::flatten(&self.0);
+        let mut out = vec![0u64; F::LIMBS];
+        check(unsafe { F::SUM(fa.as_ptr(), self.0.len(), out.as_mut_ptr()) });
+        PrimeFieldElem::from_canonical_limbs(&out)
+    }
+    /// :43-54 / :56-67
+    pub fn from(&self, idx: usize) -> Self { if idx >= self.len() { panic!("index outside the range is specified"); } PrimeFieldElems(self.0[idx..].to_vec()) }
+    pub fn to(&self, idx: usize) -> Self { if idx > self.len() { panic!("index outside the range is specified"); } PrimeFieldElems(self.0[..idx].to_vec()) }
+    /// :152-175 — every element times ONE scalar
+    pub fn scale(&self, k: &PrimeFieldElem<F>) -> Self {
+        assert!(self.len() > 0);
+        let fa = PrimeFieldElem::<F>::flatten(&self.0);
+        let mut out = vec![0u64; fa.len()];
+        check(unsafe { F::SCALE(fa.as_ptr(), k.limbs.as_ptr(), out.as_mut_ptr(), self.len()) });
+        PrimeFieldElems(PrimeFieldElem::unflatten(&out))
+    }
+}
+impl<F: FieldSpec> std::ops::Index<usize> for PrimeFieldElems<F> { type Output = PrimeFieldElem<F>; fn index(&self, i: usize) -> &PrimeFieldElem<F> { &self.0[i] } }
+macro_rules! impl_vec_op {
+    ($tr:ident, $f:ident, $batch:ident) => {
+        impl<'a, F: FieldSpec> $tr<&'a PrimeFieldElems<F>> for &'a PrimeFieldElems<F> { // prime_field_elems.rs:90-150
+            type Output = PrimeFieldElems<F>;
+            fn $f(self, rhs: &PrimeFieldElems<F>) -> PrimeFieldElems<F> { assert!(self.len() > 0 && self.len() == rhs.len()); PrimeFieldElems(PrimeFieldElem::$batch(&self.0, &rhs.0)) }
+        }
+    };
+}
+impl_vec_op!(Add, add, add_batch);
+impl_vec_op!(Sub, sub, sub_batch);
+impl_vec_op!(Mul, mul, mul_batch);
+impl<'a, F: FieldSpec> Mul<&'a PrimeFieldElem<F>> for &'a PrimeFieldElems<F> { type Output = PrimeFieldElems<F>; fn mul(self, k: &PrimeFieldElem<F>) -> PrimeFieldElems<F> { self.scale(k) } }
+
+/// `SparseVec` (building_block/field/sparse_vec.rs:15-31): size + the non-zero entries; what `Verifier::verify` takes as the statement wires
+#[derive(Clone, Debug)]
+pub struct SparseVec<F: FieldSpec> { pub size: usize, pub elems: std::collections::HashMap<usize, PrimeFieldElem<F>> }
+impl<F: FieldSpec> SparseVec<F> {
+    pub fn new(size: usize) -> Self { SparseVec { size, elems: std::collections::HashMap::new() } } // :53-64
+    pub fn set(&mut self, index: usize, n: &PrimeFieldElem<F>) { if index >= self.size { panic!("Index {} is out of range. The size of vector is {}", index, self.size); } if !n.is_zero() { self.elems.insert(index, n.clone()); } } // :70-79
+    pub fn get(&self, index: usize) -> PrimeFieldElem<F> { if index >= self.size { panic!("Index {} is out of range. The size of vector is {}", index, self.size); } self.elems.get(&index).cloned().unwrap_or_else(<PrimeFieldElem<F> as NumZero>::zero) } // :81-91
+    pub fn to_dense(&self) -> Vec<PrimeFieldElem<F>> { (0..self.size).map(|i| self.get(i)).collect() }
 }

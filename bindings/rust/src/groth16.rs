@@ -4,7 +4,7 @@
 //! The reference draws alpha, beta, gamma, delta, x (crs.rs:59-63) and r, s (prover.rs:100-101) from OS entropy inside; a drop-in
 //! caller keeps doing that and passes the draws in here (`Trapdoor`, `r`, `s`), which is also what makes results reproducible.
 use crate::ffi::{self, zkt_g1_affine, zkt_g2_affine, zkt_groth16_crs, zkt_sparse_rows};
-use crate::field::Fr;
+use crate::field::{Bls12R, Fr, PrimeField, SparseVec};
 use crate::pairing::{GTPoint, Pairing};
 use crate::points::{G1Point, G2Point};
 use crate::tower::{Fq12, Limbs};
@@ -63,8 +63,16 @@ fn dense(polys: &[Vec<Fr>], n: usize) -> Vec<u64> {
 
 impl CRS {
     fn gt_limbs(&self) -> Vec<u64> { self.gt.alpha_beta.e_clone().to_vec() }
-    /// CRS::new (crs.rs:49-146) with the trapdoor injected
-    pub fn new(n: usize, l: usize, m: usize, ui: &[Vec<Fr>], vi: &[Vec<Fr>], wi: &[Vec<Fr>], t: &Trapdoor) -> Self {
+    /// `CRS::new` with the reference's signature (crs.rs:49-53): draws alpha, beta, gamma, delta, x from `f.rand_elem(true)` in that order (crs.rs:59-63)
+    /// and builds sigma from the prover's QAP polynomials.  (`pairing` is what the reference uses for `e(alpha, beta)`, crs.rs:137-139: the library
+    /// computes the same `Pairing::tate` value.)
+    pub fn new(f: &PrimeField<Bls12R>, prover: &Prover, pairing: &Pairing) -> Self {
+        let _ = pairing;
+        let t = Trapdoor { alpha: f.rand_elem(true), beta: f.rand_elem(true), gamma: f.rand_elem(true), delta: f.rand_elem(true), x: f.rand_elem(true) };
+        CRS::new_with_trapdoor(prover.n, prover.l, prover.m, &prover.ui, &prover.vi, &prover.wi, &t)
+    }
+    /// CRS::new (crs.rs:49-146) with the trapdoor injected (reproducible; what the parity tests drive)
+    pub fn new_with_trapdoor(n: usize, l: usize, m: usize, ui: &[Vec<Fr>], vi: &[Vec<Fr>], wi: &[Vec<Fr>], t: &Trapdoor) -> Self {
         init();
         let mut buf = CrsBuf::new(n, l, m);
         let mut view = buf.view(n, l, m);
@@ -75,10 +83,17 @@ impl CRS {
     }
 }
 
-pub struct Prover { pub n: usize, pub l: usize, pub m: usize, pub wires: Vec<Fr>, pub h: Vec<Fr>, pub ui: Vec<Vec<Fr>>, pub vi: Vec<Vec<Fr>> } // prover.rs:35-46
+/// prover.rs:35-46.  Polynomials are coefficient vectors, low degree first; `Prover::new` (equation parser -> gates -> R1CS -> QAP, prover.rs:48-94) is the
+/// reference's symbolic front end and stays there (out of scope): a drop-in caller fills this struct from the QAP it already builds.
+pub struct Prover { pub f: PrimeField<Bls12R>, pub n: usize, pub l: usize, pub m: usize, pub wires: Vec<Fr>, pub h: Vec<Fr>, pub t: Vec<Fr>, pub ui: Vec<Vec<Fr>>, pub vi: Vec<Vec<Fr>>, pub wi: Vec<Vec<Fr>> }
 impl Prover {
+    /// `Prover::prove` with the reference's signature (prover.rs:96): draws r, s from `self.f.rand_elem(true)` (prover.rs:100-101)
+    pub fn prove(&self, crs: &CRS) -> Proof {
+        let (r, s) = (self.f.rand_elem(true), self.f.rand_elem(true));
+        self.prove_with(crs, &r, &s)
+    }
     /// Prover::prove (prover.rs:96-147), r and s injected
-    pub fn prove(&self, crs: &CRS, r: &Fr, s: &Fr) -> Proof {
+    pub fn prove_with(&self, crs: &CRS, r: &Fr, s: &Fr) -> Proof {
         init();
         let mut buf = CrsBuf::from_crs(crs);
         let view = buf.view(self.n, self.l, self.m);
@@ -93,8 +108,10 @@ impl Prover {
 pub struct Verifier { #[allow(dead_code)] pairing: Pairing } // verifier.rs:19-22
 impl Verifier {
     pub fn new(pairing: &Pairing) -> Self { Verifier { pairing: pairing.clone() } } // :24-28
+    /// `Verifier::verify` with the reference's signature (verifier.rs:30-35): the statement wires a_0..a_l as a SparseVec
+    pub fn verify(&self, proof: &Proof, crs: &CRS, stmt_wires: &SparseVec<Bls12R>) -> bool { self.verify_dense(proof, crs, &stmt_wires.to_dense()) }
     /// Verifier::verify (verifier.rs:30-54): e(A,B) == alpha_beta * e(sum stmt_i uvw_stmt_i, gamma) * e(C, delta)
-    pub fn verify(&self, proof: &Proof, crs: &CRS, stmt_wires: &[Fr]) -> bool {
+    pub fn verify_dense(&self, proof: &Proof, crs: &CRS, stmt_wires: &[Fr]) -> bool {
         init();
         let mut buf = CrsBuf::from_crs(crs);
         let view = buf.view(crs.n, crs.l, crs.m);

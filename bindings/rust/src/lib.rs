@@ -27,9 +27,9 @@ pub mod bulletproofs;
 pub mod signature;
 pub mod comm;
 
-pub use field::{Fq1, Fr, SecpFq, SecpFr, PrimeFieldElem};
+pub use field::{Fq1, Fr, SecpFq, SecpFr, PrimeField, PrimeFieldElem, PrimeFieldElems, SparseVec};
 pub use tower::{Fq2, Fq6, Fq12};
-pub use points::{G1Point, G2Point, SecpPoint};
+pub use points::{AffinePoint, AffinePoints, G1Point, G2Point, SecpPoint};
 pub use pairing::{GTPoint, Pairing};
 pub use polynomial::{Polynomial, G1Bases, G2Bases};
 pub use bulletproofs::Bulletproofs;

@@ -123,3 +123,55 @@ impl<'a> Neg for &'a G2Point {
     type Output = G2Point;
     fn neg(self) -> G2Point { init(); let (p, mut o) = (self.to_raw(), G2Point::zero_raw()); check(unsafe { ffi::zkt_g2_neg_batch(&p, &mut o, 1) }); G2Point::from_raw(&o) }
 }
+
+/// `AffinePoint` / `AffinePoints` of the reference's secp256k1 module (curves/secp256k1/{affine_point.rs, affine_points.rs:10-144}): the names the
+/// Bulletproofs code is written against.  `sum` and the two products are one batched library call each.
+pub type AffinePoint = SecpPoint;
+#[derive(Clone, Debug)]
+pub struct AffinePoints { pub points: Vec<AffinePoint> }
+impl AffinePoints {
+    pub fn new(points: &Vec<AffinePoint>) -> Self { AffinePoints { points: points.clone() } } // affine_points.rs:19-23
+    pub fn len(&self) -> usize { self.points.len() }
+    pub fn is_empty(&self) -> bool { self.points.is_empty() }
+    /// :25-31 — the fold from AffinePoint::zero(): an empty vector sums to the point at infinity
+    pub fn sum(&self) -> AffinePoint {
+        init();
+        let raw: Vec<zkt_secp_affine> = self.points.iter().map(|p| p.to_raw()).collect();
+        let mut o = SecpPoint::zero_raw();
+        check(unsafe { ffi::zkt_secp_sum(raw.as_ptr(), raw.len(), &mut o) });
+        SecpPoint::from_raw(&o)
+    }
+    pub fn from(&self, idx: usize) -> Self { AffinePoints { points: self.points[idx..].to_vec() } } // :50-60
+    pub fn to(&self, idx: usize) -> Self { AffinePoints { points: self.points[..idx].to_vec() } } // :62-72
+    /// :105-122 — every point times ONE scalar
+    pub fn scale<F: FieldSpec>(&self, k: &PrimeFieldElem<F>) -> Self {
+        init();
+        let raw: Vec<zkt_secp_affine> = self.points.iter().map(|p| p.to_raw()).collect();
+        let mut out = vec![SecpPoint::zero_raw(); raw.len()];
+        check(unsafe { ffi::zkt_secp_scale_batch(raw.as_ptr(), k.limbs.as_ptr(), F::LIMBS as i32, out.as_mut_ptr(), raw.len()) });
+        AffinePoints { points: out.iter().map(SecpPoint::from_raw).collect() }
+    }
+    /// :124-144 — point i times scalar i
+    pub fn mul_each<F: FieldSpec>(&self, ks: &[PrimeFieldElem<F>]) -> Self {
+        init();
+        if self.points.len() != ks.len() { panic!("Tried to multiply PrimeFieldElems of different size to AffinePoints"); }
+        let raw: Vec<zkt_secp_affine> = self.points.iter().map(|p| p.to_raw()).collect();
+        let k = PrimeFieldElem::<F>::flatten(ks);
+        let mut out = vec![SecpPoint::zero_raw(); raw.len()];
+        check(unsafe { ffi::zkt_secp_mul_batch(raw.as_ptr(), k.as_ptr(), F::LIMBS as i32, out.as_mut_ptr(), raw.len()) });
+        AffinePoints { points: out.iter().map(SecpPoint::from_raw).collect() }
+    }
+}
+impl<'a> Add<&'a AffinePoints> for &'a AffinePoints { // :84-103
+    type Output = AffinePoints;
+    fn add(self, rhs: &AffinePoints) -> AffinePoints {
+        init();
+        if self.len() != rhs.len() { panic!("Tried to add AffinePoints of diffrent length"); }
+        let (a, b): (Vec<zkt_secp_affine>, Vec<zkt_secp_affine>) = (self.points.iter().map(|p| p.to_raw()).collect(), rhs.points.iter().map(|p| p.to_raw()).collect());
+        let mut out = vec![SecpPoint::zero_raw(); a.len()];
+        check(unsafe { ffi::zkt_secp_add_batch(a.as_ptr(), b.as_ptr(), out.as_mut_ptr(), a.len()) });
+        AffinePoints { points: out.iter().map(SecpPoint::from_raw).collect() }
+    }
+}
+impl<'a, F: FieldSpec> Mul<&'a PrimeFieldElem<F>> for &'a AffinePoints { type Output = AffinePoints; fn mul(self, k: &PrimeFieldElem<F>) -> AffinePoints { self.scale(k) } }
+impl<'a, F: FieldSpec> Mul<&'a crate::field::PrimeFieldElems<F>> for &'a AffinePoints { type Output = AffinePoints; fn mul(self, ks: &crate::field::PrimeFieldElems<F>) -> AffinePoints { self.mul_each(&ks.0) } }

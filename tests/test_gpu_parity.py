@@ -601,3 +601,35 @@ def test_point_vector_sum_and_scalar_broadcast(L, grp, name, W, order):
         assert getattr(O, f"zkto_{name}_mul_batch")(ptr(pts), ptr(np.repeat(kk, n, axis=0)), 4, ptr(want), n, 8) == 0
         assert (got == want).all(), (name, k)
     zk.check(getattr(L, f"zkt_{name}_scale_batch")(pts.ctypes.data, kk.ctypes.data, 4, got.ctypes.data, 0))      # empty vector: allowed (no assert in the reference)
+
+
+def test_tate_dev_from_many_caller_streams(L):
+    """zkt_tate_batch_dev driven from EIGHT streams of the caller in one process: the pairing kernels keep 10-17 KB of scratch per
+    lane, which the runtime retains per hardware queue (5-6 GiB each) — so the library runs them on its own staging stream, ordered behind the caller's
+    stream by an event, whatever stream the caller names.  All eight results (inputs produced on the caller's stream just before) equal the host-pointer
+    call; device memory retained afterwards stays far below eight queues' worth of scratch."""
+    import torch
+    n = 256
+    rng = SplitMix64(9090)
+    g1 = np.repeat(_gen(0), n, axis=0); g2 = np.repeat(_gen(1), n, axis=0)
+    kp = ints_to_arr([rng.below(R) for _ in range(n)], 4); kq = ints_to_arr([rng.below(R) for _ in range(n)], 4)
+    P, Qs = np.zeros_like(g1), np.zeros_like(g2)
+    zk.check(L.zkt_g1_mul_batch(ptr(g1), ptr(kp), 4, ptr(P), n)); zk.check(L.zkt_g2_mul_batch(ptr(g2), ptr(kq), 4, ptr(Qs), n))
+    want = np.zeros((n, FQ12), np.uint64); zk.check(L.zkt_tate_batch(ptr(P), ptr(Qs), ptr(want), n))
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    free0 = torch.cuda.mem_get_info()[0]
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    outs = []
+    for k, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            # the inputs are produced ON the caller's stream (a copy + a roll that puts them back in place), so the ordering event matters
+            d_p = torch.roll(torch.roll(torch.from_numpy(P.view(np.int64)).cuda(non_blocking=True), k, 0), -k, 0)
+            d_q = torch.roll(torch.roll(torch.from_numpy(Qs.view(np.int64)).cuda(non_blocking=True), k, 0), -k, 0)
+            d_e = torch.empty((n, FQ12), dtype=torch.int64, device="cuda")
+            zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), n, ctypes.c_void_p(st.cuda_stream)))
+            outs.append(d_e)
+    torch.cuda.synchronize()
+    for k, d_e in enumerate(outs):
+        assert (d_e.cpu().numpy().view(np.uint64) == want).all(), f"stream {k}"
+    retained = free0 - torch.cuda.mem_get_info()[0]
+    assert retained < 8 * (1 << 30), f"{retained / 2**30:.1f} GiB retained after eight caller streams: the pairing kernels ran on the callers' queues"

@@ -470,18 +470,26 @@ int zkt_g2_mul_batch_dev(const zkt_g2_affine* p, const uint64_t* k, int limbs, z
   HIPCHK(launch_group_mul(G_G2, (const uint32_t*)p, (const uint32_t*)k, limbs * 2, (uint32_t*)out, n, (hipStream_t)stream));
   return ZKT_OK;
 }
+// The pairing kernels keep their Fq12 temporaries in 10-18 KB of scratch per lane, and the runtime sizes — and keeps — a queue's scratch for every wave slot
+// of the device: 5-6 GiB per hardware queue that ever ran one (the process aborts when its pool is spent, at ~30 GB).  A caller with
+// eight streams of its own would spend 8 x 6 GiB on them.  So the kernel never runs on the caller's stream: it runs on the library's ONE staging stream,
+// ordered behind the caller's stream by an event (the inputs were produced there), and the call returns after the result is complete, so work the caller
+// queues afterwards on ANY stream sees it.  tests/test_gpu_parity.py::test_tate_dev_from_many_caller_streams drives 8 streams through this.
 int zkt_tate_batch_dev(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out, size_t n, void* stream) {
   if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
-  hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(g.mu);
-  int rc = reset_err(s); if (rc) return rc;
+  hipStream_t s = g.stream;
+  hipEvent_t ein; HIPCHK(hipEventCreateWithFlags(&ein, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(ein, (hipStream_t)stream));
+  HIPCHK(hipStreamWaitEvent(s, ein, 0));
+  int rc = reset_err(s); if (rc) { hipEventDestroy(ein); return rc; }
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, s));
   HIPCHK(launch_tate((const uint32_t*)g1, (const uint32_t*)g2, (uint32_t*)out, n, g.d_err, s));
   HIPCHK(hipEventRecord(e1, s));
-  rc = fetch_err(s, ZKT_ERR_INFINITY);
+  rc = fetch_err(s, ZKT_ERR_INFINITY);                  // synchronises the staging stream: the pairings are done when this returns
   HIPCHK(hipEventElapsedTime(&t_kernel_ms, e0, e1)); t_kernel_name = "k_tate";
-  hipEventDestroy(e0); hipEventDestroy(e1);
+  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(ein);
   return rc;
 }
 

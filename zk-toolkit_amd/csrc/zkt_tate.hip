@@ -76,6 +76,24 @@ __global__ void __launch_bounds__(64) ZKT_TATE_ATTR k_tate_exact_marked(const ui
   st_fq12(out + i * 144, final_exponentiation(f));
 }
 
+// How many elements the passes so far left marked (counts[0]: for the 255-step loop, counts[1]: for the reference's chain).  The two redo kernels have the
+// largest scratch frames of the library (9.5 and 17 KB per lane: the runtime would keep 6 GiB of scratch on the queue for kernels that, on honest
+// input, have nothing to do), so they are launched only when an 8-byte read-back says there is work for them.
+__global__ void __launch_bounds__(256) k_count_marks(const uint32_t* __restrict__ out, size_t n, uint32_t* __restrict__ counts) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t w = out[i * 144 + TATE_MARK_WORD];
+  if (w == TATE_MARK_LONG) atomicAdd(&counts[0], 1u); else if (w == TATE_MARK_EXACT) atomicAdd(&counts[1], 1u);
+}
+static hipError_t count_marks(const uint32_t* out, size_t n, hipStream_t s, uint32_t host[2]) {
+  uint32_t* d = nullptr; hipError_t e;
+  if ((e = hipMallocAsync((void**)&d, 8, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(d, 0, 8, s)) != hipSuccess) { (void)hipFreeAsync(d, s); return e; }
+  hipLaunchKernelGGL(k_count_marks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, d);
+  if ((e = hipMemcpyAsync(host, d, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) { (void)hipFreeAsync(d, s); return e; }
+  if ((e = hipFreeAsync(d, s)) != hipSuccess) return e;
+  return hipStreamSynchronize(s);
+}
 hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s) {
   if (n == 0) return hipSuccess;
   // small batches: one pairing per 12 lanes (zkt_dpairing.hip) — ~10x lower latency per pairing, lower peak throughput.  ZKT_DTATE_MAX overrides the switch-over.
@@ -88,12 +106,16 @@ hipError_t launch_tate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, si
         (e = launch_dtate(g1, g2, out, n, err, TATE_MARK_WORD, TATE_MARK_EXACT, true, s)) != hipSuccess || (e = guard_join(s, side)) != hipSuccess) { (void)hipFreeAsync(flags, s); return e; }
     hipLaunchKernelGGL(k_tate_resolve, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)flags, g1, g2, out, n);
     if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_tate_long_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
   } else {
     hipLaunchKernelGGL(k_tate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
-    hipLaunchKernelGGL(k_tate_long_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
   }
-  hipLaunchKernelGGL(k_tate_exact_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
+  hipError_t e; uint32_t marks[2] = {0, 0};
+  if ((e = hipGetLastError()) != hipSuccess || (e = count_marks(out, n, s, marks)) != hipSuccess) return e;
+  if (marks[0]) {                                           // Q on E' outside G2 somewhere: the 255-step loop for those elements (it may hand some on)
+    hipLaunchKernelGGL(k_tate_long_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
+    if ((e = hipGetLastError()) != hipSuccess || (e = count_marks(out, n, s, marks)) != hipSuccess) return e;
+  }
+  if (marks[1]) hipLaunchKernelGGL(k_tate_exact_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, g1, g2, out, n, err);
   return hipGetLastError();
 }
 
