@@ -37,7 +37,11 @@ def test_pinocchio_vs_oracle(L, case):
     assert O.zkto_pinocchio_prove(ctypes.byref(ocrs), ptr(wires), ptr(H), len(h), ptr(dv), ptr(dy), ctypes.byref(opf)) == 0
     zk.check(L.zkt_pinocchio_prove(ctypes.byref(gcrs), ptr(wires), ptr(H), len(h), ptr(dv), ptr(dy), ctypes.byref(gpf)))
     for k in opb:
-        assert (opb[k] == gpb[k]).all(), f"proof element {k} differs"
+        if not (opb[k] == gpb[k]).all():             # say whether a second evaluation agrees with the oracle (a transient would point at a race, not at the arithmetic)
+            gpf2, gpb2 = alloc_pinocchio_proof()
+            zk.check(L.zkt_pinocchio_prove(ctypes.byref(gcrs), ptr(wires), ptr(H), len(h), ptr(dv), ptr(dy), ctypes.byref(gpf2)))
+            raise AssertionError(f"proof element {k} differs from the oracle; a second GPU evaluation {'agrees' if (opb[k] == gpb2[k]).all() else 'differs too'}; "
+                                 f"first differing word {int(np.argmax((opb[k] != gpb[k]).ravel()))} of {opb[k].size}")
     io = wires[:n_io].copy()
     both = lambda pf_o, pf_g, w: (O.zkto_pinocchio_verify(ctypes.byref(ocrs), ctypes.byref(pf_o), ptr(w)), L.zkt_pinocchio_verify(ctypes.byref(gcrs), ctypes.byref(pf_g), ptr(w)))
     assert both(opf, gpf, io) == (1, 1)

@@ -6,6 +6,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include "../../include/zkt.h"
 #include "zkt_internal.h"
 #include "zkt_constants.h"
@@ -187,6 +188,9 @@ static int streams_ready(zkt_bases_impl* h) {
   for (int k = 0; k < zkt_bases_impl::NTAIL; ++k) HIPCHK(hipStreamCreateWithPriority(&h->s_tail[k], hipStreamNonBlocking, hi));
   return ZKT_OK;
 }
+// ZKT_DEBUG_POISON=1: every MSM workspace is filled with a garbage pattern when it is allocated, so a kernel that reads a word nobody wrote gets 0xA5A5A5A5
+// instead of the zeros a fresh allocation happens to hold (tools/diag/msm_repeat.py and the MSM tests are run this way).
+static bool debug_poison() { static const bool on = [] { const char* e = getenv("ZKT_DEBUG_POISON"); return e && *e == '1'; }(); return on; }
 static int slot_ready(zkt_bases_impl* h, int k) {   // lazily create the slot's workspace
   int rc = streams_ready(h); if (rc) return rc;
   MsmSlot& S = h->slot[k];
@@ -194,6 +198,7 @@ static int slot_ready(zkt_bases_impl* h, int k) {   // lazily create the slot's 
   HIPCHK(hipEventCreateWithFlags(&S.e_in, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&S.e_sorted, hipEventDisableTiming));
   HIPCHK(hipEventCreate(&S.e_acc0)); HIPCHK(hipEventCreate(&S.e_acc1)); HIPCHK(hipEventCreateWithFlags(&S.e_done, hipEventDisableTiming));
   HIPCHK(hipMalloc(&S.workspace, h->plan.ws_bytes));
+  if (debug_poison()) { HIPCHK(hipMemset(S.workspace, 0xA5, h->plan.ws_bytes)); HIPCHK(hipDeviceSynchronize()); }
   HIPCHK(hipMalloc((void**)&S.d_result_jac, 3 * grp_coord_bytes(h->grp)));
   HIPCHK(hipMalloc((void**)&S.d_out_abi, grp_pt_bytes(h->grp)));
   HIPCHK(hipHostMalloc((void**)&S.h_out, grp_pt_bytes(h->grp), hipHostMallocDefault));
@@ -647,6 +652,7 @@ static int msm_host(int grp, const void* bases, const uint64_t* scalars, size_t 
   const size_t o_abi = 0, o_sc = padded(n * ptb), o_tab = o_sc + padded(n * 32), o_inf = o_tab + padded(n * 2 * cb), o_jac = o_inf + padded(n),
                o_out = o_jac + padded(4 * cb), o_ws = o_out + padded(ptb), total = o_ws + plan.ws_bytes;
   HIPCHK(hipMalloc((void**)&blob, total));
+  if (debug_poison()) { HIPCHK(hipMemset(blob, 0xA5, total)); HIPCHK(hipDeviceSynchronize()); }
   std::lock_guard<std::mutex> lk(g.mu);                      // g.stream is the library's staging stream
   hipStream_t s = g.stream;
   int rc = ZKT_OK;
