@@ -171,6 +171,10 @@ struct zkt_bases_impl {               // one resident base set of any group; zkt
   // VALU-bound accumulation of the current one.
   static constexpr int NTAIL = 8;   // reduce chains of alternate MSMs run side by side: each is latency-bound, not throughput-bound (large MSMs use two of them)
   hipStream_t s_sort = nullptr, s_acc = nullptr, s_tail[NTAIL] = {};
+  // a group of base sets that always work on the same job (the four sets of a Groth16 key) shares ONE set of streams: every stream beyond the
+  // hardware queues (8) is folded onto a queue that already carries another stream, and a sort queued behind someone else's reduce chain waits for it
+  // (measured: the A sum of a proof started 16 ms late behind the C1 reduce, profiles/r03_groth16_timeline.txt)
+  bool own_streams = true, acc_owned = false, grouped = false; int tail_base = 0, tail_span = 0;
   MsmSlot slot[MSM_SLOTS];
   std::mutex mu;                 // slot state: calls on one handle are serialised (submit/collect of different slots may come from different threads)
 };
@@ -180,12 +184,12 @@ struct zkt_secp_bases : zkt_bases_impl {};
 static size_t grp_pt_bytes(int grp) { return grp == G_G1 ? sizeof(zkt_g1_affine) : grp == G_G2 ? sizeof(zkt_g2_affine) : sizeof(zkt_secp_affine); }
 static size_t grp_coord_bytes(int grp) { return 4 * (grp == G_G1 ? zkt::FqC::N : grp == G_G2 ? 2 * zkt::FqC::N : zkt::SpC::N); }   // internal (Montgomery) coordinate
 static int streams_ready(zkt_bases_impl* h) {
-  if (h->s_acc) return ZKT_OK;
+  if (h->grouped || !h->own_streams || (h->s_acc && h->s_sort && h->s_tail[zkt_bases_impl::NTAIL - 1])) return ZKT_OK;
   int lo = 0, hi = 0;
   HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));        // hi = numerically smallest = highest priority
-  HIPCHK(hipStreamCreateWithPriority(&h->s_sort, hipStreamNonBlocking, hi));
-  HIPCHK(hipStreamCreateWithPriority(&h->s_acc, hipStreamNonBlocking, lo));
-  for (int k = 0; k < zkt_bases_impl::NTAIL; ++k) HIPCHK(hipStreamCreateWithPriority(&h->s_tail[k], hipStreamNonBlocking, hi));
+  if (!h->s_sort) HIPCHK(hipStreamCreateWithPriority(&h->s_sort, hipStreamNonBlocking, hi));
+  if (!h->s_acc) HIPCHK(hipStreamCreateWithPriority(&h->s_acc, hipStreamNonBlocking, lo));
+  for (int k = 0; k < zkt_bases_impl::NTAIL; ++k) if (!h->s_tail[k]) HIPCHK(hipStreamCreateWithPriority(&h->s_tail[k], hipStreamNonBlocking, hi));
   return ZKT_OK;
 }
 // ZKT_DEBUG_POISON=1: every MSM workspace is filled with a garbage pattern when it is allocated, so a kernel that reads a word nobody wrote gets 0xA5A5A5A5
@@ -517,8 +521,14 @@ static void bases_free(zkt_bases_impl* h) {
   if (!h) return;
   if (h->table) hipFree(h->table);
   if (h->inf) hipFree(h->inf);
-  for (hipStream_t st : {h->s_sort, h->s_acc}) if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
-  for (hipStream_t st : h->s_tail) if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+  if (h->own_streams) {
+    for (hipStream_t st : {h->s_sort, h->s_acc}) if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+    for (hipStream_t st : h->s_tail) if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+  } else {                                     // borrowed streams: wait for this set's own work, leave them to their owner (freed after the borrowers)
+    for (hipStream_t st : {h->s_sort, h->s_acc}) if (st) hipStreamSynchronize(st);
+    for (hipStream_t st : h->s_tail) if (st) hipStreamSynchronize(st);
+    if (h->acc_owned && h->s_acc) hipStreamDestroy(h->s_acc);
+  }
   for (MsmSlot& S : h->slot) {
     for (hipEvent_t ev : {S.e_in, S.e_sorted, S.e_acc0, S.e_acc1, S.e_done}) if (ev) hipEventDestroy(ev);
     if (S.workspace) hipFree(S.workspace); if (S.d_result_jac) hipFree(S.d_result_jac); if (S.d_out_abi) hipFree(S.d_out_abi);
@@ -546,6 +556,7 @@ static int bases_upload(int grp, const void* host, size_t n, zkt_bases_impl** ou
   return rc;
 }
 static hipStream_t slot_tail_stream(zkt_bases_impl* h, int slot) {
+  if (h->grouped) return h->s_tail[h->tail_base + slot % h->tail_span];
   const bool small = h->n < (size_t(1) << 19);
   return h->s_tail[small ? slot % zkt_bases_impl::NTAIL : slot % 2];
 }
@@ -557,7 +568,7 @@ static int msm_submit_locked(zkt_bases_impl* h, const uint64_t* dev_scalars, siz
   MsmSlot& S = h->slot[slot];
   // inputs are produced on the caller's stream: order the sort stage behind it
   HIPCHK(hipEventRecord(S.e_in, (hipStream_t)stream));
-  const bool small = h->n < (size_t(1) << 19);
+  const bool small = !h->grouped && h->n < (size_t(1) << 19);        // sets that share a key's streams always run stage by stage
   hipStream_t st = slot_tail_stream(h, slot);
   hipStream_t ss = small ? st : h->s_sort;
   HIPCHK(hipStreamWaitEvent(ss, S.e_in, 0));
@@ -612,6 +623,32 @@ static int msm_dev(zkt_bases_impl* h, const uint64_t* dev_scalars, size_t n, voi
   int rc = msm_submit_locked(h, dev_scalars, n, stream, 0);
   if (rc) return rc;
   return msm_collect_locked(h, 0, out, dev_partial_jac);
+}
+// `dst` works on `src`'s streams from now on (sort stream and reduce streams [tail_base, tail_base + tail_span); the accumulate stream too if share_acc,
+// otherwise dst gets one of its own).  Call before dst's first MSM; free dst before src.
+int zkt_internal_bases_share_streams(void* dst_, void* src_, int share_acc, int tail_base, int tail_span) {
+  zkt_bases_impl *dst = (zkt_bases_impl*)dst_, *src = (zkt_bases_impl*)src_;
+  if (!dst || !src || tail_span < 1 || tail_base < 0 || tail_base + tail_span > zkt_bases_impl::NTAIL) return ZKT_ERR_SHAPE;
+  constexpr int GROUP_TAILS = 4;
+  if (tail_base + tail_span > GROUP_TAILS) return ZKT_ERR_SHAPE;
+  int lo = 0, hi = 0; HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  {
+    std::lock_guard<std::mutex> lk(src->mu);
+    if (!src->grouped) {                       // the owner: exactly the streams the group uses (a stream that exists claims a hardware queue)
+      if (src->s_sort || src->s_acc) return ZKT_ERR_SHAPE;
+      HIPCHK(hipStreamCreateWithPriority(&src->s_sort, hipStreamNonBlocking, hi)); HIPCHK(hipStreamCreateWithPriority(&src->s_acc, hipStreamNonBlocking, lo));
+      for (int k = 0; k < GROUP_TAILS; ++k) HIPCHK(hipStreamCreateWithPriority(&src->s_tail[k], hipStreamNonBlocking, hi));
+      src->grouped = true; src->tail_base = 0; src->tail_span = 2;
+    }
+  }
+  std::lock_guard<std::mutex> lk(dst->mu);
+  if (dst->s_sort || dst->s_acc) return ZKT_ERR_SHAPE;
+  dst->own_streams = false; dst->grouped = true; dst->s_sort = src->s_sort;
+  for (int k = 0; k < GROUP_TAILS; ++k) dst->s_tail[k] = src->s_tail[k];
+  dst->tail_base = tail_base; dst->tail_span = tail_span;
+  if (share_acc) dst->s_acc = src->s_acc;
+  else { HIPCHK(hipStreamCreateWithPriority(&dst->s_acc, hipStreamNonBlocking, lo)); dst->acc_owned = true; }
+  return ZKT_OK;
 }
 // combine step of a sharded MSM: `count` Jacobian partials, `stride_words` u32 apart, summed by one wave and normalised
 int zkt_internal_jac_sum(int grp, const uint32_t* dev_partials, size_t count, size_t stride_words, hipStream_t s, void* out) {

@@ -19,7 +19,11 @@
 //   B:  [L_j(x)]_2 | beta, delta                                       scalars (B w)_j | 1, s
 //   C:  [L_j(x)]_1 | uvw_wit | [Lambda_s(x) t(x)/delta]_1 | alpha, beta, delta
 //                                                                      scalars s (A w)_j + r (B w)_j | a_i | h(n+s) | s, r, r s
-// whose affine outputs ARE the proof points — no per-proof single-lane scalar multiplication remains.  tests/test_r1cs_domain_math.py checks
+// whose affine outputs ARE the proof points — no per-proof single-lane scalar multiplication remains.
+// The C sum is evaluated as TWO resident MSMs (round 3): C1 over [L] | uvw_wit | alpha, beta, delta, whose scalars exist as soon as the mat-vecs are done,
+// and C2 over [Lambda t/delta] (n - 1 terms), the only part that waits for the quotient's six NTTs.  C1 (2n + 3 terms) then runs beside A and B under the
+// NTT chain, and what follows the chain is a third of the old C sum: sort 4.0 -> 1.3 ms and accumulate 6.5 -> 2.3 ms off a single proof's critical path
+// (profiles/r03_groth16_timeline.txt).  C = C1 + C2 is one Jacobian addition on the device.  tests/test_r1cs_domain_math.py checks
 // the identity in python integers; tests/test_gpu_groth16_r1cs.py checks the proof points bit-for-bit against the oracle's
 // restatement of the reference prover on the dense QAP.
 #include <vector>
@@ -249,12 +253,12 @@ __global__ void __launch_bounds__(256) k_hvals(const uint32_t* __restrict__ Sa, 
   st_fp<C>(h_canon + i * FW, h);
 }
 // scalar vectors of the three MSMs (canonical).  rs = {r, s} canonical.
-//   sA = [Az | 1 | r]   sB = [Bz | 1 | s]   sC = [s Az + r Bz | wires[l+1..m] | h | s | r | r s]  (h is written in place by k_hvals)
+//   sA = [Az | 1 | r]   sB = [Bz | 1 | s]   sC = [s Az + r Bz | wires[l+1..m] | s | r | r s || h]   (C1 || C2; h is written in place by k_hvals)
 __global__ void __launch_bounds__(256) k_prove_scalars(const uint32_t* __restrict__ Az, const uint32_t* __restrict__ Bz, const uint32_t* __restrict__ wires_c,
                                                        const uint32_t* __restrict__ rs, size_t n, size_t l, size_t m,
                                                        uint32_t* __restrict__ sA, uint32_t* __restrict__ sB, uint32_t* __restrict__ sC) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t nw = m - l, nh = n >= 2 ? n - 1 : 0;
+  const size_t nw = m - l;
   if (i < n) {
     Fr a = ldm(Az + i * FW), b = ldm(Bz + i * FW), r = ld_fp<C>(rs), s = ld_fp<C>(rs + FW);
     st_fp<C>(sA + i * FW, a); st_fp<C>(sB + i * FW, b);
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(256) k_prove_scalars(const uint32_t* __restric
     for (int k = 0; k < FW; ++k) sC[i * FW + k] = src[k];
   } else if (i == n + nw) {                                   // the constant tails
     Fr r = ld_fp<C>(rs), s = ld_fp<C>(rs + FW);
-    uint32_t* tA = sA + n * FW; uint32_t* tB = sB + n * FW; uint32_t* tC = sC + (n + nw + nh) * FW;
+    uint32_t* tA = sA + n * FW; uint32_t* tB = sB + n * FW; uint32_t* tC = sC + (n + nw) * FW;
     st_fp<C>(tA, fp_one<C>()); st_fp<C>(tA + FW, r);
     st_fp<C>(tB, fp_one<C>()); st_fp<C>(tB + FW, s);
     st_fp<C>(tC, s); st_fp<C>(tC + FW, r); st_fp<C>(tC + 2 * FW, fp_mul(r, s));
@@ -379,9 +383,10 @@ struct zkt_groth16_pk {
   size_t n = 0, l = 0, m = 0, N = 0; int logN = 0;
   Csr A, B, Cm;                                  // constraint rows (device), values in Montgomery form
   DBuf cinv, P, ghat, tw, twinv;                  // Fr tables
-  zkt_g1_bases *setA = nullptr, *setC = nullptr; zkt_g2_bases* setB = nullptr;   // the three resident base sets (see the file header)
-  size_t nA = 0, nC = 0;
-  size_t loA = 0, hiA = 0, loC = 0, hiC = 0;     // this shard's index range of the A/B sets and of the C set (whole sets when unsharded)
+  zkt_g1_bases *setA = nullptr, *setC1 = nullptr, *setC2 = nullptr; zkt_g2_bases* setB = nullptr;   // the resident base sets (see the file header)
+  size_t nA = 0, nC1 = 0, nC2 = 0;
+  size_t loA = 0, hiA = 0, loC1 = 0, hiC1 = 0, loC2 = 0, hiC2 = 0;     // this shard's index ranges of the A/B sets and of the two C sets (whole sets when unsharded)
+  DBuf cparts;                                   // the Jacobian partials of C1 and C2 of the proof being collected
   size_t shard = 0, nshards = 1;
   // per-proof work buffers.  The MSM scalar vectors (and r, s) are double-buffered: proof k+1's Fr stage may run while the MSMs of proof k
   // are still reading theirs (zkt_groth16_prove_r1cs_submit / _collect); everything else is consumed in stream order before it is rewritten.
@@ -391,12 +396,14 @@ struct zkt_groth16_pk {
   hipStream_t s = nullptr;
   std::recursive_mutex mu;       // calls on one key are serialised (include/zkt.h, Threading)
   ~zkt_groth16_pk() {
-    if (setA) zkt_g1_bases_free(setA); if (setC) zkt_g1_bases_free(setC); if (setB) zkt_g2_bases_free(setB);
+    if (setC1) zkt_g1_bases_free(setC1); if (setC2) zkt_g1_bases_free(setC2); if (setB) zkt_g2_bases_free(setB);
+    if (setA) zkt_g1_bases_free(setA);            // last: it owns the streams the others work on
     if (s) hipStreamDestroy(s);
   }
 };
 
 extern int zkt_internal_ready();   // zkt_api.cpp
+extern "C" int zkt_internal_bases_share_streams(void* dst, void* src, int share_acc, int tail_base, int tail_span);
 extern void zkt_internal_set_error_index(size_t i);
 
 extern "C" {
@@ -464,10 +471,10 @@ int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_spars
   RCHK(hipGetLastError());
 
   // ---- group side: fixed-base multiplications of the generators (crs.rs:85-135), written straight into the three base sets ----
-  const size_t nw = m - l, nh = n >= 2 ? n - 1 : 0, nA = n + 2, nC = n + nw + nh + 3;
-  pk->nA = nA; pk->nC = nC; pk->shard = shard; pk->nshards = nshards;
+  const size_t nw = m - l, nh = n >= 2 ? n - 1 : 0, nA = n + 2, nC1 = n + nw + 3, nC2 = nh, nC = nC1 + nC2;
+  pk->nA = nA; pk->nC1 = nC1; pk->nC2 = nC2; pk->shard = shard; pk->nshards = nshards;
   auto range = [&](size_t tot, size_t& lo, size_t& hi) { size_t base = tot / nshards, extra = tot % nshards; lo = shard * base + (shard < extra ? shard : extra); hi = lo + base + (shard < extra ? 1 : 0); };
-  range(nA, pk->loA, pk->hiA); range(nC, pk->loC, pk->hiC);
+  range(nA, pk->loA, pk->hiA); range(nC1, pk->loC1, pk->hiC1); range(nC2, pk->loC2, pk->hiC2);
   DBuf gen1, gen2, pU, pA, pB, pC, small1, small2, gt;
   ZCHK(gen1.alloc(G1B)); ZCHK(gen2.alloc(G2B)); ZCHK(pU.alloc(rows * G1B)); ZCHK(pA.alloc(nA * G1B)); ZCHK(pB.alloc(nA * G2B)); ZCHK(pC.alloc(nC * G1B));
   ZCHK(small1.alloc(3 * G1B)); ZCHK(small2.alloc(3 * G2B)); ZCHK(gt.alloc(576));
@@ -478,25 +485,30 @@ int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_spars
   RCHK(launch_generator_mul(G_G2, gen2.w(), dtrap.w() + 8, small2.w(), 1, s));           // beta
   RCHK(launch_generator_mul(G_G2, gen2.w(), dtrap.w() + 16, small2.w() + 50, 1, s));     // gamma
   RCHK(launch_generator_mul(G_G2, gen2.w(), dtrap.w() + 24, small2.w() + 100, 1, s));    // delta
-  // uvw: statement part to the verifying key, witness part into the C set
+  // uvw: statement part to the verifying key, witness part into the C1 set.  pC = [L (n) | uvw_wit (nw) | alpha, beta, delta || Lambda t/delta (nh)]
   RCHK(launch_generator_mul(G_G1, gen1.w(), y.w(), pU.w(), rows, s));
   RCHK(hipMemcpyAsync(vk->g1_uvw_stmt, pU.p, (l + 1) * G1B, hipMemcpyDeviceToHost, s));
   if (vk->g1_uvw_wit && nw) RCHK(hipMemcpyAsync(vk->g1_uvw_wit, pU.w() + (l + 1) * 26, nw * G1B, hipMemcpyDeviceToHost, s));
   if (nw) RCHK(hipMemcpyAsync(pC.w() + n * 26, pU.w() + (l + 1) * 26, nw * G1B, hipMemcpyDeviceToDevice, s));
   RCHK(launch_generator_mul(G_G1, gen1.w(), Lc.w(), pC.w(), n, s));                       // [L_j(x)]_1
   RCHK(hipMemcpyAsync(pA.p, pC.p, n * G1B, hipMemcpyDeviceToDevice, s));
-  if (nh) RCHK(launch_generator_mul(G_G1, gen1.w(), hbc.w(), pC.w() + (n + nw) * 26, nh, s));   // [Lambda_s(x) t(x)/delta]_1
+  if (nh) RCHK(launch_generator_mul(G_G1, gen1.w(), hbc.w(), pC.w() + nC1 * 26, nh, s));        // [Lambda_s(x) t(x)/delta]_1
   RCHK(launch_generator_mul(G_G2, gen2.w(), Lc.w(), pB.w(), n, s));                       // [L_j(x)]_2
   RCHK(hipMemcpyAsync(pA.w() + n * 26, small1.p, G1B, hipMemcpyDeviceToDevice, s));            // A tail: alpha, delta
   RCHK(hipMemcpyAsync(pA.w() + (n + 1) * 26, small1.w() + 52, G1B, hipMemcpyDeviceToDevice, s));
   RCHK(hipMemcpyAsync(pB.w() + n * 50, small2.p, G2B, hipMemcpyDeviceToDevice, s));            // B tail: beta, delta
   RCHK(hipMemcpyAsync(pB.w() + (n + 1) * 50, small2.w() + 100, G2B, hipMemcpyDeviceToDevice, s));
-  RCHK(hipMemcpyAsync(pC.w() + (n + nw + nh) * 26, small1.p, 3 * G1B, hipMemcpyDeviceToDevice, s));   // C tail: alpha, beta, delta
+  RCHK(hipMemcpyAsync(pC.w() + (n + nw) * 26, small1.p, 3 * G1B, hipMemcpyDeviceToDevice, s));         // C1 tail: alpha, beta, delta
   RCHK(hipStreamSynchronize(s));
   pU.release();
   ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)(pA.w() + pk->loA * 26), pk->hiA - pk->loA, s, &pk->setA)); pA.release();
   ZCHK(zkt_g2_bases_from_device((const zkt_g2_affine*)(pB.w() + pk->loA * 50), pk->hiA - pk->loA, s, &pk->setB)); pB.release();
-  ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)(pC.w() + pk->loC * 26), pk->hiC - pk->loC, s, &pk->setC)); pC.release();
+  ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)(pC.w() + pk->loC1 * 26), pk->hiC1 - pk->loC1, s, &pk->setC1));
+  ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)(pC.w() + (nC1 + pk->loC2) * 26), pk->hiC2 - pk->loC2, s, &pk->setC2)); pC.release();
+  // one set of streams for the key (owner: setA): a sort stream, the G1 accumulate stream (C1, A, C2 in turn), B's own accumulate stream, four reduce streams —
+  // with the key's own stream that is eight, one per hardware queue
+  ZCHK(zkt_internal_bases_share_streams(pk->setC1, pk->setA, 1, 0, 2)); ZCHK(zkt_internal_bases_share_streams(pk->setC2, pk->setA, 1, 0, 2));
+  ZCHK(zkt_internal_bases_share_streams(pk->setB, pk->setA, 0, 2, 2));
   RCHK(hipMemcpyAsync(derr.p, &noerr, 8, hipMemcpyHostToDevice, s));
   RCHK(launch_tate(small1.w(), small2.w(), gt.w(), 1, (unsigned long long*)derr.p, s));        // crs.rs:137-139
   RCHK(hipMemcpyAsync(vk->g1_alpha, small1.p, G1B, hipMemcpyDeviceToHost, s)); RCHK(hipMemcpyAsync(vk->g1_beta, small1.w() + 26, G1B, hipMemcpyDeviceToHost, s));
@@ -509,6 +521,7 @@ int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_spars
   // ---- per-proof work buffers ----
   ZCHK(pk->wires_c.alloc(rows * FRB)); ZCHK(pk->wires_m.alloc(rows * FRB));
   for (int k = 0; k < zkt_groth16_pk::PSLOTS; ++k) { ZCHK(pk->rs[k].alloc(2 * FRB)); ZCHK(pk->sA[k].alloc(nA * FRB)); ZCHK(pk->sB[k].alloc(nA * FRB)); ZCHK(pk->sC[k].alloc(nC * FRB)); }
+  ZCHK(pk->cparts.alloc(2 * ZKT_G1_PARTIAL_WORDS * 4));
   for (int k = 0; k < 3; ++k) { ZCHK(pk->z_m[k].alloc(n * FRB)); ZCHK(pk->f[k].alloc(N * FRB)); }
   *out = pk.release();
   return ZKT_OK;
@@ -540,8 +553,10 @@ static int prove_submit(zkt_groth16_pk* pk, int ps, const uint64_t* wires, bool 
   hipLaunchKernelGGL(k_prove_scalars, dim3(nb(n + nw + 1)), dim3(256), 0, s, (const uint32_t*)pk->z_m[0].w(), (const uint32_t*)pk->z_m[1].w(), (const uint32_t*)pk->wires_c.w(),
                      (const uint32_t*)drs.w(), n, l, m, sA.w(), sB.w(), sC.w());
   RCHK(hipGetLastError());
-  // A and B only need (A w) and (B w): they start now and run under the quotient stage
+  // A, B and the first part of C only need (A w), (B w) and the wires: they start now and run under the quotient stage
+  const size_t nC1 = pk->nC1;
   ZCHK(zkt_g2_msm_submit(pk->setB, (const uint64_t*)(sB.w() + pk->loA * FW), pk->hiA - pk->loA, s, ps));
+  ZCHK(zkt_g1_msm_submit(pk->setC1, (const uint64_t*)(sC.w() + pk->loC1 * FW), pk->hiC1 - pk->loC1, s, ps));
   ZCHK(zkt_g1_msm_submit(pk->setA, (const uint64_t*)(sA.w() + pk->loA * FW), pk->hiA - pk->loA, s, ps));
   if (n >= 2) {
     for (int k = 0; k < 3; ++k) {
@@ -550,10 +565,11 @@ static int prove_submit(zkt_groth16_pk* pk, int ps, const uint64_t* wires, bool 
       ZCHK(ntt_inverse(pk->f[k].w(), pk->logN, pk->twinv.w(), s));
     }
     hipLaunchKernelGGL(k_hvals, dim3(nb(n - 1)), dim3(256), 0, s, (const uint32_t*)pk->f[0].w(), (const uint32_t*)pk->f[1].w(), (const uint32_t*)pk->f[2].w(), (const uint32_t*)pk->P.w(), n,
-                       sC.w() + (n + nw) * FW);
+                       sC.w() + nC1 * FW);
     RCHK(hipGetLastError());
   }
-  ZCHK(zkt_g1_msm_submit(pk->setC, (const uint64_t*)(sC.w() + pk->loC * FW), pk->hiC - pk->loC, s, ps));
+  // the quotient part of C: the only MSM that waits for the NTT chain
+  ZCHK(zkt_g1_msm_submit(pk->setC2, (const uint64_t*)(sC.w() + (nC1 + pk->loC2) * FW), pk->hiC2 - pk->loC2, s, ps));
   pk->pending[ps] = true;
   return ZKT_OK;
 }
@@ -563,12 +579,17 @@ static int prove_collect(zkt_groth16_pk* pk, int ps, zkt_g1_affine* A, zkt_g2_af
   if (ps < 0 || ps >= zkt_groth16_pk::PSLOTS || !pk->pending[ps]) return ZKT_ERR_SHAPE;
   if (dev_partials ? false : (!A || !B || !Cp || pk->nshards != 1)) return ZKT_ERR_SHAPE;      // a shard can only produce partials
   pk->pending[ps] = false;
+  // C = C1 + C2: both Jacobian partials side by side in cparts, one addition on the device
+  uint32_t* cp = pk->cparts.w();
+  ZCHK(zkt_g1_msm_collect(pk->setC1, ps, nullptr, cp)); ZCHK(zkt_g1_msm_collect(pk->setC2, ps, nullptr, cp + ZKT_G1_PARTIAL_WORDS));
   if (dev_partials) {            // [A: ZKT_G1_PARTIAL_WORDS | B: ZKT_G2_PARTIAL_WORDS | C: ZKT_G1_PARTIAL_WORDS]
     ZCHK(zkt_g1_msm_collect(pk->setA, ps, nullptr, dev_partials)); ZCHK(zkt_g2_msm_collect(pk->setB, ps, nullptr, dev_partials + ZKT_G1_PARTIAL_WORDS));
-    ZCHK(zkt_g1_msm_collect(pk->setC, ps, nullptr, dev_partials + ZKT_G1_PARTIAL_WORDS + ZKT_G2_PARTIAL_WORDS));
+    RCHK(launch_msm_jac_add(G_G1, cp, cp + ZKT_G1_PARTIAL_WORDS, dev_partials + ZKT_G1_PARTIAL_WORDS + ZKT_G2_PARTIAL_WORDS, pk->s));
+    RCHK(hipStreamSynchronize(pk->s));
     return ZKT_OK;
   }
-  ZCHK(zkt_g1_msm_collect(pk->setA, ps, A, nullptr)); ZCHK(zkt_g2_msm_collect(pk->setB, ps, B, nullptr)); ZCHK(zkt_g1_msm_collect(pk->setC, ps, Cp, nullptr));
+  ZCHK(zkt_g1_msm_collect(pk->setA, ps, A, nullptr)); ZCHK(zkt_g2_msm_collect(pk->setB, ps, B, nullptr));
+  ZCHK(zkt_g1_jac_sum_dev(cp, 2, pk->s, Cp));
   return ZKT_OK;
 }
 // Prover::prove (prover.rs:96-147) with r, s injected; wires = a_0..a_m canonical, on the host or (…_dev) already in HBM.

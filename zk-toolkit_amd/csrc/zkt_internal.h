@@ -121,6 +121,8 @@ hipError_t launch_msm_precompute(int grp, uint32_t* table, uint8_t* inf, size_t 
 hipError_t launch_msm_sort(const MsmPlan& plan, const uint8_t* base_inf, const uint32_t* scalars, void* workspace, hipStream_t s);
 hipError_t launch_msm_accumulate(const MsmPlan& plan, const uint32_t* table, void* workspace, hipStream_t s);
 hipError_t launch_msm_reduce(const MsmPlan& plan, void* workspace, uint32_t* dev_result_jac, uint32_t* dev_out_abi, hipStream_t s);
+// out = a + b on two Jacobian partials (3 coordinates each)
+hipError_t launch_msm_jac_add(int grp, const uint32_t* a, const uint32_t* b, uint32_t* out, hipStream_t s);
 // sum of `count` Jacobian partials, `stride_words` u32 apart (3 coordinates each), normalised to one affine ABI point
 hipError_t launch_msm_jac_sum_to_affine(int grp, const uint32_t* jac_partials, size_t count, size_t stride_words, uint32_t* out_abi_pt, hipStream_t s);
 

@@ -606,6 +606,19 @@ __global__ void __launch_bounds__(64) k_jac_sum_to_affine(const uint32_t* __rest
   }
   if (t == 0) PtIO<F>::st(out_abi, jac_to_aff(v));
 }
+// out = a + b on Jacobian partials (3 coordinates each): two partial sums of ONE result that were accumulated over different base sets
+template <class F>
+__global__ void __launch_bounds__(64) k_jac_add(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t* __restrict__ out) {
+  if (threadIdx.x) return;
+  constexpr int CW = Coord<F>::CW;
+  const Jac<F> x{Coord<F>::ld(a), Coord<F>::ld(a + CW), Coord<F>::ld(a + 2 * CW)}, y{Coord<F>::ld(b), Coord<F>::ld(b + CW), Coord<F>::ld(b + 2 * CW)};
+  const Jac<F> r = jac_add<F>(x, y);
+  Coord<F>::st(out, r.X); Coord<F>::st(out + CW, r.Y); Coord<F>::st(out + 2 * CW, r.Z);
+}
+hipError_t PART(launch_msm_jac_add)(int grp, const uint32_t* a, const uint32_t* b, uint32_t* out, hipStream_t s) {
+  MSM_DISPATCH(grp, hipLaunchKernelGGL(k_jac_add<F>, dim3(1), dim3(64), 0, s, a, b, out));
+  return hipGetLastError();
+}
 hipError_t PART(launch_msm_jac_sum_to_affine)(int grp, const uint32_t* parts, size_t count, size_t stride, uint32_t* out_abi, hipStream_t s) {
   MSM_DISPATCH(grp, hipLaunchKernelGGL(k_jac_sum_to_affine<F>, dim3(1), dim3(64), 0, s, parts, count, stride, out_abi));
   return hipGetLastError();
@@ -620,6 +633,7 @@ hipError_t PART(launch_msm_jac_sum_to_affine)(int grp, const uint32_t* parts, si
   hipError_t launch_msm_sort##SUF(const MsmPlan&, const uint8_t*, const uint32_t*, void*, hipStream_t); \
   hipError_t launch_msm_accumulate##SUF(const MsmPlan&, const uint32_t*, void*, hipStream_t); \
   hipError_t launch_msm_reduce##SUF(const MsmPlan&, void*, uint32_t*, uint32_t*, hipStream_t); \
+  hipError_t launch_msm_jac_add##SUF(int, const uint32_t*, const uint32_t*, uint32_t*, hipStream_t); \
   hipError_t launch_msm_jac_sum_to_affine##SUF(int, const uint32_t*, size_t, size_t, uint32_t*, hipStream_t);
 ZKT_MSM_FWD(_other) ZKT_MSM_FWD(_secp)
 #define ZKT_MSM_BY_GROUP(grp, NAME, ...) ((grp) == G_G1 ? NAME##_g1(__VA_ARGS__) : (grp) == G_SECP ? NAME##_secp(__VA_ARGS__) : NAME##_other(__VA_ARGS__))
@@ -628,6 +642,7 @@ hipError_t launch_msm_precompute(int grp, uint32_t* t, uint8_t* i, size_t n, int
 hipError_t launch_msm_sort(const MsmPlan& P, const uint8_t* i, const uint32_t* k, void* w, hipStream_t s) { return ZKT_MSM_BY_GROUP(P.grp, launch_msm_sort, P, i, k, w, s); }
 hipError_t launch_msm_accumulate(const MsmPlan& P, const uint32_t* t, void* w, hipStream_t s) { return ZKT_MSM_BY_GROUP(P.grp, launch_msm_accumulate, P, t, w, s); }
 hipError_t launch_msm_reduce(const MsmPlan& P, void* w, uint32_t* j, uint32_t* o, hipStream_t s) { return ZKT_MSM_BY_GROUP(P.grp, launch_msm_reduce, P, w, j, o, s); }
+hipError_t launch_msm_jac_add(int grp, const uint32_t* a, const uint32_t* b, uint32_t* o, hipStream_t s) { return ZKT_MSM_BY_GROUP(grp, launch_msm_jac_add, grp, a, b, o, s); }
 hipError_t launch_msm_jac_sum_to_affine(int grp, const uint32_t* p, size_t c, size_t st, uint32_t* o, hipStream_t s) { return ZKT_MSM_BY_GROUP(grp, launch_msm_jac_sum_to_affine, grp, p, c, st, o, s); }
 #endif
 
