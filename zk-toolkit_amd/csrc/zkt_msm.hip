@@ -52,6 +52,17 @@ template <class F> __device__ inline void st_xy(uint32_t* p, const Xyzz<F>& a) {
   Coord<F>::st(p, a.X); Coord<F>::st(p + CW, a.Y); Coord<F>::st(p + 2 * CW, a.ZZ); Coord<F>::st(p + 3 * CW, a.ZZZ);
 }
 static int coord_words(int grp) { return grp == G_G1 ? FqC::N : grp == G_G2 ? 2 * FqC::N : SpC::N; }
+// dimensions of the atomic-free partition sort (k_part_*, below): partitions of PART_SUB buckets, tiles of PART_TILE scalars, chunks of PART_CHUNK records
+static constexpr int PART_LO = 9, PART_SUB = 1 << PART_LO, PART_TPB = 1024, PART_TILE = 4 * PART_TPB, PART_CHUNK = 8192, PART_MAXP = 2048;
+struct PartDims { uint32_t P, ntiles, maxblk; };
+static PartDims part_dims(size_t n, size_t nbuckets, int nwin) {
+  PartDims d; d.P = (uint32_t)((nbuckets + PART_SUB - 1) / PART_SUB); d.ntiles = (uint32_t)((n + PART_TILE - 1) / PART_TILE);
+  d.maxblk = d.P + (uint32_t)((size_t)nwin * n / PART_CHUNK) + 1; return d;
+}
+static size_t part_ws_bytes(size_t n, size_t nbuckets, int nwin) {
+  const PartDims d = part_dims(n, nbuckets, nwin);
+  return 1024 + (size_t)nwin * n * 2 + 256 + 2 * ((size_t)d.P * d.ntiles + 1) * 4 + ((size_t)d.P + 1) * 4 + ((size_t)d.P * d.ntiles / 2048 + 2) * 4 + 256 + (size_t)d.maxblk * PART_SUB * 4;
+}
 
 // ---------------------------------------------------------------------------------
 // plan
@@ -77,6 +88,7 @@ MsmPlan msm_plan(size_t n, int grp) {
   b += (1024 + 3 * 1025) * 4 + 2 * (p.nbuckets + 1) * 4;          // scan scratch, size bins, task counts/offsets
   b += (p.nbuckets + ent / p.chunk + 2) * (8 + XYW * 4);          // task list + partial sums of split buckets
   b += 64 * 64 * XYW * 4 + 1024;                                  // block sums of hot buckets (k_merge_hot), hot list
+  b += part_ws_bytes(n, p.nbuckets, p.nwin);
   b += 4096;
   p.ws_bytes = b;
   p.direct = 0; p.half = p.nbuckets;
@@ -113,6 +125,7 @@ MsmPlan msm_plan_direct(size_t n, int grp) {
   b += (1024 + 3 * 1025) * 4 + 2 * (p.nbuckets + 1) * 4;
   b += (p.nbuckets + ent / p.chunk + 2) * (8 + XYW * 4);
   b += 64 * 64 * XYW * 4 + 1024;
+  b += part_ws_bytes(n, p.nbuckets, p.nwin);
   b += 8192;
   p.ws_bytes = b;
   return p;
@@ -313,6 +326,117 @@ static void launch_scan(const uint32_t* in, uint32_t* out, size_t m, uint32_t* s
   hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(256), 0, s, in, m, (const uint32_t*)scratch, out);
 }
 
+// ---------------------------------------------------------------------------------
+// counting sort by bucket WITHOUT global atomics (large MSMs): two-level radix partition through LDS histograms
+// ---------------------------------------------------------------------------------
+// k_digits pays one returning global atomic per (scalar, window) — 13.6 M of them at 2^20 terms, executed at the memory side at ~25 G/s whatever the
+// occupancy: 0.55 ms for the count pass plus 0.22-0.35 ms for the scatter, and two sorts side by side in a Groth16 proof slow each other to 1.9 + 2.6 ms.
+// Here the bucket id is split into a partition (its high bits) and a position inside the partition (its low PART_LO bits):
+//   pass A  every tile of PART_TILE scalars (one 1024-thread block: long runs per partition in pass B) histograms its digits by PARTITION in LDS                 -> tilehist[partition][tile]
+//   scan    (partition-major) gives every (partition, tile) its segment of the record array
+//   pass B  the tiles recompute their digits and write (entry, low bits) records into their segments     (ranks from LDS atomics)
+//   pass C  every partition is cut into chunks of PART_CHUNK records; a block histograms the low bits of its chunk in LDS (C1), one block per partition
+//           turns the chunk histograms into running offsets and the bucket totals into counts[] / offsets[] (C1b), and the chunk blocks place their
+//           entries (C2).  A skewed input (a witness of 0/1: a million entries in one partition) is simply more chunks.
+// Every pass streams: ~310 MB at 2^20 terms instead of 13.6 M scattered read-modify-writes.  counts / offsets / entries come out exactly as from k_digits
+// (the order of the entries inside a bucket is arbitrary in both), so everything downstream is unchanged.
+template <bool SCATTER>
+static __global__ void __launch_bounds__(PART_TPB) k_part_tiles(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t n, int c, int nwin, uint32_t win_buckets,
+                                                    uint32_t P, uint32_t ntiles, uint32_t* __restrict__ tilehist, const uint32_t* __restrict__ tileoff,
+                                                    uint32_t* __restrict__ rec_ent, uint16_t* __restrict__ rec_lo) {
+  ZKT_SIDE_PRIO;
+  __shared__ uint32_t h[PART_MAXP];
+  for (uint32_t p = threadIdx.x; p < P; p += PART_TPB) h[p] = SCATTER ? tileoff[(size_t)p * ntiles + blockIdx.x] : 0u;
+  __syncthreads();
+  const uint32_t half = 1u << (c - 1);
+  for (int j = 0; j < PART_TILE / PART_TPB; ++j) {
+    const size_t i = (size_t)blockIdx.x * PART_TILE + j * PART_TPB + threadIdx.x;
+    if (i >= n) continue;
+    uint32_t k[8];
+    { const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8); const uint4 lo = sp[0], hi = sp[1];
+      k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w; }
+    uint32_t carry = 0;
+    for (int w = 0; w < nwin; ++w) {
+      const uint32_t raw = window_bits(k, w, c) + carry;
+      const uint32_t neg = raw > half;
+      const uint32_t mag = neg ? (1u << c) - raw : raw;
+      carry = neg;
+      const size_t src = win_buckets ? i : (size_t)w * n + i;
+      if (mag == 0 || inf[src]) continue;                     // infinity and zero digits contribute nothing
+      const uint32_t b = mag - 1 + (uint32_t)w * win_buckets;
+      const uint32_t pos = atomicAdd(&h[b >> PART_LO], 1u);
+      if (SCATTER) { rec_ent[pos] = (uint32_t)src | (neg << 31); rec_lo[pos] = (uint16_t)(b & (PART_SUB - 1)); }
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < P; p += PART_TPB) tilehist[(size_t)p * ntiles + blockIdx.x] = h[p];
+  }
+}
+// chunk blocks of every partition: blkoff[p] = first block of partition p, blkoff[P] = blocks in use (one block: P <= PART_MAXP)
+static __global__ void __launch_bounds__(256) k_part_blocks(const uint32_t* __restrict__ tileoff, uint32_t P, uint32_t ntiles, uint32_t* __restrict__ blkoff) {
+  ZKT_SIDE_PRIO;
+  __shared__ uint32_t lds[256];
+  constexpr int ITEMS = PART_MAXP / 256;
+  uint32_t v[ITEMS], sum = 0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const uint32_t p = threadIdx.x * ITEMS + k;
+    uint32_t cnt = 0;
+    if (p < P) { const uint32_t size = tileoff[(size_t)(p + 1) * ntiles] - tileoff[(size_t)p * ntiles]; cnt = (size + PART_CHUNK - 1) / PART_CHUNK; }
+    v[k] = cnt; sum += cnt;
+  }
+  uint32_t tot; uint32_t run = block_excl_scan_256(sum, lds, tot);
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) { const uint32_t p = threadIdx.x * ITEMS + k; if (p < P) blkoff[p] = run; run += v[k]; }
+  if (threadIdx.x == 0) blkoff[P] = tot;
+}
+// which (partition, chunk) block `blk` is: the last p with blkoff[p] <= blk
+__device__ inline uint32_t part_of_block(const uint32_t* __restrict__ blkoff, uint32_t P, uint32_t blk) {
+  uint32_t lo = 0, hi = P;                          // invariant: blkoff[lo] <= blk < blkoff[hi]
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (blkoff[mid] <= blk) lo = mid; else hi = mid; }
+  return lo;
+}
+template <bool PLACE>
+static __global__ void __launch_bounds__(256) k_part_chunks(const uint32_t* __restrict__ tileoff, uint32_t P, uint32_t ntiles, const uint32_t* __restrict__ blkoff,
+                                                     const uint32_t* __restrict__ rec_ent, const uint16_t* __restrict__ rec_lo, uint32_t* __restrict__ subhist,
+                                                     const uint32_t* __restrict__ offsets, size_t nbuckets, uint32_t* __restrict__ entries) {
+  ZKT_SIDE_PRIO;
+  __shared__ uint32_t h[PART_SUB];
+  const uint32_t blk = blockIdx.x;
+  if (blk >= blkoff[P]) return;                     // block-uniform
+  const uint32_t p = part_of_block(blkoff, P, blk), chunk = blk - blkoff[p];
+  const uint32_t pbeg = tileoff[(size_t)p * ntiles], pend = tileoff[(size_t)(p + 1) * ntiles];
+  const uint32_t beg = pbeg + chunk * PART_CHUNK, end = beg + PART_CHUNK < pend ? beg + PART_CHUNK : pend;
+  for (int t = threadIdx.x; t < PART_SUB; t += 256) {
+    const size_t b = (size_t)p * PART_SUB + t;
+    h[t] = PLACE ? (b < nbuckets ? offsets[b] + subhist[(size_t)blk * PART_SUB + t] : 0u) : 0u;
+  }
+  __syncthreads();
+  for (uint32_t r = beg + threadIdx.x; r < end; r += 256) {
+    const uint32_t pos = atomicAdd(&h[rec_lo[r]], 1u);
+    if (PLACE) entries[pos] = rec_ent[r];
+  }
+  if (!PLACE) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < PART_SUB; t += 256) subhist[(size_t)blk * PART_SUB + t] = h[t];
+  }
+}
+// one block per partition: chunk histograms -> running offsets (in place); bucket totals -> counts[], offsets[] (and offsets[nbuckets] = all entries)
+static __global__ void __launch_bounds__(PART_SUB) k_part_offsets(const uint32_t* __restrict__ tileoff, uint32_t P, uint32_t ntiles, const uint32_t* __restrict__ blkoff,
+                                                           uint32_t* __restrict__ subhist, size_t nbuckets, uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets) {
+  ZKT_SIDE_PRIO;
+  __shared__ uint32_t sc[PART_SUB];
+  const uint32_t p = blockIdx.x, t = threadIdx.x;
+  uint32_t run = 0;
+  for (uint32_t cblk = blkoff[p]; cblk < blkoff[p + 1]; ++cblk) { const uint32_t v = subhist[(size_t)cblk * PART_SUB + t]; subhist[(size_t)cblk * PART_SUB + t] = run; run += v; }
+  sc[t] = run; __syncthreads();
+  for (int d = 1; d < PART_SUB; d <<= 1) { const uint32_t x = t >= (uint32_t)d ? sc[t - d] : 0u; __syncthreads(); sc[t] += x; __syncthreads(); }
+  const size_t b = (size_t)p * PART_SUB + t;
+  if (b < nbuckets) { counts[b] = run; offsets[b] = tileoff[(size_t)p * ntiles] + sc[t] - run; }
+  if (p == P - 1 && t == 0) offsets[nbuckets] = tileoff[(size_t)P * ntiles];
+}
+
 // Work list.  A bucket of cnt entries is cut into nt = ceil(cnt / chunk) equal pieces (the first cnt % nt of them one entry longer), one
 // piece per lane ("task"), so one lane never runs an unbounded list: with random scalars at 2^20 terms every bucket (~26 entries) is a single
 // task, while skewed inputs (many equal scalars: a real witness is full of 0/1) and small MSMs (chunk from pick_chunk) spread their buckets
@@ -476,6 +600,7 @@ namespace {
 struct MsmWs {   // workspace carve-up (one per in-flight MSM)
   uint32_t *zero_begin, *counts, *cursor, *size_hist, *size_off, *size_cur, *hot, *zero_end;   // [zero_begin, zero_end) is cleared per MSM
   uint32_t *offsets, *entries, *slot, *sums, *colsum, *rowsum, *clsA, *clsB, *win_jac, *scan_tmp, *ntask, *task_off, *partial, *hot_part;
+  uint32_t *tilehist, *tileoff, *blkoff, *subhist, *part_scan; uint16_t* rec_lo;   // the partition sort (slot doubles as its record array)
   uint2* order; size_t max_tasks;
 };
 MsmWs carve(const MsmPlan& P, void* workspace) {
@@ -511,6 +636,17 @@ MsmWs carve(const MsmPlan& P, void* workspace) {
   w.order = (uint2*)ws; ws += w.max_tasks * 8;
   w.partial = (uint32_t*)ws; ws += w.max_tasks * XYW * 4;
   w.hot_part = (uint32_t*)ws; ws += (size_t)HOT_CAP * HOT_FAN * XYW * 4;
+  {
+    const PartDims d = part_dims(P.n, P.nbuckets, P.nwin);
+    ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    w.rec_lo = (uint16_t*)ws; ws += (((size_t)P.nwin * P.n * 2) + 255) & ~(size_t)255;
+    w.tilehist = (uint32_t*)ws; ws += ((size_t)d.P * d.ntiles + 1) * 4;
+    w.tileoff = (uint32_t*)ws; ws += ((size_t)d.P * d.ntiles + 1) * 4;
+    w.blkoff = (uint32_t*)ws; ws += ((size_t)d.P + 1) * 4;
+    w.part_scan = (uint32_t*)ws; ws += ((size_t)d.P * d.ntiles / 2048 + 2) * 4;
+    ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    w.subhist = (uint32_t*)ws; ws += (size_t)d.maxblk * PART_SUB * 4;
+  }
   return w;
 }
 }  // namespace
@@ -521,7 +657,22 @@ hipError_t PART(launch_msm_sort)(const MsmPlan& P, const uint8_t* inf, const uin
   MsmWs w = carve(P, workspace);
   hipError_t e;
   if ((e = hipMemsetAsync(w.zero_begin, 0, (uint8_t*)w.zero_end - (uint8_t*)w.zero_begin, s)) != hipSuccess) return e;
-  if (n) {
+  const PartDims pd = part_dims(n, B, P.nwin);
+  static const int force_sort = [] { const char* e = getenv("ZKT_MSM_SORT"); return e ? atoi(e) : 0; }();      // 1: atomics (k_digits), 2: partition sort, 0: by size
+  const bool partition = force_sort == 2 || (force_sort != 1 && (size_t)P.nwin * n >= (size_t(1) << 22));        // below ~2^18 terms the atomics are as fast and take fewer launches
+  if (n && partition && pd.P <= PART_MAXP) {
+    // large MSMs: the atomic-free two-level partition (k_part_*); the record array lives in the slot buffer
+    const uint32_t wb = P.direct ? (uint32_t)P.half : 0u;
+    hipLaunchKernelGGL(k_part_tiles<false>, dim3(pd.ntiles), dim3(PART_TPB), 0, s, scalars, inf, n, P.c, P.nwin, wb, pd.P, pd.ntiles, w.tilehist, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint16_t*)nullptr);
+    launch_scan(w.tilehist, w.tileoff, (size_t)pd.P * pd.ntiles, w.part_scan, s);
+    hipLaunchKernelGGL(k_part_tiles<true>, dim3(pd.ntiles), dim3(PART_TPB), 0, s, scalars, inf, n, P.c, P.nwin, wb, pd.P, pd.ntiles, (uint32_t*)nullptr, (const uint32_t*)w.tileoff, w.slot, w.rec_lo);
+    hipLaunchKernelGGL(k_part_blocks, dim3(1), dim3(256), 0, s, (const uint32_t*)w.tileoff, pd.P, pd.ntiles, w.blkoff);
+    hipLaunchKernelGGL(k_part_chunks<false>, dim3(pd.maxblk), dim3(256), 0, s, (const uint32_t*)w.tileoff, pd.P, pd.ntiles, (const uint32_t*)w.blkoff, (const uint32_t*)w.slot, (const uint16_t*)w.rec_lo,
+                       w.subhist, (const uint32_t*)nullptr, B, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_part_offsets, dim3(pd.P), dim3(PART_SUB), 0, s, (const uint32_t*)w.tileoff, pd.P, pd.ntiles, (const uint32_t*)w.blkoff, w.subhist, B, w.counts, w.offsets);
+    hipLaunchKernelGGL(k_part_chunks<true>, dim3(pd.maxblk), dim3(256), 0, s, (const uint32_t*)w.tileoff, pd.P, pd.ntiles, (const uint32_t*)w.blkoff, (const uint32_t*)w.slot, (const uint16_t*)w.rec_lo,
+                       w.subhist, (const uint32_t*)w.offsets, B, w.entries);
+  } else if (n) {
     const unsigned g = (unsigned)((n + 255) / 256);
     const uint32_t wb = P.direct ? (uint32_t)P.half : 0u;
     hipLaunchKernelGGL(k_digits<false>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, wb, w.counts, (const uint32_t*)nullptr, w.slot, (uint32_t*)nullptr);
