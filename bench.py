@@ -22,7 +22,7 @@ R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MSM_BYTES_PER_TERM = 128       # 96 B affine base + 32 B scalar
 PAIRING_BYTES = 864            # 96 + 192 in, 576 out
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def load_profile(name):
@@ -306,11 +306,19 @@ def main():
             g16 = {"error": repr(e), "stage": stage}
 
     # HBM traffic and instruction counts of the dominant kernel come from separate rocprofv3 --pmc passes (committed summaries), never from this run
-    traffic_prof = load_profile(PROFILE_ROUND + "_hbm_traffic_pmc.json") or load_profile("r01_hbm_traffic_pmc.json")
+    traffic_prof = load_profile(PROFILE_ROUND + "_hbm_traffic_pmc.json") or load_profile("r02_hbm_traffic_pmc.json") or load_profile("r01_hbm_traffic_pmc.json")
     traffic = None
     if traffic_prof and args.log2n == 20:
         traffic = traffic_prof.get("k_accumulate_hbm_bytes_per_launch", {}).get("uncorrected")
-    sq = load_profile(PROFILE_ROUND + "_accumulate_sq_counters.json")
+    sq = load_profile(PROFILE_ROUND + "_accumulate_sq_counters.json") or load_profile("r02_accumulate_sq_counters.json")
+    # a counter file is only as good as the kernels it was taken on: it carries the hash of the kernel sources (tools/src_hash.py); say so if they changed since
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from src_hash import kernel_sources_sha16
+        here = kernel_sources_sha16()
+    except Exception:
+        here = None
+    stale = lambda prof: None if not prof else (prof.get("kernel_sources_sha16") != here)
     valu = None
     if sq and args.log2n == 20 and "k_accumulate_g1" in sq:
         ka = sq["k_accumulate_g1"]
@@ -324,7 +332,7 @@ def main():
                 "frac_of_f32_fma_rate": ach / vp_["f32_fma_lane_ops_per_s_T"],
                 "field_mix_rate_at_this_occupancy_T": vp_.get("field_mix_at_2_waves_per_simd_T"),
                 "lane_instr_per_bucket_add": lane_instr / (13 * n),
-                "wait_any_frac": ka.get("wait_any_frac_of_wave_cycles"),
+                "wait_any_frac": ka.get("wait_any_frac_of_wave_cycles"), "counters_stale": stale(sq),
                 "source": "profiles/%s_accumulate_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES ..., folded by tools/sq_summary.py), peaks from profiles/%s_valu_ubench.txt" % (PROFILE_ROUND, PROFILE_ROUND)}
     result = {
         "metric": "G1 MSM scalar-muls/sec at 2^%d bases per GPU (BLS12-381)" % args.log2n,
@@ -339,7 +347,7 @@ def main():
                    "single_msm_latency_ms": round(latency_ms, 3) if latency_ms is not None else None},
         "roofline": {"bound": "hbm", "kernel": L.zkt_last_kernel_name().decode(),
                      "achieved": MSM_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": MSM_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": MSM_BYTES_PER_TERM * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_counters_stale": stale(traffic_prof),
                      "traffic_note": "FETCH_SIZE+WRITE_SIZE per launch from the committed rocprofv3 --pmc summary; a multiple of the algorithmic bytes by design: every term is gathered once per window from the resident window-multiple table (DESIGN.md §4)",
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": MSM_BYTES_PER_TERM * n,
                      "note": "integer-VALU bound by construction (SURVEY §8d); `valu` is the roof that binds, from hardware counters",
@@ -420,7 +428,7 @@ def main():
             zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), 1, sp)); torch.cuda.synchronize()
             t0 = time.perf_counter(); zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), 1, sp)); torch.cuda.synchronize(); lat1 = time.perf_counter() - t0
             zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), m, sp)); torch.cuda.synchronize()          # restore the full batch for the CPU comparison below
-            pt = load_profile(PROFILE_ROUND + "_tate_sq_counters.json") or load_profile("r01_tate_sq_counters.json") or {}
+            pt = load_profile(PROFILE_ROUND + "_tate_sq_counters.json") or load_profile("r02_tate_sq_counters.json") or load_profile("r01_tate_sq_counters.json") or {}
             pinstr = pt.get("valu_instr_per_pairing") or pt.get("valu_instructions_per_pairing") or (pt.get("kernels", {}).get("k_tate", {}).get("valu_instr_per_wave"))
             result["pairing"] = {"metric": "Tate pairings/sec", "value": m / dt, "batch": m, "kernel_ms": L.zkt_last_kernel_ms(),
                                  "hbm_achieved_GBs": PAIRING_BYTES * m / dt / 1e9, "hbm_frac": PAIRING_BYTES * m / dt / 1e9 / HBM_PEAK_GBS,

@@ -2,6 +2,9 @@
 """Fold a rocprofv3 --pmc counter_collection CSV (SQ counters) and the VALU micro-benchmark (tools/ubench/valu_roof.hip) into the JSON that
 bench.py reads for `roofline.valu` — so the VALU roofline fraction is reproducible from profiles/ alone, no constants typed into bench.py.
 usage: sq_summary.py OUT.json UBENCH.txt NOTE counter_collection.csv [more.csv ...]"""
+import os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys_path_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import csv, json, re, sys, collections
 out, ubench, note, files = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4:]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -32,7 +35,10 @@ for line in open(ubench):
         peaks[nm] = max(peaks[nm], rate)
         if w == 2: at2[nm] = rate
 pick = lambda frag, d: next((v for k, v in d.items() if frag in k), None)
-res = {"source": note,
+from src_hash import kernel_sources_sha16
+try: _head = subprocess.check_output(["git", "-C", sys_path_root, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+except Exception: _head = None
+res = {"source": note, "kernel_sources_sha16": kernel_sources_sha16(), "git_head_when_folded": _head,
        "units": "SQ_INSTS_* count wave-instructions (x64 = lane-instructions); SQ_WAVE_CYCLES / SQ_WAIT_ANY / SQ_BUSY_CYCLES / SQ_ACTIVE_INST_VALU count quad-cycles (MI355X_MICROARCH.md)",
        "valu_peak": {"int_mad_lane_ops_per_s_T": pick("v_mad_u64_u32", peaks), "int_mad_at_2_waves_per_simd_T": pick("v_mad_u64_u32", at2),
                      "field_mix_lane_ops_per_s_T": pick("field mix", peaks), "field_mix_at_2_waves_per_simd_T": pick("field mix", at2),
