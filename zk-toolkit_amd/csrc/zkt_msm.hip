@@ -53,7 +53,7 @@ template <class F> __device__ inline void st_xy(uint32_t* p, const Xyzz<F>& a) {
 }
 static int coord_words(int grp) { return grp == G_G1 ? FqC::N : grp == G_G2 ? 2 * FqC::N : SpC::N; }
 // dimensions of the atomic-free partition sort (k_part_*, below): partitions of PART_SUB buckets, tiles of PART_TILE scalars, chunks of PART_CHUNK records
-static constexpr int PART_LO = 9, PART_SUB = 1 << PART_LO, PART_TPB = 1024, PART_TILE = 4 * PART_TPB, PART_CHUNK = 8192, PART_MAXP = 2048;
+static constexpr int PART_LO = 9, PART_SUB = 1 << PART_LO, PART_TPB = 256, PART_TILE = 16 * PART_TPB, PART_CHUNK = 8192, PART_MAXP = 2048;
 struct PartDims { uint32_t P, ntiles, maxblk; };
 static PartDims part_dims(size_t n, size_t nbuckets, int nwin) {
   PartDims d; d.P = (uint32_t)((nbuckets + PART_SUB - 1) / PART_SUB); d.ntiles = (uint32_t)((n + PART_TILE - 1) / PART_TILE);
@@ -332,7 +332,8 @@ static void launch_scan(const uint32_t* in, uint32_t* out, size_t m, uint32_t* s
 // k_digits pays one returning global atomic per (scalar, window) — 13.6 M of them at 2^20 terms, executed at the memory side at ~25 G/s whatever the
 // occupancy: 0.55 ms for the count pass plus 0.22-0.35 ms for the scatter, and two sorts side by side in a Groth16 proof slow each other to 1.9 + 2.6 ms.
 // Here the bucket id is split into a partition (its high bits) and a position inside the partition (its low PART_LO bits):
-//   pass A  every tile of PART_TILE scalars (one 1024-thread block: long runs per partition in pass B) histograms its digits by PARTITION in LDS                 -> tilehist[partition][tile]
+//   pass A  every tile of PART_TILE scalars (16 per thread of a 256-thread block: long runs per partition in pass B, and a block small enough to find
+//           room beside the accumulate waves of a neighbouring MSM — 1024-thread blocks waited 1.8 ms for a free CU in the pipeline) histograms its digits by PARTITION in LDS                 -> tilehist[partition][tile]
 //   scan    (partition-major) gives every (partition, tile) its segment of the record array
 //   pass B  the tiles recompute their digits and write (entry, low bits) records into their segments     (ranks from LDS atomics)
 //   pass C  every partition is cut into chunks of PART_CHUNK records; a block histograms the low bits of its chunk in LDS (C1), one block per partition
