@@ -44,10 +44,14 @@ for STEP in "$@"; do
     protocols_stats) timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_protocols -- python3 tools/bench_protocols.py > $O/${TAG}_protocols_b.json 2> $O/prof_${TAG}_protocols.err || fail protocols_stats $O/prof_${TAG}_protocols.err ;;
     bp) timeout -k 10 600 python3 tools/bench_bp.py > $O/${TAG}_bp.log 2>&1 || fail bp $O/${TAG}_bp.log
       tail -12 $O/${TAG}_bp.log ;;
-    pmc_acc) timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $O/prof_${TAG}_sq_acc --output-format csv -- python3 bench.py --no-cpu --steps 8 --warmup 2 --pairings 0 --groth16-log2n 0 > $O/prof_${TAG}_sq_acc.log 2>&1 || fail pmc_acc $O/prof_${TAG}_sq_acc.log ;;
-    pmc_hbm) timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE -d $O/prof_${TAG}_hbm --output-format csv -- python3 bench.py --no-cpu --steps 8 --warmup 2 --pairings 0 --groth16-log2n 0 > $O/prof_${TAG}_hbm.log 2>&1 || fail pmc_hbm $O/prof_${TAG}_hbm.log ;;
-    pmc_tate) timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/prof_${TAG}_sq_tate --output-format csv -- python3 tools/bench_pairing.py > $O/prof_${TAG}_sq_tate.log 2>&1 || fail pmc_tate $O/prof_${TAG}_sq_tate.log ;;
-    pmc_tate_hbm) timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE -d $O/prof_${TAG}_hbm_tate --output-format csv -- python3 tools/bench_pairing.py > $O/prof_${TAG}_hbm_tate.log 2>&1 || fail pmc_tate_hbm $O/prof_${TAG}_hbm_tate.log ;;
+    pmc_acc) timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $O/prof_${TAG}_sq_acc --output-format csv -- python3 bench.py --no-cpu --no-bulletproofs --steps 8 --warmup 2 --pairings 0 --groth16-log2n 0 > $O/prof_${TAG}_sq_acc.log 2>&1 || fail pmc_acc $O/prof_${TAG}_sq_acc.log ;;
+    pmc_hbm) for CNT in FETCH_SIZE WRITE_SIZE; do      # one counter per pass: together they exceed what the hardware collects at once (rocprofv3 aborts)
+        timeout -k 10 300 rocprofv3 --pmc $CNT -d $O/prof_${TAG}_hbm_$CNT --output-format csv -- python3 bench.py --no-cpu --no-bulletproofs --steps 8 --warmup 2 --pairings 0 --groth16-log2n 0 > $O/prof_${TAG}_hbm_$CNT.log 2>&1 || fail "pmc_hbm $CNT" $O/prof_${TAG}_hbm_$CNT.log
+      done ;;
+    pmc_tate) timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/prof_${TAG}_sq_tate --output-format csv -- python3 tools/bench_pairing.py 65536 > $O/prof_${TAG}_sq_tate.log 2>&1 || fail pmc_tate $O/prof_${TAG}_sq_tate.log ;;
+    pmc_tate_hbm) for CNT in FETCH_SIZE WRITE_SIZE; do
+        timeout -k 10 300 rocprofv3 --pmc $CNT -d $O/prof_${TAG}_hbm_tate_$CNT --output-format csv -- python3 tools/bench_pairing.py 65536 > $O/prof_${TAG}_hbm_tate_$CNT.log 2>&1 || fail "pmc_tate_hbm $CNT" $O/prof_${TAG}_hbm_tate_$CNT.log
+      done ;;
     rehearsal) ZKT_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --groth16-log2n 16 --groth16-proofs 3 --pairings 4096 --no-cpu > $O/${TAG}_bench_rehearsal_2ranks_1gpu.json 2> $O/${TAG}_rehearsal.err || fail rehearsal $O/${TAG}_rehearsal.err ;;
     py:*) S="${STEP#py:}"; N=$(basename ${S%% *} .py)
       timeout -k 10 900 python3 $S > $O/${TAG}_${N}.log 2>&1 || fail "$STEP" $O/${TAG}_${N}.log
