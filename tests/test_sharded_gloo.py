@@ -1,5 +1,5 @@
 """N>1 path on CPU: world_size 2 over gloo.  The sharding + all_gather + local-combine orchestration of
-zk-toolkit_amd/sharded.py is run with the oracle injected as the compute (no GPU here) and must equal the
+tests/sharded.py (test-only orchestration helper; the product's exchange lives in csrc/zkt_comm.cpp) is run with the oracle injected as the compute (no GPU here) and must equal the
 unsharded MSM (polynomial.rs:271-281).  On GPUs bench.py runs the same orchestration with the HIP kernels."""
 import importlib, os, sys
 import numpy as np
@@ -15,7 +15,7 @@ def _worker(rank, world, port, n, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from zkt_testlib import oracle, ptr, SplitMix64, R, G1W, ints_to_arr
-    sh = importlib.import_module("zk-toolkit_amd.sharded")
+    import sharded as sh
     O = oracle()
     rng = SplitMix64(99)                                   # every rank builds the same global problem
     g = np.zeros((1, G1W), dtype=np.uint64); O.zkto_g1_generator(ptr(g))
@@ -41,7 +41,7 @@ def _worker(rank, world, port, n, q):
 
 
 def test_shard_ranges_partition():
-    sh = importlib.import_module("zk-toolkit_amd.sharded")
+    import sharded as sh
     for n in (0, 1, 7, 8, 1 << 20):
         for world in (1, 2, 3, 8):
             r = [sh.shard_range(n, k, world) for k in range(world)]
