@@ -244,8 +244,7 @@ def test_sharded_msm_partials_combine(L, name, W, order, gen_fn, pw):
     whole = np.zeros((1, W), np.uint64); zk.check(getattr(L, f"zkt_{name}_msm")(ptr(bases), ptr(ss), n, ptr(whole)))
     parts = torch.zeros((shards, pw), dtype=torch.int32, device="cuda")
     vp = lambda t: ctypes.c_void_p(t.data_ptr())
-    from importlib import import_module
-    shard_range = import_module("zk-toolkit_amd.sharded").shard_range
+    from sharded import shard_range
     for k in range(shards):
         lo, hi = shard_range(n, k, shards)
         h = ctypes.c_void_p(); zk.check(getattr(L, f"zkt_{name}_bases_upload")(ptr(bases[lo:hi].copy()), hi - lo, ctypes.byref(h)))
