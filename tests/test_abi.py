@@ -75,3 +75,13 @@ def test_generated_constants_are_in_sync(tmp_path):
     out = tmp_path / "zkt_constants.h"
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_constants.py"), str(out)], timeout=300)
     assert out.read_text() == open(os.path.join(ROOT, "zk-toolkit_amd", "csrc", "zkt_constants.h")).read()
+
+
+def test_no_base_pointer_hazard_in_the_device_code():
+    """tools/check_base_pointer.py: no device function that keeps a base pointer (s34) calls one that uses s34 as a scratch register — this toolchain lets a callee
+    do that, and the caller then returns with a garbage stack pointer (DESIGN.md §5 "A compiler limit"; found twice as silent aborts on the GPU)."""
+    import subprocess, sys
+    so = os.path.join(ROOT, "zk-toolkit_amd", "libzkt_hip.so")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_base_pointer.py"), so], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "HAZARD" not in r.stdout, r.stdout[-2000:]
+    assert r.stdout.count("0 hazards") >= 8

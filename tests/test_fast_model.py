@@ -93,3 +93,55 @@ def test_short_loop_g2_membership_is_r_torsion():
     assert fm.g2_in_subgroup(q)
     off = (q[0], fm.f2_add(q[1], (1, 0)))
     assert not fm.g2_on_curve(off) and not fm.g2_in_subgroup(off)
+
+
+# ---- decisions through the optimal-ate loop (verification entry points) -------------------------------------------------------------
+def _f12_from_ref(t):
+    """inverse of fm.to_ref_order for comparing / multiplying oracle values inside the model"""
+    probe = tuple(tuple((6 * i + 2 * j, 6 * i + 2 * j + 1) for j in range(3)) for i in range(2))
+    order = fm.to_ref_order(probe)
+    flat = [None] * 12
+    for pos, tag in enumerate(order): flat[tag] = t[pos]
+    return tuple(tuple((flat[6 * i + 2 * j], flat[6 * i + 2 * j + 1]) for j in range(3)) for i in range(2))
+
+
+def test_ate_decisions_equal_tate_decisions():
+    """prod tate(P_k, Q_k) == 1 (the faithful oracle's values) <=> prod ate(Q_k, P_k) == 1, on products that are one by construction and on near misses;
+    and the ate value is a pairing: a(Q, P)^n = a([n]Q, P) = a(Q, [n]P)."""
+    rng = SplitMix64(27)
+    a, b, c = (rng.below(R) for _ in range(3))
+    P, Qg = g1_gen(), g2_gen()
+    # e(aP, bQ) e(-cP, Q) e(P, (c - ab) Q) == 1
+    g1s = [g1_mul(P, a), g1_mul(P, R - c), P]
+    g2s = [g2_mul(Qg, b), Qg, g2_mul(Qg, (c - a * b) % R)]
+    near = [g2s[0], g2s[1], g2_mul(Qg, (c - a * b + 1) % R)]
+    rc, o, _ = pair(3, np.concatenate(g1s + g1s), np.concatenate(g2s + near))
+    assert rc == 0
+    vals = [_f12_from_ref(v) for v in fq12_from_arr(o)]
+    prod = lambda vs: fm.f12_mul(fm.f12_mul(vs[0], vs[1]), vs[2])
+    assert prod(vals[:3]) == fm.F12_1 and prod(vals[3:]) != fm.F12_1
+    ps = [_pq(p, Qg)[0] for p in g1s]
+    assert fm.ate_product_is_one(ps, [_pq(P, q)[1] for q in g2s]) is True
+    assert fm.ate_product_is_one(ps, [_pq(P, q)[1] for q in near]) is False
+    p0, q0 = _pq(P, Qg)
+    base = fm.ate_product([p0], [q0])
+    assert base != fm.F12_1 and fm.f12_pow(base, R) == fm.F12_1
+    assert fm.ate_product([_pq(g1_mul(P, 7), Qg)[0]], [q0]) == fm.f12_pow(base, 7)
+    assert fm.ate_product([p0], [_pq(P, g2_mul(Qg, 11))[1]]) == fm.f12_pow(base, 11)
+
+
+def test_ate_route_refuses_arguments_outside_their_groups():
+    """points outside G1 / G2 or off their curves never reach the ate loop (they keep the 255-step loop / the reference's chain): the model returns None,
+    and the G2 test the loop gets for free agrees with r Q = infinity"""
+    rng = SplitMix64(28)
+    p0, q0 = _pq(g1_gen(), g2_gen())
+    for _, p in degenerate_g1_points():
+        assert fm.ate_product_is_one([p], [q0]) is None
+    assert fm.ate_product_is_one([py_g1_curve_point(41)], [q0]) is None
+    assert fm.ate_product_is_one([(p0[0], (p0[1] + 1) % Q)], [q0]) is None
+    t = py_twist_point(rng)
+    assert fm.ate_line_table(t)[1] is False and fm.ate_product_is_one([p0], [t]) is None
+    g = _g2_affine(fm.g2_jac_mul(t, G2_COFACTOR))
+    assert fm.ate_line_table(g)[1] is True and fm.ate_line_table(g)[1] == fm.g2_in_subgroup(g)
+    assert fm.ate_product_is_one([p0], [(q0[0], fm.f2_add(q0[1], (1, 0)))]) is None
+    assert len(fm.ate_line_table(q0)[0]) == fm.ATE_LINES == 68

@@ -291,3 +291,40 @@ def test_cyclotomic_square_matches_generic_square(H):
         assert O.zkto_fq12_op(2, ptr(c), ptr(c), ptr(want), 1) == 0
         assert H.zkt_hostcheck_tower(12, 10, p32(c), None, p32(got)) == 0
         assert (want == got).all()
+
+
+def test_ate_product_matches_model_and_guards(H):
+    """The 63-step loop of the deciding entry points (pairing.h miller_ate_multi, its 13-product line multiplication, the line tables of shared
+    G2 points, g1_in_subgroup): final_exponentiation of the product equals the python model's value bit for bit — with the chain in the lane and with
+    tabulated lines — and arguments outside their groups are refused (they keep the older routes)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fast_model as fm
+    H.zkt_hostcheck_ate_product.argtypes = [ctypes.c_int, ctypes.c_int, _u32p, _u32p, _u32p]
+    rng = SplitMix64(93)
+    a, b, c = (rng.below(R) for _ in range(3))
+    g1s = [g1_mul(g1_gen(), a), g1_mul(g1_gen(), R - c), g1_gen()]
+    g2s = [g2_mul(g2_gen(), b), g2_gen(), g2_mul(g2_gen(), (c - a * b) % R)]
+    def model(idx):
+        ps = [g1_from_arr(g1s[i])[0] for i in idx]
+        qs = []
+        for i in idx:
+            (x1, x0), (y1, y0) = g2_from_arr(g2s[i])[0]; qs.append(((x0, x1), (y0, y1)))
+        return fm.ate_product(ps, qs)
+    one = np.zeros(72, dtype=np.uint64); one[66] = 1                          # canonical one: w0.v0.u0 (the last Fq of the {w1,w0} layout)
+    for kv, kf, idx in ((1, 0, [0]), (0, 1, [0]), (2, 0, [0, 1]), (3, 0, [0, 1, 2]), (1, 2, [0, 1, 2])):
+        got = np.zeros((1, 72), dtype=np.uint64)
+        P = np.concatenate([g1s[i] for i in idx]); Qa = np.concatenate([g2s[i] for i in idx])
+        assert H.zkt_hostcheck_ate_product(kv, kf, p32(P), p32(Qa), p32(got)) == 0, (kv, kf)
+        want = fm.to_ref_order(model(idx))
+        assert tuple(fq12_from_arr(got)[0]) == tuple(want), (kv, kf)
+        assert (got[0] == one).all() == (len(idx) == 3)                        # the three-pair product is one by construction
+    got = np.zeros((1, 72), dtype=np.uint64)
+    q_ok = g2s[0]
+    for label, pt in degenerate_g1_points():
+        assert H.zkt_hostcheck_ate_product(1, 0, p32(g1_arr([pt])), p32(q_ok), p32(got)) == -1, label
+    tw = g2_arr([to_abi_g2(py_twist_point(rng))])
+    assert H.zkt_hostcheck_ate_product(1, 0, p32(g1s[0]), p32(tw), p32(got)) == -1                   # on E', outside G2: caught where the chain ends
+    assert H.zkt_hostcheck_ate_product(0, 1, p32(g1s[0]), p32(tw), p32(got)) == -1                   # ... and by the table builder, agreeing with g2_in_subgroup (no bit 8)
+    (x1, x0), (y1, y0) = g2_from_arr(q_ok)[0]
+    assert H.zkt_hostcheck_ate_product(1, 0, p32(g1s[0]), p32(g2_arr([((x1, x0), (y1, (y0 + 1) % Q))])), p32(got)) == -1

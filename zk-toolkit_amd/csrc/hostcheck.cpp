@@ -133,4 +133,36 @@ int zkt_hostcheck_short_loop_guards(const uint32_t* g1, const uint32_t* g2) {
   bool ok; (void)miller_g1_g2_short(p.x, p.y, q.x, q.y, ok);
   return (g1_on_curve(p.x, p.y) ? 1 : 0) | (ok ? 2 : 0) | (g2_on_curve(q.x, q.y) && g2_in_subgroup(q.x, q.y) ? 4 : 0) | (g2_on_curve(q.x, q.y) ? 8 : 0);
 }
+// The 63-step (optimal-ate) product of the deciding entry points (pairing.h): kv pairs whose Q runs its own chain, then kf pairs whose Q comes as a line table built here.
+// Returns -1 when a guard refuses an argument (the kernels then leave the element to the older routes), else writes final_exponentiation(prod f_{|x|,Q_k}(P_k)).
+// bit 8 of the return value: the table builder's G2 verdict for the tabulated points disagreed with g2_in_subgroup (0 expected).
+int zkt_hostcheck_ate_product(int kv, int kf, const uint32_t* g1, const uint32_t* g2, uint32_t* o) {
+  const int K = kv + kf;
+  if (K < 1 || K > 3) return -2;
+  Fq xp[3], yp[3]; Fq2 xq[3], yq[3];
+  static uint32_t tabs[3][ATE_LINES * ATE_LINE_WORDS];
+  const uint32_t* tp[3] = {tabs[0], tabs[1], tabs[2]};
+  int odd = 0;
+  for (int k = 0; k < K; ++k) {
+    Aff<FqOps> p = PtIO<FqOps>::ld(g1 + k * ABI_G1_WORDS); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(g2 + k * ABI_G2_WORDS);
+    if (p.inf || q.inf) return -3;
+    if (!g1_on_curve(p.x, p.y) || !g1_in_subgroup(p.x, p.y) || !g2_on_curve(q.x, q.y)) return -1;
+    xp[k] = p.x; yp[k] = p.y; xq[k] = q.x; yq[k] = q.y;
+    if (k >= kv) {
+      const bool in = ate_line_table(q.x, q.y, tabs[k - kv]);
+      if (in != g2_in_subgroup(q.x, q.y)) odd = 256;
+      if (!in) return -1 - odd;
+    }
+  }
+  bool q_ok = false; Fq12 f;
+  if (kv == 1 && kf == 0) f = miller_ate_multi<1, 0>(xp, yp, xq, yq, tp, q_ok);
+  else if (kv == 2 && kf == 0) f = miller_ate_multi<2, 0>(xp, yp, xq, yq, tp, q_ok);
+  else if (kv == 3 && kf == 0) f = miller_ate_multi<3, 0>(xp, yp, xq, yq, tp, q_ok);
+  else if (kv == 1 && kf == 2) f = miller_ate_multi<1, 2>(xp, yp, xq, yq, tp, q_ok);
+  else if (kv == 0 && kf == 1) f = miller_ate_multi<0, 1>(xp, yp, xq, yq, tp, q_ok);
+  else return -2;
+  if (!q_ok) return -1;
+  st_fq12(o, final_exponentiation(f));
+  return odd;
+}
 }

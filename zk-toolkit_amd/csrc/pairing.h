@@ -124,7 +124,7 @@ ZKT_FN bool g2_on_curve(const Fq2& xq, const Fq2& yq) {
 }
 // Q in G2  <=>  Q on E' (the caller's check) and psi(Q) = [x] Q, psi = twist o Frobenius o untwist (x < 0: psi(Q) = -[|x|] Q).
 // psi^2 - t psi + q = 0 on E', t = x + 1 and q = x (mod r); r is prime to the cofactor of E'(Fq2), so the r-torsion of E'(Fq2) is G2.
-ZKT_FN bool g2_in_subgroup(const Fq2& xq, const Fq2& yq) {
+ZKT_HD bool g2_in_subgroup_inl(const Fq2& xq, const Fq2& yq) {
   const Aff<Fq2Ops> q{xq, yq, false};
   Jac<Fq2Ops> a = jac_from_aff(q);
   for (int i = 62; i >= 0; --i) {                              // |x| = 0xd201000000010000: 63 doublings, 5 additions
@@ -137,6 +137,7 @@ ZKT_FN bool g2_in_subgroup(const Fq2& xq, const Fq2& yq) {
   const Fq2 ZZ = fq2_sqr(a.Z);
   return fq2_eq(a.X, fq2_mul(px, ZZ)) && fq2_eq(a.Y, fq2_neg(fq2_mul(py, fq2_mul(ZZ, a.Z))));
 }
+ZKT_FN bool g2_in_subgroup(const Fq2& xq, const Fq2& yq) { return g2_in_subgroup_inl(xq, yq); }
 // V == (BETA xp, -yp) for a Jacobian V?  After the loop over x^2, V = x^2 P; -x^2 is the eigenvalue of phi(x, y) = (BETA x, y) on G1, so this is
 // phi(P) = [-x^2] P, and phi^2 + phi + 1 = 0 turns it into [x^4 - x^2 + 1] P = r P = infinity (and conversely) — six multiplications, once per pairing.
 ZKT_FN bool miller_pt_is_x2(const MillerPt& V, const Fq& xp, const Fq& yp) {
@@ -280,9 +281,10 @@ ZKT_FN Fq12 fq12_pow_e1(const Fq12& a) {
 // f^((q^12-1)/r), exact.  Four named Fq12 buffers (g, a, b, t) are reused; a destination never aliases a source.
 // SHORT: the argument is the value of the 127-step loop (miller_g1_g2_short) and the result is raised to 2 x^2 - 1 on the way out, which makes it the
 // Tate value: eta^(2x^2-1) = pi^2(eta)^2 conj(eta), one Frobenius, one cyclotomic squaring, one product (derivation at miller_g1_g2_short).
-// The correction lives HERE and not in the caller on purpose: the very same four calls placed in tate_short (after this function had returned)
-// faulted on MI355X with ROCm 7.2 (memory access fault inside the scratch aperture, also with pi applied twice instead of pi^2), while inside this
-// function they run — kept where the toolchain is known to produce working code, and covered by tests/test_gpu_parity.py on every run.
+// (Round 2 found that the very same four calls placed in tate_short, after this function had returned, faulted inside the scratch aperture.  Round 3 found why:
+//  this function keeps a base pointer (s34) and restores its stack pointer from it on the way out; fq12_frob<1>, as a called function, parked a literal in s34, which
+//  this toolchain lets a callee do — the function returned with a garbage stack pointer and only callers that made no further call survived.  pi^1 is now inlined here
+//  (fq12_frob_inl) and tools/check_base_pointer.py scans every object for the pattern.)
 template <bool SHORT> ZKT_FN Fq12 final_exponentiation_t(const Fq12& f) {
   Fq12 g, a, b, t;
   t = fq12_inv(f);
@@ -293,7 +295,7 @@ template <bool SHORT> ZKT_FN Fq12 final_exponentiation_t(const Fq12& f) {
   g = a;
   a = fq12_pow_e1(g);                      // ^e1
   t = fq12_pow_xabs(a); t = fq12_conj(t);  // a^x (x < 0: conjugate = inverse in the cyclotomic subgroup)
-  b = fq12_frob<1>(a);
+  b = fq12_frob_inl<1>(a);
   a = fq12_mul(t, b);                      // a := ^(x+q)
   t = fq12_pow_xabs(a); t = fq12_conj(t);
   b = fq12_pow_xabs(t); b = fq12_conj(b);  // b = a^(x^2)
@@ -317,14 +319,170 @@ ZKT_HD Fq12 final_exponentiation(const Fq12& f) { return final_exponentiation_t<
 // r P != infinity: miller_g1_g2_exact).  tate = eta^(2 x^2 - 1) for eta = final_exponentiation(f_{x^2,P}(Q)): final_exponentiation_t<true>.
 // Kept as ONE function so that the kernels that use it stay small: load, call, store.
 enum { TATE_ROUTE_SHORT = 0, TATE_ROUTE_LONG = 1, TATE_ROUTE_EXACT = 2 };
-ZKT_FN int tate_short(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq, Fq12& r) {
-  if (!g1_on_curve(xp, yp) || !g2_on_curve(xq, yq)) return TATE_ROUTE_EXACT;
-  if (!g2_in_subgroup(xq, yq)) return TATE_ROUTE_LONG;
+// (two functions on purpose: the one that holds the Fq12 keeps a base pointer and must not call g2_in_subgroup, which parks literals in s34 — see ZKT_ATE_STEP)
+ZKT_FN bool tate_short_value(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq, Fq12& r) {
   bool in_g1;
   Fq12 f = miller_g1_g2_short(xp, yp, xq, yq, in_g1);
-  if (!in_g1) return TATE_ROUTE_EXACT;
+  if (!in_g1) return false;
   r = final_exponentiation_t<true>(f);
-  return TATE_ROUTE_SHORT;
+  return true;
+}
+ZKT_HD int tate_short(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& yq, Fq12& r) {
+  if (!g1_on_curve(xp, yp) || !g2_on_curve(xq, yq)) return TATE_ROUTE_EXACT;
+  if (!g2_in_subgroup(xq, yq)) return TATE_ROUTE_LONG;
+  return tate_short_value(xp, yp, xq, yq, r) ? TATE_ROUTE_SHORT : TATE_ROUTE_EXACT;
+}
+
+// ---- the 63-step loop (optimal ate) for the entry points that only DECIDE ---------------------------------------------------------
+// verifier.rs:30-54, signature.rs:34-39, pinocchio/verifier.rs:31-85 compare GTPoints and return a bool.  For P in G1, Q in G2 the ate pairing
+// a(Q, P) = f_{|x|,Q}(P)^((q^12-1)/r) is bilinear and non-degenerate on the same cyclic groups of prime order r, hence a(Q, P) = tate(P, Q)^c for ONE unit
+// c (mod r): prod_k tate(P_k, Q_k) == 1  <=>  prod_k a(Q_k, P_k) == 1.  (c has no closed form the model could check — the two argument orders of the Tate
+// pairing are tied by the Weil pairing — so the entry points that return VALUES keep the 127-step loop.)  Python model: oracle/fast_model.py
+// (ate_product_is_one), checked against the faithful oracle's tate() products by tests/test_fast_model.py.
+// The loop runs on Q (Jacobian over Fq2 on the twist E'); a line evaluated at P, multiplied by w and by Fq2 factors the final exponentiation kills, is
+//   a0 xp + a1 yp w + c4 w^4       with (a0, a1, c4) in Fq2 depending on Q ONLY
+// so a Q shared by a batch (a key's gamma, delta) is tabulated once (k_ate_key_prep, zkt_pairing.hip) and costs no point arithmetic in the lanes.
+// The chain ends on [|x|] Q: the G2 membership test psi(Q) = [x] Q is free.  P in G1 no longer is (the chain on P is gone): g1_in_subgroup.
+// The two steps and the end test are INLINED into the loops that use them (ZKT_ATE_STEP).  As called functions they broke their callers on this toolchain: a
+// function with 64-byte aligned locals keeps its incoming stack pointer in s34 (the base pointer), the inter-procedural register allocation does not count s34 among
+// the registers such a caller needs kept, and these three park literals there (found as a silent abort of k_pairing_product_check_ate; DESIGN.md §5 "A compiler limit").
+// tools/check_base_pointer.py scans an object for that pattern.
+#define ZKT_ATE_STEP ZKT_HD
+struct AteLine { Fq2 a0, a1, c4; };
+static constexpr int ATE_LINES = 68;                       // 63 doublings + 5 additions: |x| = 0xd201000000010000
+static constexpr int ATE_LINE_WORDS = 6 * FqC::N;          // a table entry: the three Fq2 in the kernels' own limb form (not an ABI type)
+// tangent at T scaled by 2YZ^3 xi:  a0 = -xi 3X^2 Z^2,  a1 = xi 2YZ^3,  c4 = 3X^3 - 2Y^2;  T <- 2T
+ZKT_ATE_STEP void ate_dbl_step(Jac<Fq2Ops>& T, AteLine& l) {
+  const Fq2 X = T.X, Y = T.Y, Z = T.Z;
+  const Fq2 A = fq2_sqr(X), B = fq2_sqr(Y), C = fq2_sqr(B), ZZ = fq2_sqr(Z);
+  const Fq2 D = fq2_dbl(fq2_sub(fq2_sub(fq2_sqr(fq2_add(X, B)), A), C));
+  const Fq2 E = fq2_add(fq2_dbl(A), A);
+  const Fq2 X3 = fq2_sub2(fq2_sqr(E), fq2_zero(), D);
+  const Fq2 Y3 = fq2_sub(fq2_mul(E, fq2_sub(D, X3)), fq2_dbl(fq2_dbl(fq2_dbl(C))));
+  const Fq2 Z3 = fq2_dbl(fq2_mul(Y, Z));
+  l.a0 = fq2_mul_xi(fq2_neg(fq2_mul(E, ZZ)));
+  l.a1 = fq2_mul_xi(fq2_mul(Z3, ZZ));
+  l.c4 = fq2_sub(fq2_mul(E, X), fq2_dbl(B));
+  T.X = X3; T.Y = Y3; T.Z = Z3;
+}
+// chord through T and Q scaled by Z3 xi:  a0 = -xi R,  a1 = xi Z3,  c4 = R xq - Z3 yq;  T <- T + Q.  T = +-Q (possible only for a Q of small order,
+// outside G2) gives Z3 = 0, which every later step keeps: the membership test at the end of the loop then fails and the element takes its old route.
+ZKT_ATE_STEP void ate_add_step(Jac<Fq2Ops>& T, const Fq2& xq, const Fq2& yq, AteLine& l) {
+  const Fq2 X = T.X, Y = T.Y, Z = T.Z;
+  const Fq2 ZZ = fq2_sqr(Z), H = fq2_sub(fq2_mul(xq, ZZ), X), Rr = fq2_sub(fq2_mul(fq2_mul(yq, ZZ), Z), Y);
+  const Fq2 HH = fq2_sqr(H), HHH = fq2_mul(H, HH), V = fq2_mul(X, HH);
+  const Fq2 X3 = fq2_sub2(fq2_sqr(Rr), HHH, V);
+  const Fq2 Y3 = fq2_mulsub(Rr, fq2_sub(V, X3), Y, HHH);
+  const Fq2 Z3 = fq2_mul(Z, H);
+  l.a0 = fq2_mul_xi(fq2_neg(Rr));
+  l.a1 = fq2_mul_xi(Z3);
+  l.c4 = fq2_mulsub(Rr, xq, Z3, yq);
+  T.X = X3; T.Y = Y3; T.Z = Z3;
+}
+// T == psi(Q) up to sign: T = [|x|] Q and x < 0, so Q in G2 <=> T == -psi(Q) (g2_in_subgroup above, with the chain already done)
+ZKT_ATE_STEP bool ate_end_is_psi(const Jac<Fq2Ops>& T, const Fq2& xq, const Fq2& yq) {
+  if (fq2_is_zero(T.Z)) return false;
+  const Fq2 px = fq2_mul(fq2_const([](int i) { return g2_psi_x_limb(0, i); }, [](int i) { return g2_psi_x_limb(1, i); }), fq2_conj(xq));
+  const Fq2 py = fq2_mul(fq2_const([](int i) { return g2_psi_y_limb(0, i); }, [](int i) { return g2_psi_y_limb(1, i); }), fq2_conj(yq));
+  const Fq2 ZZ = fq2_sqr(T.Z);
+  return fq2_eq(T.X, fq2_mul(px, ZZ)) && fq2_eq(T.Y, fq2_neg(fq2_mul(py, fq2_mul(ZZ, T.Z))));
+}
+// P in G1 <=> P on E (the caller's check) and [x^2] P == (BETA x, -y): the 127-step chain on P alone (no lines)
+ZKT_FN bool g1_in_subgroup(const Fq& xp, const Fq& yp) {
+  const Aff<FqOps> p{xp, yp, false};
+  Jac<FqOps> a = jac_from_aff(p);
+  for (int i = 0; i < MILLER_X2_NBITS; ++i) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w = (j == (i >> 5)) ? miller_x2_bits_word(j) : w;
+    a = jac_dbl(a);
+    if ((w >> (i & 31)) & 1) a = jac_add_aff(a, p);
+  }
+  if (jac_is_inf(a)) return false;
+  const Fq ZZ = fp_sqr(a.Z);
+  return fp_eq(fp_mul(fp_mul(g1_beta_const(), xp), ZZ), a.X) && fp_eq(fp_mul(fp_mul(yp, ZZ), a.Z), fp_neg(a.Y));
+}
+// f * (c0 + c1 w + c4 w^4) = (x + y w)(A + c1 w),  A = c0 + c4 v^2:  13 Fq2 products.
+//   x A and (x + y)(A + c1) are products with the sparse Fq6 element (s0, 0, s4): x0 s0, x2 s4, (x0 + x2)(s0 + s4), x1 s0, x1 s4 — five each;
+//   y c1 is three; then c0' = xA + v (y c1),  c1' = (x + y)(A + c1) - xA - y c1.
+ZKT_HD void fq6_mul_sparse04(const Fq6& x, const Fq2& s0, const Fq2& s4, Fq2& r0, Fq2& r1, Fq2& r2) {
+  const Fq2 p0 = fq2_mul(x.c0, s0), p2 = fq2_mul(x.c2, s4), q0 = fq2_mul(x.c1, s0), q4 = fq2_mul(x.c1, s4);
+  r2 = fq2_subsub(fq2_mul(fq2_add(x.c0, x.c2), fq2_add(s0, s4)), p0, p2);      // x0 s4 + x2 s0
+  r0 = fq2_add_mul_xi(p0, q4);                                                 // x0 s0 + xi x1 s4
+  r1 = fq2_add_mul_xi(q0, p2);                                                 // x1 s0 + xi x2 s4
+}
+ZKT_FN Fq12 fq12_mul_ate_line(const Fq12& f, const Fq2& c0, const Fq2& c1, const Fq2& c4) {
+  const Fq6 &x = f.c0, &y = f.c1;
+  Fq2 a0, a1, a2, s0, s1, s2;
+  fq6_mul_sparse04(x, c0, c4, a0, a1, a2);
+  const Fq2 b0 = fq2_mul(y.c0, c1), b1 = fq2_mul(y.c1, c1), b2 = fq2_mul(y.c2, c1);
+  fq6_mul_sparse04(fq6_add(x, y), fq2_add(c0, c1), c4, s0, s1, s2);
+  Fq12 r;
+  r.c0.c0 = fq2_add_mul_xi(a0, b2); r.c0.c1 = fq2_add(a1, b0); r.c0.c2 = fq2_add(a2, b1);
+  r.c1.c0 = fq2_subsub(s0, a0, b0); r.c1.c1 = fq2_subsub(s1, a1, b1); r.c1.c2 = fq2_subsub(s2, a2, b2);
+  return r;
+}
+ZKT_HD AteLine ld_ate_line(const uint32_t* p) {
+  AteLine l; Fq* e[6] = {&l.a0.c0, &l.a0.c1, &l.a1.c0, &l.a1.c1, &l.c4.c0, &l.c4.c1};
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int i = 0; i < FqC::N; ++i) e[k]->v[i] = p[k * FqC::N + i];
+  return l;
+}
+ZKT_HD void st_ate_line(uint32_t* p, const AteLine& l) {
+  const Fq* e[6] = {&l.a0.c0, &l.a0.c1, &l.a1.c0, &l.a1.c1, &l.c4.c0, &l.c4.c1};
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int i = 0; i < FqC::N; ++i) p[k * FqC::N + i] = e[k]->v[i];
+}
+ZKT_HD bool ate_bit(int i) { return (BLS_X_ABS >> i) & 1; }
+// The 68 line triples of one Q in loop order; returns Q in G2 (Q on E' is the caller's check).
+ZKT_FN bool ate_line_table(const Fq2& xq, const Fq2& yq, uint32_t* tab) {
+  Jac<Fq2Ops> T{xq, yq, fq2_one()};
+  AteLine l; int li = 0;
+  for (int i = 62; i >= 0; --i) {
+    ate_dbl_step(T, l); st_ate_line(tab + (size_t)(li++) * ATE_LINE_WORDS, l);
+    if (ate_bit(i)) { ate_add_step(T, xq, yq, l); st_ate_line(tab + (size_t)(li++) * ATE_LINE_WORDS, l); }
+  }
+  return ate_end_is_psi(T, xq, yq);
+}
+// prod_{k<KV} f_{|x|,Q_k}(P_k) * prod_{j<KF} f_{|x|,Q'_j}(P_{KV+j}) up to factors the final exponentiation kills.  The KV pairs bring their own Q_k (chain in
+// the lane), the KF pairs the line table of a shared Q'_j.  q_in_g2 <- every Q_k is in G2 (Q_k on E' is the caller's check, as are all the P's).
+template <int KV, int KF>
+ZKT_FN Fq12 miller_ate_multi(const Fq* xp, const Fq* yp, const Fq2* xq, const Fq2* yq, const uint32_t* const* tab, bool& q_in_g2) {
+  Jac<Fq2Ops> T[KV > 0 ? KV : 1];
+  for (int k = 0; k < KV; ++k) T[k] = Jac<Fq2Ops>{xq[k], yq[k], fq2_one()};
+  AteLine l;
+  Fq12 f = fq12_one(), ft;
+  int li = 0;
+  for (int i = 62; i >= 0; --i) {
+    if (i != 62) { ft = fq12_sqr(f); f = ft; }
+    for (int k = 0; k < KV; ++k) {
+      ate_dbl_step(T[k], l);
+      ft = fq12_mul_ate_line(f, fq2_mul_fq(l.a0, xp[k]), fq2_mul_fq(l.a1, yp[k]), l.c4); f = ft;
+    }
+    for (int j = 0; j < KF; ++j) {
+      l = ld_ate_line(tab[j] + (size_t)li * ATE_LINE_WORDS);
+      ft = fq12_mul_ate_line(f, fq2_mul_fq(l.a0, xp[KV + j]), fq2_mul_fq(l.a1, yp[KV + j]), l.c4); f = ft;
+    }
+    ++li;
+    if (ate_bit(i)) {                                                          // wave-uniform
+      for (int k = 0; k < KV; ++k) {
+        ate_add_step(T[k], xq[k], yq[k], l);
+        ft = fq12_mul_ate_line(f, fq2_mul_fq(l.a0, xp[k]), fq2_mul_fq(l.a1, yp[k]), l.c4); f = ft;
+      }
+      for (int j = 0; j < KF; ++j) {
+        l = ld_ate_line(tab[j] + (size_t)li * ATE_LINE_WORDS);
+        ft = fq12_mul_ate_line(f, fq2_mul_fq(l.a0, xp[KV + j]), fq2_mul_fq(l.a1, yp[KV + j]), l.c4); f = ft;
+      }
+      ++li;
+    }
+  }
+  q_in_g2 = true;
+  for (int k = 0; k < KV; ++k) q_in_g2 = q_in_g2 && ate_end_is_psi(T[k], xq[k], yq[k]);
+  return f;
 }
 
 // ---- raw Miller values and the Weil pairing, bit-exact (row a14) ------------------------------------

@@ -244,7 +244,9 @@ template <int K> ZKT_HD Fq2 frob_coeff(const Fq2& a, int idx) {
   if (K == 2) return fq2_mul_fq(c, frob2_fq(idx));
   return fq2_mul(c, frob_const<1>(idx));
 }
-template <int K> ZKT_FN Fq12 fq12_frob(const Fq12& a) {
+// (the inlined form is for callers that keep a base pointer — final_exponentiation_t: as a called function pi^1 parks literals in s34, which such a caller needs
+//  kept and this toolchain does not keep; pairing.h "ZKT_ATE_STEP", tools/check_base_pointer.py)
+template <int K> ZKT_HD Fq12 fq12_frob_inl(const Fq12& a) {
   // basis w^i: 0->c0.c0, 1->c1.c0, 2->c0.c1, 3->c1.c1, 4->c0.c2, 5->c1.c2
   Fq12 r;
   r.c0.c0 = frob_coeff<K>(a.c0.c0, 0); r.c1.c0 = frob_coeff<K>(a.c1.c0, 1);
@@ -252,6 +254,7 @@ template <int K> ZKT_FN Fq12 fq12_frob(const Fq12& a) {
   r.c0.c2 = frob_coeff<K>(a.c0.c2, 4); r.c1.c2 = frob_coeff<K>(a.c1.c2, 5);
   return r;
 }
+template <int K> ZKT_FN Fq12 fq12_frob(const Fq12& a) { return fq12_frob_inl<K>(a); }
 
 // f * (a + b v^2 + c v w) with a in Fq, b,c in Fq2: the value of a Miller line at
 // an untwisted G2 point has exactly these slots (g12_point.rs:47-68).

@@ -64,7 +64,11 @@ hipError_t launch_fixed_muls_batch(int grp, const uint32_t* tables, const uint32
 hipError_t launch_miller_exact(int which, const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, hipStream_t s);
 hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
                                  const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* ok, size_t n,
-                                 unsigned long long* err, hipStream_t s);
+                                 unsigned long long* err, hipStream_t s, const uint32_t* ate_key = nullptr);
+// what a verifying key contributes to the 63-step loop (line tables of gamma and delta, the ate counterpart of alpha_beta, verdicts on its points); layout at k_ate_key_prep
+static constexpr size_t ATE_KEY_WORDS = 2 * (size_t)68 * 84 + 144 + 1;
+hipError_t launch_ate_key_prep(const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma, const uint32_t* delta, const uint32_t* uvw_stmt, int n_stmt,
+                               uint32_t* key, hipStream_t s);
 size_t dproduct_limit();      // elements x pairs up to which the verification entry points use the lane-distributed kernels
 // stmt_tables (optional): fixed-base tables of the n_stmt statement points (launch_fixed_tables), which replace the statement's 255-step scalar multiplications
 hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt_tables, const uint32_t* stmt, int n_stmt,

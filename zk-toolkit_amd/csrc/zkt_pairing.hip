@@ -157,6 +157,112 @@ __global__ void __launch_bounds__(64) k_stmt_sums(const uint32_t* __restrict__ t
   for (int j = 0; j < n_stmt; ++j) acc = jac_add_aff(acc, PtIO<FqOps>::ld(terms + ((size_t)j * n + i) * ABI_G1_WORDS));
   PtIO<FqOps>::st(out + i * ABI_G1_WORDS, jac_to_aff(acc));
 }
+// ---- the deciding entry points on the 63-step loop (pairing.h, "optimal ate") ---------------------------------------------------------
+// What a verifying key contributes, prepared ONCE per key (the host caches it by the key's bytes, zkt_protocols.hip ate_key_for):
+//   words [0, T)      the 68 line triples of gamma          T = ATE_LINES * ATE_LINE_WORDS
+//   words [T, 2T)     ... of delta
+//   words [2T, +144)  final_exponentiation(f_{|x|,beta}(alpha)) — the ate counterpart of the key's alpha_beta (compared in the ABI's Fq12 layout)
+//   word  2T + 144    bit 0 gamma in G2, bit 1 delta in G2, bit 2 alpha in G1 and beta in G2, bit 3 every statement point in G1
+// The host uses the 63-step kernel for a key only when all four bits are set AND the key's alpha_beta equals tate(alpha, beta) (one small-batch pairing).
+__global__ void __launch_bounds__(64) k_ate_key_prep(const uint32_t* __restrict__ alpha, const uint32_t* __restrict__ beta, const uint32_t* __restrict__ gamma,
+                                                     const uint32_t* __restrict__ delta, const uint32_t* __restrict__ uvw_stmt, int n_stmt, uint32_t* __restrict__ key) {
+  constexpr size_t T = (size_t)ATE_LINES * ATE_LINE_WORDS;
+  const int j = threadIdx.x;
+  if (blockIdx.x == 0) {
+    if (j < 2) {
+      Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(j == 0 ? gamma : delta);
+      if (!q.inf && g2_on_curve(q.x, q.y) && ate_line_table(q.x, q.y, key + j * T)) atomicOr(key + 2 * T + 144, 1u << j);
+    }
+  } else if (blockIdx.x == 1) {
+    if (j == 0) {
+      Aff<FqOps> p = PtIO<FqOps>::ld(alpha); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(beta);
+      if (!p.inf && !q.inf && g1_on_curve(p.x, p.y) && g1_in_subgroup(p.x, p.y) && g2_on_curve(q.x, q.y)) {
+        bool in_g2;
+        const uint32_t* none[1] = {nullptr};
+        Fq12 f = miller_ate_multi<1, 0>(&p.x, &p.y, &q.x, &q.y, none, in_g2);
+        if (in_g2) { st_fq12(key + 2 * T, final_exponentiation(f)); atomicOr(key + 2 * T + 144, 4u); }
+      }
+    }
+  } else {
+    bool ok = true;
+    if (j < n_stmt) {
+      Aff<FqOps> p = PtIO<FqOps>::ld(uvw_stmt + (size_t)j * ABI_G1_WORDS);
+      ok = p.inf || (g1_on_curve(p.x, p.y) && g1_in_subgroup(p.x, p.y));      // infinity is the neutral element: a statement point may be it
+    }
+    if (__ballot(!ok) == 0 && j == 0 && n_stmt <= 64) atomicOr(key + 2 * T + 144, 8u);
+  }
+}
+hipError_t launch_ate_key_prep(const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma, const uint32_t* delta, const uint32_t* uvw_stmt, int n_stmt,
+                               uint32_t* key, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(key + 2 * (size_t)ATE_LINES * ATE_LINE_WORDS + 144, 0, sizeof(uint32_t), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_ate_key_prep, dim3(3), dim3(64), 0, s, alpha, beta, gamma, delta, uvw_stmt, n_stmt, key);
+  return hipGetLastError();
+}
+// e(A,B) == alpha_beta e(S,gamma) e(C,delta)  <=>  a(B,A) a(gamma,-S) a(delta,-C) == a(beta,alpha): B runs its chain in the lane (its G2 test comes with it),
+// gamma and delta bring their tables, S is a sum of multiples of statement points tested with the key.  A and C are tested here (127 doublings each).
+// Whatever does not fit — a point off its curve or outside its group — is marked OK_REDO and decided by the older kernels behind this one.
+__global__ void __launch_bounds__(64) k_groth16_verify_ate(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, const uint32_t* __restrict__ C,
+                                                           const uint32_t* __restrict__ S_pre, const uint32_t* __restrict__ key,
+                                                           uint32_t* __restrict__ ok, size_t n, unsigned long long* err) {
+  constexpr size_t T = (size_t)ATE_LINES * ATE_LINE_WORDS;
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Aff<FqOps> S = PtIO<FqOps>::ld(S_pre + i * ABI_G1_WORDS), a = PtIO<FqOps>::ld(A + i * ABI_G1_WORDS), c = PtIO<FqOps>::ld(C + i * ABI_G1_WORDS);
+  Aff<Fq2Ops> b = PtIO<Fq2Ops>::ld(B + i * ABI_G2_WORDS);
+  if (a.inf || b.inf || c.inf || S.inf) { atomicMin(err, (unsigned long long)i); ok[i] = 0; return; }   // tate() with infinity panics (gamma, delta: tested with the key)
+  if (!g1_on_curve(a.x, a.y) || !g1_on_curve(c.x, c.y) || !g2_on_curve(b.x, b.y) || !g1_in_subgroup(a.x, a.y) || !g1_in_subgroup(c.x, c.y)) { ok[i] = OK_REDO; return; }
+  Fq xp[3] = {a.x, S.x, c.x}, yp[3] = {a.y, fp_neg(S.y), fp_neg(c.y)};
+  const uint32_t* tabs[2] = {key, key + T};
+  bool in_g2;
+  Fq12 f = miller_ate_multi<1, 2>(xp, yp, &b.x, &b.y, tabs, in_g2);
+  if (!in_g2) { ok[i] = OK_REDO; return; }
+  uint32_t got[144]; st_fq12(got, final_exponentiation(f));
+  uint32_t diff = 0;
+  for (int k = 0; k < 144; ++k) diff |= got[k] ^ key[2 * T + k];
+  ok[i] = diff == 0;
+}
+// G1 points shared by a whole batch (stride 0: the generator in signature verification): curve equation and subgroup membership once per launch.
+__global__ void __launch_bounds__(64) k_shared_g1_guards(PairArgs a, int K, uint32_t* __restrict__ good) {
+  const int k = threadIdx.x;
+  bool ok = false;
+  if (k < K && a.s1[k] == 0) {
+    Aff<FqOps> p = PtIO<FqOps>::ld(a.g1[k]);
+    ok = !p.inf && g1_on_curve(p.x, p.y) && g1_in_subgroup(p.x, p.y);
+  }
+  const unsigned long long b = __ballot(ok);
+  if (k == 0) good[0] = (uint32_t)(b & 15u);
+}
+// prod_k tate(+-P_k, Q_k) == 1 decided on the 63-step loop: every Q_k runs its chain in the lane and is tested where it ends, every P_k is tested first
+// (bit k of p_good[0]: P_k is shared by the batch and was tested by k_shared_g1_guards).  ok[i] = OK_REDO leaves the element to the kernels behind.
+template <int K>
+__global__ void __launch_bounds__(64) k_pairing_product_check_ate(PairArgs a, uint32_t* __restrict__ ok, size_t n, unsigned long long* err, const uint32_t* __restrict__ p_good) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Fq xp[K], yp[K]; Fq2 xq[K], yq[K];
+  bool inf = false;
+  for (int k = 0; k < K; ++k) {
+    Aff<FqOps> p = PtIO<FqOps>::ld(a.g1[k] + i * a.s1[k]);
+    Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(a.g2[k] + i * a.s2[k]);
+    inf = inf || p.inf || q.inf;
+    xp[k] = p.x; yp[k] = a.neg[k] ? fp_neg(p.y) : p.y; xq[k] = q.x; yq[k] = q.y;
+  }
+  if (inf) { atomicMin(err, (unsigned long long)i); ok[i] = 0; return; }
+  const uint32_t known = p_good[0];
+  for (int k = 0; k < K; ++k) {
+    const bool p_ok = ((known >> k) & 1) || (g1_on_curve(xp[k], yp[k]) && g1_in_subgroup(xp[k], yp[k]));
+    if (!p_ok || !g2_on_curve(xq[k], yq[k])) { ok[i] = OK_REDO; return; }
+  }
+  bool in_g2;
+  const uint32_t* none[1] = {nullptr};
+  Fq12 f = miller_ate_multi<K, 0>(xp, yp, xq, yq, none, in_g2);
+  if (!in_g2) { ok[i] = OK_REDO; return; }
+  uint32_t got[144]; st_fq12(got, final_exponentiation(f));
+  uint32_t diff = got[132] ^ 1u;
+  for (int k = 0; k < 144; ++k) if (k != 132) diff |= got[k];
+  ok[i] = diff == 0;
+}
+
 // e(A,B) == alpha_beta e(S,gamma) e(C,delta) per proof on the lane-distributed kernels; tmp: n_stmt * n G1 points, S: n G1 points (device)
 hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt_tables, const uint32_t* stmt, int n_stmt,
                                        const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* tmp, uint32_t* S, uint32_t* ok, size_t n,
@@ -188,8 +294,22 @@ hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, con
 }
 hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
                                  const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* ok, size_t n,
-                                 unsigned long long* err, hipStream_t s) {
+                                 unsigned long long* err, hipStream_t s, const uint32_t* ate_key) {
   if (n == 0) return hipSuccess;
+  if (ate_key && n_stmt >= 1 && n_stmt <= 12) {             // a key the 63-step loop may serve (k_ate_key_prep): statement sums, the ate kernel, the older kernel for what it marked
+    uint32_t *tmp = nullptr, *S = nullptr; hipError_t e;
+    if ((e = hipMallocAsync((void**)&tmp, (size_t)n_stmt * n * ABI_G1_WORDS * 4, s)) != hipSuccess) return e;
+    if ((e = hipMallocAsync((void**)&S, n * ABI_G1_WORDS * 4, s)) != hipSuccess) { (void)hipFreeAsync(tmp, s); return e; }
+    MulSegs segs; segs.n = n_stmt;
+    for (int j = 0; j < n_stmt; ++j) segs.s[j] = MulSeg{uvw_stmt + (size_t)j * ABI_G1_WORDS, stmt + (size_t)j * 8, tmp + (size_t)j * n * ABI_G1_WORDS, (uint32_t)n, 0u, (uint32_t)(n_stmt * 8)};
+    if ((e = launch_group_mul_segs(G_G1, segs, 8, s)) != hipSuccess) { (void)hipFreeAsync(tmp, s); (void)hipFreeAsync(S, s); return e; }
+    hipLaunchKernelGGL(k_stmt_sums, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)tmp, n_stmt, S, n);
+    hipLaunchKernelGGL(k_groth16_verify_ate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, (const uint32_t*)S, ate_key, ok, n, err);
+    hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr, (const uint32_t*)S);
+    if ((e = hipFreeAsync(tmp, s)) != hipSuccess) return e;
+    if ((e = hipFreeAsync(S, s)) != hipSuccess) return e;
+    return hipGetLastError();
+  }
   uint32_t* good = nullptr; hipError_t e;                   // gamma and delta are the same for every proof: their G2 membership is decided by one wave, not by every lane
   if ((e = hipMallocAsync((void**)&good, sizeof(uint32_t), s)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_shared_g2_guards, dim3(1), dim3(64), 0, s, gamma, delta, good);
@@ -269,7 +389,17 @@ hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, 
     hipLaunchKernelGGL(k_product_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)flags, ok, n);
     if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
   }
-#define ZKT_PRODUCT_CHECK(KK) if (!small) hipLaunchKernelGGL((k_pairing_product_check<KK, true>), g, t, 0, s, a, ok, n, err, 0); \
+  // large batches: the 63-step loop decides; what it marks (an argument outside its group) goes to the 255-step kernel as before.  ZKT_PRODUCT_LOOP=127 keeps
+  // the round-2 kernel (the twisted-ate loop over x^2) for A/B measurements.
+  static const bool ate = [] { const char* e = getenv("ZKT_PRODUCT_LOOP"); return !(e && atoi(e) == 127); }();
+  uint32_t* p_good = nullptr;
+  if (!small && ate) {
+    hipError_t e;
+    if ((e = hipMallocAsync((void**)&p_good, sizeof(uint32_t), s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_shared_g1_guards, dim3(1), dim3(64), 0, s, a, K, p_good);
+  }
+#define ZKT_PRODUCT_CHECK(KK) if (!small) { if (ate) hipLaunchKernelGGL((k_pairing_product_check_ate<KK>), g, t, 0, s, a, ok, n, err, (const uint32_t*)p_good); \
+                                            else hipLaunchKernelGGL((k_pairing_product_check<KK, true>), g, t, 0, s, a, ok, n, err, 0); } \
                               hipLaunchKernelGGL((k_pairing_product_check<KK, false>), g, t, 0, s, a, ok, n, err, 1)
   switch (K) {
     case 1: ZKT_PRODUCT_CHECK(1); break;
@@ -279,6 +409,7 @@ hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, 
     default: return hipErrorInvalidValue;
   }
 #undef ZKT_PRODUCT_CHECK
+  if (p_good) { hipError_t e = hipFreeAsync(p_good, s); if (e != hipSuccess) return e; }
   return hipGetLastError();
 }
 

@@ -412,6 +412,37 @@ std::shared_ptr<void> stmt_tables_for(const zkt_g1_affine* pts, size_t n_stmt, c
   victim->tables = t; victim->key.assign((const uint8_t*)pts, (const uint8_t*)pts + kb); victim->stamp = ++g_stmt_clock;
   return t;
 }
+// What the 63-step verification kernel needs of a key (k_ate_key_prep, zkt_pairing.hip), kept for the last few keys like the tables above.  A key is served by that
+// kernel only if its points lie in their groups AND its alpha_beta is the Tate pairing of its alpha and beta — the reference compares against the stored GTPoint
+// (verifier.rs:48), so a key whose alpha_beta is anything else keeps the value-comparing kernels.  `usable` caches that verdict too.
+struct AteKey { std::vector<uint8_t> key; std::shared_ptr<void> dev; bool usable = false; uint64_t stamp = 0; };
+std::mutex g_ate_mu; AteKey g_ate[4]; uint64_t g_ate_clock = 0;
+std::shared_ptr<void> ate_key_for(const zkt_groth16_crs* c, size_t n_stmt, const uint32_t* dU, const uint32_t* dg, const uint32_t* dd, hipStream_t s) {
+  static const bool off = [] { const char* e = getenv("ZKT_PRODUCT_LOOP"); return e && atoi(e) == 127; }();
+  if (off || n_stmt < 1 || n_stmt > 12 || !c->g1_alpha || !c->g2_beta) return nullptr;
+  std::vector<uint8_t> kb(G1B + 3 * G2B + 576 + n_stmt * G1B);
+  uint8_t* w = kb.data();
+  memcpy(w, c->g1_alpha, G1B); w += G1B; memcpy(w, c->g2_beta, G2B); w += G2B; memcpy(w, c->g2_gamma, G2B); w += G2B; memcpy(w, c->g2_delta, G2B); w += G2B;
+  memcpy(w, c->gt_alpha_beta, 576); w += 576; memcpy(w, c->g1_uvw_stmt, n_stmt * G1B);
+  std::lock_guard<std::mutex> lk(g_ate_mu);
+  AteKey* victim = &g_ate[0];
+  for (AteKey& e : g_ate) {
+    if (e.stamp && e.key == kb) { e.stamp = ++g_ate_clock; return e.usable ? e.dev : nullptr; }
+    if (e.stamp < victim->stamp) victim = &e;
+  }
+  void* mem = nullptr;
+  if (hipMalloc(&mem, ATE_KEY_WORDS * 4) != hipSuccess) return nullptr;
+  std::shared_ptr<void> dev(mem, [](void* q) { if (q) hipFree(q); });
+  Dev dal(G1B), dbe(G2B), dgt(576), derr(8);
+  unsigned long long noerr = NO_ERR, e2 = NO_ERR; uint32_t flags = 0; uint64_t gt[72];
+  if (up(dal, c->g1_alpha, G1B, s) || up(dbe, c->g2_beta, G2B, s) || up(derr, &noerr, 8, s)) return nullptr;
+  if (launch_ate_key_prep(dal.w(), dbe.w(), dg, dd, dU, (int)n_stmt, (uint32_t*)mem, s) != hipSuccess) return nullptr;
+  if (launch_tate(dal.w(), dbe.w(), dgt.w(), 1, (unsigned long long*)derr.p, s) != hipSuccess) return nullptr;
+  if (down(&flags, (uint32_t*)mem + ATE_KEY_WORDS - 1, 4, s) || down(gt, dgt.p, 576, s) || down(&e2, derr.p, 8, s) || hipStreamSynchronize(s) != hipSuccess) return nullptr;
+  victim->key = std::move(kb); victim->dev = dev; victim->stamp = ++g_ate_clock;
+  victim->usable = flags == 15u && e2 == NO_ERR && memcmp(gt, c->gt_alpha_beta, 576) == 0;
+  return victim->usable ? dev : nullptr;
+}
 }  // namespace
 extern "C" {
 
@@ -523,7 +554,8 @@ int zkt_groth16_verify_batch(const zkt_groth16_crs* c, const zkt_g1_affine* A, c
     if (e2 != NO_ERR) { zkt_internal_set_error_index((size_t)e2); return ZKT_ERR_INFINITY; }
     return ZKT_OK;
   }
-  PCHK(launch_groth16_verify(dA.w(), dB.w(), dC.w(), dU.w(), dW.w(), (int)n_stmt, dg.w(), dd.w(), dab.w(), dok.w(), n_proofs, (unsigned long long*)derr.p, s));
+  const std::shared_ptr<void> akey = ate_key_for(c, n_stmt, dU.w(), dg.w(), dd.w(), s);      // held until the synchronisation below; null: the value-comparing kernels
+  PCHK(launch_groth16_verify(dA.w(), dB.w(), dC.w(), dU.w(), dW.w(), (int)n_stmt, dg.w(), dd.w(), dab.w(), dok.w(), n_proofs, (unsigned long long*)derr.p, s, (const uint32_t*)akey.get()));
   unsigned long long e = NO_ERR;
   if ((rc = down(ok, dok.p, n_proofs * 4, s)) || (rc = down(&e, derr.p, 8, s))) return rc;
   PCHK(hipStreamSynchronize(s));
@@ -613,6 +645,7 @@ extern "C" void zkt_internal_clear_caches() {             // zkt_shutdown: devic
   zkt_pinocchio_clear_caches();
   { std::lock_guard<std::mutex> lk(g_bpc.mu); g_bpc.ctx.reset(); g_bpc.key.clear(); }
   { std::lock_guard<std::mutex> lk(g_stmt_mu); for (StmtTables& e : g_stmt) { e.tables.reset(); e.key.clear(); e.stamp = 0; } }
+  { std::lock_guard<std::mutex> lk(g_ate_mu); for (AteKey& e : g_ate) { e.dev.reset(); e.key.clear(); e.stamp = 0; e.usable = false; } }
 }
 extern "C" {
 int zkt_bp_ipa_ctx_create(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u, zkt_bp_ipa_ctx** out) {
