@@ -273,6 +273,14 @@ typedef struct {
 int zkt_pinocchio_setup(zkt_pinocchio_crs* crs, const uint64_t* vi, const uint64_t* wi, const uint64_t* yi, const uint64_t* rnd);
 int zkt_pinocchio_prove(const zkt_pinocchio_crs* crs, const uint64_t* wires, const uint64_t* h, size_t h_len,
                         const uint64_t* delta_v, const uint64_t* delta_y, zkt_pinocchio_proof* proof);
+/* The prover with the evaluation key resident (the reference keeps its EvaluationKeys in the CRS for every prove call, pinocchio/prover.rs:98-103): the ten base
+ * sets of prover.rs:133-156 stay in HBM with their window-multiple tables, a proof uploads the wire values once and runs its ten multi-scalar multiplications
+ * through the pipelined resident interface.  Same arguments and the same nine proof points as zkt_pinocchio_prove; a handle serves one proof at a time. */
+typedef struct zkt_pinocchio_pk zkt_pinocchio_pk;
+int zkt_pinocchio_pk_create(const zkt_pinocchio_crs* crs, zkt_pinocchio_pk** out);
+int zkt_pinocchio_prove_resident(zkt_pinocchio_pk* pk, const uint64_t* wires, const uint64_t* h, size_t h_len,
+                                 const uint64_t* delta_v, const uint64_t* delta_y, zkt_pinocchio_proof* proof);
+void zkt_pinocchio_pk_free(zkt_pinocchio_pk* pk);
 /* 1 accept, 0 reject, negative = -status (a pairing argument at infinity panics in the reference); the five equalities are
  * decided in the reference's order (a rejection by an earlier one wins over a panic of a later one).  Up to 12 io wires: fixed-base
  * tables of the key's io points are built on first sight of a key (~30 ms) and kept for the last two keys, a verification then takes

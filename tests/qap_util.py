@@ -250,3 +250,7 @@ def pinocchio_instance(Amat, Bmat, Cmat, wit):
     deg = lambda q: max([k for k, c in enumerate(q) if c % R] + [0])
     max_degree = max([deg(q) for P in (vi, wi, yi) for q in P] + [deg(p), deg(t)]) + 1      # prover.rs:68-78
     return dense(vi, n), dense(wi, n), dense(yi, n), h, max_degree
+
+
+def qap_util_pin_ek(): return list(_PIN_EK)
+def qap_util_pin_vk(): return list(_PIN_VK)

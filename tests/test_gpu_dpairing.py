@@ -75,13 +75,14 @@ def test_small_batch_tate_vs_oracle(L, n):
 
 
 def test_large_batch_kernels_still_covered_in_a_forced_process():
-    """Small batches now take the lane-distributed kernels, so the one-element-per-lane kernels (k_tate, k_groth16_verify,
-    k_pairing_product_check) would only be reached by the 2^16-element tests.  Re-run the small parity tests of every pairing consumer in ONE
+    """Small batches now take the lane-distributed kernels, so the one-element-per-lane kernels (k_tate, k_groth16_verify_ate with the key's line and
+    statement tables — the chain circuit's statement is a full-size field element —, k_pairing_product_check_ate and the older kernels behind them)
+    would only be reached by the 2^16-element tests.  Re-run the small parity tests of every pairing consumer in ONE
     child process with the switch-over forced to zero (ZKT_DTATE_MAX = ZKT_DPRODUCT_MAX = 0): same oracle, other kernels."""
     import os, subprocess, sys
     env = dict(os.environ, ZKT_DTATE_MAX="0", ZKT_DPRODUCT_MAX="0")
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = "test_small_batch_tate_vs_oracle or verify_batch_mixed or outside_the_subgroup or signature or sign_verify or pinocchio_vs_oracle and cubic or tate_and_weil or bilinear"
+    sel = "test_small_batch_tate_vs_oracle or verify_batch_mixed or groth16_chain_circuit or outside_the_subgroup or signature or sign_verify or pinocchio_vs_oracle and cubic or tate_and_weil or bilinear"
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout

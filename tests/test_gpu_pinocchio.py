@@ -117,3 +117,72 @@ def test_pinocchio_verify_points_outside_g2(L):
     o, g = both(); assert (o, g) in ((0, 0), (1, 1)) or (o < 0 and g < 0)
     pbuf["g2_w_mid_s"][:] = keep["g2_w_mid_s"]
     assert both() == (1, 1)
+
+
+@pytest.mark.parametrize("case", ["cubic", "chain9"])
+def test_pinocchio_resident_prover_equals_one_shot(L, case):
+    """zkt_pinocchio_prove_resident (evaluation key in HBM, wires uploaded once, ten pipelined MSMs) gives the nine proof points of zkt_pinocchio_prove, which the
+    test above pins to the oracle's prover.rs:98-170 — twice on one handle, and the proof verifies."""
+    A, B, C, wit, l = example_cubic() if case == "cubic" else chain_circuit(int(case[5:]))
+    n, n_io = len(A), l + 1
+    V, W, Y, h, max_degree = pinocchio_instance(A, B, C, wit)
+    rng = SplitMix64(177 + n)
+    rnd = ints_to_arr([rng.below(R - 1) + 1 for _ in range(8)], 4)
+    wires, H = ints_to_arr(wit, 4), ints_to_arr(h, 4)
+    crs, cbuf = alloc_pinocchio(n, n_io, len(wit) - n_io, max_degree)
+    zk.check(L.zkt_pinocchio_setup(ctypes.byref(crs), ptr(V), ptr(W), ptr(Y), ptr(rnd)))
+    pk = ctypes.c_void_p()
+    zk.check(L.zkt_pinocchio_pk_create(ctypes.byref(crs), ctypes.byref(pk)))
+    try:
+        for rep in range(2):
+            dv, dy = ints_to_arr([rng.below(R - 1) + 1], 4), ints_to_arr([rng.below(R - 1) + 1], 4)
+            pf1, b1 = alloc_pinocchio_proof(); pf2, b2 = alloc_pinocchio_proof()
+            zk.check(L.zkt_pinocchio_prove(ctypes.byref(crs), ptr(wires), ptr(H), len(h), ptr(dv), ptr(dy), ctypes.byref(pf1)))
+            zk.check(L.zkt_pinocchio_prove_resident(pk, ptr(wires), ptr(H), len(h), ptr(dv), ptr(dy), ctypes.byref(pf2)))
+            for k in b1:
+                assert (b1[k] == b2[k]).all(), (rep, k)
+            assert L.zkt_pinocchio_verify(ctypes.byref(crs), ctypes.byref(pf2), ptr(wires[:n_io].copy())) == 1
+        assert L.zkt_pinocchio_prove_resident(pk, ptr(wires), ptr(H), max_degree + 1, ptr(dv), ptr(dy), ctypes.byref(pf2)) == ZKT_ERR_SHAPE      # polynomial.rs:289-291
+    finally:
+        L.zkt_pinocchio_pk_free(pk)
+
+
+def test_pinocchio_resident_prover_2p16_wires_by_linearity(L):
+    """The prover at the size the protocol runs (2^16 mid wires, quotient of degree 2^16 - 1): an evaluation key whose every base is a KNOWN multiple of the
+    generator, so each proof point is generator * (a sum computed here with python integers) — prover.rs:124-161 restated on the exponents."""
+    n_mid, n_io, deg = 1 << 16, 3, 1 << 16
+    gen = np.random.Generator(np.random.PCG64(31))
+    def scal(cnt):
+        a = gen.integers(0, 2**63, size=(cnt, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(2); return a
+    g1 = np.zeros((1, G1W), np.uint64); O.zkto_g1_generator(ptr(g1)); g2 = np.zeros((1, G2W), np.uint64); O.zkto_g2_generator(ptr(g2))
+    crs, buf = alloc_pinocchio(n_mid, n_io, n_mid, deg)
+    exps = {}
+    for name, w, c in [e for e in (qap_util_pin_ek() + qap_util_pin_vk())]:
+        cnt = buf[name].shape[0]
+        k = scal(cnt); exps[name] = [int(limbs_to_int(r)) % R for r in k]
+        if w == G1W: zk.check(L.zkt_bls_public_keys_batch(ptr(k), cnt, ptr(buf[name])))            # generator * k through the comb table
+        else: zk.check(L.zkt_g2_mul_batch(ptr(np.repeat(g2, cnt, axis=0)), ptr(k), 4, ptr(buf[name]), cnt))
+    wires = scal(n_io + n_mid); wires[5] = 0; wires[6] = np.array([1, 0, 0, 0], np.uint64)
+    H = scal(deg)
+    dv, dy = scal(1), scal(1)
+    wv = [int(limbs_to_int(r)) for r in wires]; hv = [int(limbs_to_int(r)) for r in H]
+    dvi, dyi = int(limbs_to_int(dv[0])), int(limbs_to_int(dy[0]))
+    mid = wv[n_io:]
+    dot = lambda name, vals: sum(a * b for a, b in zip(exps[name], vals)) % R
+    t, avt, ayt, bt, one2 = exps["t"][0], exps["alpha_v_t"][0], exps["alpha_y_t"][0], exps["beta_t"][0], exps["one_g2"][0]
+    w_s = (dot("g2_wk_mid", mid) + dot("wk_io", wv[:n_io])) % R
+    want = {"v_mid_s": (t * dvi + dot("vk_mid", mid)) % R, "g1_w_mid_s": dot("g1_wk_mid", mid), "g2_w_mid_s": dot("g2_wk_mid", mid), "y_mid_s": (t * dyi + dot("yk_mid", mid)) % R,
+            "alpha_v_mid_s": (avt * dvi + dot("alpha_vk_mid", mid)) % R, "alpha_w_mid_s": dot("alpha_wk_mid", mid), "alpha_y_mid_s": (ayt * dyi + dot("alpha_yk_mid", mid)) % R,
+            "beta_vwy_mid_s": (bt * dvi + bt * dyi + dot("beta_vwy_k_mid", mid)) % R, "h_s": (dot("si", hv) + w_s * dvi - one2 * dyi) % R}
+    pk = ctypes.c_void_p()
+    zk.check(L.zkt_pinocchio_pk_create(ctypes.byref(crs), ctypes.byref(pk)))
+    try:
+        pf, pb = alloc_pinocchio_proof()
+        zk.check(L.zkt_pinocchio_prove_resident(pk, ptr(wires), ptr(H), deg, ptr(dv), ptr(dy), ctypes.byref(pf)))
+        for name, e in want.items():
+            exp = np.zeros((1, pb[name].shape[1]), np.uint64)
+            if pb[name].shape[1] == G1W: assert O.zkto_g1_mul_batch(ptr(g1), ptr(ints_to_arr([e], 4)), 4, ptr(exp), 1, 1) == 0
+            else: assert O.zkto_g2_mul_batch(ptr(g2), ptr(ints_to_arr([e], 4)), 4, ptr(exp), 1, 1) == 0
+            assert (pb[name] == exp).all(), name
+    finally:
+        L.zkt_pinocchio_pk_free(pk)

@@ -258,6 +258,56 @@ hipError_t launch_fixed_muls_batch(int grp, const uint32_t* tables, const uint32
   else hipLaunchKernelGGL(k_fixed_muls_batch<Fq2Ops>, dim3((unsigned)(n * n_pts)), dim3(64), 0, s, tables, k, out, n, n_pts);
   return hipGetLastError();
 }
+// ---- statement sums of a large verification batch from 8-bit window tables (Groth16 verifier.rs:41-45) ---------------------------------------------------
+// S_i = sum_j stmt[i][j] * U_j for 65,536 proofs is 196,608 scalar multiplications by the SAME n_stmt points: a 255-step chain each (1.2 M multiply-adds) when done
+// as variable-base multiplications.  The key's cache entry instead carries, per statement point, the 32 x 256 Jacobian multiples d * 256^w * U_j (1.4 MB per point,
+// built once per key: k_stmt_wide_tables, one lane per (point, window)); a proof's lane then adds one table entry per scalar byte — 32 n_stmt additions and ONE
+// inversion for the affine S_i.  Entry 0 of a window is the point at infinity, which the complete addition absorbs.
+static constexpr int WIDE_WINDOWS = 32, WIDE_ENTRIES = 256, WIDE_JW = 3 * FqC::N;      // words per Jacobian entry in the kernels' own limb form
+__device__ inline void st_jac_words(uint32_t* p, const Jac<FqOps>& a) {
+#pragma unroll
+  for (int i = 0; i < FqC::N; ++i) { p[i] = a.X.v[i]; p[FqC::N + i] = a.Y.v[i]; p[2 * FqC::N + i] = a.Z.v[i]; }
+}
+__device__ inline Jac<FqOps> ld_jac_words(const uint32_t* p) {
+  Jac<FqOps> a;
+#pragma unroll
+  for (int i = 0; i < FqC::N; ++i) { a.X.v[i] = p[i]; a.Y.v[i] = p[FqC::N + i]; a.Z.v[i] = p[2 * FqC::N + i]; }
+  return a;
+}
+__global__ void __launch_bounds__(64) k_stmt_wide_tables(const uint32_t* __restrict__ points, int n_pts, uint32_t* __restrict__ tables) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= n_pts * WIDE_WINDOWS) return;
+  const int j = t / WIDE_WINDOWS, w = t % WIDE_WINDOWS;
+  Jac<FqOps> base = jac_from_aff(PtIO<FqOps>::ld(points + (size_t)j * ABI_G1_WORDS));
+  for (int d = 0; d < 8 * w; ++d) base = jac_dbl(base);
+  uint32_t* out = tables + ((size_t)j * WIDE_WINDOWS + w) * WIDE_ENTRIES * WIDE_JW;
+  Jac<FqOps> acc = jac_inf<FqOps>();
+  for (int d = 0; d < WIDE_ENTRIES; ++d) { st_jac_words(out + (size_t)d * WIDE_JW, acc); acc = jac_add<FqOps>(acc, base); }
+}
+__global__ void __launch_bounds__(64) k_stmt_sums_wide(const uint32_t* __restrict__ tables, const uint32_t* __restrict__ stmt, int n_stmt, uint32_t* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Jac<FqOps> acc = jac_inf<FqOps>();
+  for (int j = 0; j < n_stmt; ++j) {
+    const uint32_t* k = stmt + (i * n_stmt + j) * 8;                  // canonical Fr, eight 32-bit words
+    for (int w = 0; w < WIDE_WINDOWS; ++w) {
+      const uint32_t d = (k[w >> 2] >> ((w & 3) * 8)) & 255u;
+      if (d) acc = jac_add<FqOps>(acc, ld_jac_words(tables + (((size_t)j * WIDE_WINDOWS + w) * WIDE_ENTRIES + d) * WIDE_JW));
+    }
+  }
+  PtIO<FqOps>::st(out + i * ABI_G1_WORDS, jac_to_aff(acc));
+}
+size_t stmt_wide_table_words(int n_pts) { return (size_t)n_pts * WIDE_WINDOWS * WIDE_ENTRIES * WIDE_JW; }
+hipError_t launch_stmt_wide_tables(const uint32_t* points, int n_pts, uint32_t* tables, hipStream_t s) {
+  if (n_pts < 1 || n_pts > 12) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_stmt_wide_tables, dim3((unsigned)((n_pts * WIDE_WINDOWS + 63) / 64)), dim3(64), 0, s, points, n_pts, tables);
+  return hipGetLastError();
+}
+hipError_t launch_stmt_sums_wide(const uint32_t* tables, const uint32_t* stmt, int n_stmt, uint32_t* out, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_stmt_sums_wide, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, tables, stmt, n_stmt, out, n);
+  return hipGetLastError();
+}
 hipError_t launch_fixed_muls(int grp, const FixedMuls& f, hipStream_t s) {
   if (grp != G_SECP || f.n < 0 || f.n > 16) return hipErrorInvalidValue;
   if (f.n == 0) return hipSuccess;

@@ -69,6 +69,10 @@ hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uin
 static constexpr size_t ATE_KEY_WORDS = 2 * (size_t)68 * 84 + 144 + 1;
 hipError_t launch_ate_key_prep(const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma, const uint32_t* delta, const uint32_t* uvw_stmt, int n_stmt,
                                uint32_t* key, hipStream_t s);
+// 8-bit window tables of a key's statement points and the statement sums of a large batch from them (zkt_group.hip)
+size_t stmt_wide_table_words(int n_pts);
+hipError_t launch_stmt_wide_tables(const uint32_t* points, int n_pts, uint32_t* tables, hipStream_t s);
+hipError_t launch_stmt_sums_wide(const uint32_t* tables, const uint32_t* stmt, int n_stmt, uint32_t* out, size_t n, hipStream_t s);
 size_t dproduct_limit();      // elements x pairs up to which the verification entry points use the lane-distributed kernels
 // stmt_tables (optional): fixed-base tables of the n_stmt statement points (launch_fixed_tables), which replace the statement's 255-step scalar multiplications
 hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt_tables, const uint32_t* stmt, int n_stmt,

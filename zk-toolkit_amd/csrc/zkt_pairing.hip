@@ -297,16 +297,12 @@ hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uin
                                  unsigned long long* err, hipStream_t s, const uint32_t* ate_key) {
   if (n == 0) return hipSuccess;
   if (ate_key && n_stmt >= 1 && n_stmt <= 12) {             // a key the 63-step loop may serve (k_ate_key_prep): statement sums, the ate kernel, the older kernel for what it marked
-    uint32_t *tmp = nullptr, *S = nullptr; hipError_t e;
-    if ((e = hipMallocAsync((void**)&tmp, (size_t)n_stmt * n * ABI_G1_WORDS * 4, s)) != hipSuccess) return e;
-    if ((e = hipMallocAsync((void**)&S, n * ABI_G1_WORDS * 4, s)) != hipSuccess) { (void)hipFreeAsync(tmp, s); return e; }
-    MulSegs segs; segs.n = n_stmt;
-    for (int j = 0; j < n_stmt; ++j) segs.s[j] = MulSeg{uvw_stmt + (size_t)j * ABI_G1_WORDS, stmt + (size_t)j * 8, tmp + (size_t)j * n * ABI_G1_WORDS, (uint32_t)n, 0u, (uint32_t)(n_stmt * 8)};
-    if ((e = launch_group_mul_segs(G_G1, segs, 8, s)) != hipSuccess) { (void)hipFreeAsync(tmp, s); (void)hipFreeAsync(S, s); return e; }
-    hipLaunchKernelGGL(k_stmt_sums, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (const uint32_t*)tmp, n_stmt, S, n);
+    uint32_t* S = nullptr; hipError_t e;
+    if ((e = hipMallocAsync((void**)&S, n * ABI_G1_WORDS * 4, s)) != hipSuccess) return e;
+    // the statement sums from the key's 8-bit window tables (behind the line tables in the key buffer): 32 additions per wire instead of a 255-step chain
+    if ((e = launch_stmt_sums_wide(ate_key + ATE_KEY_WORDS, stmt, n_stmt, S, n, s)) != hipSuccess) { (void)hipFreeAsync(S, s); return e; }
     hipLaunchKernelGGL(k_groth16_verify_ate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, (const uint32_t*)S, ate_key, ok, n, err);
     hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr, (const uint32_t*)S);
-    if ((e = hipFreeAsync(tmp, s)) != hipSuccess) return e;
     if ((e = hipFreeAsync(S, s)) != hipSuccess) return e;
     return hipGetLastError();
   }

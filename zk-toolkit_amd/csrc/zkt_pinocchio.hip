@@ -301,6 +301,118 @@ int zkt_pinocchio_prove(const zkt_pinocchio_crs* c, const uint64_t* wires, const
   return ZKT_OK;
 }
 
+}  // extern "C"
+// ---- the prover with the evaluation key resident (round 3) --------------------------------------------------------------------------------------
+// Prover::prove (prover.rs:98-170) is ten multi-scalar multiplications: seven G1 and one G2 sum over the SAME mid-wire values (prover.rs:133-141), the quotient
+// h over the powers s^i in G2 (:143-146) and the io wires over wk_io in G2 (:151-156).  zkt_pinocchio_prove hands each of them to the one-shot entry points, which
+// upload the bases and build their plan on every call (50 ms at 32 constraints, seconds at 2^16).  An evaluation key is long-lived, so this handle keeps its ten
+// base sets in HBM with their window-multiple tables (zkt_g1_bases / zkt_g2_bases), uploads the wire values ONCE per proof and runs the ten sums through the
+// pipelined submit/collect interface; the G1 sets share one group of streams, the G2 sets another (zkt_internal_bases_share_streams: a stream is a hardware queue).
+extern "C" int zkt_internal_bases_share_streams(void* dst, void* src, int share_acc, int tail_base, int tail_span);
+struct zkt_pinocchio_pk {
+  size_t n_io = 0, n_mid = 0, max_degree = 0;
+  zkt_g1_bases* g1[7] = {};                       // vk, g1_wk, yk, alpha_vk, alpha_wk, alpha_yk, beta_vwy_k (mid)
+  zkt_g2_bases *g2_wk = nullptr, *si = nullptr, *wk_io = nullptr;
+  zkt_g1_affine t{}, alpha_v_t{}, alpha_y_t{}, beta_t{}; zkt_g2_affine one_g2{};
+  void *d_wires = nullptr, *d_h = nullptr;
+  std::mutex mu;                                  // a handle serves one proof at a time
+  ~zkt_pinocchio_pk() {
+    if (wk_io) zkt_g2_bases_free(wk_io);
+    if (si) zkt_g2_bases_free(si);
+    for (int k = 6; k >= 1; --k) if (g1[k]) zkt_g1_bases_free(g1[k]);
+    if (g2_wk) zkt_g2_bases_free(g2_wk);          // owner of the G2 group's streams: after si and wk_io
+    if (g1[0]) zkt_g1_bases_free(g1[0]);          // owner of the G1 group's streams: last
+    if (d_wires) hipFree(d_wires);
+    if (d_h) hipFree(d_h);
+  }
+};
+extern "C" {
+int zkt_pinocchio_pk_create(const zkt_pinocchio_crs* c, zkt_pinocchio_pk** out) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!c || !out || !c->t || !c->alpha_v_t || !c->alpha_y_t || !c->beta_t || !c->one_g2) return ZKT_ERR_SHAPE;
+  std::unique_ptr<zkt_pinocchio_pk> pk(new zkt_pinocchio_pk);
+  pk->n_io = c->n_io; pk->n_mid = c->n_mid; pk->max_degree = c->max_degree;
+  pk->t = *c->t; pk->alpha_v_t = *c->alpha_v_t; pk->alpha_y_t = *c->alpha_y_t; pk->beta_t = *c->beta_t; pk->one_g2 = *c->one_g2;
+  const zkt_g1_affine* b1[7] = {c->vk_mid, c->g1_wk_mid, c->yk_mid, c->alpha_vk_mid, c->alpha_wk_mid, c->alpha_yk_mid, c->beta_vwy_k_mid};
+  if (c->n_mid) {
+    for (int k = 0; k < 7; ++k) {
+      if (!b1[k]) return ZKT_ERR_SHAPE;
+      ZRC(zkt_g1_bases_upload(b1[k], c->n_mid, &pk->g1[k]));
+      if (k) ZRC(zkt_internal_bases_share_streams(pk->g1[k], pk->g1[0], 1, k % 4, 1));      // below 2^19 terms a slot runs its whole MSM on its reduce stream: four side by side
+    }
+    if (!c->g2_wk_mid) return ZKT_ERR_SHAPE;
+    ZRC(zkt_g2_bases_upload(c->g2_wk_mid, c->n_mid, &pk->g2_wk));
+  }
+  if (c->max_degree) {
+    if (!c->si) return ZKT_ERR_SHAPE;
+    ZRC(zkt_g2_bases_upload(c->si, c->max_degree, &pk->si));
+    if (pk->g2_wk) ZRC(zkt_internal_bases_share_streams(pk->si, pk->g2_wk, 1, 2, 1));
+  }
+  if (c->n_io) {
+    if (!c->wk_io) return ZKT_ERR_SHAPE;
+    ZRC(zkt_g2_bases_upload(c->wk_io, c->n_io, &pk->wk_io));
+    if (pk->g2_wk) ZRC(zkt_internal_bases_share_streams(pk->wk_io, pk->g2_wk, 1, 3, 1));
+  }
+  if (hipMalloc(&pk->d_wires, (c->n_io + c->n_mid ? c->n_io + c->n_mid : 1) * FRB) != hipSuccess || hipMalloc(&pk->d_h, (c->max_degree ? c->max_degree : 1) * FRB) != hipSuccess) return ZKT_ERR_DEVICE;
+  *out = pk.release();
+  return ZKT_OK;
+}
+void zkt_pinocchio_pk_free(zkt_pinocchio_pk* pk) { delete pk; }
+// Prover::prove (prover.rs:98-170) on a resident key: same arguments and the same nine proof points as zkt_pinocchio_prove
+int zkt_pinocchio_prove_resident(zkt_pinocchio_pk* pk, const uint64_t* wires, const uint64_t* h, size_t h_len, const uint64_t* delta_v, const uint64_t* delta_y,
+                                 zkt_pinocchio_proof* pf) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!pk || !wires || !delta_v || !delta_y || !pf || (h_len && !h) || h_len > pk->max_degree) return ZKT_ERR_SHAPE;
+  std::lock_guard<std::mutex> lk(pk->mu);
+  const size_t nio = pk->n_io, nmid = pk->n_mid;
+  hipStream_t s = nullptr;
+  QCHK(hipMemcpyAsync(pk->d_wires, wires, (nio + nmid) * FRB, hipMemcpyHostToDevice, s));
+  // the quotient is padded with zeros to the key's max_degree terms (the resident set has a fixed length; a zero scalar adds nothing)
+  if (h_len) QCHK(hipMemcpyAsync(pk->d_h, h, h_len * FRB, hipMemcpyHostToDevice, s));
+  if (h_len < pk->max_degree) QCHK(hipMemsetAsync((char*)pk->d_h + h_len * FRB, 0, (pk->max_degree - h_len) * FRB, s));
+  const uint64_t* d_mid = (const uint64_t*)pk->d_wires + nio * 4;
+  // every sum in flight at once; whatever was submitted is collected below even after an error (a slot left pending would block the next proof)
+  int rc = ZKT_OK, r2; bool sub1[7] = {}, sub_w = false, sub_h = false, sub_io = false;
+  if (nmid) {
+    for (int k = 0; k < 7 && rc == ZKT_OK; ++k) { rc = zkt_g1_msm_submit(pk->g1[k], d_mid, nmid, s, 0); sub1[k] = rc == ZKT_OK; }
+    if (rc == ZKT_OK) { rc = zkt_g2_msm_submit(pk->g2_wk, d_mid, nmid, s, 0); sub_w = rc == ZKT_OK; }
+  }
+  if (rc == ZKT_OK && h_len) { rc = zkt_g2_msm_submit(pk->si, (const uint64_t*)pk->d_h, pk->max_degree, s, 0); sub_h = rc == ZKT_OK; }
+  if (rc == ZKT_OK && nio) { rc = zkt_g2_msm_submit(pk->wk_io, (const uint64_t*)pk->d_wires, nio, s, 0); sub_io = rc == ZKT_OK; }
+  // randomisation terms (prover.rs:124-131) while the sums run: t dv, t dy, alpha_v_t dv, alpha_y_t dy, beta_t dv, beta_t dy
+  zkt_g1_affine pts[6] = {pk->t, pk->t, pk->alpha_v_t, pk->alpha_y_t, pk->beta_t, pk->beta_t}, rnd[6];
+  uint64_t sc[24];
+  const uint64_t* which[6] = {delta_v, delta_y, delta_v, delta_y, delta_v, delta_y};
+  for (int k = 0; k < 6; ++k) memcpy(sc + 4 * k, which[k], 32);
+  const int rc_r = rc == ZKT_OK ? zkt_g1_mul_batch(pts, sc, 4, rnd, 6) : ZKT_OK;
+  zkt_g1_affine sums[7]; zkt_g2_affine sw2, h_s, w_io;
+  memset(sums, 0, sizeof(sums)); memset(&sw2, 0, sizeof(sw2)); memset(&h_s, 0, sizeof(h_s)); memset(&w_io, 0, sizeof(w_io));
+  for (int k = 0; k < 7; ++k) sums[k].is_infinity = 1;
+  sw2.is_infinity = 1; h_s.is_infinity = 1; w_io.is_infinity = 1;
+  for (int k = 0; k < 7; ++k) if (sub1[k] && (r2 = zkt_g1_msm_collect(pk->g1[k], 0, &sums[k], nullptr)) != ZKT_OK) rc = r2;
+  if (sub_w && (r2 = zkt_g2_msm_collect(pk->g2_wk, 0, &sw2, nullptr)) != ZKT_OK) rc = r2;
+  if (sub_h && (r2 = zkt_g2_msm_collect(pk->si, 0, &h_s, nullptr)) != ZKT_OK) rc = r2;
+  if (sub_io && (r2 = zkt_g2_msm_collect(pk->wk_io, 0, &w_io, nullptr)) != ZKT_OK) rc = r2;
+  if (rc != ZKT_OK) return rc;
+  if (rc_r != ZKT_OK) return rc_r;
+  const zkt_g1_affine &sv = sums[0], &sw1 = sums[1], &sy = sums[2], &sav = sums[3], &saw = sums[4], &say = sums[5], &sb = sums[6];
+  zkt_g1_affine bsum;
+  ZRC(zkt_g1_add_batch(&rnd[4], &rnd[5], &bsum, 1));
+  zkt_g1_affine lhs[5] = {rnd[0], rnd[1], rnd[2], rnd[3], bsum}, rhs[5] = {sv, sy, sav, say, sb}, out5[5];
+  ZRC(zkt_g1_add_batch(lhs, rhs, out5, 5));
+  *pf->v_mid_s = out5[0]; *pf->y_mid_s = out5[1]; *pf->alpha_v_mid_s = out5[2]; *pf->alpha_y_mid_s = out5[3]; *pf->beta_vwy_mid_s = out5[4];
+  *pf->g1_w_mid_s = sw1; *pf->g2_w_mid_s = sw2; *pf->alpha_w_mid_s = saw;
+  // adjusted h(s) (prover.rs:148-161): h_s + w_s delta_v - one_g2 delta_y
+  zkt_g2_affine w_s, two[2], muls[2], nody, t2;
+  ZRC(zkt_g2_add_batch(&sw2, &w_io, &w_s, 1));
+  two[0] = w_s; two[1] = pk->one_g2;
+  uint64_t sc2[8]; memcpy(sc2, delta_v, 32); memcpy(sc2 + 4, delta_y, 32);
+  ZRC(zkt_g2_mul_batch(two, sc2, 4, muls, 2));
+  ZRC(zkt_g2_neg_batch(&muls[1], &nody, 1));
+  ZRC(zkt_g2_add_batch(&h_s, &muls[0], &t2, 1)); ZRC(zkt_g2_add_batch(&t2, &nody, pf->h_s, 1));
+  return ZKT_OK;
+}
+
 // Verifier::verify (verifier.rs:31-85): 1 accept, 0 reject, negative = -status (a tate() argument at infinity panics in the reference).
 // The checks are evaluated in the reference's order, so a rejection by an earlier check wins over a panic of a later one.
 int zkt_pinocchio_verify(const zkt_pinocchio_crs* c, const zkt_pinocchio_proof* pf, const uint64_t* io_wires) {

@@ -431,12 +431,13 @@ std::shared_ptr<void> ate_key_for(const zkt_groth16_crs* c, size_t n_stmt, const
     if (e.stamp < victim->stamp) victim = &e;
   }
   void* mem = nullptr;
-  if (hipMalloc(&mem, ATE_KEY_WORDS * 4) != hipSuccess) return nullptr;
+  if (hipMalloc(&mem, (ATE_KEY_WORDS + stmt_wide_table_words((int)n_stmt)) * 4) != hipSuccess) return nullptr;      // [line tables, alpha_beta, verdicts | statement tables]
   std::shared_ptr<void> dev(mem, [](void* q) { if (q) hipFree(q); });
   Dev dal(G1B), dbe(G2B), dgt(576), derr(8);
   unsigned long long noerr = NO_ERR, e2 = NO_ERR; uint32_t flags = 0; uint64_t gt[72];
   if (up(dal, c->g1_alpha, G1B, s) || up(dbe, c->g2_beta, G2B, s) || up(derr, &noerr, 8, s)) return nullptr;
   if (launch_ate_key_prep(dal.w(), dbe.w(), dg, dd, dU, (int)n_stmt, (uint32_t*)mem, s) != hipSuccess) return nullptr;
+  if (launch_stmt_wide_tables(dU, (int)n_stmt, (uint32_t*)mem + ATE_KEY_WORDS, s) != hipSuccess) return nullptr;
   if (launch_tate(dal.w(), dbe.w(), dgt.w(), 1, (unsigned long long*)derr.p, s) != hipSuccess) return nullptr;
   if (down(&flags, (uint32_t*)mem + ATE_KEY_WORDS - 1, 4, s) || down(gt, dgt.p, 576, s) || down(&e2, derr.p, 8, s) || hipStreamSynchronize(s) != hipSuccess) return nullptr;
   victim->key = std::move(kb); victim->dev = dev; victim->stamp = ++g_ate_clock;
