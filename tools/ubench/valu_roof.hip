@@ -14,17 +14,25 @@
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-enum { FMA_F32, PK_FMA_F32, ADD_U32, AND_B32, LSHR_B64, MUL_LO, MAD64, MIX_FIELD, NOPS };
+enum { FMA_F32, PK_FMA_F32, ADD_U32, AND_B32, LSHR_B64, MUL_LO, MAD64, MIX_FIELD, FMA_F64, ADD_F64, LSHL_ADD_U64, MIX_DPF, NOPS };
 static const char* NAMES[NOPS] = {"v_fma_f32 (control)", "v_pk_fma_f32 (2 fma/lane)", "v_add_u32", "v_and_b32", "v_lshrrev_b64", "v_mul_lo_u32", "v_mad_u64_u32",
-                                  "field mix: 4 mad64 + lshr64 + and + mul_lo + add"};
+                                  "field mix: 4 mad64 + lshr64 + and + mul_lo + add", "v_fma_f64", "v_add_f64", "v_lshl_add_u64",
+                                  "fp64 limb product: fma64 + add64 + fma64 + 2 lshl_add_u64"};
+// Round 3 (review item 9, go / no-go): the Montgomery product on 8 x 52-bit limbs held as doubles.  One limb product a_i b_j < 2^104 is
+//   hi = fma_rz(a, b, 2^104)      mantissa field = a b >> 52
+//   lo = fma_rz(a, b, (2^104 + 2^52) - hi)      mantissa field = a b mod 2^52
+// and both raw bit patterns are added into 64-bit column sums (the exponent patterns are subtracted once per column): 2 v_fma_f64 + 1 v_add_f64 + 2 64-bit integer adds
+// per limb product, 64 + 72 limb products per Fq product (8 x 8 for a b, 8 rounds of (1 + 8) for the reduction) = 680 instructions + ~70 of carry propagation and
+// integer <-> double moves, against 392 v_mad_u64_u32 + ~110 others for the 14 x 28-bit form the library uses.  The last row is that instruction mix.
 // instructions issued per inner step (8 independent chains) for each op
-__host__ __device__ constexpr int instr_per_step(int op) { return op == MIX_FIELD ? 8 * 8 : 8; }
+__host__ __device__ constexpr int instr_per_step(int op) { return op == MIX_FIELD ? 8 * 8 : op == MIX_DPF ? 8 * 5 : 8; }
 
 template <int OP> __global__ void __launch_bounds__(64) rate(uint64_t* out, unsigned long long* clk, int iters, uint32_t seed) {
   uint64_t acc[8]; float f[8]; uint64_t p[8];      // p: two packed f32
+  double d[8], e[8]; const double dx = 4503599627370495.0 - threadIdx.x, dy = 4503599627370001.0 + seed, c1 = 0x1p104, c2 = 0x1p104 + 0x1p52;
   uint32_t x = threadIdx.x * 2654435761u + seed, y = x ^ 0x9e3779b9u;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { acc[i] = x + i; f[i] = 1.0f + i; p[i] = 0x3f8000003f800000ull + i; }
+  for (int i = 0; i < 8; ++i) { acc[i] = x + i; f[i] = 1.0f + i; p[i] = 0x3f8000003f800000ull + i; d[i] = 1.0 + i; e[i] = 2.0 + i; }
   float fx = 1.0000001f, fy = 0.9999999f; const uint64_t px = 0x3f8000013f7fffffull;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
@@ -39,6 +47,13 @@ template <int OP> __global__ void __launch_bounds__(64) rate(uint64_t* out, unsi
         if (OP == LSHR_B64) asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(acc[i]));
         if (OP == MUL_LO) { uint32_t lo = (uint32_t)acc[i]; asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(lo) : "v"(y)); acc[i] = lo; }
         if (OP == MAD64) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(y) : "vcc");
+        if (OP == FMA_F64) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(d[i]) : "v"(dx), "v"(dy));
+        if (OP == ADD_F64) asm volatile("v_add_f64 %0, %1, %0" : "+v"(d[i]) : "v"(dx));
+        if (OP == LSHL_ADD_U64) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[i]) : "v"(p[i]));
+        if (OP == MIX_DPF) {         // one limb product of the fp64 form: hi, the offset, lo, and the two raw patterns added into the column sums
+          asm volatile("v_fma_f64 %0, %3, %4, %5\n\tv_add_f64 %1, %6, -%0\n\tv_fma_f64 %1, %3, %4, %1\n\tv_lshl_add_u64 %2, %0, 0, %2\n\tv_lshl_add_u64 %2, %1, 0, %2"
+                       : "=&v"(d[i]), "=&v"(e[i]), "+v"(acc[i]) : "v"(dx), "v"(dy), "v"(c1), "v"(c2));
+        }
         if (OP == MIX_FIELD) {       // one column of the 28-bit-limb Montgomery product: MADs into a 64-bit accumulator, then shift, mask, m = lo * inv, add
           asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\tv_mad_u64_u32 %0, vcc, %1, %1, %0\n\tv_mad_u64_u32 %0, vcc, %2, %2, %0\n\t"
                        "v_lshrrev_b64 %0, 28, %0" : "+v"(acc[i]) : "v"(x), "v"(y) : "vcc");
@@ -52,7 +67,7 @@ template <int OP> __global__ void __launch_bounds__(64) rate(uint64_t* out, unsi
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   uint64_t s = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s += acc[i] + (uint64_t)f[i] + p[i];
+  for (int i = 0; i < 8; ++i) s += acc[i] + (uint64_t)f[i] + p[i] + (uint64_t)__double_as_longlong(d[i]) + (uint64_t)__double_as_longlong(e[i]);
   out[(size_t)blockIdx.x * 64 + threadIdx.x] = s + x;
   if (threadIdx.x == 0) { clk[2 * (size_t)blockIdx.x] = t1 - t0; clk[2 * (size_t)blockIdx.x + 1] = r1 - r0; }
 }
@@ -89,6 +104,7 @@ int main() {
   for (int w : {1, 2, 4, 8}) {
     run<FMA_F32>(w, 4000); run<PK_FMA_F32>(w, 4000); run<ADD_U32>(w, 4000); run<AND_B32>(w, 4000); run<LSHR_B64>(w, 4000); run<MUL_LO>(w, 4000); run<MAD64>(w, 4000);
     run<MIX_FIELD>(w, 1000);
+    if (w <= 4) { run<FMA_F64>(w, 4000); run<ADD_F64>(w, 4000); run<LSHL_ADD_U64>(w, 4000); run<MIX_DPF>(w, 1500); }
   }
   return 0;
 }
