@@ -80,7 +80,7 @@ def test_large_batch_kernels_still_covered_in_a_forced_process():
     would only be reached by the 2^16-element tests.  Re-run the small parity tests of every pairing consumer in ONE
     child process with the switch-over forced to zero (ZKT_DTATE_MAX = ZKT_DPRODUCT_MAX = 0): same oracle, other kernels."""
     import os, subprocess, sys
-    env = dict(os.environ, ZKT_DTATE_MAX="0", ZKT_DPRODUCT_MAX="0")
+    env = dict(os.environ, ZKT_DTATE_MAX="0", ZKT_DPRODUCT_MAX="0", ZKT_MSM_GRAPH="0")      # ... and the small MSMs of these protocols issued launch by launch, not as graph replays
     here = os.path.dirname(os.path.abspath(__file__))
     sel = "test_small_batch_tate_vs_oracle or verify_batch_mixed or groth16_chain_circuit or outside_the_subgroup or signature or sign_verify or pinocchio_vs_oracle and cubic or tate_and_weil or bilinear"
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)

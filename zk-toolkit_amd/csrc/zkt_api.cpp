@@ -159,6 +159,9 @@ struct MsmSlot {                      // one in-flight MSM: workspace, result bu
   uint32_t* d_out_abi = nullptr;      // one ABI point
   uint8_t* h_out = nullptr;           // pinned, one ABI point
   bool busy = false;
+  // graph replay of a small MSM's pipeline (msm_submit_locked): executable graphs captured on this slot, keyed by the scalar vector's address
+  static constexpr int NGRAPH = 4;
+  hipGraphExec_t gexec[NGRAPH] = {}; const void* gkey[NGRAPH] = {}; unsigned gnext = 0; bool timed = false;
 };
 struct zkt_bases_impl {               // one resident base set of any group; zkt_g1_bases / zkt_g2_bases / zkt_secp_bases are this
   size_t n = 0;
@@ -195,6 +198,12 @@ static int streams_ready(zkt_bases_impl* h) {
 // ZKT_DEBUG_POISON=1: every MSM workspace is filled with a garbage pattern when it is allocated, so a kernel that reads a word nobody wrote gets 0xA5A5A5A5
 // instead of the zeros a fresh allocation happens to hold (tools/diag/msm_repeat.py and the MSM tests are run this way).
 static bool debug_poison() { static const bool on = [] { const char* e = getenv("ZKT_DEBUG_POISON"); return e && *e == '1'; }(); return on; }
+// The pipeline of an MSM below 2^19 terms is replayed as one graph launch per submit (msm_submit_locked); ZKT_MSM_GRAPH=0 issues its launches one by one instead.
+// Round 2 took this out because the 65,536-bit range-proof test aborted; round 3 found why (tools/diag/rp_graph.py): the captured graph held runtime-owned nodes — the
+// hipMemsetAsync of the counters and the copy of the result — and replaying such a graph after ANY later hipFree in the process (a torch cache flush, a second context
+// freeing its build scratch) ended in a memory access fault.  With kernel nodes only (k_zero_words clears the counters, the copy follows the graph on the stream) the
+// replay survives all of that: every variant of the diagnostic, and the whole GPU suite, run in this mode.
+static bool msm_graphs() { static const bool on = [] { const char* e = getenv("ZKT_MSM_GRAPH"); return !(e && *e == '0'); }(); return on; }
 static int slot_ready(zkt_bases_impl* h, int k) {   // lazily create the slot's workspace
   int rc = streams_ready(h); if (rc) return rc;
   MsmSlot& S = h->slot[k];
@@ -531,6 +540,7 @@ static void bases_free(zkt_bases_impl* h) {
   }
   for (MsmSlot& S : h->slot) {
     for (hipEvent_t ev : {S.e_in, S.e_sorted, S.e_acc0, S.e_acc1, S.e_done}) if (ev) hipEventDestroy(ev);
+    for (hipGraphExec_t& ge : S.gexec) if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
     if (S.workspace) hipFree(S.workspace); if (S.d_result_jac) hipFree(S.d_result_jac); if (S.d_out_abi) hipFree(S.d_out_abi);
     if (S.h_out) hipHostFree(S.h_out);
   }
@@ -568,10 +578,40 @@ static int msm_submit_locked(zkt_bases_impl* h, const uint64_t* dev_scalars, siz
   MsmSlot& S = h->slot[slot];
   // inputs are produced on the caller's stream: order the sort stage behind it
   HIPCHK(hipEventRecord(S.e_in, (hipStream_t)stream));
-  const bool small = !h->grouped && h->n < (size_t(1) << 19);        // sets that share a key's streams always run stage by stage
+  const bool small = h->n < (size_t(1) << 19);       // (a set that shares a key's streams runs on the group's reduce stream for this slot: slot_tail_stream)
   hipStream_t st = slot_tail_stream(h, slot);
   hipStream_t ss = small ? st : h->s_sort;
   HIPCHK(hipStreamWaitEvent(ss, S.e_in, 0));
+  if (small && msm_graphs()) {
+    // A small MSM is ~20 launches of a few microseconds of GPU time each: the protocols that run several of them side by side (a range proof's five, a Pinocchio proof's
+    // ten) are bound by the rate at which the host can submit them.  The whole pipeline of a slot — memsets, sort, accumulate, reduce, the copy of the result — touches only
+    // the slot's own buffers and the scalar vector (kernel launches only: the counters are cleared by a kernel of the pipeline's own), so it is captured ONCE per (slot, scalar address) on the slot's stream and replayed as one graph launch.  Nothing inside
+    // the capture waits on or records an event (the input dependency is the stream wait above, completion is e_done below); the slot is not busy here, so no launch of an
+    // executable graph that gets evicted is still in flight.
+    int hit = -1;
+    for (int k = 0; k < MsmSlot::NGRAPH; ++k) if (S.gexec[k] && S.gkey[k] == (const void*)dev_scalars) hit = k;
+    if (hit < 0) {
+      hit = (int)(S.gnext++ % MsmSlot::NGRAPH);
+      if (S.gexec[hit]) { (void)hipGraphExecDestroy(S.gexec[hit]); S.gexec[hit] = nullptr; }
+      hipGraph_t graph = nullptr;
+      HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+      hipError_t e = launch_msm_sort(h->plan, h->inf, (const uint32_t*)dev_scalars, S.workspace, st);
+      if (e == hipSuccess) e = launch_msm_accumulate(h->plan, h->table, S.workspace, st);
+      if (e == hipSuccess) e = launch_msm_reduce(h->plan, S.workspace, S.d_result_jac, S.d_out_abi, st);
+      const hipError_t e2 = hipStreamEndCapture(st, &graph);                 // always: the stream must leave capture mode
+      if (e != hipSuccess || e2 != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); HIPCHK(e != hipSuccess ? e : (e2 != hipSuccess ? e2 : hipErrorUnknown)); }
+      e = hipGraphInstantiate(&S.gexec[hit], graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) { S.gexec[hit] = nullptr; HIPCHK(e); }
+      S.gkey[hit] = (const void*)dev_scalars;
+    }
+    HIPCHK(hipGraphLaunch(S.gexec[hit], st));
+    HIPCHK(hipMemcpyAsync(S.h_out, S.d_out_abi, grp_pt_bytes(h->grp), hipMemcpyDeviceToHost, st));      // kernels only inside the graph: the copy of the result follows it on the stream
+    HIPCHK(hipEventRecord(S.e_done, st));
+    S.timed = false; S.busy = true;
+    return ZKT_OK;
+  }
+  S.timed = true;
   HIPCHK(launch_msm_sort(h->plan, h->inf, (const uint32_t*)dev_scalars, S.workspace, ss));
   HIPCHK(hipEventRecord(S.e_sorted, ss));
   // a large MSM fills the chip, so its stages queue on per-stage streams (sort of MSM k+1 under the accumulation of MSM k); below 2^19 terms every
@@ -599,7 +639,7 @@ static int msm_collect_locked(zkt_bases_impl* h, int slot, void* out, uint32_t* 
   }
   if (out) memcpy(out, S.h_out, grp_pt_bytes(h->grp));
   float ms = 0.f;
-  if (hipEventElapsedTime(&ms, S.e_acc0, S.e_acc1) == hipSuccess) { t_kernel_ms = ms; t_kernel_name = "k_accumulate"; }
+  if (S.timed && hipEventElapsedTime(&ms, S.e_acc0, S.e_acc1) == hipSuccess) { t_kernel_ms = ms; t_kernel_name = "k_accumulate"; }
   S.busy = false;
   return ZKT_OK;
 }

@@ -652,12 +652,27 @@ MsmWs carve(const MsmPlan& P, void* workspace) {
 }
 }  // namespace
 
+// The pipeline clears its counters with a kernel of its own rather than hipMemsetAsync: inside a captured graph (zkt_api.cpp, msm_submit_locked) a memset becomes a
+// runtime-owned node, and the pipeline's launches should be the same objects whether they are issued or replayed.
+static __global__ void __launch_bounds__(256) k_zero_words(uint4* __restrict__ p, size_t quads, uint32_t* __restrict__ tail, int tail_words) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < quads) p[i] = uint4{0u, 0u, 0u, 0u};
+  if (i < (size_t)tail_words) tail[i] = 0u;
+}
+static hipError_t zero_async(void* ptr, size_t bytes, hipStream_t s) {      // ptr 16-byte aligned (workspace carve), bytes a multiple of 4
+  if (bytes == 0) return hipSuccess;
+  if (((uintptr_t)ptr & 15u) || (bytes & 3u)) return hipMemsetAsync(ptr, 0, bytes, s);
+  const size_t quads = bytes / 16; const int tail = (int)((bytes % 16) / 4);
+  const size_t items = quads > (size_t)tail ? quads : (size_t)tail;
+  hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (uint4*)ptr, quads, (uint32_t*)ptr + quads * 4, tail);
+  return hipGetLastError();
+}
 // stage 1 (atomic/memory bound): signed digits, counting sort by bucket, bucket order by population
 hipError_t PART(launch_msm_sort)(const MsmPlan& P, const uint8_t* inf, const uint32_t* scalars, void* workspace, hipStream_t s) {
   const size_t B = P.nbuckets, n = P.n;
   MsmWs w = carve(P, workspace);
   hipError_t e;
-  if ((e = hipMemsetAsync(w.zero_begin, 0, (uint8_t*)w.zero_end - (uint8_t*)w.zero_begin, s)) != hipSuccess) return e;
+  if ((e = zero_async(w.zero_begin, (uint8_t*)w.zero_end - (uint8_t*)w.zero_begin, s)) != hipSuccess) return e;
   const PartDims pd = part_dims(n, B, P.nwin);
   static const int force_sort = [] { const char* e = getenv("ZKT_MSM_SORT"); return e ? atoi(e) : 0; }();      // 1: atomics (k_digits), 2: partition sort, 0: by size
   const bool partition = force_sort == 2 || (force_sort != 1 && (size_t)P.nwin * n >= (size_t(1) << 22));        // below ~2^18 terms the atomics are as fast and take fewer launches
@@ -680,7 +695,7 @@ hipError_t PART(launch_msm_sort)(const MsmPlan& P, const uint8_t* inf, const uin
     launch_scan(w.counts, w.offsets, B, w.scan_tmp, s);
     hipLaunchKernelGGL(k_digits<true>, dim3(g), dim3(256), 0, s, scalars, inf, n, P.c, P.nwin, wb, (uint32_t*)nullptr, (const uint32_t*)w.offsets, w.slot, w.entries);
   } else {
-    if ((e = hipMemsetAsync(w.offsets, 0, (B + 1) * 4, s)) != hipSuccess) return e;
+    if ((e = zero_async(w.offsets, (B + 1) * 4, s)) != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k_task_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, P.chunk, w.ntask, w.size_hist);
   launch_scan(w.ntask, w.task_off, B, w.scan_tmp, s);
