@@ -262,3 +262,50 @@ def test_config5_range_proof_65536_bits(L):
     a2 = a.copy(); a2[123, 0] ^= np.uint64(1)
     assert L.zkt_bp_inner_product_argument_ctx(ctx, ptr(P), ptr(a2), ptr(b), ptr(xs), None) == 0
     L.zkt_bp_ipa_ctx_free(ctx)
+
+
+def test_verification_batches_at_full_size_decide_element_by_element(L):
+    """The deciding entry points at the size where the one-element-per-lane 63-step kernels run (above the small-batch switch-over): 32,768 BLS signatures and 16,384
+    Groth16 proofs, valid except at scattered positions that carry a wrong key, a swapped signature, a point outside G2 (left to the 255-step kernel), a tampered C, a wrong
+    statement.  Exactly those positions must be rejected; the construction (sk * H(m) verifies under sk * g1, signature.rs:28-39; one proof replicated) is the checker here,
+    the small parity tests pin the same kernels to the oracle in the forced child process."""
+    from qap_util import example_cubic, qap_from_r1cs, dense, alloc_crs
+    n = 1 << 15
+    msgs = [b"m%06d" % i for i in range(n)]
+    off = np.zeros(n + 1, np.uint64); off[1:] = np.cumsum([len(m) for m in msgs])
+    buf = np.frombuffer(b"".join(msgs), dtype=np.uint8).copy()
+    sks = rand_scalars(41, n, R); sks[sks.sum(axis=1) == 0] = 1
+    pks = np.zeros((n, G1W), np.uint64); zk.check(L.zkt_bls_public_keys_batch(ptr(sks), n, ptr(pks)))
+    sig = np.zeros((n, G2W), np.uint64); zk.check(L.zkt_bls_sign_batch(buf.ctypes.data, off.ctypes.data, ptr(sks), n, ptr(sig)))
+    bad = {7: "key", 4099: "sig", 20000: "twist", n - 1: "key"}
+    pks_t, sig_t = pks.copy(), sig.copy()
+    for i, what in bad.items():
+        if what == "key": pks_t[i] = pks[i - 1]
+        elif what == "sig": sig_t[i] = sig[i + 1]
+        else: sig_t[i] = g2_arr([to_abi_g2(py_twist_point(SplitMix64(9)))])[0]
+    ok = np.zeros(n, np.uint32)
+    zk.check(L.zkt_bls_verify_batch(buf.ctypes.data, off.ctypes.data, ptr(sig_t), ptr(pks_t), n, ok.ctypes.data))
+    assert sorted(int(i) for i in np.nonzero(ok == 0)[0]) == sorted(bad)
+    # Groth16: one valid proof of the reference's example, replicated
+    A_, B_, C_, wit, l = example_cubic()
+    nn, m = len(A_), len(wit) - 1
+    ui, vi, wi, h, _ = qap_from_r1cs(A_, B_, C_, wit)
+    U, V, W = dense(ui, nn), dense(vi, nn), dense(wi, nn)
+    fr = lambda v: ints_to_arr([v], 4)
+    rng = SplitMix64(171); trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+    crs, cbuf = alloc_crs(nn, l, m)
+    zk.check(L.zkt_groth16_setup(ctypes.byref(crs), ptr(U), ptr(V), ptr(W), *[ptr(t) for t in trap]))
+    pa, pb, pc = np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64)
+    zk.check(L.zkt_groth16_prove(ctypes.byref(crs), ptr(U), ptr(V), ptr(ints_to_arr(wit, 4)), ptr(ints_to_arr(h, 4)), len(h), ptr(fr(12345)), ptr(fr(6789)), ptr(pa), ptr(pb), ptr(pc)))
+    k = 1 << 14
+    As, Bs, Cs = np.repeat(pa, k, axis=0), np.repeat(pb, k, axis=0), np.repeat(pc, k, axis=0)
+    stmts = np.repeat(ints_to_arr(wit[:l + 1], 4).reshape(1, -1), k, axis=0).copy()
+    badp = {3: "C", 5000: "stmt", 9999: "B-twist", k - 1: "stmt-big"}
+    for i, what in badp.items():
+        if what == "C": Cs[i] = pa[0]
+        elif what == "stmt": stmts[i].reshape(l + 1, 4)[l, 0] ^= np.uint64(1)
+        elif what == "B-twist": Bs[i] = g2_arr([to_abi_g2(py_twist_point(SplitMix64(10)))])[0]
+        else: stmts[i].reshape(l + 1, 4)[l] = rand_scalars(43, 1, R)[0]             # a full-size field element: the statement tables' long path
+    okp = np.zeros(k, np.uint32)
+    zk.check(L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(stmts), l + 1, k, okp.ctypes.data))
+    assert sorted(int(i) for i in np.nonzero(okp == 0)[0]) == sorted(badp)
