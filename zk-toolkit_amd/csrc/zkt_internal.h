@@ -81,7 +81,8 @@ hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, con
 // prod_k tate(+-P_k, Q_k) == 1 per element, K <= 4 pairs sharing one Miller squaring chain and one final exponentiation.
 // Slot k reads its G1 point at g1[k] + i*s1[k] words (stride 0 = the same point for every element), likewise G2; neg[k] negates P_k.
 struct PairArgs { const uint32_t* g1[4]; const uint32_t* g2[4]; uint32_t s1[4], s2[4]; uint32_t neg[4]; };
-hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s);
+// p_trusted: bit k set = slot k's G1 point is a constant of the library known to lie in G1 (no membership test spent on it)
+hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s, uint32_t p_trusted = 0);
 // lane-distributed pairing (zkt_dpairing.hip): diagnostic Fq12 ops on the distributed form
 hipError_t launch_dfq12_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n, hipStream_t s);
 // one pairing per 12 lanes; elements whose P is outside G1 get out[i*144 + mark_word] = mark (see zkt_tate.hip)

@@ -339,6 +339,10 @@ static void launch_scan(const uint32_t* in, uint32_t* out, size_t m, uint32_t* s
 //   pass C  every partition is cut into chunks of PART_CHUNK records; a block histograms the low bits of its chunk in LDS (C1), one block per partition
 //           turns the chunk histograms into running offsets and the bucket totals into counts[] / offsets[] (C1b), and the chunk blocks place their
 //           entries (C2).  A skewed input (a witness of 0/1: a million entries in one partition) is simply more chunks.
+// (Round 3 also measured both scatter passes with their runs staged through LDS — records grouped by partition / bucket in a 48-56 KB stage and written out in order, to
+//  cure the 7x write amplification the counters show (592 + 369 MB written for 82 + 54 MB of payload).  Pass C2 took the same 165 us staged as direct, pass B 893 us
+//  instead of 313 (its 4096-scalar tile only fits the stage in eight partition ranges, each re-deriving the digits): the partial-sector writes are absorbed by the memory
+//  side, the passes are bound by their LDS atomics and latency.  Taken out again.)
 // Every pass streams: ~310 MB at 2^20 terms instead of 13.6 M scattered read-modify-writes.  counts / offsets / entries come out exactly as from k_digits
 // (the order of the entries inside a bucket is arbitrary in both), so everything downstream is unchanged.
 template <bool SCATTER>

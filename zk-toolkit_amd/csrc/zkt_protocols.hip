@@ -1166,7 +1166,7 @@ int zkt_bls_verify_batch(const uint8_t* msgs, const uint64_t* offsets, const zkt
   PairArgs a{};
   a.g1[0] = dgen1.w(); a.s1[0] = 0; a.g2[0] = dsig.w(); a.s2[0] = 50; a.neg[0] = 0;
   a.g1[1] = dpk.w(); a.s1[1] = 26; a.g2[1] = dH.w(); a.s2[1] = 50; a.neg[1] = 1;
-  PCHK(launch_pairing_product_check(a, 2, dok.w(), n, (unsigned long long*)derr.p, s));
+  PCHK(launch_pairing_product_check(a, 2, dok.w(), n, (unsigned long long*)derr.p, s, 1u));      // slot 0's P is the G1 generator (signature.rs:36)
   if ((rc = down(ok, dok.p, n * 4, s)) || (rc = down(&e, derr.p, 8, s))) return rc;
   PCHK(hipStreamSynchronize(s));
   if (e != NO_ERR) { zkt_internal_set_error_index((size_t)e); return ZKT_ERR_INFINITY; }
