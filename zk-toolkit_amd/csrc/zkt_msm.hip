@@ -53,7 +53,7 @@ template <class F> __device__ inline void st_xy(uint32_t* p, const Xyzz<F>& a) {
 }
 static int coord_words(int grp) { return grp == G_G1 ? FqC::N : grp == G_G2 ? 2 * FqC::N : SpC::N; }
 // dimensions of the atomic-free partition sort (k_part_*, below): partitions of PART_SUB buckets, tiles of PART_TILE scalars, chunks of PART_CHUNK records
-static constexpr int PART_LO = 9, PART_SUB = 1 << PART_LO, PART_TPB = 256, PART_TILE = 16 * PART_TPB, PART_CHUNK = 8192, PART_MAXP = 2048;
+static constexpr int PART_LO = 9, PART_SUB = 1 << PART_LO, PART_TPB = 256, PART_TILE = 4 * PART_TPB, PART_CHUNK = 8192, PART_MAXP = 2048;
 struct PartDims { uint32_t P, ntiles, maxblk; };
 static PartDims part_dims(size_t n, size_t nbuckets, int nwin) {
   PartDims d; d.P = (uint32_t)((nbuckets + PART_SUB - 1) / PART_SUB); d.ntiles = (uint32_t)((n + PART_TILE - 1) / PART_TILE);
@@ -61,7 +61,7 @@ static PartDims part_dims(size_t n, size_t nbuckets, int nwin) {
 }
 static size_t part_ws_bytes(size_t n, size_t nbuckets, int nwin) {
   const PartDims d = part_dims(n, nbuckets, nwin);
-  return 1024 + (size_t)nwin * n * 2 + 256 + 2 * ((size_t)d.P * d.ntiles + 1) * 4 + ((size_t)d.P + 1) * 4 + ((size_t)d.P * d.ntiles / 2048 + 2) * 4 + 256 + (size_t)d.maxblk * PART_SUB * 4;
+  return 1024 + (size_t)nwin * n * 8 + 256 + 2 * ((size_t)d.P * d.ntiles + 1) * 4 + ((size_t)d.P + 1) * 4 + ((size_t)d.P * d.ntiles / 2048 + 2) * 4 + 256 + (size_t)d.maxblk * PART_SUB * 4;
 }
 
 // ---------------------------------------------------------------------------------
@@ -332,10 +332,12 @@ static void launch_scan(const uint32_t* in, uint32_t* out, size_t m, uint32_t* s
 // k_digits pays one returning global atomic per (scalar, window) — 13.6 M of them at 2^20 terms, executed at the memory side at ~25 G/s whatever the
 // occupancy: 0.55 ms for the count pass plus 0.22-0.35 ms for the scatter, and two sorts side by side in a Groth16 proof slow each other to 1.9 + 2.6 ms.
 // Here the bucket id is split into a partition (its high bits) and a position inside the partition (its low PART_LO bits):
-//   pass A  every tile of PART_TILE scalars (16 per thread of a 256-thread block: long runs per partition in pass B, and a block small enough to find
-//           room beside the accumulate waves of a neighbouring MSM — 1024-thread blocks waited 1.8 ms for a free CU in the pipeline) histograms its digits by PARTITION in LDS                 -> tilehist[partition][tile]
+//   pass A  every tile of PART_TILE scalars (4 per thread of a 256-thread block: 1,024 blocks at 2^20 terms — with 16 per thread the pass had one block per CU and took
+//           140 us instead of 57; a block small enough to find room beside the accumulate waves of a neighbouring MSM — 1024-thread blocks waited 1.8 ms for a
+//           free CU in the pipeline) histograms its digits by PARTITION in LDS                 -> tilehist[partition][tile]
 //   scan    (partition-major) gives every (partition, tile) its segment of the record array
-//   pass B  the tiles recompute their digits and write (entry, low bits) records into their segments     (ranks from LDS atomics)
+//   pass B  the tiles recompute their digits and write (entry, low bits) records into their segments     (ranks from LDS atomics; ONE 8-byte store per record:
+//           the pass is bound by the NUMBER of scattered stores — 316 us with a 4-byte and a 2-byte store per record, 180 us with one)
 //   pass C  every partition is cut into chunks of PART_CHUNK records; a block histograms the low bits of its chunk in LDS (C1), one block per partition
 //           turns the chunk histograms into running offsets and the bucket totals into counts[] / offsets[] (C1b), and the chunk blocks place their
 //           entries (C2).  A skewed input (a witness of 0/1: a million entries in one partition) is simply more chunks.
@@ -348,29 +350,38 @@ static void launch_scan(const uint32_t* in, uint32_t* out, size_t m, uint32_t* s
 template <bool SCATTER>
 static __global__ void __launch_bounds__(PART_TPB) k_part_tiles(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, size_t n, int c, int nwin, uint32_t win_buckets,
                                                     uint32_t P, uint32_t ntiles, uint32_t* __restrict__ tilehist, const uint32_t* __restrict__ tileoff,
-                                                    uint32_t* __restrict__ rec_ent, uint16_t* __restrict__ rec_lo) {
+                                                    uint2* __restrict__ rec) {
   ZKT_SIDE_PRIO;
   __shared__ uint32_t h[PART_MAXP];
   for (uint32_t p = threadIdx.x; p < P; p += PART_TPB) h[p] = SCATTER ? tileoff[(size_t)p * ntiles + blockIdx.x] : 0u;
   __syncthreads();
   const uint32_t half = 1u << (c - 1);
-  for (int j = 0; j < PART_TILE / PART_TPB; ++j) {
-    const size_t i = (size_t)blockIdx.x * PART_TILE + j * PART_TPB + threadIdx.x;
-    if (i >= n) continue;
-    uint32_t k[8];
-    { const uint4* sp = reinterpret_cast<const uint4*>(scalars + i * 8); const uint4 lo = sp[0], hi = sp[1];
-      k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w; }
-    uint32_t carry = 0;
+  // two scalars per trip: their loads, and the LDS atomic -> store chains of their digits, are in flight together (one scalar at a time the pass is a latency chain)
+  for (int j = 0; j < PART_TILE / PART_TPB; j += 2) {
+    const size_t i0 = (size_t)blockIdx.x * PART_TILE + j * PART_TPB + threadIdx.x, i1 = i0 + PART_TPB;
+    const bool v0 = i0 < n, v1 = i1 < n;
+    uint32_t k0[8] = {}, k1[8] = {};
+    if (v0) { const uint4* sp = reinterpret_cast<const uint4*>(scalars + i0 * 8); const uint4 lo = sp[0], hi = sp[1];
+      k0[0] = lo.x; k0[1] = lo.y; k0[2] = lo.z; k0[3] = lo.w; k0[4] = hi.x; k0[5] = hi.y; k0[6] = hi.z; k0[7] = hi.w; }
+    if (v1) { const uint4* sp = reinterpret_cast<const uint4*>(scalars + i1 * 8); const uint4 lo = sp[0], hi = sp[1];
+      k1[0] = lo.x; k1[1] = lo.y; k1[2] = lo.z; k1[3] = lo.w; k1[4] = hi.x; k1[5] = hi.y; k1[6] = hi.z; k1[7] = hi.w; }
+    uint32_t carry0 = 0, carry1 = 0;
     for (int w = 0; w < nwin; ++w) {
-      const uint32_t raw = window_bits(k, w, c) + carry;
-      const uint32_t neg = raw > half;
-      const uint32_t mag = neg ? (1u << c) - raw : raw;
-      carry = neg;
-      const size_t src = win_buckets ? i : (size_t)w * n + i;
-      if (mag == 0 || inf[src]) continue;                     // infinity and zero digits contribute nothing
-      const uint32_t b = mag - 1 + (uint32_t)w * win_buckets;
-      const uint32_t pos = atomicAdd(&h[b >> PART_LO], 1u);
-      if (SCATTER) { rec_ent[pos] = (uint32_t)src | (neg << 31); rec_lo[pos] = (uint16_t)(b & (PART_SUB - 1)); }
+      const uint32_t raw0 = window_bits(k0, w, c) + carry0, raw1 = window_bits(k1, w, c) + carry1;
+      const uint32_t neg0 = raw0 > half, neg1 = raw1 > half;
+      const uint32_t mag0 = neg0 ? (1u << c) - raw0 : raw0, mag1 = neg1 ? (1u << c) - raw1 : raw1;
+      carry0 = neg0; carry1 = neg1;
+      const size_t src0 = win_buckets ? i0 : (size_t)w * n + i0, src1 = win_buckets ? i1 : (size_t)w * n + i1;
+      const bool a0 = v0 && mag0 != 0 && !inf[src0], a1 = v1 && mag1 != 0 && !inf[src1];       // infinity and zero digits contribute nothing
+      const uint32_t b0 = mag0 - 1 + (uint32_t)w * win_buckets, b1 = mag1 - 1 + (uint32_t)w * win_buckets;
+      uint32_t pos0 = 0, pos1 = 0;
+      if (a0) pos0 = atomicAdd(&h[b0 >> PART_LO], 1u);
+      if (a1) pos1 = atomicAdd(&h[b1 >> PART_LO], 1u);
+      if (SCATTER) {
+        // ONE 8-byte store per record (entry, low bits): the pass is bound by the number of scattered stores, not by their bytes (two stores per record: 285 us)
+        if (a0) rec[pos0] = make_uint2((uint32_t)src0 | (neg0 << 31), b0 & (PART_SUB - 1));
+        if (a1) rec[pos1] = make_uint2((uint32_t)src1 | (neg1 << 31), b1 & (PART_SUB - 1));
+      }
     }
   }
   if (!SCATTER) {
@@ -404,7 +415,7 @@ __device__ inline uint32_t part_of_block(const uint32_t* __restrict__ blkoff, ui
 }
 template <bool PLACE>
 static __global__ void __launch_bounds__(256) k_part_chunks(const uint32_t* __restrict__ tileoff, uint32_t P, uint32_t ntiles, const uint32_t* __restrict__ blkoff,
-                                                     const uint32_t* __restrict__ rec_ent, const uint16_t* __restrict__ rec_lo, uint32_t* __restrict__ subhist,
+                                                     const uint2* __restrict__ rec, uint32_t* __restrict__ subhist,
                                                      const uint32_t* __restrict__ offsets, size_t nbuckets, uint32_t* __restrict__ entries) {
   ZKT_SIDE_PRIO;
   __shared__ uint32_t h[PART_SUB];
@@ -418,9 +429,17 @@ static __global__ void __launch_bounds__(256) k_part_chunks(const uint32_t* __re
     h[t] = PLACE ? (b < nbuckets ? offsets[b] + subhist[(size_t)blk * PART_SUB + t] : 0u) : 0u;
   }
   __syncthreads();
-  for (uint32_t r = beg + threadIdx.x; r < end; r += 256) {
-    const uint32_t pos = atomicAdd(&h[rec_lo[r]], 1u);
-    if (PLACE) entries[pos] = rec_ent[r];
+  // four records per lane and trip: the loads of a trip are in flight together (the loop is a chain of load -> LDS atomic -> store otherwise: 165 us for 136 MB)
+  uint32_t r = beg + threadIdx.x;
+  for (; r + 3 * 256 < end; r += 4 * 256) {
+    const uint2 r0 = rec[r], r1 = rec[r + 256], r2 = rec[r + 512], r3 = rec[r + 768];
+    const uint32_t p0 = atomicAdd(&h[r0.y], 1u), p1 = atomicAdd(&h[r1.y], 1u), p2 = atomicAdd(&h[r2.y], 1u), p3 = atomicAdd(&h[r3.y], 1u);
+    if (PLACE) { entries[p0] = r0.x; entries[p1] = r1.x; entries[p2] = r2.x; entries[p3] = r3.x; }
+  }
+  for (; r < end; r += 256) {
+    const uint2 rr = rec[r];
+    const uint32_t pos = atomicAdd(&h[rr.y], 1u);
+    if (PLACE) entries[pos] = rr.x;
   }
   if (!PLACE) {
     __syncthreads();
@@ -605,7 +624,7 @@ namespace {
 struct MsmWs {   // workspace carve-up (one per in-flight MSM)
   uint32_t *zero_begin, *counts, *cursor, *size_hist, *size_off, *size_cur, *hot, *zero_end;   // [zero_begin, zero_end) is cleared per MSM
   uint32_t *offsets, *entries, *slot, *sums, *colsum, *rowsum, *clsA, *clsB, *win_jac, *scan_tmp, *ntask, *task_off, *partial, *hot_part;
-  uint32_t *tilehist, *tileoff, *blkoff, *subhist, *part_scan; uint16_t* rec_lo;   // the partition sort (slot doubles as its record array)
+  uint32_t *tilehist, *tileoff, *blkoff, *subhist, *part_scan; uint2* rec;   // the partition sort; rec = (entry, low bits of the bucket id) per digit
   uint2* order; size_t max_tasks;
 };
 MsmWs carve(const MsmPlan& P, void* workspace) {
@@ -644,7 +663,7 @@ MsmWs carve(const MsmPlan& P, void* workspace) {
   {
     const PartDims d = part_dims(P.n, P.nbuckets, P.nwin);
     ws = (uint8_t*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    w.rec_lo = (uint16_t*)ws; ws += (((size_t)P.nwin * P.n * 2) + 255) & ~(size_t)255;
+    w.rec = (uint2*)ws; ws += (((size_t)P.nwin * P.n * 8) + 255) & ~(size_t)255;
     w.tilehist = (uint32_t*)ws; ws += ((size_t)d.P * d.ntiles + 1) * 4;
     w.tileoff = (uint32_t*)ws; ws += ((size_t)d.P * d.ntiles + 1) * 4;
     w.blkoff = (uint32_t*)ws; ws += ((size_t)d.P + 1) * 4;
@@ -683,14 +702,14 @@ hipError_t PART(launch_msm_sort)(const MsmPlan& P, const uint8_t* inf, const uin
   if (n && partition && pd.P <= PART_MAXP) {
     // large MSMs: the atomic-free two-level partition (k_part_*); the record array lives in the slot buffer
     const uint32_t wb = P.direct ? (uint32_t)P.half : 0u;
-    hipLaunchKernelGGL(k_part_tiles<false>, dim3(pd.ntiles), dim3(PART_TPB), 0, s, scalars, inf, n, P.c, P.nwin, wb, pd.P, pd.ntiles, w.tilehist, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint16_t*)nullptr);
+    hipLaunchKernelGGL(k_part_tiles<false>, dim3(pd.ntiles), dim3(PART_TPB), 0, s, scalars, inf, n, P.c, P.nwin, wb, pd.P, pd.ntiles, w.tilehist, (const uint32_t*)nullptr, (uint2*)nullptr);
     launch_scan(w.tilehist, w.tileoff, (size_t)pd.P * pd.ntiles, w.part_scan, s);
-    hipLaunchKernelGGL(k_part_tiles<true>, dim3(pd.ntiles), dim3(PART_TPB), 0, s, scalars, inf, n, P.c, P.nwin, wb, pd.P, pd.ntiles, (uint32_t*)nullptr, (const uint32_t*)w.tileoff, w.slot, w.rec_lo);
+    hipLaunchKernelGGL(k_part_tiles<true>, dim3(pd.ntiles), dim3(PART_TPB), 0, s, scalars, inf, n, P.c, P.nwin, wb, pd.P, pd.ntiles, (uint32_t*)nullptr, (const uint32_t*)w.tileoff, w.rec);
     hipLaunchKernelGGL(k_part_blocks, dim3(1), dim3(256), 0, s, (const uint32_t*)w.tileoff, pd.P, pd.ntiles, w.blkoff);
-    hipLaunchKernelGGL(k_part_chunks<false>, dim3(pd.maxblk), dim3(256), 0, s, (const uint32_t*)w.tileoff, pd.P, pd.ntiles, (const uint32_t*)w.blkoff, (const uint32_t*)w.slot, (const uint16_t*)w.rec_lo,
+    hipLaunchKernelGGL(k_part_chunks<false>, dim3(pd.maxblk), dim3(256), 0, s, (const uint32_t*)w.tileoff, pd.P, pd.ntiles, (const uint32_t*)w.blkoff, (const uint2*)w.rec,
                        w.subhist, (const uint32_t*)nullptr, B, (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_part_offsets, dim3(pd.P), dim3(PART_SUB), 0, s, (const uint32_t*)w.tileoff, pd.P, pd.ntiles, (const uint32_t*)w.blkoff, w.subhist, B, w.counts, w.offsets);
-    hipLaunchKernelGGL(k_part_chunks<true>, dim3(pd.maxblk), dim3(256), 0, s, (const uint32_t*)w.tileoff, pd.P, pd.ntiles, (const uint32_t*)w.blkoff, (const uint32_t*)w.slot, (const uint16_t*)w.rec_lo,
+    hipLaunchKernelGGL(k_part_chunks<true>, dim3(pd.maxblk), dim3(256), 0, s, (const uint32_t*)w.tileoff, pd.P, pd.ntiles, (const uint32_t*)w.blkoff, (const uint2*)w.rec,
                        w.subhist, (const uint32_t*)w.offsets, B, w.entries);
   } else if (n) {
     const unsigned g = (unsigned)((n + 255) / 256);
