@@ -69,6 +69,7 @@ assert okv.all()
 # the same batch with full-size statement values (public inputs are field elements: hashes, commitments): every proof is then rejected, the work is the same
 # except for the statement sums, which no longer profit from short scalars
 big = np.random.Generator(np.random.PCG64(5)).integers(0, 2**63, size=(k * (l + 1), 4), dtype=np.uint64); big[:, 3] >>= np.uint64(2)
+zk.check(L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(big), l + 1, k, okv.ctypes.data))      # untimed first call, like the valid batch above
 t0 = time.perf_counter(); zk.check(L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(big), l + 1, k, okv.ctypes.data)); t_vb = time.perf_counter() - t0
 assert not okv.any()
 ocrs = Crs(n=nn, l=l, m=m)
