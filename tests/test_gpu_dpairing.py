@@ -86,3 +86,15 @@ def test_large_batch_kernels_still_covered_in_a_forced_process():
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_127_step_verification_kernels_still_covered_in_a_forced_process():
+    """The deciding entry points run the 63-step loop by default (lane-distributed kernels for small batches, one element per lane for large ones); ZKT_PRODUCT_LOOP=127 keeps
+    the 127-step kernels of round 2 for A/B measurements.  Re-run the signature and product-check parity tests on them in one child process: same oracle, older kernels."""
+    import os, subprocess, sys
+    env = dict(os.environ, ZKT_PRODUCT_LOOP="127")
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = "verify_batch_matches_reference_decision or pairing_product_check or pinocchio_vs_oracle and cubic"
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

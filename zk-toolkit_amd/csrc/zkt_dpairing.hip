@@ -26,7 +26,7 @@ constexpr uint32_t M28 = (1u << 28) - 1;
 // image = expanded operand: slots X[6] Y[6] NY[6] S[6] T[6]
 constexpr int IX = 0, IY = 6, INY = 12, IS = 18, IT = 24, IMG_SLOTS = 30;
 constexpr int NIMG = 3;
-constexpr int PT_SLOTS = 48;
+constexpr int PT_SLOTS = 52;
 constexpr int GROUP_SLOTS = NIMG * IMG_SLOTS + PT_SLOTS;
 constexpr int GROUP_WORDS = GROUP_SLOTS * SW;
 
@@ -620,6 +620,215 @@ __global__ void __launch_bounds__(64) k_dproduct(PairArgs a, const uint32_t* __r
   }
 }
 
+
+// =====================================================================================================================================
+// The 63-step loop (optimal ate, pairing.h "Decisions through the 63-step loop") on the lane groups, for the DECIDING entry points at small batch sizes.
+// The chain runs on Q: a Jacobian point over Fq2 on the twist, its six Fq coordinates in numbered slots.  An Fq2 product or square is TWO rows of a level
+// (real part a0 b0 - a1 b1, imaginary part a0 b1 + a1 b0; a square's imaginary part 2 a0 a1 is one product and a doubling in the linear follow-up), so
+// a level of twelve lanes carries six of them: a doubling is three levels, an addition five, as on the G1 side.  Formulas and scalings are those of
+// ate_dbl_step / ate_add_step (pairing.h): line = a0 xp + a1 yp w + c4 w^4 with a0 = -xi E ZZ (or -xi R), a1 = xi Z3 ZZ (or xi Z3), c4 = E X - 2B (or R xq - Z3 yq),
+// D = 4 X B in place of 2((X + B)^2 - A - C).  The line image holds coefficients 0, 1 and 4 (S = x - y, T = x + y forms for the two that can wrap).
+// The chain ends on [|x|] Q, which is compared with -psi(Q): Q in G2.  P on E and in G1, Q on E' are tested by k_ate_guards beside this kernel.
+// =====================================================================================================================================
+enum : int { A_TX0 = PT0, A_TX1, A_TY0, A_TY1, A_TZ0, A_TZ1, A_QX0, A_QX1, A_QY0, A_QY1, A_XP, A_YP, A_ZERO, A_DUMMY,
+             A_E0, A_E1, A_B0, A_B1, A_ZZ0, A_ZZ1, A_Z30, A_Z31, A_C0, A_C1, A_XB0, A_XB1, A_EE0, A_EE1, A_EX0, A_EX1, A_EZ0, A_EZ1, A_ZQ0, A_ZQ1,
+             A_DX0, A_DX1, A_C80, A_C81, A_LA0, A_LA1, A_LB0, A_LB1, A_LBS, A_LBT, A_RV0, A_RV1, A_YH0, A_YH1, A_END,
+             // the addition step reuses the doubling's temporaries (nothing but T, Q and P lives across steps)
+             A_H0 = A_E0, A_H1 = A_E1, A_ZZZ0 = A_B0, A_ZZZ1 = A_B1, A_R0 = A_C0, A_R1 = A_C1, A_HH0 = A_XB0, A_HH1 = A_XB1, A_HHH0 = A_EE0, A_HHH1 = A_EE1,
+             A_V0 = A_EX0, A_V1 = A_EX1, A_RR0 = A_EZ0, A_RR1 = A_EZ1, A_RQ0 = A_ZQ0, A_RQ1 = A_ZQ1, A_YQ0 = A_DX0, A_YQ1 = A_DX1, A_VX0 = A_C80, A_VX1 = A_C81 };
+static_assert(A_END - PT0 <= PT_SLOTS, "point slot file too small for the ate step");
+constexpr int LA_X(int k) { return SL(LINE_IMG, IX, k); }
+constexpr int LA_Y(int k) { return SL(LINE_IMG, IY, k); }
+constexpr int LA_S(int k) { return SL(LINE_IMG, IS, k); }
+constexpr int LA_T(int k) { return SL(LINE_IMG, IT, k); }
+#define ANOP_ {A_ZERO, A_ZERO, A_ZERO, A_ZERO, A_DUMMY, A_ZERO, A_DUMMY, 1, 0, 0, 0}
+// real / imaginary part of the Fq2 product (u0 + u1 i)(v0 + v1 i) into `d`;  square: real part as a product with itself, imaginary part 2 u0 u1 through the follow-up
+#define ARE(u0, u1, v0, v1, d) {u0, v0, u1, v1, d, A_ZERO, A_DUMMY, 1, 0, 0, 1}
+#define AIM(u0, u1, v0, v1, d) {u0, v1, u1, v0, d, A_ZERO, A_DUMMY, 1, 0, 0, 0}
+#define ASQI(u0, u1, d, c) {u0, u1, A_ZERO, A_ZERO, A_DUMMY, A_ZERO, d, c, 0, 0, 0}
+#define AFQ(u, s, d) {u, s, A_ZERO, A_ZERO, d, A_ZERO, A_DUMMY, 1, 0, 0, 0}
+__device__ const LOp ADBL_L1[12] = {
+  {A_TX0, A_TX0, A_TX1, A_TX1, A_DUMMY, A_ZERO, A_E0, 3, 0, 0, 1},          // E = 3 X^2
+  ASQI(A_TX0, A_TX1, A_E1, 6),
+  ARE(A_TY0, A_TY1, A_TY0, A_TY1, A_B0), ASQI(A_TY0, A_TY1, A_B1, 2),        // B = Y^2
+  ARE(A_TZ0, A_TZ1, A_TZ0, A_TZ1, A_ZZ0), ASQI(A_TZ0, A_TZ1, A_ZZ1, 2),      // ZZ = Z^2
+  {A_TY0, A_TZ0, A_TY1, A_TZ1, A_DUMMY, A_ZERO, A_Z30, 2, 0, 0, 1},          // Z3 = 2 Y Z
+  {A_TY0, A_TZ1, A_TY1, A_TZ0, A_DUMMY, A_ZERO, A_Z31, 2, 0, 0, 0},
+  ANOP_, ANOP_, ANOP_, ANOP_};
+__device__ const LOp ADBL_L2[12] = {
+  ARE(A_B0, A_B1, A_B0, A_B1, A_C0), ASQI(A_B0, A_B1, A_C1, 2),              // C = B^2
+  ARE(A_TX0, A_TX1, A_B0, A_B1, A_XB0), AIM(A_TX0, A_TX1, A_B0, A_B1, A_XB1),   // X B  (D = 4 X B)
+  ARE(A_E0, A_E1, A_E0, A_E1, A_EE0), ASQI(A_E0, A_E1, A_EE1, 2),
+  ARE(A_E0, A_E1, A_TX0, A_TX1, A_EX0), AIM(A_E0, A_E1, A_TX0, A_TX1, A_EX1),
+  ARE(A_E0, A_E1, A_ZZ0, A_ZZ1, A_EZ0), AIM(A_E0, A_E1, A_ZZ0, A_ZZ1, A_EZ1),
+  ARE(A_Z30, A_Z31, A_ZZ0, A_ZZ1, A_ZQ0), AIM(A_Z30, A_Z31, A_ZZ0, A_ZZ1, A_ZQ1)};
+__device__ const LOp ADBL_L3[12] = {
+  {A_E0, A_DX0, A_E1, A_DX1, A_DUMMY, A_C80, A_TY0, 1, 1, 0, 1},             // Y3 = E (D - X3) - 8C
+  {A_E0, A_DX1, A_E1, A_DX0, A_DUMMY, A_C81, A_TY1, 1, 1, 0, 0},
+  AFQ(A_LA0, A_XP, LA_X(0)), AFQ(A_LA1, A_XP, LA_Y(0)),                      // c0 = a0 xp
+  AFQ(A_LB0, A_YP, LA_X(1)), AFQ(A_LB1, A_YP, LA_Y(1)), AFQ(A_LBS, A_YP, LA_S(1)), AFQ(A_LBT, A_YP, LA_T(1)),      // c1 = a1 yp and its s, t forms
+  ANOP_, ANOP_, ANOP_, ANOP_};
+__device__ const LOp AADD_L1[12] = { ARE(A_TZ0, A_TZ1, A_TZ0, A_TZ1, A_ZZ0), ASQI(A_TZ0, A_TZ1, A_ZZ1, 2), ANOP_, ANOP_, ANOP_, ANOP_, ANOP_, ANOP_, ANOP_, ANOP_, ANOP_, ANOP_};
+__device__ const LOp AADD_L2[12] = {
+  {A_QX0, A_ZZ0, A_QX1, A_ZZ1, A_DUMMY, A_TX0, A_H0, 1, 1, 0, 1},            // H = xq ZZ - X
+  {A_QX0, A_ZZ1, A_QX1, A_ZZ0, A_DUMMY, A_TX1, A_H1, 1, 1, 0, 0},
+  ARE(A_ZZ0, A_ZZ1, A_TZ0, A_TZ1, A_ZZZ0), AIM(A_ZZ0, A_ZZ1, A_TZ0, A_TZ1, A_ZZZ1),
+  ANOP_, ANOP_, ANOP_, ANOP_, ANOP_, ANOP_, ANOP_, ANOP_};
+__device__ const LOp AADD_L3[12] = {
+  {A_QY0, A_ZZZ0, A_QY1, A_ZZZ1, A_DUMMY, A_TY0, A_R0, 1, 1, 0, 1},          // R = yq ZZZ - Y   (R overwrites nothing it reads: ZZZ lives in the B slots, R in the C slots)
+  {A_QY0, A_ZZZ1, A_QY1, A_ZZZ0, A_DUMMY, A_TY1, A_R1, 1, 1, 0, 0},
+  ARE(A_H0, A_H1, A_H0, A_H1, A_HH0), ASQI(A_H0, A_H1, A_HH1, 2),
+  ARE(A_TZ0, A_TZ1, A_H0, A_H1, A_Z30), AIM(A_TZ0, A_TZ1, A_H0, A_H1, A_Z31),       // Z3 = Z H
+  ANOP_, ANOP_, ANOP_, ANOP_, ANOP_, ANOP_};
+__device__ const LOp AADD_L4[12] = {
+  ARE(A_H0, A_H1, A_HH0, A_HH1, A_HHH0), AIM(A_H0, A_H1, A_HH0, A_HH1, A_HHH1),
+  ARE(A_TX0, A_TX1, A_HH0, A_HH1, A_V0), AIM(A_TX0, A_TX1, A_HH0, A_HH1, A_V1),
+  ARE(A_R0, A_R1, A_R0, A_R1, A_RR0), ASQI(A_R0, A_R1, A_RR1, 2),
+  ARE(A_R0, A_R1, A_QX0, A_QX1, A_RQ0), AIM(A_R0, A_R1, A_QX0, A_QX1, A_RQ1),
+  ARE(A_Z30, A_Z31, A_QY0, A_QY1, A_YQ0), AIM(A_Z30, A_Z31, A_QY0, A_QY1, A_YQ1),
+  ANOP_, ANOP_};
+__device__ const LOp AADD_L5[12] = {
+  ARE(A_R0, A_R1, A_VX0, A_VX1, A_RV0), AIM(A_R0, A_R1, A_VX0, A_VX1, A_RV1),
+  ARE(A_TY0, A_TY1, A_HHH0, A_HHH1, A_YH0), AIM(A_TY0, A_TY1, A_HHH0, A_HHH1, A_YH1),
+  AFQ(A_LA0, A_XP, LA_X(0)), AFQ(A_LA1, A_XP, LA_Y(0)),
+  AFQ(A_LB0, A_YP, LA_X(1)), AFQ(A_LB1, A_YP, LA_Y(1)), AFQ(A_LBS, A_YP, LA_S(1)), AFQ(A_LBT, A_YP, LA_T(1)),
+  ANOP_, ANOP_};
+// what both steps leave for the line: a0 = -xi e, a1 = xi z (with the s, t forms of a1 for the w^1 coefficient's wrap) and c4 with its four forms
+__device__ inline void ate_line_glue(const Ctx& c, const Fq& e0, const Fq& e1, const Fq& z0, const Fq& z1, const Fq& c40, const Fq& c41) {
+  const Fq b0 = fp_sub(z0, z1), b1 = fp_add(z0, z1);
+  store0(c, A_LA0, fp_sub(e1, e0)); store0(c, A_LA1, fp_neg(fp_add(e0, e1)));
+  store0(c, A_LB0, b0); store0(c, A_LB1, b1); store0(c, A_LBS, fp_sub(b0, b1)); store0(c, A_LBT, fp_add(b0, b1));
+  store0(c, LA_X(4), c40); store0(c, LA_Y(4), c41); store0(c, LA_S(4), fp_sub(c40, c41)); store0(c, LA_T(4), fp_add(c40, c41));
+}
+__device__ __attribute__((noinline)) void apoint_dbl(const Ctx& c) {
+  level<true>(c, ADBL_L1, 0);
+  level<true>(c, ADBL_L2, 0);
+  {   // D = 4 XB; X3 = E^2 - 2D; DX = D - X3; C8 = 8C; c4 = E X - 2B; a0 = -xi E ZZ; a1 = xi Z3 ZZ     (every lane computes, the first stores)
+    const Fq xb0 = slotv(c, A_XB0), xb1 = slotv(c, A_XB1), ee0 = slotv(c, A_EE0), ee1 = slotv(c, A_EE1), c0 = slotv(c, A_C0), c1 = slotv(c, A_C1);
+    const Fq ex0 = slotv(c, A_EX0), ex1 = slotv(c, A_EX1), b0 = slotv(c, A_B0), b1 = slotv(c, A_B1), ez0 = slotv(c, A_EZ0), ez1 = slotv(c, A_EZ1);
+    const Fq zq0 = slotv(c, A_ZQ0), zq1 = slotv(c, A_ZQ1), z30 = slotv(c, A_Z30), z31 = slotv(c, A_Z31);
+    const Fq d0 = fp_dbl(fp_dbl(xb0)), d1 = fp_dbl(fp_dbl(xb1));
+    const Fq x30 = fp_sub2(ee0, fp_zero<FqC>(), d0), x31 = fp_sub2(ee1, fp_zero<FqC>(), d1);
+    gsync();
+    store0(c, A_DX0, fp_sub(d0, x30)); store0(c, A_DX1, fp_sub(d1, x31));
+    store0(c, A_C80, fp_dbl(fp_dbl(fp_dbl(c0)))); store0(c, A_C81, fp_dbl(fp_dbl(fp_dbl(c1))));
+    ate_line_glue(c, ez0, ez1, zq0, zq1, fp_sub2(ex0, fp_zero<FqC>(), b0), fp_sub2(ex1, fp_zero<FqC>(), b1));
+    store0(c, A_TX0, x30); store0(c, A_TX1, x31); store0(c, A_TZ0, z30); store0(c, A_TZ1, z31);
+    gsync();
+  }
+  level<true>(c, ADBL_L3, 0);
+}
+__device__ __attribute__((noinline)) void apoint_add(const Ctx& c) {
+  level<true>(c, AADD_L1, 0);
+  level<true>(c, AADD_L2, 0);
+  level<true>(c, AADD_L3, 0);
+  level<true>(c, AADD_L4, 0);
+  {   // X3 = R^2 - HHH - 2V; VX = V - X3; c4 = R xq - Z3 yq; a0 = -xi R; a1 = xi Z3
+    const Fq rr0 = slotv(c, A_RR0), rr1 = slotv(c, A_RR1), h0 = slotv(c, A_HHH0), h1 = slotv(c, A_HHH1), v0 = slotv(c, A_V0), v1 = slotv(c, A_V1);
+    const Fq r0 = slotv(c, A_R0), r1 = slotv(c, A_R1), z30 = slotv(c, A_Z30), z31 = slotv(c, A_Z31);
+    const Fq rq0 = slotv(c, A_RQ0), rq1 = slotv(c, A_RQ1), yq0 = slotv(c, A_YQ0), yq1 = slotv(c, A_YQ1);
+    const Fq x30 = fp_sub2(rr0, h0, v0), x31 = fp_sub2(rr1, h1, v1);
+    gsync();
+    store0(c, A_VX0, fp_sub(v0, x30)); store0(c, A_VX1, fp_sub(v1, x31));
+    ate_line_glue(c, r0, r1, z30, z31, fp_sub(rq0, yq0), fp_sub(rq1, yq1));
+    store0(c, A_TX0, x30); store0(c, A_TX1, x31); store0(c, A_TZ0, z30); store0(c, A_TZ1, z31);
+    gsync();
+  }
+  level<true>(c, AADD_L5, 0);
+  {   // Y3 = R (V - X3) - Y HHH
+    const Fq rv0 = slotv(c, A_RV0), rv1 = slotv(c, A_RV1), yh0 = slotv(c, A_YH0), yh1 = slotv(c, A_YH1);
+    gsync();
+    store0(c, A_TY0, fp_sub(rv0, yh0)); store0(c, A_TY1, fp_sub(rv1, yh1));
+    gsync();
+  }
+}
+// my coefficient of A * L for a line with coefficients 0, 1 and 4 (all in Fq2): three complex products, the wrapped ones through the s, t forms
+__device__ __attribute__((noinline)) Fq dot_line_ate(const uint32_t* A, const uint32_t* L, int m, int part) {
+  Cols k; cols_zero(k);
+#pragma unroll 1
+  for (int t = 0; t < 3; ++t) {
+    const int kk = t == 0 ? 0 : (t == 1 ? 1 : 4);
+    int j = m - kk; const bool wrap = j < 0; if (wrap) j += 6;
+    const Fq p1 = lld(A + (IX + j) * SW);
+    const Fq u1 = lld(L + ((part ? (wrap ? IT : IY) : (wrap ? IS : IX)) + kk) * SW);
+    cols_mac(k, p1, u1);
+    const Fq p2 = lld(A + ((part ? IY : INY) + j) * SW);
+    const Fq u2 = lld(L + ((part ? (wrap ? IS : IX) : (wrap ? IT : IY)) + kk) * SW);
+    cols_mac(k, p2, u2);
+  }
+  return cols_reduce(k);
+}
+__device__ inline Fq d_mul_line_ate(const Ctx& c, const Fq& f) {
+  expand_first(c.img(0), f, c.r, c.dummy);
+  return dot_line_ate(c.img(0), c.img(LINE_IMG), c.r.m, c.r.part);
+}
+// f_{|x|,Q}(P) up to factors the final exponentiation kills, as miller_ate_multi<1,0> (pairing.h); q_in_g2 <- the chain ended on -psi(Q)
+__device__ __attribute__((noinline)) Fq d_miller_ate(const Ctx& c, const Aff<FqOps>& p, const Aff<Fq2Ops>& q, bool& q_in_g2) {
+  store0(c, A_TX0, q.x.c0); store0(c, A_TX1, q.x.c1); store0(c, A_TY0, q.y.c0); store0(c, A_TY1, q.y.c1); store0(c, A_TZ0, fp_one<FqC>()); store0(c, A_TZ1, fp_zero<FqC>());
+  store0(c, A_QX0, q.x.c0); store0(c, A_QX1, q.x.c1); store0(c, A_QY0, q.y.c0); store0(c, A_QY1, q.y.c1);
+  store0(c, A_XP, p.x); store0(c, A_YP, p.y); store0(c, A_ZERO, fp_zero<FqC>());
+  gsync();
+  Fq f = d_one(c);
+#pragma unroll 1
+  for (int i = 62; i >= 0; --i) {
+    if (i != 62) f = d_sqr(c, f);
+    apoint_dbl(c);
+    f = d_mul_line_ate(c, f);
+    if ((BLS_X_ABS >> i) & 1) { apoint_add(c); f = d_mul_line_ate(c, f); }
+  }
+  Jac<Fq2Ops> T;
+  T.X = Fq2{slotv(c, A_TX0), slotv(c, A_TX1)}; T.Y = Fq2{slotv(c, A_TY0), slotv(c, A_TY1)}; T.Z = Fq2{slotv(c, A_TZ0), slotv(c, A_TZ1)};
+  q_in_g2 = ate_end_is_psi(T, q.x, q.y);
+  return f;
+}
+// prod_k a(Q_k, +-P_k) == target (or == 1) per element on the 63-step loop, K <= 4 pairs in K groups of one wave (layout and contract of k_dproduct).  `target` is the ate
+// counterpart of a key's alpha_beta (k_ate_key_prep).  An element with a Q outside G2 gets ok = 2 (OK_REDO of zkt_pairing.hip): the 255-step kernel behind decides it.
+template <int K>
+__global__ void __launch_bounds__(64) k_dproduct_ate(PairArgs a, const uint32_t* __restrict__ target, uint32_t* __restrict__ ok, size_t n, unsigned long long* err,
+                                                     const uint8_t* __restrict__ kcount) {
+  __shared__ uint32_t lds[LDS_WORDS];
+  const Ctx c = make_ctx(lds);
+  constexpr int EPB = GPW / K;
+  const int lane = threadIdx.x;
+  const int grp = lane / GL < GPW ? lane / GL : GPW - 1;
+  const bool idle = grp >= EPB * K;
+  const int eb = idle ? 0 : grp / K, pair = idle ? 0 : grp % K;
+  size_t e = (size_t)blockIdx.x * EPB + eb;
+  const bool live = !idle && e < n && lane < GPW * GL;
+  if (e >= n) e = n - 1;
+  uint32_t* lead = lds + (idle ? grp : eb * K) * GROUP_WORDS;
+  Aff<FqOps> p = PtIO<FqOps>::ld(a.g1[pair] + e * a.s1[pair]);
+  Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(a.g2[pair] + e * a.s2[pair]);
+  bool inf = p.inf || q.inf;
+  if (inf) { p.x = fp_one<FqC>(); p.y = fp_one<FqC>(); q.x = fq2_one(); q.y = fq2_one(); }
+  if (a.neg[pair]) p.y = fp_neg(p.y);
+  bool q_ok;
+  Fq f = d_miller_ate(c, p, q, q_ok);
+  if (kcount && pair >= (int)kcount[e]) { f = d_one(c); q_ok = true; inf = false; }
+  const int start = eb * K * GL;
+  const unsigned long long emask = (K * GL >= 64 ? ~0ull : ((1ull << (K * GL)) - 1ull)) << start;
+  const unsigned long long bad_inf = __ballot(inf) & emask, bad_q = __ballot(!q_ok) & emask;
+#pragma unroll 1
+  for (int k = 1; k < K; ++k) {
+    expand(pair == k && !idle ? lead + 1 * IMG_SLOTS * SW : c.img(2), f, c.r, c.dummy);
+    expand_first(c.img(0), f, c.r, c.dummy);
+    const Fq prod = dot_mul(c.img(0), lead + 1 * IMG_SLOTS * SW, c.r.m, c.r.part);
+    f = (pair == 0) ? prod : f;
+  }
+  const Fq r = d_final_exp<false>(c, f);
+  uint32_t w[12]; fp_to_words(r, w);
+  uint32_t diff = 0;
+  const int off = abi_word(c.r.m, c.r.part);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) diff |= w[i] ^ (target ? target[off + i] : (off == 132 && i == 0 ? 1u : 0u));
+  const unsigned long long lmask = ((1ull << GL) - 1ull) << start;
+  const unsigned long long neq = __ballot(diff != 0) & lmask;
+  if (live && pair == 0 && c.r.g == 0) {
+    if (bad_inf) { atomicMin(err, (unsigned long long)e); ok[e] = 0; }
+    else if (bad_q) ok[e] = 2u;
+    else ok[e] = neq == 0 ? 1u : 0u;
+  }
+}
 }  // namespace dp
 
 hipError_t launch_dfq12_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n, hipStream_t s) {
@@ -641,6 +850,18 @@ hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uin
     default: return hipErrorInvalidValue;
   }
 #undef ZKT_DPRODUCT
+  return hipGetLastError();
+}
+hipError_t launch_dproduct_ate(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s, const uint8_t* kcount) {
+  if (n == 0) return hipSuccess;
+  auto blocks = [&](int epb) { return dim3((unsigned)((n + epb - 1) / epb)); };
+  switch (K) {
+    case 1: hipLaunchKernelGGL((dp::k_dproduct_ate<1>), blocks(5), dim3(64), 0, s, a, target, ok, n, err, kcount); break;
+    case 2: hipLaunchKernelGGL((dp::k_dproduct_ate<2>), blocks(2), dim3(64), 0, s, a, target, ok, n, err, kcount); break;
+    case 3: hipLaunchKernelGGL((dp::k_dproduct_ate<3>), blocks(1), dim3(64), 0, s, a, target, ok, n, err, kcount); break;
+    case 4: hipLaunchKernelGGL((dp::k_dproduct_ate<4>), blocks(1), dim3(64), 0, s, a, target, ok, n, err, kcount); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 hipError_t launch_dtate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, size_t n, unsigned long long* err, uint32_t mark_word, uint32_t mark, bool short_loop, hipStream_t s) {

@@ -77,7 +77,7 @@ size_t dproduct_limit();      // elements x pairs up to which the verification e
 // stmt_tables (optional): fixed-base tables of the n_stmt statement points (launch_fixed_tables), which replace the statement's 255-step scalar multiplications
 hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt_tables, const uint32_t* stmt, int n_stmt,
                                        const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* tmp, uint32_t* S, uint32_t* ok, size_t n,
-                                       unsigned long long* err, hipStream_t s);
+                                       unsigned long long* err, hipStream_t s, const uint32_t* ate_target = nullptr);
 // prod_k tate(+-P_k, Q_k) == 1 per element, K <= 4 pairs sharing one Miller squaring chain and one final exponentiation.
 // Slot k reads its G1 point at g1[k] + i*s1[k] words (stride 0 = the same point for every element), likewise G2; neg[k] negates P_k.
 struct PairArgs { const uint32_t* g1[4]; const uint32_t* g2[4]; uint32_t s1[4], s2[4]; uint32_t neg[4]; };
@@ -90,6 +90,9 @@ hipError_t launch_dtate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, s
 // prod_k tate(+-P_k, Q_k) == target (NULL: == 1) with the K Miller loops in K lane groups of one wave (small batches)
 // kcount (optional, device): element i multiplies only its first kcount[i] <= K pairs; its unused slots must hold a copy of its pair 0
 hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, bool short_loop, hipStream_t s, const uint8_t* kcount = nullptr);
+// the same decision on the 63-step loop (target: the ate counterpart of a key's alpha_beta, or NULL for == 1); ok = 2 where a Q is outside G2 (left to the kernels behind)
+hipError_t launch_dproduct_ate(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s, const uint8_t* kcount = nullptr);
+hipError_t launch_ate_guards(const PairArgs& a, int K, uint32_t* flags, size_t n, hipStream_t s, uint32_t p_skip = 0);      // flags[i] = 1: every P of element i on E and in G1, every Q on E'
 // Small batches of products with DIFFERENT pair counts in one launch (K = the largest): the 127-step kernels with their guards beside them, as
 // launch_pairing_product_check does for n*K <= the small-batch limit, but WITHOUT the 255-step / exact re-evaluation: ok[i] = 2 means "element i does not fit
 // the short loop, evaluate it another way".  n * K must be within the small-batch limit.

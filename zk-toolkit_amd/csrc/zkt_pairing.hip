@@ -44,6 +44,30 @@ __global__ void __launch_bounds__(64) k_short_loop_guards(PairArgs a, int K, uin
   }
   flags[i] = fits;
 }
+// the same for the 63-step loop of the lane-distributed kernels (k_dproduct_ate): P on E and in G1 (the chain on P is gone, so its membership is tested here, 127
+// doublings on E), Q on E'; Q in G2 comes out of the loop itself
+// One lane per (element, pair), four lanes per element: the membership test of a P is a 127-doubling chain on one lane (1.7 ms), and with the K of them in one lane
+// this kernel, not the pairing beside it, was the critical path of a single verification.  p_skip: bit k = pair k's P needs no test (a sum of multiples of key points that
+// were tested with the key).
+__global__ void __launch_bounds__(64) k_ate_guards(PairArgs a, int K, uint32_t* __restrict__ flags, size_t n, uint32_t p_skip) {
+  const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x, i = t >> 2;
+  const int k = (int)(t & 3);
+  bool bad = false;
+  if (i < n && k < K) {
+    Aff<FqOps> p = PtIO<FqOps>::ld(a.g1[k] + i * a.s1[k]);
+    Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(a.g2[k] + i * a.s2[k]);
+    if (!p.inf && !q.inf)                                          // the reference's panic on infinity: reported by the main kernel, nothing to redo
+      bad = !(g2_on_curve(q.x, q.y) && (((p_skip >> k) & 1) || (g1_on_curve(p.x, p.y) && g1_in_subgroup(p.x, p.y))));
+  }
+  const unsigned long long b = __ballot(bad);
+  if (i < n && k == 0) flags[i] = ((b >> (threadIdx.x & ~3)) & 15ull) ? 0u : 1u;
+}
+static bool small_ate() { static const bool on = [] { const char* e = getenv("ZKT_PRODUCT_LOOP"); return !(e && atoi(e) == 127); }(); return on; }
+hipError_t launch_ate_guards(const PairArgs& a, int K, uint32_t* flags, size_t n, hipStream_t s, uint32_t p_skip) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_ate_guards, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, s, a, K, flags, n, p_skip);
+  return hipGetLastError();
+}
 hipError_t launch_short_loop_guards(const PairArgs& a, int K, uint32_t* flags, size_t n, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_short_loop_guards, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a, K, flags, n);
@@ -266,7 +290,7 @@ __global__ void __launch_bounds__(64) k_pairing_product_check_ate(PairArgs a, ui
 // e(A,B) == alpha_beta e(S,gamma) e(C,delta) per proof on the lane-distributed kernels; tmp: n_stmt * n G1 points, S: n G1 points (device)
 hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt_tables, const uint32_t* stmt, int n_stmt,
                                        const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* tmp, uint32_t* S, uint32_t* ok, size_t n,
-                                       unsigned long long* err, hipStream_t s) {
+                                       unsigned long long* err, hipStream_t s, const uint32_t* ate_target) {
   if (n == 0) return hipSuccess;
   if (n_stmt < 1 || n_stmt > 12) return hipErrorInvalidValue;
   hipError_t e;
@@ -285,8 +309,11 @@ hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, con
   // 127-step loops on the lane-distributed kernels, their preconditions checked beside them; what fails is redone by the 255-step kernel
   uint32_t* flags = nullptr; hipStream_t side;
   if ((e = hipMallocAsync((void**)&flags, n * sizeof(uint32_t), s)) != hipSuccess) return e;
-  if ((e = guard_fork(s, &side)) != hipSuccess || (e = launch_short_loop_guards(a, 3, flags, n, side)) != hipSuccess ||
-      (e = launch_dproduct(a, 3, alpha_beta, ok, n, err, true, s)) != hipSuccess || (e = guard_join(s, side)) != hipSuccess) { (void)hipFreeAsync(flags, s); return e; }
+  // ate_target (the key's ate counterpart of alpha_beta, k_ate_key_prep): the 63-step loop, its guards beside it; otherwise the 127-step loop against alpha_beta itself
+  const bool ate = ate_target && small_ate();
+  if ((e = guard_fork(s, &side)) != hipSuccess || (e = (ate ? launch_ate_guards(a, 3, flags, n, side, 2u) : launch_short_loop_guards(a, 3, flags, n, side))) != hipSuccess ||
+      (e = (ate ? launch_dproduct_ate(a, 3, ate_target, ok, n, err, s) : launch_dproduct(a, 3, alpha_beta, ok, n, err, true, s))) != hipSuccess ||
+      (e = guard_join(s, side)) != hipSuccess) { (void)hipFreeAsync(flags, s); return e; }
   hipLaunchKernelGGL(k_product_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)flags, ok, n);
   if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr, (const uint32_t*)S);
@@ -366,8 +393,10 @@ hipError_t launch_pairing_product_check_counts(const PairArgs& a, int K, const u
   if (K < 1 || K > 4 || !kcount || n * (size_t)K > dproduct_limit()) return hipErrorInvalidValue;
   uint32_t* flags = nullptr; hipStream_t side; hipError_t e;
   if ((e = hipMallocAsync((void**)&flags, n * sizeof(uint32_t), s)) != hipSuccess) return e;
-  if ((e = guard_fork(s, &side)) != hipSuccess || (e = launch_short_loop_guards(a, K, flags, n, side)) != hipSuccess ||          // the unused slots repeat pair 0: same verdict
-      (e = launch_dproduct(a, K, nullptr, ok, n, err, true, s, kcount)) != hipSuccess || (e = guard_join(s, side)) != hipSuccess) { (void)hipFreeAsync(flags, s); return e; }
+  const bool ate = small_ate();
+  if ((e = guard_fork(s, &side)) != hipSuccess || (e = (ate ? launch_ate_guards(a, K, flags, n, side) : launch_short_loop_guards(a, K, flags, n, side))) != hipSuccess ||          // the unused slots repeat pair 0: same verdict
+      (e = (ate ? launch_dproduct_ate(a, K, nullptr, ok, n, err, s, kcount) : launch_dproduct(a, K, nullptr, ok, n, err, true, s, kcount))) != hipSuccess ||
+      (e = guard_join(s, side)) != hipSuccess) { (void)hipFreeAsync(flags, s); return e; }
   hipLaunchKernelGGL(k_product_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)flags, ok, n);
   if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
   return hipGetLastError();
@@ -380,8 +409,10 @@ hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, 
   if (small) {                             // 127-step loops on the lane-distributed kernels, their preconditions checked beside them
     uint32_t* flags = nullptr; hipStream_t side; hipError_t e;
     if ((e = hipMallocAsync((void**)&flags, n * sizeof(uint32_t), s)) != hipSuccess) return e;
-    if ((e = guard_fork(s, &side)) != hipSuccess || (e = launch_short_loop_guards(a, K, flags, n, side)) != hipSuccess ||
-        (e = launch_dproduct(a, K, nullptr, ok, n, err, true, s)) != hipSuccess || (e = guard_join(s, side)) != hipSuccess) { (void)hipFreeAsync(flags, s); return e; }
+    const bool sate = small_ate();
+    if ((e = guard_fork(s, &side)) != hipSuccess || (e = (sate ? launch_ate_guards(a, K, flags, n, side, p_trusted) : launch_short_loop_guards(a, K, flags, n, side))) != hipSuccess ||
+        (e = (sate ? launch_dproduct_ate(a, K, nullptr, ok, n, err, s) : launch_dproduct(a, K, nullptr, ok, n, err, true, s))) != hipSuccess ||
+        (e = guard_join(s, side)) != hipSuccess) { (void)hipFreeAsync(flags, s); return e; }
     hipLaunchKernelGGL(k_product_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)flags, ok, n);
     if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
   }

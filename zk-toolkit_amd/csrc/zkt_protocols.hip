@@ -548,7 +548,9 @@ int zkt_groth16_verify_batch(const zkt_groth16_crs* c, const zkt_g1_affine* A, c
     Dev dtmp(n_stmt * n_proofs * G1B), dS(n_proofs * G1B);
     if (!dtmp.p || !dS.p) return ZKT_ERR_DEVICE;
     const std::shared_ptr<void> tabs = stmt_tables_for(c->g1_uvw_stmt, n_stmt, dU.w(), s);     // held until the synchronisation below
-    PCHK(launch_groth16_verify_small(dA.w(), dB.w(), dC.w(), dU.w(), (const uint32_t*)tabs.get(), dW.w(), (int)n_stmt, dg.w(), dd.w(), dab.w(), dtmp.w(), dS.w(), dok.w(), n_proofs, (unsigned long long*)derr.p, s));
+    const std::shared_ptr<void> akey = ate_key_for(c, n_stmt, dU.w(), dg.w(), dd.w(), s);      // null: a key the 63-step loop may not serve (ate_key_for) -> the 127-step loop against alpha_beta
+    const uint32_t* ate_target = akey ? (const uint32_t*)akey.get() + 2 * (size_t)68 * 84 : nullptr;
+    PCHK(launch_groth16_verify_small(dA.w(), dB.w(), dC.w(), dU.w(), (const uint32_t*)tabs.get(), dW.w(), (int)n_stmt, dg.w(), dd.w(), dab.w(), dtmp.w(), dS.w(), dok.w(), n_proofs, (unsigned long long*)derr.p, s, ate_target));
     unsigned long long e2 = NO_ERR;
     if ((rc = down(ok, dok.p, n_proofs * 4, s)) || (rc = down(&e2, derr.p, 8, s))) return rc;
     PCHK(hipStreamSynchronize(s));
