@@ -130,6 +130,15 @@ def test_ate_decisions_equal_tate_decisions():
     assert fm.ate_product([p0], [_pq(P, g2_mul(Qg, 11))[1]]) == fm.f12_pow(base, 11)
 
 
+def test_three_times_the_exact_final_exponent():
+    """final_exp_3h(f) = final_exp_fast(f)^3 for arbitrary f (the identity 3h = (x-1)^2 (x+q)(x^2+q^2-1) + 3), and cubing is a bijection of G_T (3 is prime to r)"""
+    rng = SplitMix64(29)
+    f = tuple(tuple((rng.below(Q), rng.below(Q)) for _ in range(3)) for _ in range(2))
+    e = fm.final_exp_fast(f)
+    assert fm.final_exp_3h(f) == fm.f12_mul(fm.f12_sqr(e), e)
+    assert R % 3 != 0 and fm.final_exp_3h(fm.F12_1) == fm.F12_1
+
+
 def test_ate_route_refuses_arguments_outside_their_groups():
     """points outside G1 / G2 or off their curves never reach the ate loop (they keep the 255-step loop / the reference's chain): the model returns None,
     and the G2 test the loop gets for free agrees with r Q = infinity"""

@@ -313,6 +313,37 @@ template <bool SHORT> ZKT_FN Fq12 final_exponentiation_t(const Fq12& f) {
   }
 }
 ZKT_HD Fq12 final_exponentiation(const Fq12& f) { return final_exponentiation_t<false>(f); }
+// f^(3 (q^12-1)/r) for the entry points that only DECIDE: the hard part as (x-1)^2 (x+q)(x^2+q^2-1) + 3, three times the exact exponent, reached without the
+// division by three that costs the exact one its windowed 126-bit power (two more powers by x and a cube instead: ~18 Fq12 products fewer).  3 is prime to r, so
+// "== 1" and "== the key's constant raised the same way" decide exactly what they decide with the exact exponent (oracle/fast_model.py final_exp_3h,
+// tests/test_fast_model.py).  Values keep final_exponentiation_t.
+ZKT_FN Fq12 final_exponentiation_3h(const Fq12& f) {
+  Fq12 g, a, b, t;
+  t = fq12_inv(f);
+  a = fq12_conj(f);
+  g = fq12_mul(a, t);                      // ^(q^6-1)
+  t = fq12_frob<2>(g);
+  a = fq12_mul(t, g);                      // ^(q^2+1): easy part
+  g = a;
+  t = fq12_pow_xabs(g); t = fq12_conj(t);  // g^x
+  b = fq12_conj(g);
+  a = fq12_mul(t, b);                      // g^(x-1)
+  t = fq12_pow_xabs(a); t = fq12_conj(t);
+  b = fq12_conj(a);
+  a = fq12_mul(t, b);                      // g^((x-1)^2)
+  t = fq12_pow_xabs(a); t = fq12_conj(t);
+  b = fq12_frob_inl<1>(a);                 // inlined: this function keeps a base pointer (see final_exponentiation_t)
+  a = fq12_mul(t, b);                      // ^(x+q)
+  t = fq12_pow_xabs(a); t = fq12_conj(t);
+  b = fq12_pow_xabs(t); b = fq12_conj(b);  // a^(x^2)
+  t = fq12_frob<2>(a);
+  b = fq12_mul(b, t);
+  t = fq12_conj(a);
+  a = fq12_mul(b, t);                      // ^(x^2+q^2-1)
+  t = fq12_cyclotomic_sqr(g);
+  b = fq12_mul(t, g);                      // g^3
+  return fq12_mul(a, b);
+}
 
 // One Tate pairing through the 127-step loop, with every precondition tested.  Returns TATE_ROUTE_SHORT and the value in r, or the route the element
 // must take instead: TATE_ROUTE_LONG (Q on E' but outside G2: miller_g1_g2 + final_exponentiation) or TATE_ROUTE_EXACT (a point off its curve, or

@@ -503,6 +503,27 @@ template <bool SHORT> __device__ __attribute__((noinline)) Fq d_final_exp(const 
   }
 }
 
+// f^(3 (q^12-1)/r): final_exponentiation_3h (pairing.h) — for the deciding kernels only
+__device__ __attribute__((noinline)) Fq d_final_exp_3h(const Ctx& c, const Fq& f) {
+  Fq t = d_inv(c, f);
+  Fq a = d_conj(c, f);
+  Fq g = d_mul(c, a, t);
+  t = d_frob2(c, g);
+  g = d_mul(c, t, g);                            // easy part
+  t = d_mul(c, d_conj(c, d_pow_xabs(c, g)), d_conj(c, g));      // g^(x-1)
+  a = d_mul(c, d_conj(c, d_pow_xabs(c, t)), d_conj(c, t));      // g^((x-1)^2)
+  t = d_conj(c, d_pow_xabs(c, a));
+  Fq b = d_frob1(c, a);
+  a = d_mul(c, t, b);                            // ^(x+q)
+  t = d_conj(c, d_pow_xabs(c, a));
+  b = d_conj(c, d_pow_xabs(c, t));
+  t = d_frob2(c, a);
+  b = d_mul(c, b, t);
+  t = d_conj(c, a);
+  a = d_mul(c, b, t);                            // ^(x^2+q^2-1)
+  return d_mul(c, a, d_mul(c, d_cyc_sqr(c, g), g));             // * g^3
+}
+
 // f_{r-1,P}(untwist(Q)) up to Fq6 factors for the group's pair, as miller_g1_g2 (pairing.h); in_g1 <- r P == infinity.
 // SHORT: f_{x^2,P} over the 127 bits of x^2 as miller_g1_g2_short — the callers have Q's membership of G2 and the curve equations checked by
 // k_short_loop_guards beside this kernel, and redo what fails them.
@@ -815,7 +836,7 @@ __global__ void __launch_bounds__(64) k_dproduct_ate(PairArgs a, const uint32_t*
     const Fq prod = dot_mul(c.img(0), lead + 1 * IMG_SLOTS * SW, c.r.m, c.r.part);
     f = (pair == 0) ? prod : f;
   }
-  const Fq r = d_final_exp<false>(c, f);
+  const Fq r = d_final_exp_3h(c, f);
   uint32_t w[12]; fp_to_words(r, w);
   uint32_t diff = 0;
   const int off = abi_word(c.r.m, c.r.part);

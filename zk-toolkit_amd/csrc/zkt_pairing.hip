@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(64) k_ate_key_prep(const uint32_t* __restrict_
         bool in_g2;
         const uint32_t* none[1] = {nullptr};
         Fq12 f = miller_ate_multi<1, 0>(&p.x, &p.y, &q.x, &q.y, none, in_g2);
-        if (in_g2) { st_fq12(key + 2 * T, final_exponentiation(f)); atomicOr(key + 2 * T + 144, 4u); }
+        if (in_g2) { st_fq12(key + 2 * T, final_exponentiation_3h(f)); atomicOr(key + 2 * T + 144, 4u); }
       }
     }
   } else {
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(64) k_groth16_verify_ate(const uint32_t* __res
   bool in_g2;
   Fq12 f = miller_ate_multi<1, 2>(xp, yp, &b.x, &b.y, tabs, in_g2);
   if (!in_g2) { ok[i] = OK_REDO; return; }
-  uint32_t got[144]; st_fq12(got, final_exponentiation(f));
+  uint32_t got[144]; st_fq12(got, final_exponentiation_3h(f));      // three times the exact exponent: decisions only (pairing.h)
   uint32_t diff = 0;
   for (int k = 0; k < 144; ++k) diff |= got[k] ^ key[2 * T + k];
   ok[i] = diff == 0;
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(64) k_pairing_product_check_ate(PairArgs a, ui
   const uint32_t* none[1] = {nullptr};
   Fq12 f = miller_ate_multi<K, 0>(xp, yp, xq, yq, none, in_g2);
   if (!in_g2) { ok[i] = OK_REDO; return; }
-  uint32_t got[144]; st_fq12(got, final_exponentiation(f));
+  uint32_t got[144]; st_fq12(got, final_exponentiation_3h(f));      // three times the exact exponent: decisions only (pairing.h)
   uint32_t diff = got[132] ^ 1u;
   for (int k = 0; k < 144; ++k) if (k != 132) diff |= got[k];
   ok[i] = diff == 0;
