@@ -93,6 +93,23 @@ hipError_t launch_group_pred(int grp, int pred, const uint32_t* pts, const uint3
   return hipGetLastError();
 }
 
+// P on E and in G1 for up to four point arrays in one launch (what the 63-step verification kernels need of their G1 arguments, pairing.h g1_in_subgroup): out[k * n + i].
+// Its own kernel because it needs ~110 registers: four waves per SIMD here, against the one wave of a 512-register verification kernel in which the same 127-doubling
+// chain issued at less than half the rate.  A point at infinity reads as fitting (the verification kernels report it as the reference's panic themselves).
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_g1_fits(G1Fits f, uint32_t* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (i >= n) return;
+  const Aff<FqOps> p = PtIO<FqOps>::ld(f.pts[k] + i * f.stride[k]);
+  out[(size_t)k * n + i] = p.inf || (g1_on_curve(p.x, p.y) && g1_in_subgroup(p.x, p.y));
+}
+hipError_t launch_g1_fits(const G1Fits& f, int K, uint32_t* out, size_t n, hipStream_t s) {
+  if (n == 0 || K == 0) return hipSuccess;
+  if (K < 0 || K > 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_g1_fits, dim3(nblk(n, 64), (unsigned)K), dim3(64), 0, s, f, out, n);
+  return hipGetLastError();
+}
+
 // Several independent batched scalar multiplications in ONE launch.  A 255-step double-and-add costs ~4 ms of latency however few
 // points it covers, so callers that issue many small independent ones per step (every level of the inner-product argument,
 // bulletproofs.rs:36-47) pay that latency once instead of six times.

@@ -33,6 +33,9 @@ hipError_t launch_group_add(int grp, const uint32_t* a, const uint32_t* b, uint3
 hipError_t launch_group_neg(int grp, const uint32_t* a, uint32_t* out, size_t n, hipStream_t s);
 hipError_t launch_group_mul(int grp, const uint32_t* pts, const uint32_t* scalars, int scalar_words, uint32_t* out, size_t n, hipStream_t s, bool fixed_base = false, bool fixed_scalar = false);
 // pred 0: on the curve (is_rational_point); pred 1: order * P == infinity (order: little-endian u32 words on the device)
+// out[k * n + i] = point i of array k lies on E and in G1 (or is the point at infinity); K <= 4 arrays, `stride` in u32 words
+struct G1Fits { const uint32_t* pts[4]; uint32_t stride[4]; };
+hipError_t launch_g1_fits(const G1Fits& f, int K, uint32_t* out, size_t n, hipStream_t s);
 hipError_t launch_group_pred(int grp, int pred, const uint32_t* pts, const uint32_t* order, int order_words, uint32_t* out, size_t n, hipStream_t s);
 hipError_t launch_group_sum_inplace(int grp, uint32_t* pts, size_t n, hipStream_t s);
 // several independent batched scalar multiplications in one launch (strides in u32 words, 0 = broadcast one point / one scalar)

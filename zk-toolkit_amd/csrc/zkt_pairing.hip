@@ -228,14 +228,14 @@ hipError_t launch_ate_key_prep(const uint32_t* alpha, const uint32_t* beta, cons
 // Whatever does not fit — a point off its curve or outside its group — is marked OK_REDO and decided by the older kernels behind this one.
 __global__ void __launch_bounds__(64) k_groth16_verify_ate(const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, const uint32_t* __restrict__ C,
                                                            const uint32_t* __restrict__ S_pre, const uint32_t* __restrict__ key,
-                                                           uint32_t* __restrict__ ok, size_t n, unsigned long long* err) {
+                                                           uint32_t* __restrict__ ok, size_t n, unsigned long long* err, const uint32_t* __restrict__ fits) {
   constexpr size_t T = (size_t)ATE_LINES * ATE_LINE_WORDS;
   size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   Aff<FqOps> S = PtIO<FqOps>::ld(S_pre + i * ABI_G1_WORDS), a = PtIO<FqOps>::ld(A + i * ABI_G1_WORDS), c = PtIO<FqOps>::ld(C + i * ABI_G1_WORDS);
   Aff<Fq2Ops> b = PtIO<Fq2Ops>::ld(B + i * ABI_G2_WORDS);
   if (a.inf || b.inf || c.inf || S.inf) { atomicMin(err, (unsigned long long)i); ok[i] = 0; return; }   // tate() with infinity panics (gamma, delta: tested with the key)
-  if (!g1_on_curve(a.x, a.y) || !g1_on_curve(c.x, c.y) || !g2_on_curve(b.x, b.y) || !g1_in_subgroup(a.x, a.y) || !g1_in_subgroup(c.x, c.y)) { ok[i] = OK_REDO; return; }
+  if (!fits[i] || !fits[n + i] || !g2_on_curve(b.x, b.y)) { ok[i] = OK_REDO; return; }       // fits: A, C on E and in G1 (k_g1_fits, run at four waves per SIMD before this kernel)
   Fq xp[3] = {a.x, S.x, c.x}, yp[3] = {a.y, fp_neg(S.y), fp_neg(c.y)};
   const uint32_t* tabs[2] = {key, key + T};
   bool in_g2;
@@ -260,7 +260,8 @@ __global__ void __launch_bounds__(64) k_shared_g1_guards(PairArgs a, int K, uint
 // prod_k tate(+-P_k, Q_k) == 1 decided on the 63-step loop: every Q_k runs its chain in the lane and is tested where it ends, every P_k is tested first
 // (bit k of p_good[0]: P_k is shared by the batch and was tested by k_shared_g1_guards).  ok[i] = OK_REDO leaves the element to the kernels behind.
 template <int K>
-__global__ void __launch_bounds__(64) k_pairing_product_check_ate(PairArgs a, uint32_t* __restrict__ ok, size_t n, unsigned long long* err, const uint32_t* __restrict__ p_good, uint32_t p_trusted) {
+__global__ void __launch_bounds__(64) k_pairing_product_check_ate(PairArgs a, uint32_t* __restrict__ ok, size_t n, unsigned long long* err, const uint32_t* __restrict__ p_good, uint32_t p_trusted,
+                                                                  const uint32_t* __restrict__ fits) {
   size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   Fq xp[K], yp[K]; Fq2 xq[K], yq[K];
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(64) k_pairing_product_check_ate(PairArgs a, ui
   if (inf) { atomicMin(err, (unsigned long long)i); ok[i] = 0; return; }
   const uint32_t known = p_trusted | (p_good ? p_good[0] : 0u);      // p_trusted: slots whose P is a constant of the library (the G1 generator in signature verification)
   for (int k = 0; k < K; ++k) {
-    const bool p_ok = ((known >> k) & 1) || (g1_on_curve(xp[k], yp[k]) && g1_in_subgroup(xp[k], yp[k]));
+    const bool p_ok = ((known >> k) & 1) || fits[(size_t)k * n + i] != 0;      // fits: k_g1_fits, run before this kernel for the slots that are not shared
     if (!p_ok || !g2_on_curve(xq[k], yq[k])) { ok[i] = OK_REDO; return; }
   }
   bool in_g2;
@@ -328,7 +329,12 @@ hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uin
     if ((e = hipMallocAsync((void**)&S, n * ABI_G1_WORDS * 4, s)) != hipSuccess) return e;
     // the statement sums from the key's 8-bit window tables (behind the line tables in the key buffer): 32 additions per wire instead of a 255-step chain
     if ((e = launch_stmt_sums_wide(ate_key + ATE_KEY_WORDS, stmt, n_stmt, S, n, s)) != hipSuccess) { (void)hipFreeAsync(S, s); return e; }
-    hipLaunchKernelGGL(k_groth16_verify_ate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, (const uint32_t*)S, ate_key, ok, n, err);
+    uint32_t* fits = nullptr;
+    if ((e = hipMallocAsync((void**)&fits, 2 * n * sizeof(uint32_t), s)) != hipSuccess) { (void)hipFreeAsync(S, s); return e; }
+    G1Fits gf{}; gf.pts[0] = A; gf.stride[0] = ABI_G1_WORDS; gf.pts[1] = C; gf.stride[1] = ABI_G1_WORDS;
+    if ((e = launch_g1_fits(gf, 2, fits, n, s)) != hipSuccess) { (void)hipFreeAsync(S, s); (void)hipFreeAsync(fits, s); return e; }
+    hipLaunchKernelGGL(k_groth16_verify_ate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, (const uint32_t*)S, ate_key, ok, n, err, (const uint32_t*)fits);
+    if ((e = hipFreeAsync(fits, s)) != hipSuccess) { (void)hipFreeAsync(S, s); return e; }
     hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr, (const uint32_t*)S);
     if ((e = hipFreeAsync(S, s)) != hipSuccess) return e;
     return hipGetLastError();
@@ -427,7 +433,15 @@ hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, 
     if ((e = hipMallocAsync((void**)&p_good, sizeof(uint32_t), s)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_shared_g1_guards, dim3(1), dim3(64), 0, s, a, K, p_good);
   }
-#define ZKT_PRODUCT_CHECK(KK) if (!small) { if (ate) hipLaunchKernelGGL((k_pairing_product_check_ate<KK>), g, t, 0, s, a, ok, n, err, (const uint32_t*)p_good, p_trusted); \
+  uint32_t* fits = nullptr;
+  if (!small && ate) {            // membership of the per-element G1 arguments at high occupancy (shared slots: p_good / p_trusted; their rows of `fits` are not read)
+    hipError_t e;
+    if ((e = hipMallocAsync((void**)&fits, (size_t)K * n * sizeof(uint32_t), s)) != hipSuccess) return e;
+    G1Fits gf{};
+    for (int k = 0; k < K; ++k) { gf.pts[k] = a.g1[k]; gf.stride[k] = a.s1[k]; }
+    if ((e = launch_g1_fits(gf, K, fits, n, s)) != hipSuccess) { (void)hipFreeAsync(fits, s); return e; }
+  }
+#define ZKT_PRODUCT_CHECK(KK) if (!small) { if (ate) hipLaunchKernelGGL((k_pairing_product_check_ate<KK>), g, t, 0, s, a, ok, n, err, (const uint32_t*)p_good, p_trusted, (const uint32_t*)fits); \
                                             else hipLaunchKernelGGL((k_pairing_product_check<KK, true>), g, t, 0, s, a, ok, n, err, 0); } \
                               hipLaunchKernelGGL((k_pairing_product_check<KK, false>), g, t, 0, s, a, ok, n, err, 1)
   switch (K) {
@@ -439,6 +453,7 @@ hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, 
   }
 #undef ZKT_PRODUCT_CHECK
   if (p_good) { hipError_t e = hipFreeAsync(p_good, s); if (e != hipSuccess) return e; }
+  if (fits) { hipError_t e = hipFreeAsync(fits, s); if (e != hipSuccess) return e; }
   return hipGetLastError();
 }
 
