@@ -299,9 +299,13 @@ def main():
                 t0 = time.perf_counter()
                 ok = L.zkt_groth16_verify(ctypes.byref(vk1), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(stmt), gl + 1)
                 g16["verify_first_call_ms"] = (time.perf_counter() - t0) * 1e3; g16["verifies"] = bool(ok == 1)
-                t0 = time.perf_counter()                 # second call: the small-batch kernels, their side stream and the allocator pool exist now
+                t0 = time.perf_counter()                 # second call on this key: the library now builds the key's tables for the 63-step loop (first sight is served without them)
                 ok2 = L.zkt_groth16_verify(ctypes.byref(vk1), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(stmt), gl + 1)
-                g16["verify_ms"] = (time.perf_counter() - t0) * 1e3; g16["verifies"] = g16["verifies"] and bool(ok2 == 1)
+                g16["verify_second_call_ms"] = (time.perf_counter() - t0) * 1e3
+                tv = []
+                for _ in range(5):                       # steady state: every later verification against the key
+                    t0 = time.perf_counter(); ok2 &= L.zkt_groth16_verify(ctypes.byref(vk1), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(stmt), gl + 1); tv.append(time.perf_counter() - t0)
+                g16["verify_ms"] = sorted(tv)[2] * 1e3; g16["verifies"] = g16["verifies"] and bool(ok2 == 1)
         except Exception as e:      # never lose the headline line to the secondary leg; every collective above is preceded by an all-ranks agreement
             g16 = {"error": repr(e), "stage": stage}
 

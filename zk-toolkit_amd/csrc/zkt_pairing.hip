@@ -186,8 +186,8 @@ __global__ void __launch_bounds__(64) k_stmt_sums(const uint32_t* __restrict__ t
 //   words [0, T)      the 68 line triples of gamma          T = ATE_LINES * ATE_LINE_WORDS
 //   words [T, 2T)     ... of delta
 //   words [2T, +144)  final_exponentiation(f_{|x|,beta}(alpha)) — the ate counterpart of the key's alpha_beta (compared in the ABI's Fq12 layout)
-//   word  2T + 144    bit 0 gamma in G2, bit 1 delta in G2, bit 2 alpha in G1 and beta in G2, bit 3 every statement point in G1
-// The host uses the 63-step kernel for a key only when all four bits are set AND the key's alpha_beta equals tate(alpha, beta) (one small-batch pairing).
+//   word  2T + 144    bit 0 gamma in G2, bit 1 delta in G2, bit 2 alpha in G1 and beta on E', bit 3 every statement point in G1, bit 4 beta in G2 (k_dab_ate, which writes the pairing)
+// The host uses the 63-step kernel for a key only when all five bits are set AND the key's alpha_beta equals tate(alpha, beta) (one small-batch pairing).
 __global__ void __launch_bounds__(64) k_ate_key_prep(const uint32_t* __restrict__ alpha, const uint32_t* __restrict__ beta, const uint32_t* __restrict__ gamma,
                                                      const uint32_t* __restrict__ delta, const uint32_t* __restrict__ uvw_stmt, int n_stmt, uint32_t* __restrict__ key) {
   constexpr size_t T = (size_t)ATE_LINES * ATE_LINE_WORDS;
@@ -198,14 +198,9 @@ __global__ void __launch_bounds__(64) k_ate_key_prep(const uint32_t* __restrict_
       if (!q.inf && g2_on_curve(q.x, q.y) && ate_line_table(q.x, q.y, key + j * T)) atomicOr(key + 2 * T + 144, 1u << j);
     }
   } else if (blockIdx.x == 1) {
-    if (j == 0) {
+    if (j == 0) {       // alpha on E and in G1, beta on E'; beta in G2 and the pairing itself come from k_dab_ate (bit 4), one lane group instead of this one lane
       Aff<FqOps> p = PtIO<FqOps>::ld(alpha); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(beta);
-      if (!p.inf && !q.inf && g1_on_curve(p.x, p.y) && g1_in_subgroup(p.x, p.y) && g2_on_curve(q.x, q.y)) {
-        bool in_g2;
-        const uint32_t* none[1] = {nullptr};
-        Fq12 f = miller_ate_multi<1, 0>(&p.x, &p.y, &q.x, &q.y, none, in_g2);
-        if (in_g2) { st_fq12(key + 2 * T, final_exponentiation_3h(f)); atomicOr(key + 2 * T + 144, 4u); }
-      }
+      if (!p.inf && !q.inf && g1_on_curve(p.x, p.y) && g1_in_subgroup(p.x, p.y) && g2_on_curve(q.x, q.y)) atomicOr(key + 2 * T + 144, 4u);
     }
   } else {
     bool ok = true;
@@ -221,7 +216,7 @@ hipError_t launch_ate_key_prep(const uint32_t* alpha, const uint32_t* beta, cons
   hipError_t e = hipMemsetAsync(key + 2 * (size_t)ATE_LINES * ATE_LINE_WORDS + 144, 0, sizeof(uint32_t), s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_ate_key_prep, dim3(3), dim3(64), 0, s, alpha, beta, gamma, delta, uvw_stmt, n_stmt, key);
-  return hipGetLastError();
+  return launch_dab_ate(alpha, beta, key + 2 * (size_t)ATE_LINES * ATE_LINE_WORDS, key + 2 * (size_t)ATE_LINES * ATE_LINE_WORDS + 144, 16u, s);
 }
 // e(A,B) == alpha_beta e(S,gamma) e(C,delta)  <=>  a(B,A) a(gamma,-S) a(delta,-C) == a(beta,alpha): B runs its chain in the lane (its G2 test comes with it),
 // gamma and delta bring their tables, S is a sum of multiples of statement points tested with the key.  A and C are tested here (127 doublings each).

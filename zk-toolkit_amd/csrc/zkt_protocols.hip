@@ -417,7 +417,10 @@ std::shared_ptr<void> stmt_tables_for(const zkt_g1_affine* pts, size_t n_stmt, c
 // (verifier.rs:48), so a key whose alpha_beta is anything else keeps the value-comparing kernels.  `usable` caches that verdict too.
 struct AteKey { std::vector<uint8_t> key; std::shared_ptr<void> dev; bool usable = false; uint64_t stamp = 0; };
 std::mutex g_ate_mu; AteKey g_ate[4]; uint64_t g_ate_clock = 0;
-std::shared_ptr<void> ate_key_for(const zkt_groth16_crs* c, size_t n_stmt, const uint32_t* dU, const uint32_t* dg, const uint32_t* dd, hipStream_t s) {
+// `eager` = build the entry at first sight of the key (large batches: the tables pay for themselves inside the call).  A small batch on a key never seen before is
+// served by the 127-step kernels, which need nothing of the key (a one-off verification costs 6 ms, not 6 + 20); the key is remembered and gets its entry at second sight.
+std::vector<uint8_t> g_ate_seen_once;
+std::shared_ptr<void> ate_key_for(const zkt_groth16_crs* c, size_t n_stmt, const uint32_t* dU, const uint32_t* dg, const uint32_t* dd, hipStream_t s, bool eager) {
   static const bool off = [] { const char* e = getenv("ZKT_PRODUCT_LOOP"); return e && atoi(e) == 127; }();
   if (off || n_stmt < 1 || n_stmt > 12 || !c->g1_alpha || !c->g2_beta) return nullptr;
   std::vector<uint8_t> kb(G1B + 3 * G2B + 576 + n_stmt * G1B);
@@ -430,6 +433,7 @@ std::shared_ptr<void> ate_key_for(const zkt_groth16_crs* c, size_t n_stmt, const
     if (e.stamp && e.key == kb) { e.stamp = ++g_ate_clock; return e.usable ? e.dev : nullptr; }
     if (e.stamp < victim->stamp) victim = &e;
   }
+  if (!eager && g_ate_seen_once != kb) { g_ate_seen_once = kb; return nullptr; }
   void* mem = nullptr;
   if (hipMalloc(&mem, (ATE_KEY_WORDS + stmt_wide_table_words((int)n_stmt)) * 4) != hipSuccess) return nullptr;      // [line tables, alpha_beta, verdicts | statement tables]
   std::shared_ptr<void> dev(mem, [](void* q) { if (q) hipFree(q); });
@@ -441,7 +445,7 @@ std::shared_ptr<void> ate_key_for(const zkt_groth16_crs* c, size_t n_stmt, const
   if (launch_tate(dal.w(), dbe.w(), dgt.w(), 1, (unsigned long long*)derr.p, s) != hipSuccess) return nullptr;
   if (down(&flags, (uint32_t*)mem + ATE_KEY_WORDS - 1, 4, s) || down(gt, dgt.p, 576, s) || down(&e2, derr.p, 8, s) || hipStreamSynchronize(s) != hipSuccess) return nullptr;
   victim->key = std::move(kb); victim->dev = dev; victim->stamp = ++g_ate_clock;
-  victim->usable = flags == 15u && e2 == NO_ERR && memcmp(gt, c->gt_alpha_beta, 576) == 0;
+  victim->usable = flags == 31u && e2 == NO_ERR && memcmp(gt, c->gt_alpha_beta, 576) == 0;
   return victim->usable ? dev : nullptr;
 }
 }  // namespace
@@ -548,7 +552,7 @@ int zkt_groth16_verify_batch(const zkt_groth16_crs* c, const zkt_g1_affine* A, c
     Dev dtmp(n_stmt * n_proofs * G1B), dS(n_proofs * G1B);
     if (!dtmp.p || !dS.p) return ZKT_ERR_DEVICE;
     const std::shared_ptr<void> tabs = stmt_tables_for(c->g1_uvw_stmt, n_stmt, dU.w(), s);     // held until the synchronisation below
-    const std::shared_ptr<void> akey = ate_key_for(c, n_stmt, dU.w(), dg.w(), dd.w(), s);      // null: a key the 63-step loop may not serve (ate_key_for) -> the 127-step loop against alpha_beta
+    const std::shared_ptr<void> akey = ate_key_for(c, n_stmt, dU.w(), dg.w(), dd.w(), s, false);      // null: a key the 63-step loop may not serve, or a key seen for the first time (ate_key_for) -> the 127-step loop against alpha_beta
     const uint32_t* ate_target = akey ? (const uint32_t*)akey.get() + 2 * (size_t)68 * 84 : nullptr;
     PCHK(launch_groth16_verify_small(dA.w(), dB.w(), dC.w(), dU.w(), (const uint32_t*)tabs.get(), dW.w(), (int)n_stmt, dg.w(), dd.w(), dab.w(), dtmp.w(), dS.w(), dok.w(), n_proofs, (unsigned long long*)derr.p, s, ate_target));
     unsigned long long e2 = NO_ERR;
@@ -557,7 +561,7 @@ int zkt_groth16_verify_batch(const zkt_groth16_crs* c, const zkt_g1_affine* A, c
     if (e2 != NO_ERR) { zkt_internal_set_error_index((size_t)e2); return ZKT_ERR_INFINITY; }
     return ZKT_OK;
   }
-  const std::shared_ptr<void> akey = ate_key_for(c, n_stmt, dU.w(), dg.w(), dd.w(), s);      // held until the synchronisation below; null: the value-comparing kernels
+  const std::shared_ptr<void> akey = ate_key_for(c, n_stmt, dU.w(), dg.w(), dd.w(), s, true);      // held until the synchronisation below; null: the value-comparing kernels
   PCHK(launch_groth16_verify(dA.w(), dB.w(), dC.w(), dU.w(), dW.w(), (int)n_stmt, dg.w(), dd.w(), dab.w(), dok.w(), n_proofs, (unsigned long long*)derr.p, s, (const uint32_t*)akey.get()));
   unsigned long long e = NO_ERR;
   if ((rc = down(ok, dok.p, n_proofs * 4, s)) || (rc = down(&e, derr.p, 8, s))) return rc;
@@ -648,7 +652,7 @@ extern "C" void zkt_internal_clear_caches() {             // zkt_shutdown: devic
   zkt_pinocchio_clear_caches();
   { std::lock_guard<std::mutex> lk(g_bpc.mu); g_bpc.ctx.reset(); g_bpc.key.clear(); }
   { std::lock_guard<std::mutex> lk(g_stmt_mu); for (StmtTables& e : g_stmt) { e.tables.reset(); e.key.clear(); e.stamp = 0; } }
-  { std::lock_guard<std::mutex> lk(g_ate_mu); for (AteKey& e : g_ate) { e.dev.reset(); e.key.clear(); e.stamp = 0; e.usable = false; } }
+  { std::lock_guard<std::mutex> lk(g_ate_mu); for (AteKey& e : g_ate) { e.dev.reset(); e.key.clear(); e.stamp = 0; e.usable = false; } g_ate_seen_once.clear(); }
 }
 extern "C" {
 int zkt_bp_ipa_ctx_create(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u, zkt_bp_ipa_ctx** out) {
