@@ -8,6 +8,7 @@
 //!   `Polynomial`           building_block/field/polynomial.rs:271-293 (eval_with_g1_hidings / eval_with_g2_hidings)
 //!   `groth16::*`           zk/w_trusted_setup/groth16/zktoolkit_based/{crs,prover,verifier,proof}.rs
 //!   `Bulletproofs`         zk/wo_trusted_setup/bulletproofs.rs
+//!   `pinocchio::*`         zk/w_trusted_setup/pinocchio/{crs,prover,verifier,proof,witness}.rs
 //!   `Signer`, `PrivateKey` building_block/curves/bls12_381/{signature,private_key}.rs
 //! and forwards to the batch-first C ABI (`ffi`, generated from include/zkt.h).  Conventions carried over from the only native
 //! backend the reference has (building_block/mcl/): one global `init` behind `Once` that panics on failure (mcl_initializer.rs:4-15),
@@ -25,6 +26,7 @@ pub mod polynomial;
 pub mod groth16;
 pub mod bulletproofs;
 pub mod signature;
+pub mod pinocchio;
 pub mod comm;
 
 pub use field::{Fq1, Fr, SecpFq, SecpFr, PrimeField, PrimeFieldElem, PrimeFieldElems, SparseVec};

@@ -119,6 +119,18 @@ def test_reference_signatures_are_present_verbatim():
     # the struct the reference's CRS::new reads from carries the reference's fields (prover.rs:35-46)
     assert re.search(r"pub struct Prover \{ pub f: PrimeField<Bls12R>, pub n: usize, pub l: usize, pub m: usize, pub wires: Vec<Fr>, pub h: Vec<Fr>, pub t: Vec<Fr>, "
                      r"pub ui: Vec<Vec<Fr>>, pub vi: Vec<Vec<Fr>>, pub wi: Vec<Vec<Fr>> \}", g16)
+    # Pinocchio: crs.rs:48-51, prover.rs:96, verifier.rs:31-36; draws in the reference's order (crs.rs:58-64,82; prover.rs:103-104); struct fields of crs.rs:12-39, proof.rs:8-18
+    pin = _norm(open(os.path.join(RS, "pinocchio.rs")).read())
+    assert "pub fn new(f: &PrimeField<Bls12R>, p: &Prover) -> Self" in pin
+    assert "pub fn prove(&self, crs: &CRS) -> Proof" in pin
+    assert "pub fn verify(&self, proof: &Proof, crs: &CRS, witness_io: &SparseVec<Bls12R>) -> bool" in pin
+    assert re.search(r"r_v: f\.rand_elem\(true\), r_w: f\.rand_elem\(true\), alpha_v: f\.rand_elem\(true\), alpha_w: f\.rand_elem\(true\), alpha_y: f\.rand_elem\(true\), beta: f\.rand_elem\(true\), "
+                     r"gamma: f\.rand_elem\(true\), s: f\.rand_elem\(true\)", pin)
+    assert "let (delta_v, delta_y) = (self.f.rand_elem(true), self.f.rand_elem(true));" in pin
+    for field in ("vk_mid", "g1_wk_mid", "g2_wk_mid", "yk_mid", "alpha_vk_mid", "alpha_wk_mid", "alpha_yk_mid", "si", "beta_vwy_k_mid", "one_g1", "one_g2", "alpha_v", "alpha_w", "alpha_y",
+                  "gamma", "beta_gamma", "vk_io", "wk_io", "yk_io", "alpha_v_t", "alpha_y_t", "beta_t", "v_mid_s", "g1_w_mid_s", "g2_w_mid_s", "y_mid_s", "h_s", "alpha_v_mid_s",
+                  "alpha_w_mid_s", "alpha_y_mid_s", "beta_vwy_mid_s"):
+        assert re.search(r"pub %s: (Vec<)?G[12]Point" % field, pin), field
     src = "".join(open(os.path.join(RS, f)).read() for f in os.listdir(RS) if f.endswith(".rs"))
     for needle in ("pub struct PrimeField<", "pub fn rand_elem(&self, exclude_zero: bool)", "pub struct PrimeFieldElems<", "pub fn sum(&self)", "pub struct AffinePoints",
                    "pub type AffinePoint = SecpPoint", "pub struct SparseVec<"):
