@@ -166,13 +166,17 @@ __global__ void __launch_bounds__(1024) k_ipa_fold_tail(uint32_t* __restrict__ A
 __global__ void __launch_bounds__(256) k_ipa_verdict_scalars(const uint32_t* __restrict__ AL, const uint32_t* __restrict__ BL, const uint32_t* __restrict__ ch,
                                                              const uint32_t* __restrict__ wH0, size_t N, int levels, uint32_t* __restrict__ sF) {
   typedef SnC C;
+  // the 4 * levels challenge values in Montgomery form, converted ONCE per block (every thread used to convert all of them itself: a third of this kernel's multiplications)
+  __shared__ uint32_t chm[4 * 32 * C::N];
+  for (int q = threadIdx.x; q < 4 * levels && q < 4 * 32; q += 256) st_raw<C>(chm + q * C::N, ld_fp<C>(ch + q * 8));
+  __syncthreads();
   size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; if (k >= N) return;
   Fp<C> wg = fp_one<C>(), wh = wH0 ? ld_fp<C>(wH0 + k * 8) : fp_one<C>();              // Montgomery form in registers
   Fp<C> cg = fp_zero<C>(), chh = fp_zero<C>();
   for (int j = 0; j < levels; ++j) {
     const size_t n = N >> j, np = n / 2, o = 2 * N - ((2 * N) >> j), i = k & (n - 1);
     const bool hi = i >= np; const size_t idx = hi ? i - np : np + i;                      // k_ipa_level_scalars: a[(hi ? j : np + j)]
-    const Fp<C> x = ld_fp<C>(ch + j * 32), xi = ld_fp<C>(ch + j * 32 + 8), x2 = ld_fp<C>(ch + j * 32 + 16), x2i = ld_fp<C>(ch + j * 32 + 24);
+    const Fp<C> x = ld_raw<C>(chm + (j * 4 + 0) * C::N), xi = ld_raw<C>(chm + (j * 4 + 1) * C::N), x2 = ld_raw<C>(chm + (j * 4 + 2) * C::N), x2i = ld_raw<C>(chm + (j * 4 + 3) * C::N);
     const Fp<C> sg = fp_mul(ld_fp<C>(AL + (o + idx) * 8), wg), sh = fp_mul(ld_fp<C>(BL + (o + idx) * 8), wh);
     cg = fp_add(cg, fp_mul(hi ? x2 : x2i, sg));                                           // gg_hi * a_lo belongs to L (x^2), gg_lo * a_hi to R (x^-2)
     chh = fp_add(chh, fp_mul(hi ? x2i : x2, sh));                                         // hh_lo * b_hi belongs to L, hh_hi * b_lo to R
@@ -182,7 +186,10 @@ __global__ void __launch_bounds__(256) k_ipa_verdict_scalars(const uint32_t* __r
   st_fp<C>(sF + k * 8, fp_sub(fp_mul(ld_fp<C>(AL + of * 8), wg), cg));
   st_fp<C>(sF + (N + k) * 8, fp_sub(fp_mul(ld_fp<C>(BL + of * 8), wh), chh));
 }
-// block (j, side): cL_j = <a_lo, b_hi> (side 0) or cR_j = <a_hi, b_lo> (side 1) of level j (:36-37), times x_j^2 / x_j^-2, into part[2j + side] (Montgomery form)
+// blocks (j, side, y): cL_j = <a_lo, b_hi> (side 0) or cR_j = <a_hi, b_lo> (side 1) of level j (:36-37), times x_j^2 / x_j^-2, as IPA_DOT_SPLIT partial sums
+// part[(2j + side) * IPA_DOT_SPLIT + y] (Montgomery form).  (One block per (j, side) made the top level's 32,768 products a chain of 128 per thread: 0.44 ms of the
+// argument's 2 ms on 32 of 256 CUs.)
+static constexpr int IPA_DOT_SPLIT = 16;
 __global__ void __launch_bounds__(256) k_ipa_u_dots(const uint32_t* __restrict__ AL, const uint32_t* __restrict__ BL, const uint32_t* __restrict__ ch, size_t N,
                                                     uint32_t* __restrict__ part) {
   typedef SnC C;
@@ -191,13 +198,13 @@ __global__ void __launch_bounds__(256) k_ipa_u_dots(const uint32_t* __restrict__
   const size_t n = N >> j, np = n / 2, o = 2 * N - ((2 * N) >> j);
   const uint32_t* av = AL + (o + (side ? np : 0)) * 8; const uint32_t* bv = BL + (o + (side ? 0 : np)) * 8;
   Fp<C> acc = fp_zero<C>();
-  for (size_t i = t; i < np; i += 256) acc = fp_add(acc, fp_mul(ld_fp<C>(av + i * 8), ld_fp<C>(bv + i * 8)));
+  for (size_t i = (size_t)blockIdx.y * 256 + t; i < np; i += (size_t)256 * IPA_DOT_SPLIT) acc = fp_add(acc, fp_mul(ld_fp<C>(av + i * 8), ld_fp<C>(bv + i * 8)));
   st_raw<C>(lds + t * C::N, acc); __syncthreads();
   for (int d = 128; d >= 1; d >>= 1) {
     if (t < d) { acc = fp_add(acc, ld_raw<C>(lds + (t + d) * C::N)); st_raw<C>(lds + t * C::N, acc); }
     __syncthreads();
   }
-  if (t == 0) st_raw<C>(part + blockIdx.x * 8, fp_mul(acc, ld_fp<C>(ch + j * 32 + (side ? 24 : 16))));
+  if (t == 0) st_raw<C>(part + ((size_t)blockIdx.x * IPA_DOT_SPLIT + blockIdx.y) * 8, fp_mul(acc, ld_fp<C>(ch + j * 32 + (side ? 24 : 16))));
 }
 // sF[2N] = a_fin b_fin - sum of the parts (the coefficient of u)
 __global__ void __launch_bounds__(64) k_ipa_u_scalar(const uint32_t* __restrict__ AL, const uint32_t* __restrict__ BL, const uint32_t* __restrict__ part, size_t N, int levels,
@@ -206,7 +213,7 @@ __global__ void __launch_bounds__(64) k_ipa_u_scalar(const uint32_t* __restrict_
   if (threadIdx.x || blockIdx.x) return;
   const size_t of = 2 * N - ((2 * N) >> levels);
   Fp<C> v = fp_mul(ld_fp<C>(AL + of * 8), ld_fp<C>(BL + of * 8));
-  for (int i = 0; i < 2 * levels; ++i) v = fp_sub(v, ld_raw<C>(part + i * 8));
+  for (int i = 0; i < 2 * levels * IPA_DOT_SPLIT; ++i) v = fp_sub(v, ld_raw<C>(part + i * 8));
   st_fp<C>(sF + 2 * N * 8, v);
 }
 
@@ -604,7 +611,7 @@ struct zkt_bp_ipa_ctx {
   explicit zkt_bp_ipa_ctx(size_t n)
       : N(n), NB(2 * n + 1), levels(log2z(n)), lv1(levels ? levels : 1), dbase(NB * SPB), da(N * FRB), db(N * FRB), da2(N * FRB), db2(N * FRB), dwG(N * FRB), dwH(N * FRB),
         dsc((size_t)IPA_SLOTS * NB * FRB), dPp(SPB), dx(lv1 * FRB), dch(4 * FRB), dsq(lv1 * 2 * FRB), dc(2 * FRB), dlr(lv1 * 2 * SPB), dm(lv1 * 2 * SPB), dt(SPB), dcomb(NB * FRB),
-        dAL(2 * N * FRB), dBL(2 * N * FRB), dchall(lv1 * 4 * FRB), dpart(lv1 * 2 * FRB) {}
+        dAL(2 * N * FRB), dBL(2 * N * FRB), dchall(lv1 * 4 * FRB), dpart(lv1 * 2 * 16 * FRB) {}      // dpart: IPA_DOT_SPLIT (16) partial sums per (level, side)
   bool ok() const { return dfix.p && dbase.p && da.p && db.p && da2.p && db2.p && dwG.p && dwH.p && dsc.p && dPp.p && dx.p && dch.p && dsq.p && dc.p && dlr.p && dm.p && dt.p && dcomb.p && dAL.p && dBL.p && dchall.p && dpart.p; }
   ~zkt_bp_ipa_ctx() {
     for (hipStream_t x : side) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
@@ -696,7 +703,7 @@ static int ipa_verdict_submit(zkt_bp_ipa_ctx* c, const uint64_t* a, const uint64
   if (lv < levels) hipLaunchKernelGGL(k_ipa_fold_tail, dim3(1), dim3(1024), 0, s, AL, BL, (const uint32_t*)CH, N, (int)lv, (int)levels);
   uint32_t* sF = c->dsc.w() + (size_t)slot * NB * 8;            // the slot's scalar buffer
   hipLaunchKernelGGL(k_ipa_verdict_scalars, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (const uint32_t*)AL, (const uint32_t*)BL, (const uint32_t*)CH, wH0, N, (int)levels, sF);
-  hipLaunchKernelGGL(k_ipa_u_dots, dim3((unsigned)(2 * levels)), dim3(256), 0, s, (const uint32_t*)AL, (const uint32_t*)BL, (const uint32_t*)CH, N, c->dpart.w());
+  hipLaunchKernelGGL(k_ipa_u_dots, dim3((unsigned)(2 * levels), IPA_DOT_SPLIT), dim3(256), 0, s, (const uint32_t*)AL, (const uint32_t*)BL, (const uint32_t*)CH, N, c->dpart.w());
   hipLaunchKernelGGL(k_ipa_u_scalar, dim3(1), dim3(64), 0, s, (const uint32_t*)AL, (const uint32_t*)BL, (const uint32_t*)c->dpart.w(), N, (int)levels, sF);
   if (hipGetLastError() != hipSuccess) return ZKT_ERR_DEVICE;
   return zkt_secp_msm_submit(c->set, (const uint64_t*)sF, NB, s, slot);
