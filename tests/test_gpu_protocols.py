@@ -348,3 +348,34 @@ def test_g1_one_shot_msm_sizes_by_linearity(L, n):
     zk.check(L.zkt_g1_msm(ptr(bases), ptr(ss), n, ptr(got)))
     tot = sum(limbs_to_int(a) * limbs_to_int(b) for a, b in zip(ks, ss)) % R
     assert (got == g1_arr([py_g1_mul(G1_GEN, tot)])).all()
+
+
+def test_groth16_verify_with_several_keys(L):
+    """The verifier keeps what a key contributes to the 63-step loop (line tables of gamma and delta, the ate counterpart of alpha_beta, statement tables) for the last four
+    keys, builds an entry at the SECOND sight of a key (first sight is served by the 127-step kernels) and evicts the least recently used one.  Five keys in rotation, each
+    verified three times in a row and revisited after its entry has been evicted: every decision equals the oracle's, for the valid proof and for a wrong statement."""
+    A_, B_, C_, wit, l = example_cubic()
+    n, m = len(A_), len(wit) - 1
+    ui, vi, wi, h, _ = qap_from_r1cs(A_, B_, C_, wit)
+    U, V, W = dense(ui, n), dense(vi, n), dense(wi, n)
+    wires, H = ints_to_arr(wit, 4), ints_to_arr(h, 4)
+    stmt = ints_to_arr(wit[:l + 1], 4)
+    bad = stmt.copy(); bad[l, 0] ^= np.uint64(1)
+    keys = []
+    for k in range(5):
+        rng = SplitMix64(900 + k); trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+        crs, buf = alloc_crs(n, l, m)
+        zk.check(L.zkt_groth16_setup(ctypes.byref(crs), ptr(U), ptr(V), ptr(W), *[ptr(t) for t in trap]))
+        pf = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+        zk.check(L.zkt_groth16_prove(ctypes.byref(crs), ptr(U), ptr(V), ptr(wires), ptr(H), len(h), ptr(fr(rng.below(R - 1) + 1)), ptr(fr(rng.below(R - 1) + 1)), *[ptr(x) for x in pf]))
+        keys.append((crs, buf, pf))
+    seen = {}
+    def both(k, j, st, tag):                                              # key k, the proof made for key j; the oracle's decision is computed once per case (three tate() calls)
+        crs, pf = keys[k][0], keys[j][2]
+        if (k, j, tag) not in seen: seen[(k, j, tag)] = O.zkto_groth16_verify(ctypes.byref(crs), *[ptr(x) for x in pf], ptr(st), l + 1)
+        return (seen[(k, j, tag)], L.zkt_groth16_verify(ctypes.byref(crs), *[ptr(x) for x in pf], ptr(st), l + 1))
+    for k in (0, 1, 2, 3, 4, 0, 2, 4, 1):
+        for _ in range(3):
+            assert both(k, k, stmt, "ok") == (1, 1)
+        assert both(k, k, bad, "bad") == (0, 0)
+        assert both(k, (k + 1) % 5, stmt, "other") == (0, 0)              # a proof made for another key
