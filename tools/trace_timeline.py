@@ -11,6 +11,7 @@ ev.sort()
 acc = [e for e in ev if e[2].startswith('k_accumulate')]
 nlast = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 t0 = acc[-nlast][0]; t1 = max(e[1] for e in ev)
+if len(sys.argv) > 4: t0 = [e for e in ev if e[2].startswith(sys.argv[4])][-1][0]      # window from the last launch of this kernel (e.g. k_to_mont = start of a proof)
 sel = [e for e in ev if e[0] >= t0]
 print("window ms %.3f for %d accumulates -> %.3f ms per MSM" % ((t1 - t0) / 1e6, nlast, (acc[-1][0] - acc[-nlast][0]) / 1e6 / (nlast - 1)))
 d = collections.defaultdict(list)

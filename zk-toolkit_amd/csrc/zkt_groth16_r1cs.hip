@@ -193,8 +193,9 @@ __global__ void __launch_bounds__(256) k_uvw(const uint32_t* __restrict__ consts
 // consecutive radix-2 stages (butterfly distances 2^lo .. 2^(lo+cnt-1)) on a tile of 2^cnt strided rows x 2^cbits
 // adjacent columns (<= 1024 elements, 32 KB), every element read and written once per launch, rows of >= 128 B contiguous.
 // logN = 21 is three launches per transform (10 + 8 + 3 stages) instead of 21.
-static constexpr int NTT_TILE_LOG = 10, NTT_TPB = 256;
-template <bool DIF>
+static constexpr int NTT_TILE_LOG = 10;
+static int ntt_tpb() { static const int v = [] { const char* e = getenv("ZKT_NTT_TPB"); return e && atoi(e) == 64 ? 64 : 256; }(); return v; }
+template <bool DIF, int NTT_TPB>
 __global__ void __launch_bounds__(NTT_TPB) k_ntt_group(uint32_t* __restrict__ a, int logN, int lo, int cnt, int cbits, const uint32_t* __restrict__ tw,
                                                        const uint32_t* __restrict__ mulvec) {
   __shared__ uint32_t lds[(1 << NTT_TILE_LOG) * FW];
@@ -326,18 +327,21 @@ int ntt_groups(int logN, NttGroup* g) {
   }
   return k;
 }
+template <int TPB>
+static void ntt_launch(bool dif, const NttGroup& g, uint32_t* a, int logN, const uint32_t* tw, const uint32_t* mulvec, hipStream_t s) {
+  const dim3 grid((unsigned)(((size_t)1 << logN) >> (g.cnt + g.cbits)));
+  if (dif) hipLaunchKernelGGL((k_ntt_group<true, TPB>), grid, dim3(TPB), 0, s, a, logN, g.lo, g.cnt, g.cbits, tw, mulvec);
+  else hipLaunchKernelGGL((k_ntt_group<false, TPB>), grid, dim3(TPB), 0, s, a, logN, g.lo, g.cnt, g.cbits, tw, mulvec);
+}
 // forward: natural -> bit-reversed; if `mulvec`, the spectrum is multiplied by it on the way out
 int ntt_forward(uint32_t* a, int logN, const uint32_t* tw, const uint32_t* mulvec, hipStream_t s) {
   NttGroup g[8]; const int k = ntt_groups(logN, g);
-  for (int i = k - 1; i >= 0; --i)
-    hipLaunchKernelGGL(k_ntt_group<true>, dim3((unsigned)(((size_t)1 << logN) >> (g[i].cnt + g[i].cbits))), dim3(NTT_TPB), 0, s, a, logN, g[i].lo, g[i].cnt, g[i].cbits, tw,
-                       i == 0 ? mulvec : (const uint32_t*)nullptr);
+  for (int i = k - 1; i >= 0; --i) { const uint32_t* mv = i == 0 ? mulvec : (const uint32_t*)nullptr; if (ntt_tpb() == 64) ntt_launch<64>(true, g[i], a, logN, tw, mv, s); else ntt_launch<256>(true, g[i], a, logN, tw, mv, s); }
   RCHK(hipGetLastError()); return ZKT_OK;
 }
 int ntt_inverse(uint32_t* a, int logN, const uint32_t* twinv, hipStream_t s) {
   NttGroup g[8]; const int k = ntt_groups(logN, g);
-  for (int i = 0; i < k; ++i)
-    hipLaunchKernelGGL(k_ntt_group<false>, dim3((unsigned)(((size_t)1 << logN) >> (g[i].cnt + g[i].cbits))), dim3(NTT_TPB), 0, s, a, logN, g[i].lo, g[i].cnt, g[i].cbits, twinv, (const uint32_t*)nullptr);
+  for (int i = 0; i < k; ++i) { if (ntt_tpb() == 64) ntt_launch<64>(false, g[i], a, logN, twinv, nullptr, s); else ntt_launch<256>(false, g[i], a, logN, twinv, nullptr, s); }
   RCHK(hipGetLastError()); return ZKT_OK;
 }
 void spmv(const Csr& M, const uint32_t* vec, uint32_t* out, hipStream_t s) {
@@ -393,9 +397,12 @@ struct zkt_groth16_pk {
   static constexpr int PSLOTS = 2;
   DBuf wires_c, wires_m, z_m[3], f[3], sA[PSLOTS], sB[PSLOTS], sC[PSLOTS], rs[PSLOTS];
   bool pending[PSLOTS] = {false, false};
-  hipStream_t s = nullptr;
+  hipStream_t s = nullptr, sq = nullptr;        // the key's stream (head of the Fr stage, collection) and the quotient stage's own (three transform pairs; high priority)
+  hipEvent_t e_head = nullptr, e_q = nullptr;   // (A w), (B w), (C w) and the scalar vectors are ready / the quotient stage has consumed them
   std::recursive_mutex mu;       // calls on one key are serialised (include/zkt.h, Threading)
   ~zkt_groth16_pk() {
+    if (sq) { (void)hipStreamSynchronize(sq); hipStreamDestroy(sq); }
+    if (e_head) hipEventDestroy(e_head); if (e_q) hipEventDestroy(e_q);
     if (setC1) zkt_g1_bases_free(setC1); if (setC2) zkt_g1_bases_free(setC2); if (setB) zkt_g2_bases_free(setB);
     if (setA) zkt_g1_bases_free(setA);            // last: it owns the streams the others work on
     if (s) hipStreamDestroy(s);
@@ -425,7 +432,9 @@ int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_spars
   const size_t rows = m + 1;
   int logN = 1; while (((size_t)1 << logN) < 2 * n) ++logN;
   const size_t N = (size_t)1 << logN; pk->N = N; pk->logN = logN;
-  RCHK(hipStreamCreateWithFlags(&pk->s, hipStreamNonBlocking));
+  { int lo = 0, hi = 0; RCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    RCHK(hipStreamCreateWithFlags(&pk->s, hipStreamNonBlocking)); RCHK(hipStreamCreateWithPriority(&pk->sq, hipStreamNonBlocking, hi));
+    RCHK(hipEventCreateWithFlags(&pk->e_head, hipEventDisableTiming)); RCHK(hipEventCreateWithFlags(&pk->e_q, hipEventDisableTiming)); }
   hipStream_t s = pk->s;
   Csr At, Bt, Ct;
   ZCHK(upload_csr(A, n, rows, pk->A, At, s)); ZCHK(upload_csr(B, n, rows, pk->B, Bt, s)); ZCHK(upload_csr(Cmat, n, rows, pk->Cm, Ct, s));
@@ -507,8 +516,17 @@ int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_spars
   ZCHK(zkt_g1_bases_from_device((const zkt_g1_affine*)(pC.w() + (nC1 + pk->loC2) * 26), pk->hiC2 - pk->loC2, s, &pk->setC2)); pC.release();
   // one set of streams for the key (owner: setA): a sort stream, the G1 accumulate stream (C1, A, C2 in turn), B's own accumulate stream, four reduce streams —
   // with the key's own stream that is eight, one per hardware queue
-  ZCHK(zkt_internal_bases_share_streams(pk->setC1, pk->setA, 1, 0, 2)); ZCHK(zkt_internal_bases_share_streams(pk->setC2, pk->setA, 1, 0, 2));
-  ZCHK(zkt_internal_bases_share_streams(pk->setB, pk->setA, 0, 2, 2));
+  // Sets below 2^19 terms (small circuits, and every shard of a proof spread over several GPUs) run their whole MSM on ONE stream each (zkt_api.cpp, msm_submit_locked): there
+  // A, C1, C2 and B get a reduce stream each, so the four sums of a proof run side by side instead of one after the other (a rank's share of a 2^20-constraint proof
+  // over 8 GPUs)
+  const bool side_by_side = std::max(std::max(pk->hiA - pk->loA, pk->hiC1 - pk->loC1), pk->hiC2 - pk->loC2) < ((size_t)1 << 19);
+  if (side_by_side) {
+    ZCHK(zkt_internal_bases_share_streams(pk->setC1, pk->setA, 1, 1, 1)); ZCHK(zkt_internal_bases_share_streams(pk->setC2, pk->setA, 1, 3, 1));
+    ZCHK(zkt_internal_bases_share_streams(pk->setB, pk->setA, 0, 2, 1));
+  } else {
+    ZCHK(zkt_internal_bases_share_streams(pk->setC1, pk->setA, 1, 0, 2)); ZCHK(zkt_internal_bases_share_streams(pk->setC2, pk->setA, 1, 0, 2));
+    ZCHK(zkt_internal_bases_share_streams(pk->setB, pk->setA, 0, 2, 2));
+  }
   RCHK(hipMemcpyAsync(derr.p, &noerr, 8, hipMemcpyHostToDevice, s));
   RCHK(launch_tate(small1.w(), small2.w(), gt.w(), 1, (unsigned long long*)derr.p, s));        // crs.rs:137-139
   RCHK(hipMemcpyAsync(vk->g1_alpha, small1.p, G1B, hipMemcpyDeviceToHost, s)); RCHK(hipMemcpyAsync(vk->g1_beta, small1.w() + 26, G1B, hipMemcpyDeviceToHost, s));
@@ -545,6 +563,7 @@ static int prove_submit(zkt_groth16_pk* pk, int ps, const uint64_t* wires, bool 
   hipStream_t s = pk->s;
   DBuf &sA = pk->sA[ps], &sB = pk->sB[ps], &sC = pk->sC[ps], &drs = pk->rs[ps];
   uint64_t rs[8]; memcpy(rs, r, 32); memcpy(rs + 4, s_, 32);
+  RCHK(hipStreamWaitEvent(s, pk->e_q, 0));        // z_m and f are shared by the proof slots: the previous proof's quotient stage has to be through with them
   RCHK(hipMemcpyAsync(drs.p, rs, 64, hipMemcpyHostToDevice, s));
   RCHK(hipMemcpyAsync(pk->wires_c.p, wires, rows * FRB, wires_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_to_mont, dim3(nb(rows)), dim3(256), 0, s, (const uint32_t*)pk->wires_c.w(), pk->wires_m.w(), rows);
@@ -553,23 +572,30 @@ static int prove_submit(zkt_groth16_pk* pk, int ps, const uint64_t* wires, bool 
   hipLaunchKernelGGL(k_prove_scalars, dim3(nb(n + nw + 1)), dim3(256), 0, s, (const uint32_t*)pk->z_m[0].w(), (const uint32_t*)pk->z_m[1].w(), (const uint32_t*)pk->wires_c.w(),
                      (const uint32_t*)drs.w(), n, l, m, sA.w(), sB.w(), sC.w());
   RCHK(hipGetLastError());
-  // A, B and the first part of C only need (A w), (B w) and the wires: they start now and run under the quotient stage
+  // The quotient stage is enqueued FIRST, on a stream of its own: its launches cost the host ~0.1 ms, an MSM submission 0.5-0.7 ms, and the quotient's MSM is the end of the
+  // critical path (on a shard of a proof the chain used to start 2.4 ms into the proof, behind three submissions; on one GPU it delayed the collection of the proof before).
+  // A, B and the first part of C only need (A w), (B w) and the wires: their input event is recorded on `s`, which the chain is not on.
   const size_t nC1 = pk->nC1;
-  ZCHK(zkt_g2_msm_submit(pk->setB, (const uint64_t*)(sB.w() + pk->loA * FW), pk->hiA - pk->loA, s, ps));
-  ZCHK(zkt_g1_msm_submit(pk->setC1, (const uint64_t*)(sC.w() + pk->loC1 * FW), pk->hiC1 - pk->loC1, s, ps));
-  ZCHK(zkt_g1_msm_submit(pk->setA, (const uint64_t*)(sA.w() + pk->loA * FW), pk->hiA - pk->loA, s, ps));
+  hipStream_t q = s;
   if (n >= 2) {
+    q = pk->sq;
+    RCHK(hipEventRecord(pk->e_head, s)); RCHK(hipStreamWaitEvent(q, pk->e_head, 0));
     for (int k = 0; k < 3; ++k) {
-      hipLaunchKernelGGL(k_prep_f, dim3(nb(N)), dim3(256), 0, s, (const uint32_t*)pk->z_m[k].w(), (const uint32_t*)pk->cinv.w(), n, N, pk->f[k].w());
-      ZCHK(ntt_forward(pk->f[k].w(), pk->logN, pk->tw.w(), pk->ghat.w(), s));          // spectrum * spectrum of 1/d (and 1/N)
-      ZCHK(ntt_inverse(pk->f[k].w(), pk->logN, pk->twinv.w(), s));
+      hipLaunchKernelGGL(k_prep_f, dim3(nb(N)), dim3(256), 0, q, (const uint32_t*)pk->z_m[k].w(), (const uint32_t*)pk->cinv.w(), n, N, pk->f[k].w());
+      ZCHK(ntt_forward(pk->f[k].w(), pk->logN, pk->tw.w(), pk->ghat.w(), q));          // spectrum * spectrum of 1/d (and 1/N)
+      ZCHK(ntt_inverse(pk->f[k].w(), pk->logN, pk->twinv.w(), q));
     }
-    hipLaunchKernelGGL(k_hvals, dim3(nb(n - 1)), dim3(256), 0, s, (const uint32_t*)pk->f[0].w(), (const uint32_t*)pk->f[1].w(), (const uint32_t*)pk->f[2].w(), (const uint32_t*)pk->P.w(), n,
+    hipLaunchKernelGGL(k_hvals, dim3(nb(n - 1)), dim3(256), 0, q, (const uint32_t*)pk->f[0].w(), (const uint32_t*)pk->f[1].w(), (const uint32_t*)pk->f[2].w(), (const uint32_t*)pk->P.w(), n,
                        sC.w() + nC1 * FW);
     RCHK(hipGetLastError());
+    RCHK(hipEventRecord(pk->e_q, q));
   }
-  // the quotient part of C: the only MSM that waits for the NTT chain
-  ZCHK(zkt_g1_msm_submit(pk->setC2, (const uint64_t*)(sC.w() + (nC1 + pk->loC2) * FW), pk->hiC2 - pk->loC2, s, ps));
+  // the sums, longest first; the quotient part of C is the only one that waits for the NTT chain (its input event is recorded on `s` behind k_hvals)
+  hipStream_t in = s;          // (waiting for the chain instead — all four sums behind it — was measured on a shard of 8: 8.2 ms against 7.6)
+  ZCHK(zkt_g2_msm_submit(pk->setB, (const uint64_t*)(sB.w() + pk->loA * FW), pk->hiA - pk->loA, in, ps));
+  ZCHK(zkt_g1_msm_submit(pk->setC1, (const uint64_t*)(sC.w() + pk->loC1 * FW), pk->hiC1 - pk->loC1, in, ps));
+  ZCHK(zkt_g1_msm_submit(pk->setC2, (const uint64_t*)(sC.w() + (nC1 + pk->loC2) * FW), pk->hiC2 - pk->loC2, q, ps));
+  ZCHK(zkt_g1_msm_submit(pk->setA, (const uint64_t*)(sA.w() + pk->loA * FW), pk->hiA - pk->loA, in, ps));
   pk->pending[ps] = true;
   return ZKT_OK;
 }
