@@ -21,6 +21,7 @@ cp $O/${T}_groth16_2p20_kernel_stats.csv $P/${T}_groth16_2p20_kernel_stats.csv
 cp $O/${T}_g16_timeline.txt $P/${T}_groth16_timeline.txt
 cp $O/${T}_protocols.json $P/${T}_protocols.json
 cp "$(newest "$O/prof_${T}_protocols/*/*kernel_stats.csv")" $P/${T}_protocols_kernel_stats.csv
+[ -f $O/${T}_g16_shard.txt ] && cp $O/${T}_g16_shard.txt $P/${T}_groth16_shard_of_8.txt
 [ -f $O/${T}_bp.log ] && grep -v "amdgpu.ids" $O/${T}_bp.log > $P/${T}_bulletproofs_latency.txt
 echo "folded into $P/${T}_*  (kernel sources $(python3 tools/src_hash.py))"
 python3 - "$P/${T}_tate_memory_counters.json" <<'PY'

@@ -8,6 +8,7 @@
 #   bench_stats       rocprofv3 --kernel-trace --stats of bench.py (MSM + pairing legs) -> prof_<tag>_stats/
 #   msm_latency       tools/bench_msm_latency.py under rocprofv3 --kernel-trace -> <tag>_msm_latency_kernel_trace.txt
 #   groth16_stats     tools/bench_groth16.py at 2^20 under rocprofv3 --kernel-trace --stats -> prof_<tag>_g16/ + timeline
+#   g16_shard         one rank's share of a 2^20-constraint proof sharded over 8 GPUs (ranks 0, 3, 7, a fresh process each) + the kernel timeline of one share
 #   protocols         tools/bench_protocols.py -> <tag>_protocols.json
 #   protocols_stats   the same under rocprofv3 --kernel-trace --stats
 #   bp                tools/bench_bp.py (range proof / inner-product argument)
@@ -39,6 +40,15 @@ for STEP in "$@"; do
       grep -v "^[WEI]2026" $O/prof_${TAG}_g16.log | tail -4
       cp $(ls $O/prof_${TAG}_g16/*/*kernel_stats.csv | head -1) $O/${TAG}_groth16_2p20_kernel_stats.csv
       python3 tools/trace_timeline.py $(ls $O/prof_${TAG}_g16/*/*kernel_trace.csv | head -1) 3 140 > $O/${TAG}_g16_timeline.txt 2>&1 || true ;;
+    g16_shard) : > $O/${TAG}_g16_shard.txt
+      for RK in 0 3 7; do
+        timeout -k 10 300 python3 tools/bench_groth16.py --log-n 20 --proofs 8 --shard-of 8 --rank $RK > $O/${TAG}_g16_shard_$RK.log 2>&1 || fail "g16_shard $RK" $O/${TAG}_g16_shard_$RK.log
+        grep "^rank" $O/${TAG}_g16_shard_$RK.log >> $O/${TAG}_g16_shard.txt
+      done
+      timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/prof_${TAG}_g16_shard -- python3 tools/bench_groth16.py --log-n 20 --proofs 3 --shard-of 8 --rank 3 > $O/prof_${TAG}_g16_shard.log 2>&1 || fail g16_shard $O/prof_${TAG}_g16_shard.log
+      echo "--- kernel timeline of one share (rank 3; rocprofv3 --kernel-trace, from the proof's first kernel):" >> $O/${TAG}_g16_shard.txt
+      python3 tools/trace_timeline.py $(ls -t $O/prof_${TAG}_g16_shard/*/*kernel_trace.csv | head -1) 3 200 k_to_mont | grep -v "k_scan\|k_zero" >> $O/${TAG}_g16_shard.txt 2>&1 || true
+      head -4 $O/${TAG}_g16_shard.txt ;;
     protocols) timeout -k 10 900 python3 tools/bench_protocols.py > $O/${TAG}_protocols.json 2> $O/${TAG}_protocols.err || fail protocols $O/${TAG}_protocols.err
       cat $O/${TAG}_protocols.json | cut -c1-1500 ;;
     protocols_stats) timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_protocols -- python3 tools/bench_protocols.py > $O/${TAG}_protocols_b.json 2> $O/prof_${TAG}_protocols.err || fail protocols_stats $O/prof_${TAG}_protocols.err ;;

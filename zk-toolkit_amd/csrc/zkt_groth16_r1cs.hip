@@ -193,9 +193,10 @@ __global__ void __launch_bounds__(256) k_uvw(const uint32_t* __restrict__ consts
 // consecutive radix-2 stages (butterfly distances 2^lo .. 2^(lo+cnt-1)) on a tile of 2^cnt strided rows x 2^cbits
 // adjacent columns (<= 1024 elements, 32 KB), every element read and written once per launch, rows of >= 128 B contiguous.
 // logN = 21 is three launches per transform (10 + 8 + 3 stages) instead of 21.
-static constexpr int NTT_TILE_LOG = 10;
-static int ntt_tpb() { static const int v = [] { const char* e = getenv("ZKT_NTT_TPB"); return e && atoi(e) == 64 ? 64 : 256; }(); return v; }
-template <bool DIF, int NTT_TPB>
+// (one-wave workgroups for the transform were measured at the end of round 3, in case its four-wave workgroups were what starved beside an accumulate grid: 9.1 ms against 7.6
+// for a shard of a proof, 40 against 50 proofs/s on one GPU — not that)
+static constexpr int NTT_TILE_LOG = 10, NTT_TPB = 256;
+template <bool DIF>
 __global__ void __launch_bounds__(NTT_TPB) k_ntt_group(uint32_t* __restrict__ a, int logN, int lo, int cnt, int cbits, const uint32_t* __restrict__ tw,
                                                        const uint32_t* __restrict__ mulvec) {
   __shared__ uint32_t lds[(1 << NTT_TILE_LOG) * FW];
@@ -327,21 +328,18 @@ int ntt_groups(int logN, NttGroup* g) {
   }
   return k;
 }
-template <int TPB>
-static void ntt_launch(bool dif, const NttGroup& g, uint32_t* a, int logN, const uint32_t* tw, const uint32_t* mulvec, hipStream_t s) {
-  const dim3 grid((unsigned)(((size_t)1 << logN) >> (g.cnt + g.cbits)));
-  if (dif) hipLaunchKernelGGL((k_ntt_group<true, TPB>), grid, dim3(TPB), 0, s, a, logN, g.lo, g.cnt, g.cbits, tw, mulvec);
-  else hipLaunchKernelGGL((k_ntt_group<false, TPB>), grid, dim3(TPB), 0, s, a, logN, g.lo, g.cnt, g.cbits, tw, mulvec);
-}
 // forward: natural -> bit-reversed; if `mulvec`, the spectrum is multiplied by it on the way out
 int ntt_forward(uint32_t* a, int logN, const uint32_t* tw, const uint32_t* mulvec, hipStream_t s) {
   NttGroup g[8]; const int k = ntt_groups(logN, g);
-  for (int i = k - 1; i >= 0; --i) { const uint32_t* mv = i == 0 ? mulvec : (const uint32_t*)nullptr; if (ntt_tpb() == 64) ntt_launch<64>(true, g[i], a, logN, tw, mv, s); else ntt_launch<256>(true, g[i], a, logN, tw, mv, s); }
+  for (int i = k - 1; i >= 0; --i)
+    hipLaunchKernelGGL(k_ntt_group<true>, dim3((unsigned)(((size_t)1 << logN) >> (g[i].cnt + g[i].cbits))), dim3(NTT_TPB), 0, s, a, logN, g[i].lo, g[i].cnt, g[i].cbits, tw,
+                       i == 0 ? mulvec : (const uint32_t*)nullptr);
   RCHK(hipGetLastError()); return ZKT_OK;
 }
 int ntt_inverse(uint32_t* a, int logN, const uint32_t* twinv, hipStream_t s) {
   NttGroup g[8]; const int k = ntt_groups(logN, g);
-  for (int i = 0; i < k; ++i) { if (ntt_tpb() == 64) ntt_launch<64>(false, g[i], a, logN, twinv, nullptr, s); else ntt_launch<256>(false, g[i], a, logN, twinv, nullptr, s); }
+  for (int i = 0; i < k; ++i)
+    hipLaunchKernelGGL(k_ntt_group<false>, dim3((unsigned)(((size_t)1 << logN) >> (g[i].cnt + g[i].cbits))), dim3(NTT_TPB), 0, s, a, logN, g[i].lo, g[i].cnt, g[i].cbits, twinv, (const uint32_t*)nullptr);
   RCHK(hipGetLastError()); return ZKT_OK;
 }
 void spmv(const Csr& M, const uint32_t* vec, uint32_t* out, hipStream_t s) {
