@@ -215,6 +215,23 @@ def test_config4_groth16_2p20(L):
     assert L.zkt_groth16_verify(ctypes.byref(vk), ptr(A), ptr(B), ptr(C), ptr(bad_stmt), l + 1) == 0      # wrong statement
     assert L.zkt_groth16_verify(ctypes.byref(vk), ptr(A), ptr(B), ptr(A), ptr(stmt), l + 1) == 0          # tampered proof element
     assert L.zkt_groth16_verify(ctypes.byref(vk), ptr(A2), ptr(B2), ptr(C2), ptr(stmt), l + 1) == 0       # proof from the violating witness
+    # BASELINE config 4 proper: ONE proof over 8 ranks.  The eight ranks' keys in turn on this card (index ranges of 2^17 / 2^18 terms: the sums run on the small-set
+    # path, side by side), each rank's three Jacobian partials, then the combine step of the exchange — the unsharded proof bit for bit.
+    W = 8
+    parts = torch.zeros((W, zk.GROTH16_PARTIAL_WORDS), dtype=torch.int32, device="cuda")
+    for k in range(W):
+        vk2, vbuf2 = alloc_crs(1, l, m); vk2.g1_uvw_wit = None
+        pk2 = ctypes.c_void_p()
+        zk.check(L.zkt_groth16_setup_r1cs_sharded(n, l, m, *[ctypes.addressof(x) for x in structs], *[t.ctypes.data for t in trap], k, W, ctypes.addressof(vk2), ctypes.addressof(pk2)))
+        for _ in range(2):                                                            # twice: the second proof replays the sums' graphs
+            zk.check(L.zkt_groth16_prove_r1cs_partials(pk2, d_w.data_ptr(), r.ctypes.data, s.ctypes.data, parts[k].data_ptr()))
+        L.zkt_groth16_pk_free(pk2)
+    torch.cuda.synchronize()
+    a, b = zk.G1_PARTIAL_WORDS, zk.G1_PARTIAL_WORDS + zk.G2_PARTIAL_WORDS
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    pa, pb, pc = parts[:, :a].contiguous(), parts[:, a:b].contiguous(), parts[:, b:].contiguous()
+    zk.check(L.zkt_g1_jac_sum_dev(vp(pa), W, None, ptr(A2))); zk.check(L.zkt_g2_jac_sum_dev(vp(pb), W, None, ptr(B2))); zk.check(L.zkt_g1_jac_sum_dev(vp(pc), W, None, ptr(C2)))
+    assert (A2 == A).all() and (B2 == B).all() and (C2 == C).all(), "proof sharded over 8 ranks differs from the unsharded proof"
 
 
 def test_config5_range_proof_65536_bits(L):
