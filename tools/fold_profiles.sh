@@ -13,6 +13,9 @@ python3 tools/sq_summary.py $P/${T}_accumulate_sq_counters.json $UB "rocprofv3 -
 python3 tools/pmc_summary.py $P/${T}_hbm_traffic_pmc.json "rocprofv3 --pmc FETCH_SIZE (one pass) and --pmc WRITE_SIZE (another) -- $BENCHCMD (MI355X, round ${T#r}, final build; tools/gpu_job.sh $T pmc_hbm)" "$(newest "$O/prof_${T}_hbm_FETCH_SIZE/*/*counter_collection.csv")" "$(newest "$O/prof_${T}_hbm_WRITE_SIZE/*/*counter_collection.csv")"
 python3 tools/sq_summary.py $P/${T}_tate_sq_counters.json $UB "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -- python3 tools/bench_pairing.py 65536 (MI355X, round ${T#r}, final build; tools/gpu_job.sh $T pmc_tate)" "$(newest "$O/prof_${T}_sq_tate/*/*counter_collection.csv")"
 python3 tools/pmc_summary.py $P/${T}_tate_memory_counters.json "rocprofv3 --pmc FETCH_SIZE (one pass) / --pmc WRITE_SIZE (another) -- python3 tools/bench_pairing.py 65536 (MI355X, round ${T#r}, final build; tools/gpu_job.sh $T pmc_tate_hbm).  Averages per launch at 65,536 pairings." "$(newest "$O/prof_${T}_hbm_tate_FETCH_SIZE/*/*counter_collection.csv")" "$(newest "$O/prof_${T}_hbm_tate_WRITE_SIZE/*/*counter_collection.csv")"
+if ls $O/prof_${T}_hbm_verify_FETCH_SIZE/*/*counter_collection.csv > /dev/null 2>&1; then
+python3 tools/pmc_summary.py $P/${T}_verify_memory_counters.json "rocprofv3 --pmc FETCH_SIZE (one pass) / --pmc WRITE_SIZE (another) -- python3 tools/bench_g16_batch_verify.py 65536 (MI355X, round ${T#r}, final build; tools/gpu_job.sh $T pmc_verify_hbm)" "$(newest "$O/prof_${T}_hbm_verify_FETCH_SIZE/*/*counter_collection.csv")" "$(newest "$O/prof_${T}_hbm_verify_WRITE_SIZE/*/*counter_collection.csv")"
+fi
 cp $O/${T}_bench.json $P/${T}_bench.json
 cp $O/${T}_bench_msm_pairing.json $P/${T}_bench_msm_pairing.json
 cp "$(newest "$O/prof_${T}_stats/*/*kernel_stats.csv")" $P/${T}_bench_kernel_stats.csv

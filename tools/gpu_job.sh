@@ -13,6 +13,7 @@
 #   protocols_stats   the same under rocprofv3 --kernel-trace --stats
 #   bp                tools/bench_bp.py (range proof / inner-product argument)
 #   pmc_acc | pmc_hbm | pmc_tate | pmc_tate_hbm   counter passes (their own runs: no trace domains beside --pmc)
+#   pmc_verify_hbm    FETCH_SIZE / WRITE_SIZE passes over tools/bench_g16_batch_verify.py (the 63-step deciding kernels)
 #   rehearsal         two ranks on one card through the callback transport (bench.py --gpus 2, gloo)
 #   py:<script> [..]  python3 <script> -> <tag>_<script>.log
 #   cmd:<shell>       any shell command (quoted)
@@ -61,6 +62,9 @@ for STEP in "$@"; do
     pmc_tate) timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/prof_${TAG}_sq_tate --output-format csv -- python3 tools/bench_pairing.py 65536 > $O/prof_${TAG}_sq_tate.log 2>&1 || fail pmc_tate $O/prof_${TAG}_sq_tate.log ;;
     pmc_tate_hbm) for CNT in FETCH_SIZE WRITE_SIZE; do
         timeout -k 10 300 rocprofv3 --pmc $CNT -d $O/prof_${TAG}_hbm_tate_$CNT --output-format csv -- python3 tools/bench_pairing.py 65536 > $O/prof_${TAG}_hbm_tate_$CNT.log 2>&1 || fail "pmc_tate_hbm $CNT" $O/prof_${TAG}_hbm_tate_$CNT.log
+      done ;;
+    pmc_verify_hbm) for CNT in FETCH_SIZE WRITE_SIZE; do
+        timeout -k 10 300 rocprofv3 --pmc $CNT -d $O/prof_${TAG}_hbm_verify_$CNT --output-format csv -- python3 tools/bench_g16_batch_verify.py 65536 > $O/prof_${TAG}_hbm_verify_$CNT.log 2>&1 || fail "pmc_verify_hbm $CNT" $O/prof_${TAG}_hbm_verify_$CNT.log
       done ;;
     rehearsal) ZKT_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --groth16-log2n 16 --groth16-proofs 3 --pairings 4096 --no-cpu > $O/${TAG}_bench_rehearsal_2ranks_1gpu.json 2> $O/${TAG}_rehearsal.err || fail rehearsal $O/${TAG}_rehearsal.err ;;
     py:*) S="${STEP#py:}"; N=$(basename ${S%% *} .py)
