@@ -172,6 +172,7 @@ struct zkt_bases_impl {               // one resident base set of any group; zkt
   // software pipeline: the three stages of consecutive MSMs run on three streams (sort | accumulate | reduce),
   // chained by events, so the atomic-bound sort and the latency-bound reduce of neighbours hide under the
   // VALU-bound accumulation of the current one.
+  static constexpr int GROUP_TAILS = 4;   // reduce streams of a group of sets that share their streams (zkt_internal_bases_share_streams)
   static constexpr int NTAIL = 8;   // reduce chains of alternate MSMs run side by side: each is latency-bound, not throughput-bound (large MSMs use two of them)
   hipStream_t s_sort = nullptr, s_acc = nullptr, s_tail[NTAIL] = {};
   // a group of base sets that always work on the same job (the four sets of a Groth16 key) shares ONE set of streams: every stream beyond the
@@ -566,7 +567,7 @@ static int bases_upload(int grp, const void* host, size_t n, zkt_bases_impl** ou
   return rc;
 }
 static hipStream_t slot_tail_stream(zkt_bases_impl* h, int slot) {
-  if (h->grouped) return h->s_tail[h->tail_base + slot % h->tail_span];
+  if (h->grouped) return h->s_tail[(h->tail_base + slot % h->tail_span) % zkt_bases_impl::GROUP_TAILS];      // a span may wrap around the group's four reduce streams
   const bool small = h->n < (size_t(1) << 19);
   return h->s_tail[small ? slot % zkt_bases_impl::NTAIL : slot % 2];
 }
@@ -668,9 +669,9 @@ static int msm_dev(zkt_bases_impl* h, const uint64_t* dev_scalars, size_t n, voi
 // otherwise dst gets one of its own).  Call before dst's first MSM; free dst before src.
 int zkt_internal_bases_share_streams(void* dst_, void* src_, int share_acc, int tail_base, int tail_span) {
   zkt_bases_impl *dst = (zkt_bases_impl*)dst_, *src = (zkt_bases_impl*)src_;
-  if (!dst || !src || tail_span < 1 || tail_base < 0 || tail_base + tail_span > zkt_bases_impl::NTAIL) return ZKT_ERR_SHAPE;
-  constexpr int GROUP_TAILS = 4;
-  if (tail_base + tail_span > GROUP_TAILS) return ZKT_ERR_SHAPE;
+  if (!dst || !src || tail_span < 1 || tail_base < 0) return ZKT_ERR_SHAPE;
+  constexpr int GROUP_TAILS = zkt_bases_impl::GROUP_TAILS;
+  if (tail_base >= GROUP_TAILS || tail_span > GROUP_TAILS) return ZKT_ERR_SHAPE;
   int lo = 0, hi = 0; HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
   {
     std::lock_guard<std::mutex> lk(src->mu);
