@@ -22,7 +22,7 @@ R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MSM_BYTES_PER_TERM = 128       # 96 B affine base + 32 B scalar
 PAIRING_BYTES = 864            # 96 + 192 in, 576 out
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def load_profile(name):
@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--pairings", type=int, default=1 << 16, help="pairings in the secondary measurement (0 = skip)")
     ap.add_argument("--groth16-log2n", type=int, default=20, help="constraints (log2) of the Groth16 prove+verify leg (0 = skip)")
     ap.add_argument("--groth16-proofs", type=int, default=8)
+    ap.add_argument("--g2-log2n", type=int, default=20, help="terms (log2) of the resident G2 MSM leg: the B sum of a Groth16 proof (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-bulletproofs", dest="bulletproofs", action="store_false", help="skip the Bulletproofs leg (BASELINE config 5)")
     ap.add_argument("--scalar-dist", default="uniform", choices=["uniform", "ones", "bits"],
@@ -168,22 +169,34 @@ def main():
     elif args.scalar_dist == "bits":
         h_scalars[:, 1:] = 0; h_scalars[:, 0] &= np.uint64(1)
     d_scalars = torch.from_numpy(h_scalars.view(np.int64)).to(dev)
+    # a SECOND scalar set: the timed loop alternates between the two (step i takes set i % 2) and the last result of EACH is checked at full size, so no step can
+    # have been served from anything the previous one left behind
+    h_scalars_b = rand_scalars_mod_r(5 + 1000 * rank, n)
+    if args.scalar_dist == "ones":
+        h_scalars_b[:] = 0; h_scalars_b[:, 0] = 2
+    elif args.scalar_dist == "bits":
+        h_scalars_b[:, 1:] = 0; h_scalars_b[:, 0] &= np.uint64(1)
+    d_scalars_b = torch.from_numpy(h_scalars_b.view(np.int64)).to(dev)
     out = np.zeros((1, 13), dtype=np.uint64)
     outp = out.ctypes.data_as(ctypes.c_void_p)
+    last_of_set = [None, None]
 
     DEPTH = int(os.environ.get("ZKT_BENCH_DEPTH", "5"))   # MSMs in flight: sort / accumulate / reduce-tail of consecutive MSMs overlap
     NSLOT = 8          # ZKT_MSM_SLOTS
 
     def run(handle, d_sc, nterms, steps):
-        """exactly `steps` MSMs, submitted back to back, each collected (result on the host, after the exchange for N>1) before returning"""
+        """exactly `steps` MSMs, submitted back to back, each collected (result on the host, after the exchange for N>1) before returning.
+        d_sc: one scalar buffer, or a pair — step i then takes buffer i % 2 and the last result of each is kept in last_of_set"""
         kms = []
+        pair = isinstance(d_sc, (tuple, list))
         for i in range(steps + DEPTH):
             if i >= DEPTH:
-                slot = (i - DEPTH) % NSLOT
+                j = i - DEPTH; slot = j % NSLOT
                 zk.check(L.zkt_g1_msm_collect(handle, slot, outp, None) if world == 1 else L.zkt_g1_msm_sharded_collect(handle, slot, outp))
                 kms.append(L.zkt_last_kernel_ms())
+                if pair: last_of_set[j % 2] = out.copy()
             if i < steps:
-                zk.check(L.zkt_g1_msm_submit(handle, vp(d_sc), nterms, sp, i % NSLOT))
+                zk.check(L.zkt_g1_msm_submit(handle, vp(d_sc[i % 2] if pair else d_sc), nterms, sp, i % NSLOT))
         return kms
 
     def timed(handle, d_sc, nterms, steps):
@@ -202,14 +215,15 @@ def main():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         zk.check(L.zkt_g1_msm_dev(h, vp(d_scalars), n, sp, outp, None))
         latency_ms = (time.perf_counter() - t0) * 1e3
-    elapsed, kern_ms = timed(h, d_scalars, n, args.steps)
+    elapsed, kern_ms = timed(h, (d_scalars, d_scalars_b), n, args.steps)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n * args.steps / elapsed
     k_ms = float(np.mean(kern_ms))
     k_ms_note = None
     if not k_ms > 0:           # below 2^19 terms the library replays an MSM's pipeline as one graph launch: no HIP events around its accumulate kernel
         k_ms, k_ms_note = ms_per_step, "no per-kernel events at this size (graph replay): the whole-step time stands in for the kernel time, so `achieved` is a lower bound"
-    headline_point = out.copy()
+    headline_point = last_of_set[0] if last_of_set[0] is not None else out.copy()
+    headline_point_b = last_of_set[1]
 
     # strong scaling beside the weak headline: ONE 2^log2n-term MSM cut into `world` index ranges
     strong = None
@@ -299,10 +313,15 @@ def main():
                 g16["sharded"]["equals_unsharded_proof"] = bool(all((a == b).all() for a, b in zip(sharded_proof, gp)))
             if rank == 0:
                 stmt = wires[:gl + 1].copy()
+                # a verifier that knows its key prepares it once (zkt_groth16_vk_prepare: the per-key tables of the 63-step loop); every verification after that is a
+                # steady-state call.  (Without the call the library serves a key's first small batch with kernels that need no tables and builds them at the second:
+                # ~11 / ~23 / ~5 ms for calls 1 / 2 / 3+, tools/bench_verify_latency.py.)
+                L.zkt_groth16_vk_prepare.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+                t0 = time.perf_counter(); rc_prep = L.zkt_groth16_vk_prepare(ctypes.byref(vk1), gl + 1); g16["vk_prepare_ms"] = (time.perf_counter() - t0) * 1e3
                 t0 = time.perf_counter()
                 ok = L.zkt_groth16_verify(ctypes.byref(vk1), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(stmt), gl + 1)
-                g16["verify_first_call_ms"] = (time.perf_counter() - t0) * 1e3; g16["verifies"] = bool(ok == 1)
-                t0 = time.perf_counter()                 # second call on this key: the library now builds the key's tables for the 63-step loop (first sight is served without them)
+                g16["verify_first_call_ms"] = (time.perf_counter() - t0) * 1e3; g16["verifies"] = bool(ok == 1) and rc_prep == 0
+                t0 = time.perf_counter()
                 ok2 = L.zkt_groth16_verify(ctypes.byref(vk1), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(stmt), gl + 1)
                 g16["verify_second_call_ms"] = (time.perf_counter() - t0) * 1e3
                 tv = []
@@ -364,11 +383,13 @@ def main():
 
     # parity check of the timed configuration at full size, by linearity: bases are k_i*G, so the MSM over all ranks
     # must equal (sum_i k_i s_i mod r)*G — python integers only, independent of the HIP path
-    tot = sum(int.from_bytes(a.tobytes(), "little") * int.from_bytes(b.tobytes(), "little") for a, b in zip(h_k, h_scalars)) % R_MOD
+    k_ints = [int.from_bytes(a.tobytes(), "little") for a in h_k]
+    tot = sum(k * int.from_bytes(b.tobytes(), "little") for k, b in zip(k_ints, h_scalars)) % R_MOD
+    tot_b = sum(k * int.from_bytes(b.tobytes(), "little") for k, b in zip(k_ints, h_scalars_b)) % R_MOD
     if world > 1:
         parts = [None] * world
-        dist.all_gather_object(parts, tot)
-        tot = sum(parts) % R_MOD
+        dist.all_gather_object(parts, (tot, tot_b))
+        tot = sum(p[0] for p in parts) % R_MOD; tot_b = sum(p[1] for p in parts) % R_MOD
     # N > 1: the pairing metric over all GPUs — independent batches per GPU, index-range partition, no exchange; rank 0's own leg below keeps the details
     pairing_all = None
     if world > 1 and args.pairings > 0:
@@ -400,7 +421,10 @@ def main():
     if rank == 0:
         if pairing_all is not None: result["pairing_all_gpus"] = pairing_all
         want = g1_arr([py_g1_mul(G1_GEN, tot)])          # plain python-integer affine arithmetic: independent of the HIP path and of oracle/
-        result["config"]["full_size_check"] = "ok" if (want == headline_point).all() else "MISMATCH"
+        ok_a = (want == headline_point).all()
+        ok_b = headline_point_b is None or (g1_arr([py_g1_mul(G1_GEN, tot_b)]) == headline_point_b).all()
+        result["config"]["full_size_check"] = "ok" if (ok_a and ok_b) else "MISMATCH"
+        result["config"]["full_size_check_note"] = "the timed loop alternates two scalar sets; the last result of each is compared with (sum k_i s_i mod r) G computed in python integers"
         failed = failed or result["config"]["full_size_check"] != "ok"
 
         # the one-shot host-pointer call at the same size (no resident table: PCIe + table-free plan), so the cost of residency is visible
@@ -428,16 +452,24 @@ def main():
             d_p = d_bases[:m].contiguous()
             d_e = torch.empty((m, 72), dtype=torch.int64, device=dev)
             zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), m, sp))   # warm
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), m, sp))
-            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            tps, kps = [], []
+            for _ in range(5):                         # five timed launches, the median is the figure
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), m, sp))
+                torch.cuda.synchronize(); tps.append(time.perf_counter() - t0); kps.append(L.zkt_last_kernel_ms())
+            dt = sorted(tps)[2]; k_tate_ms = sorted(kps)[2]
             # latency of ONE pairing: batches this small take the lane-distributed kernel (csrc/zkt_dpairing.hip, one pairing per 12 lanes)
             zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), 1, sp)); torch.cuda.synchronize()
             t0 = time.perf_counter(); zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), 1, sp)); torch.cuda.synchronize(); lat1 = time.perf_counter() - t0
             zk.check(L.zkt_tate_batch_dev(vp(d_p), vp(d_q), vp(d_e), m, sp)); torch.cuda.synchronize()          # restore the full batch for the CPU comparison below
             pt = load_profile(PROFILE_ROUND + "_tate_sq_counters.json") or load_profile("r02_tate_sq_counters.json") or load_profile("r01_tate_sq_counters.json") or {}
             pinstr = pt.get("valu_instr_per_pairing") or pt.get("valu_instructions_per_pairing") or (pt.get("kernels", {}).get("k_tate", {}).get("valu_instr_per_wave"))
-            result["pairing"] = {"metric": "Tate pairings/sec", "value": m / dt, "batch": m, "kernel_ms": L.zkt_last_kernel_ms(),
+            tmem = load_profile(PROFILE_ROUND + "_tate_memory_counters.json") or load_profile("r03_tate_memory_counters.json") or {}
+            result["pairing"] = {"metric": "Tate pairings/sec", "value": m / dt, "batch": m, "kernel_ms": k_tate_ms, "launches_timed": 5, "ms_all": [round(t * 1e3, 3) for t in tps],
+                                 "roofline": {"bound": "hbm", "kernel": "k_tate", "achieved": PAIRING_BYTES * m / (k_tate_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": PAIRING_BYTES * m / (k_tate_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": PAIRING_BYTES * m,
+                                              "traffic": (lambda kt: (kt.get("FETCH_SIZE_KB_avg_per_launch", 0) + kt.get("WRITE_SIZE_KB_avg_per_launch", 0)) * 1024 if kt else None)((tmem.get("kernels", {}) or {}).get("k_tate")) if m == 1 << 16 else None, "traffic_counters_stale": stale(tmem) if tmem else None,
+                                              "note": "integer-VALU bound (pairing.valu); the traffic is the per-lane scratch frame of the Fq12 temporaries, not algorithmic bytes"},
                                  "hbm_achieved_GBs": PAIRING_BYTES * m / dt / 1e9, "hbm_frac": PAIRING_BYTES * m / dt / 1e9 / HBM_PEAK_GBS,
                                  "single_pairing_latency_ms": round(lat1 * 1e3, 3),
                                  "small_batch_note": "n <= 24,576 runs one pairing per 12 lanes (lane-distributed kernel): ~5 ms for 1..2048 pairings; larger batches one pairing per lane"}
@@ -445,6 +477,46 @@ def main():
                 peak = sq["valu_peak"]["int_mad_lane_ops_per_s_T"]
                 result["pairing"]["valu"] = {"achieved": pinstr * m / dt / 1e12, "peak": peak, "unit": "T lane-instr/s", "frac": pinstr * m / dt / 1e12 / peak,
                                              "source": "SQ_INSTS_VALU / SQ_WAVES of the pairing kernel (committed rocprofv3 --pmc summary)"}
+
+        # The B sum of a Groth16 proof (eval_with_g2_hidings, polynomial.rs:283-293): a resident G2 MSM at the proof's size — the largest slice of a proof.
+        # Pipelined like the headline; checked at full size by linearity in python integers; VALU / traffic from the committed counter passes.
+        if world == 1 and args.g2_log2n > 0:
+            try:
+                from zkt_testlib import G2_GEN, py_g2_mul, g2_arr, to_abi_g2
+                gn2 = 1 << args.g2_log2n
+                g2g = np.zeros((1, 25), dtype=np.uint64)
+                (x1, x0), (y1, y0) = G2_GEN
+                g2g[0, 0:6] = int_to_limbs(x1, 6); g2g[0, 6:12] = int_to_limbs(x0, 6); g2g[0, 12:18] = int_to_limbs(y1, 6); g2g[0, 18:24] = int_to_limbs(y0, 6)
+                hk2 = rand_scalars_mod_r(31, gn2); hs2 = rand_scalars_mod_r(32, gn2)
+                t_gen = torch.from_numpy(np.repeat(g2g, gn2, axis=0).view(np.int64)).to(dev); t_k = torch.from_numpy(hk2.view(np.int64)).to(dev)
+                t_b = torch.empty((gn2, 25), dtype=torch.int64, device=dev)
+                zk.check(L.zkt_g2_mul_batch_dev(vp(t_gen), vp(t_k), 4, vp(t_b), gn2, sp)); torch.cuda.synchronize(); del t_gen
+                h2 = ctypes.c_void_p(); t0 = time.perf_counter(); zk.check(L.zkt_g2_bases_from_device(vp(t_b), gn2, sp, ctypes.byref(h2))); t_setup2 = time.perf_counter() - t0
+                t_s = torch.from_numpy(hs2.view(np.int64)).to(dev)
+                o2 = np.zeros((1, 25), np.uint64); o2p = o2.ctypes.data_as(ctypes.c_void_p)
+
+                def run2(k, depth=3):
+                    for i in range(k + depth):
+                        if i >= depth: zk.check(L.zkt_g2_msm_collect(h2, (i - depth) % NSLOT, o2p, None))
+                        if i < k: zk.check(L.zkt_g2_msm_submit(h2, vp(t_s), gn2, sp, i % NSLOT))
+                run2(2); torch.cuda.synchronize()
+                t0 = time.perf_counter(); run2(8); torch.cuda.synchronize(); dt2 = (time.perf_counter() - t0) / 8
+                zk.check(L.zkt_g2_msm_dev(h2, vp(t_s), gn2, sp, o2p, None)); torch.cuda.synchronize()
+                t0 = time.perf_counter(); zk.check(L.zkt_g2_msm_dev(h2, vp(t_s), gn2, sp, o2p, None)); lat2 = time.perf_counter() - t0
+                tot2 = sum(int.from_bytes(a.tobytes(), "little") * int.from_bytes(b.tobytes(), "little") for a, b in zip(hk2, hs2)) % R_MOD
+                ok2 = bool((o2 == g2_arr([to_abi_g2(py_g2_mul(((x0, x1), (y0, y1)), tot2))])).all())
+                L.zkt_g2_bases_free(h2); del t_b, t_s, t_k
+                g2sq = load_profile(PROFILE_ROUND + "_g2_msm_sq_counters.json") or {}
+                g2blk = {"metric": "G2 MSM scalar-muls/sec at 2^%d bases (resident, pipelined)" % args.g2_log2n, "value": gn2 / dt2, "ms_per_msm": dt2 * 1e3, "single_msm_latency_ms": round(lat2 * 1e3, 3),
+                         "bases_setup_s": round(t_setup2, 3), "full_size_check": "ok" if ok2 else "MISMATCH",
+                         "plan": "sort -> XYZZ accumulate on lane pairs (k_accumulate_g2_pair) -> four-lane reduce; affine pair-tree rounds: %s (ZKT_G2_AFFINE_ROUNDS, off by default: profiles/r04_batched_affine_go_no_go.md)" % os.environ.get("ZKT_G2_AFFINE_ROUNDS", "0"),
+                         "roofline": {"bound": "hbm", "achieved": 224 * gn2 / dt2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 224 * gn2 / dt2 / 1e9 / HBM_PEAK_GBS,
+                                      "algorithmic_bytes_per_msm": 224 * gn2, "note": "192 B base + 32 B scalar per term over the whole pipelined step (sort, accumulate and reduce kernels of consecutive MSMs overlap); integer-VALU bound",
+                                      "counters": g2sq.get("summary"), "counters_stale": stale(g2sq) if g2sq else None}}
+                result["g2_msm"] = g2blk
+                failed = failed or not ok2
+            except Exception as e:
+                result["g2_msm"] = {"error": repr(e)}
 
         # BASELINE config 5: Bulletproofs range proof over 65,536 bits (64 bits x 1024 values) and its inner-product argument, generators resident
         if world == 1 and args.bulletproofs:

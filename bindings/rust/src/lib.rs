@@ -28,6 +28,7 @@ pub mod bulletproofs;
 pub mod signature;
 pub mod pinocchio;
 pub mod comm;
+pub mod reference_paths;
 
 pub use field::{Fq1, Fr, SecpFq, SecpFr, PrimeField, PrimeFieldElem, PrimeFieldElems, SparseVec};
 pub use tower::{Fq2, Fq6, Fq12};
@@ -36,6 +37,9 @@ pub use pairing::{GTPoint, Pairing};
 pub use polynomial::{Polynomial, G1Bases, G2Bases};
 pub use bulletproofs::Bulletproofs;
 pub use signature::{PrivateKey, Signer};
+/// the reference crate's own module paths (`building_block::curves::bls12_381::g1_point::G1Point`, `zk::w_trusted_setup::groth16::zktoolkit_based::prover::Prover`, ...)
+/// and its runtime-order `PrimeField` / `PrimeFieldElem`: reference_paths.rs
+pub use reference_paths::{building_block, zk};
 
 use std::ffi::CStr;
 use std::sync::Once;

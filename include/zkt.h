@@ -230,6 +230,11 @@ int zkt_groth16_prove(const zkt_groth16_crs* crs, const uint64_t* ui, const uint
  * one final exponentiation (the decision is a bool, so this is parity-safe).  stmt_wires: n_proofs x n_stmt.  ok[i] = 1/0. */
 int zkt_groth16_verify_batch(const zkt_groth16_crs* crs, const zkt_g1_affine* A, const zkt_g2_affine* B, const zkt_g1_affine* C,
                              const uint64_t* stmt_wires, size_t n_stmt, size_t n_proofs, uint32_t* ok);
+/* Optional, once per verifying key: build the per-key tables of the verification fast path now (statement points' fixed-base tables, line tables of gamma and delta,
+ * the ate counterpart of alpha_beta: ~20 ms).  Without it the library serves the FIRST small-batch verification against a key with kernels that need nothing of the
+ * key and builds the tables at the second (a one-off verification costs 6 ms, not 26; the second call then takes ~23 ms, later ones ~5 ms); a caller that knows its key
+ * avoids that bump.  Keys are cached by their bytes (last four).  Decisions do not depend on whether this was called. */
+int zkt_groth16_vk_prepare(const zkt_groth16_crs* crs, size_t n_stmt);
 /* returns 1 accept, 0 reject, negative = -status (a pairing argument at infinity panics in the reference) */
 int zkt_groth16_verify(const zkt_groth16_crs* crs, const zkt_g1_affine* A, const zkt_g2_affine* B, const zkt_g1_affine* C,
                        const uint64_t* stmt_wires, size_t n_stmt);
@@ -239,10 +244,15 @@ int zkt_groth16_verify(const zkt_groth16_crs* crs, const zkt_g1_affine* A, const
  * negates slot j's G1 point (e(-P,Q) = e(P,Q)^-1), so e(P1,Q1) == e(P2,Q2) e(P3,Q3) is k = 3, negate = {0,1,1}.  The k Miller
  * loops share one squaring chain and one final exponentiation (the decision is a bool, so this is parity-safe).  ok[i] = 1/0;
  * ZKT_ERR_INFINITY (+index) if an argument is the point at infinity (the reference's tate() panics).
- * Precondition shared by every verification entry point (this one, zkt_groth16_verify*, zkt_bls_verify_batch, zkt_pinocchio_verify): the
- * rewriting of lhs == rhs as a product == 1 uses e(-P,Q) = e(P,Q)^-1, which holds for P of order r.  A G1 argument with r P != infinity is
- * detected and the element FAILS (ok = 0) instead of being evaluated as the reference would ("Deviations"). */
+ * Shared by every verification entry point (this one, zkt_groth16_verify*, zkt_bls_verify_batch, zkt_pinocchio_verify): the rewriting of
+ * lhs == rhs as a product == 1 uses e(-P,Q) = e(P,Q)^-1, which holds for P of order r on the curve.  An element with a G1 argument outside the
+ * order-r subgroup, or with a point off its curve, is detected and evaluated the reference's way instead: every pairing of both sides through the
+ * reference's own Miller chain and the exact final exponentiation, slots with negate = 0 on the left, the others (un-negated) on the right, Fq12
+ * equality (verifier.rs:36-53, signature.rs:34-39) — the reference's accept / reject, or ZKT_ERR_INFINITY (+index) where its tate() panics. */
 int zkt_pairing_product_check_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, const uint8_t* negate, size_t k, size_t n, uint32_t* ok);
+/* on != 0: such elements are REJECTED (ok = 0) without the reference's evaluation — the behaviour of earlier versions of this library, for hosts that
+ * treat a point outside its group as an attack and do not want to spend ~0.1 s of one lane on it.  Process-wide; also ZKT_VERIFY_FAIL_CLOSED=1. */
+void zkt_verify_set_fail_closed(int on);
 /* f-4: BLS signatures, Signer signature.rs:8-40.  Messages are n byte strings, concatenated, offsets[n+1].
  * G2Point::hash_to_g2point g2_point.rs:84-88 (the bytes as a big-endian integer, reduced mod r, times the G2 generator);
  * sign = hash * sk (signature.rs:28-31, computed as generator * (h * sk mod r): the same group element; sk = 4-limb PrivateKey.value, private_key.rs:10-27; gen_public_key is
@@ -414,7 +424,9 @@ void zkt_groth16_pk_free(zkt_groth16_pk* pk);
  * and a local combine on every rank — an elliptic-curve sum is not an RCCL reduction op.  Every rank returns the same affine result.
  * Transport: RCCL over xGMI (zkt_comm_unique_id on rank 0, the id shipped by the host like ncclGetUniqueId's, zkt_comm_init on every
  * rank after zkt_init), or a host callback for hosts that bring their own exchange (MPI, gloo, tests): fn all-gathers bytes_per_rank
- * bytes from every rank's `send` into `recv` (rank-major) and returns 0. */
+ * bytes from every rank's `send` into `recv` (rank-major) and returns 0.  The callback runs inside a collective entry point: it may call
+ * zkt_comm_rank / zkt_comm_world (lock-free), but no other collective entry point.  zkt_comm_init with world == 1 needs no RCCL library (the
+ * exchange is then a device-to-device copy; with the library present a one-rank communicator runs the same calls as an 8-rank one). */
 #define ZKT_COMM_ID_BYTES 128
 typedef int (*zkt_allgather_fn)(void* ctx, const void* send, void* recv, size_t bytes_per_rank);
 int zkt_comm_unique_id(uint8_t id[ZKT_COMM_ID_BYTES]);
@@ -443,6 +455,9 @@ int zkt_g1_mul_batch_dev(const zkt_g1_affine* dev_points, const uint64_t* dev_sc
                          zkt_g1_affine* dev_out, size_t n, void* stream);
 int zkt_g2_mul_batch_dev(const zkt_g2_affine* dev_points, const uint64_t* dev_scalars, int scalar_limbs,
                          zkt_g2_affine* dev_out, size_t n, void* stream);
+/* BLOCKING, unlike the other *_dev entry points: the pairings run on the library's one staging stream, ordered behind `stream` by an event, and the call
+ * returns when the result is complete (work queued afterwards on any stream sees it).  Calls are serialised against each other and against the
+ * other staged entry points; the library spends no per-caller-stream scratch on them ("Device-resident use"). */
 int zkt_tate_batch_dev(const zkt_g1_affine* dev_g1, const zkt_g2_affine* dev_g2, uint64_t* dev_out_fq12,
                        size_t n, void* stream);
 int zkt_fq_mul_batch_dev(const uint64_t* dev_a, const uint64_t* dev_b, uint64_t* dev_out, size_t n, void* stream);

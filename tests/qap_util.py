@@ -254,3 +254,61 @@ def pinocchio_instance(Amat, Bmat, Cmat, wit):
 
 def qap_util_pin_ek(): return list(_PIN_EK)
 def qap_util_pin_vk(): return list(_PIN_VK)
+
+
+def groth16_proof_scalars(mats, wires, l, trap, r, s):
+    """The discrete logarithms of a Groth16 proof's (A, B, C) in python integers, O(n + nnz): with the trapdoor known,
+         A = (alpha + a(x) + r delta) G1,   B = (beta + b(x) + s delta) G2,
+         C = ((beta U_wit + alpha V_wit + W_wit + a(x) b(x) - c(x)) / delta + s A + r B - r s delta) G1      (prover.rs:96-147, crs.rs:65-121)
+       where a(x) = sum_j (A w)_j L_j(x) over the Lagrange basis of {1..n} (qap.rs:33-97), U_wit = the same with the witness columns only, and
+       h(x) t(x) = a(x) b(x) - c(x) for a satisfying witness (prover.rs:64-71).  One batch inversion for the n values x - j.
+       mats: three CSR triples (rowptr, col, val[nnz,4] u64); wires: (m+1, 4) u64; trap = [alpha, beta, gamma, delta, x] as 1x4 u64 arrays.
+       Independent of the HIP path AND of the oracle."""
+    from zkt_testlib import R
+    to_int = lambda a: [int.from_bytes(np.ascontiguousarray(row).tobytes(), "little") for row in np.asarray(a).reshape(-1, 4)]
+    alpha, beta, gamma, delta, x = (to_int(t)[0] for t in trap)
+    r, s = to_int(r)[0], to_int(s)[0]
+    w = to_int(wires)
+    n = len(mats[0][0]) - 1
+    # L_j(x) = t(x) / ((x - j) t'(j)),  t'(j) = (-1)^(n-j) (j-1)! (n-j)!
+    fact = [1] * (n + 1)
+    for k in range(1, n + 1): fact[k] = fact[k - 1] * k % R
+    d = [(x - j) % R for j in range(1, n + 1)]
+    pre = [1] * (n + 1)
+    for j in range(n): pre[j + 1] = pre[j] * d[j] % R
+    tx = pre[n]
+    assert tx != 0, "x lies in the domain"
+    inv_run = pow(pre[n] * 1, -1, R)
+    dinv = [0] * n
+    for j in range(n - 1, -1, -1):
+        dinv[j] = inv_run * pre[j] % R
+        inv_run = inv_run * d[j] % R
+    # 1 / ((j-1)! (n-j)!) by one more batch inversion
+    den = [fact[j - 1] * fact[n - j] % R for j in range(1, n + 1)]
+    pre2 = [1] * (n + 1)
+    for j in range(n): pre2[j + 1] = pre2[j] * den[j] % R
+    inv_run = pow(pre2[n], -1, R)
+    Lx = [0] * n
+    for j in range(n - 1, -1, -1):
+        di = inv_run * pre2[j] % R
+        inv_run = inv_run * den[j] % R
+        v = tx * dinv[j] % R * di % R
+        Lx[j] = v if (n - (j + 1)) % 2 == 0 else (R - v) % R
+    def evals(M):
+        rowptr, col, val = M
+        rp = [int(v) for v in rowptr]; cl = [int(c) for c in col]; vl = to_int(val)
+        full = wit = 0
+        for j in range(n):
+            fj = wj = 0
+            for k in range(rp[j], rp[j + 1]):
+                t = vl[k] * w[cl[k]]
+                fj += t
+                if cl[k] > l: wj += t
+            full += fj % R * Lx[j]; wit += wj % R * Lx[j]
+        return full % R, wit % R
+    (a, U), (b, V), (c, W) = evals(mats[0]), evals(mats[1]), evals(mats[2])
+    As = (alpha + a + r * delta) % R
+    Bs = (beta + b + s * delta) % R
+    dinv_ = pow(delta, -1, R)
+    Cs = ((beta * U + alpha * V + W + a * b - c) * dinv_ + s * As + r * Bs - r * s * delta) % R
+    return As, Bs, Cs

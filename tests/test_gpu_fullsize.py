@@ -10,7 +10,7 @@ import ctypes, importlib, time
 import numpy as np
 import pytest
 from zkt_testlib import *
-from qap_util import chain_circuit_sparse, sparse_struct, alloc_crs
+from qap_util import chain_circuit_sparse, sparse_struct, alloc_crs, groth16_proof_scalars
 
 pytestmark = pytest.mark.gpu
 zk = importlib.import_module("zk-toolkit_amd")
@@ -197,6 +197,13 @@ def test_config4_groth16_2p20(L):
     zk.check(L.zkt_groth16_setup_r1cs(n, l, m, *[ctypes.addressof(x) for x in structs], *[t.ctypes.data for t in trap], ctypes.addressof(vk), ctypes.addressof(pk)))
     A, B, C = np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64)
     zk.check(L.zkt_groth16_prove_r1cs(pk, wires.ctypes.data, r.ctypes.data, s.ctypes.data, A.ctypes.data, B.ctypes.data, C.ctypes.data))
+    # the proof POINTS at full size, bit for bit: their discrete logarithms from the injected trapdoor in O(n) python-integer arithmetic, times the generators in
+    # python integers (qap_util.groth16_proof_scalars; neither the HIP path nor the oracle on the checking side)
+    As, Bs, Cs = groth16_proof_scalars(mats, wires, l, trap, r, s)
+    (gx1, gx0), (gy1, gy0) = G2_GEN
+    assert (A == g1_arr([py_g1_mul(G1_GEN, As)])).all(), "A at 2^20 constraints"
+    assert (B == g2_arr([to_abi_g2(py_g2_mul(((gx0, gx1), (gy0, gy1)), Bs))])).all(), "B at 2^20 constraints"
+    assert (C == g1_arr([py_g1_mul(G1_GEN, Cs)])).all(), "C at 2^20 constraints"
     # the device-resident and the pipelined entry points give the same proof
     d_w = torch.from_numpy(wires.view(np.int64)).cuda()
     A2, B2, C2 = np.zeros_like(A), np.zeros_like(B), np.zeros_like(C)

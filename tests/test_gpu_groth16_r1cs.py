@@ -55,6 +55,30 @@ def test_r1cs_path_matches_reference_algorithm(L, case):
     L.zkt_groth16_pk_free(pk)
 
 
+def test_one_constraint_key_proves_again_after_device_memory_was_freed(L):
+    """A one-constraint key has an EMPTY quotient base set (n - 1 = 0 terms): its zero-term MSM is captured as a graph like any other, and that graph must hold kernel
+    nodes only — a runtime-owned memset node faults on the first replay after any later hipFree (graph replay).  The counters of a zero-term sort are cleared by
+    k_zero_words whatever their alignment (zkt_msm.hip zero_async; round-3 advisor finding): prove, free device memory elsewhere in the process, prove again — same proof."""
+    import torch
+    A, B, C, wit, l = chain_circuit(1)
+    n, m = len(A), len(wit) - 1
+    rng = SplitMix64(4243)
+    trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+    r, s = fr(rng.below(R - 1) + 1), fr(rng.below(R - 1) + 1)
+    wires = ints_to_arr(wit, 4)
+    vk, vbuf, pk = _r1cs_setup(L, (A, B, C), n, l, m, trap)
+    proofs = []
+    for rep in range(4):
+        gp = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+        zk.check(L.zkt_groth16_prove_r1cs(pk, wires.ctypes.data, r.ctypes.data, s.ctypes.data, *[x.ctypes.data for x in gp]))
+        proofs.append(gp)
+        junk = torch.empty(1 << 24, dtype=torch.int64, device="cuda"); junk.fill_(rep); torch.cuda.synchronize(); del junk; torch.cuda.empty_cache()      # a hipFree between replays
+    for gp in proofs[1:]:
+        assert all((a == b).all() for a, b in zip(proofs[0], gp))
+    assert L.zkt_groth16_verify(ctypes.byref(vk), ptr(proofs[0][0]), ptr(proofs[0][1]), ptr(proofs[0][2]), ptr(ints_to_arr(wit[:l + 1], 4)), l + 1) == 1
+    L.zkt_groth16_pk_free(pk)
+
+
 @pytest.mark.parametrize("n", [1000, 5000])
 def test_r1cs_path_larger_sizes_verify(L, n):
     """beyond the sizes the quadratic oracle can follow: the proof must verify (verifier.rs:30-54), and must stop
@@ -74,6 +98,31 @@ def test_r1cs_path_larger_sizes_verify(L, n):
     zk.check(L.zkt_groth16_prove_r1cs(pk, w2.ctypes.data, r.ctypes.data, s.ctypes.data, *[x.ctypes.data for x in gp]))
     assert L.zkt_groth16_verify(ctypes.byref(vk), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(stmt), l + 1) == 0
     L.zkt_groth16_pk_free(pk)
+
+
+def _g2_gen_c0c1():
+    (x1, x0), (y1, y0) = G2_GEN
+    return ((x0, x1), (y0, y1))
+
+
+@pytest.mark.parametrize("n", [1000, 1 << 16])
+def test_r1cs_proof_points_equal_python_integer_multiples(L, n):
+    """Beyond the oracle's reach (its dense prover is O(m n)) the proof POINTS are still checkable: with the trapdoor injected the discrete logarithms of
+    A, B, C are O(n) python-integer arithmetic (qap_util.groth16_proof_scalars, checked against the coefficient-form prover on the CPU by
+    tests/test_r1cs_domain_math.py), and the points are those multiples of the generators in python integers — no HIP code and no oracle code on the
+    checking side (prover.rs:96-147, crs.rs:49-146)."""
+    mats, wires, l, m = chain_circuit_sparse(n, seed=23)
+    rng = SplitMix64(4321 + n)
+    trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+    r, s = fr(rng.below(R - 1) + 1), fr(rng.below(R - 1) + 1)
+    vk, vbuf, pk = _r1cs_setup(L, mats, n, l, m, trap)
+    gp = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+    zk.check(L.zkt_groth16_prove_r1cs(pk, wires.ctypes.data, r.ctypes.data, s.ctypes.data, *[x.ctypes.data for x in gp]))
+    L.zkt_groth16_pk_free(pk)
+    As, Bs, Cs = groth16_proof_scalars(mats, wires, l, trap, r, s)
+    assert (gp[0] == g1_arr([py_g1_mul(G1_GEN, As)])).all(), "A"
+    assert (gp[1] == g2_arr([to_abi_g2(py_g2_mul(_g2_gen_c0c1(), Bs))])).all(), "B"
+    assert (gp[2] == g1_arr([py_g1_mul(G1_GEN, Cs)])).all(), "C"
 
 
 def test_r1cs_sharded_proof_equals_unsharded(L):

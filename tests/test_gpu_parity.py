@@ -424,16 +424,39 @@ def test_pairing_g1_argument_outside_the_subgroup(L):
     oc, sg = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
     zk.check(L.zkt_g1_is_on_curve_batch(ptr(P), oc.ctypes.data, n)); zk.check(L.zkt_g1_in_subgroup_batch(ptr(P), sg.ctypes.data, n))
     assert oc.all() and sg.sum() == n - len(value_cases) and all(sg[3 + 29 * k] == 0 for k in range(len(value_cases)))
-    # the verification kernels fail closed on them: e(P,Q) e(-P,Q) == 1 is only reported for P of order r
+    # The deciding entry points evaluate such elements the reference's way — lhs = tate(P0, Q0), rhs = tate(P1, Q1), Fq12 equality (signature.rs:34-39) — where the
+    # product form "tate(P0,Q0) tate(-P1,Q1) == 1" is only valid for points of order r.  Element i compares (P_i, Q_i) with (P_i, Q_i) when i is even (equal sides: accept,
+    # for ANY point the reference gives a value on) and with (P_{i+1}, Q_{i+1}) when i is odd (different pairs: reject), so the degenerate points (odd positions 3 + 29 k,
+    # and their even neighbours' partners) meet both outcomes; the oracle's GT values decide what is expected.
+    g1s, g2s = np.zeros((2 * n, G1W), np.uint64), np.zeros((2 * n, G2W), np.uint64)
+    for i in range(n):
+        j = i if i % 2 == 0 else (i + 1) % n
+        g1s[2 * i], g2s[2 * i], g1s[2 * i + 1], g2s[2 * i + 1] = P[i], Qs[i], P[j], Qs[j]
+    expect = [int((want[i] == want[i if i % 2 == 0 else (i + 1) % n]).all()) for i in range(n)]
+    # a degenerate point on the RIGHT side too: element 4 compares (P_4, Q_4) with (P_3, Q_3) — P_3 is outside G1
+    g1s[2 * 4 + 1], g2s[2 * 4 + 1] = P[3], Qs[3]; expect[4] = int((want[4] == want[3]).all())
     ok = np.zeros(n, np.uint32)
+    zk.check(L.zkt_pairing_product_check_batch(ptr(g1s), ptr(g2s), (ctypes.c_uint8 * 2)(0, 1), 2, n, ok.ctypes.data))
+    assert [int(v) for v in ok] == expect and sum(expect) == n // 2 - 1      # every even element but the fourth
+    # ... and the same elements with the left pair repeated on the right: equal sides, accepted whatever the order of P
     zk.check(L.zkt_pairing_product_check_batch(ptr(np.repeat(P, 2, axis=0)), ptr(np.repeat(Qs, 2, axis=0)), (ctypes.c_uint8 * 2)(0, 1), 2, n, ok.ctypes.data))
-    assert [int(v) for v in ok] == [int(v) for v in sg]
+    assert ok.all()
+    # fail-closed mode (the behaviour of earlier versions, kept behind an explicit switch): an element with a G1 argument outside the subgroup is rejected outright
+    L.zkt_verify_set_fail_closed(1)
+    try:
+        zk.check(L.zkt_pairing_product_check_batch(ptr(np.repeat(P, 2, axis=0)), ptr(np.repeat(Qs, 2, axis=0)), (ctypes.c_uint8 * 2)(0, 1), 2, n, ok.ctypes.data))
+        assert [int(v) for v in ok] == [int(v) for v in sg]
+    finally:
+        L.zkt_verify_set_fail_closed(0)
     # (2) points on which the reference panics: ZKT_ERR_INFINITY with the index of the first such element
     for k, pt in enumerate(panic_cases): P[40 + 7 * k] = g1_arr([pt])[0]
     assert L.zkt_tate_batch(ptr(P), ptr(Qs), ptr(got), n) == ZKT_ERR_INFINITY and L.zkt_last_error_index() == 40
     idx = ctypes.c_size_t(0)
     assert O.zkto_pairing_batch(3, ptr(P), ptr(Qs), ptr(want), n, 1, ctypes.byref(idx)) == ZKT_ERR_INFINITY and idx.value == 40
     assert L.zkt_miller_g1g2_batch(ptr(P), ptr(Qs), ptr(graw), n) == ZKT_ERR_INFINITY and L.zkt_last_error_index() == 40
+    # the deciding entry points report the reference's panic the same way (first such element)
+    assert L.zkt_pairing_product_check_batch(ptr(np.repeat(P, 2, axis=0)), ptr(np.repeat(Qs, 2, axis=0)), (ctypes.c_uint8 * 2)(0, 1), 2, n, ok.ctypes.data) == ZKT_ERR_INFINITY
+    assert L.zkt_last_error_index() == 40
 
 
 def test_generators_and_curve_predicates(L):
@@ -534,7 +557,8 @@ def test_pairing_g2_argument_outside_the_subgroup(L):
     # the fused product check takes the same routes: e(P,Q) e(-P,Q) == 1 holds for P in G1 and ANY Q on the twist (255-step kernel behind the 127-step one)
     ok = np.zeros(n, np.uint32)
     zk.check(L.zkt_pairing_product_check_batch(ptr(np.repeat(P, 2, axis=0)), ptr(np.repeat(Qs, 2, axis=0)), (ctypes.c_uint8 * 2)(0, 1), 2, n, ok.ctypes.data))
-    assert all(int(ok[i]) == 1 for i in range(n) if i not in (11, 50)) and (not off_p_has_value or int(ok[50]) == 0)
+    # (element 50, P off its curve: both sides are the same pair, and the reference's own evaluation — which such an element now gets — finds them equal; round 3 failed it closed)
+    assert all(int(ok[i]) == 1 for i in range(n) if i not in (11, 50)) and (not off_p_has_value or int(ok[50]) == 1)
 
 
 @pytest.mark.parametrize("pre,mod,w", [("fq", Q, 6), ("fr", R, 4), ("sp", SECP_P, 4), ("sn", SECP_N, 4)])

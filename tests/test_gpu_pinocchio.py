@@ -119,6 +119,25 @@ def test_pinocchio_verify_points_outside_g2(L):
     assert both() == (1, 1)
 
 
+def test_pinocchio_verify_g1_points_outside_the_subgroup(L):
+    """A proof carrying a G1 element on the curve outside the order-r subgroup: the reference pairs it all the same (a value that depends on the point's order) or panics
+    inside tate (rational_function.rs:36); verifier.rs:43-84 then accepts, rejects or unwinds accordingly.  The engine must reach the same outcome — such elements leave
+    the product form and are evaluated side by side through the reference's chain (zkt_pairing.hip, k_product_exact_marked)."""
+    crs, cbuf, pf, pbuf, io = _instance(L, 5, 778)
+    both = lambda: (O.zkto_pinocchio_verify(ctypes.byref(crs), ctypes.byref(pf), ptr(io)), L.zkt_pinocchio_verify(ctypes.byref(crs), ctypes.byref(pf), ptr(io)))
+    assert both() == (1, 1)
+    seen = set()
+    for field in ("alpha_v_mid_s", "y_mid_s", "beta_vwy_mid_s"):
+        keep = pbuf[field].copy()
+        for label, pt in degenerate_g1_points():
+            pbuf[field][:] = g1_arr([pt])
+            o, g = both()
+            assert (o, g) in ((0, 0), (1, 1)) or (o < 0 and g < 0), (field, label, o, g)
+            seen.add(o if o >= 0 else -1)
+        pbuf[field][:] = keep
+    assert both() == (1, 1) and 0 in seen
+
+
 @pytest.mark.parametrize("case", ["cubic", "chain9"])
 def test_pinocchio_resident_prover_equals_one_shot(L, case):
     """zkt_pinocchio_prove_resident (evaluation key in HBM, wires uploaded once, ten pipelined MSMs) gives the nine proof points of zkt_pinocchio_prove, which the

@@ -196,7 +196,6 @@ def test_groth16_verify_batch_mixed(L):              # f-2: fused 3-pairing veri
         assert O.zkto_groth16_verify(ctypes.byref(crs), ptr(As[i:i + 1].copy()), ptr(Bs[i:i + 1].copy()), ptr(Cs[i:i + 1].copy()), ptr(stmts[i:i + 1].copy()), l + 1) == int(ok[i])
     # The large-batch kernel decides on the 63-step loop and compares with the ate counterpart of alpha_beta, which it may do only for a key whose alpha_beta IS
     # tate(alpha, beta): the reference compares against the stored GTPoint (verifier.rs:48).  A key carrying another GT element keeps the value-comparing kernels.
-    # And a proof whose A or C lies on the curve outside G1 is left to the older kernels, which fail closed (INTEGRATION.md "Deviations").
     keep = buf["gt_alpha_beta"].copy()
     g1g = np.zeros((1, G1W), np.uint64); O.zkto_g1_generator(ptr(g1g)); g2g = np.zeros((1, G2W), np.uint64); O.zkto_g2_generator(ptr(g2g))
     zk.check(L.zkt_tate_batch(ptr(g1g), ptr(g2g), ptr(buf["gt_alpha_beta"]), 1))
@@ -204,10 +203,28 @@ def test_groth16_verify_batch_mixed(L):              # f-2: fused 3-pairing veri
     want = [O.zkto_groth16_verify(ctypes.byref(crs), ptr(As[i:i + 1].copy()), ptr(Bs[i:i + 1].copy()), ptr(Cs[i:i + 1].copy()), ptr(stmts[i:i + 1].copy()), l + 1) for i in range(k)]
     assert ok.tolist() == want == [0] * k
     buf["gt_alpha_beta"][:] = keep
-    A5 = As[5].copy(); As[5] = g1_arr([degenerate_g1_points()[0][1]])[0]
-    zk.check(L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(stmts), l + 1, k, ok.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
-    assert ok.tolist() == [1, 1, 0, 1, 0, 0]
-    As[5] = A5
+    # A (then C) on the curve outside G1: the reference evaluates tate(A, B) and the right side and compares, or panics inside tate (verifier.rs:36-53,
+    # rational_function.rs:36) — the engine must give that accept / reject / panic, element by element; the oracle's three-tate verifier is the checker.
+    for which, arr in (("A", As), ("C", Cs)):
+        for label, pt in degenerate_g1_points():
+            keep5 = arr[5].copy(); arr[5] = g1_arr([pt])[0]
+            want5 = O.zkto_groth16_verify(ctypes.byref(crs), ptr(As[5:6].copy()), ptr(Bs[5:6].copy()), ptr(Cs[5:6].copy()), ptr(stmts[5:6].copy()), l + 1)
+            rc = L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(stmts), l + 1, k, ok.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+            idx = L.zkt_last_error_index()
+            one = L.zkt_groth16_verify(ctypes.byref(crs), ptr(As[5:6].copy()), ptr(Bs[5:6].copy()), ptr(Cs[5:6].copy()), ptr(stmts[5:6].copy()), l + 1)
+            if want5 < 0:
+                assert rc == ZKT_ERR_INFINITY and idx == 5 and one == -ZKT_ERR_INFINITY, (which, label)
+            else:
+                assert rc == ZKT_OK and ok.tolist() == [1, 1, 0, 1, 0, want5] and one == want5, (which, label)
+            arr[5] = keep5
+    L.zkt_verify_set_fail_closed(1)                  # the explicit switch back to round 3's behaviour: such a proof is rejected without the reference's evaluation
+    try:
+        A5 = As[5].copy(); As[5] = g1_arr([degenerate_g1_points()[0][1]])[0]
+        zk.check(L.zkt_groth16_verify_batch(ctypes.byref(crs), ptr(As), ptr(Bs), ptr(Cs), ptr(stmts), l + 1, k, ok.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+        assert ok.tolist() == [1, 1, 0, 1, 0, 0]
+        As[5] = A5
+    finally:
+        L.zkt_verify_set_fail_closed(0)
     # G2 arguments outside the subgroup: the fast kernels need B, gamma, delta in G2 (127-step loop) and redo such proofs on the 255-step kernels —
     # a proof whose B is a twist point outside G2, then a verifying key whose gamma is one: verdicts as the oracle's three-tate verifier gives them
     rng2 = SplitMix64(72)

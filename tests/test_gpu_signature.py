@@ -91,6 +91,18 @@ def test_verify_batch_matches_reference_decision(L):
     sig_inf = sig.copy(); sig_inf[3] = 0; sig_inf[3, 24] = 1
     rc = L.zkt_bls_verify_batch(buf.ctypes.data, off.ctypes.data, ptr(sig_inf), ptr(pks), n, ok.ctypes.data)
     assert rc == ZKT_ERR_INFINITY and L.zkt_last_error_index() == 3
+    # a public key on the curve OUTSIDE G1: Signer::verify evaluates tate(pk, H) whatever pk is — a value that depends on pk's order, or a panic when a multiple of
+    # pk met by the Miller chain is infinity (rational_function.rs:36).  The engine gives the reference's decision (both sides through the reference's chain), not a
+    # blanket rejection; the oracle's two tate() calls are the checker.
+    rc, lhs0, _ = pair(3, np.repeat(g1, n, axis=0), sig); assert rc == 0
+    for label, pt in degenerate_g1_points():
+        pks_d = pks.copy(); pks_d[5] = g1_arr([pt])[0]
+        rc_o, rhs_d, _ = pair(3, pks_d[5:6].copy(), H[5:6].copy())
+        rc = L.zkt_bls_verify_batch(buf.ctypes.data, off.ctypes.data, ptr(sig), ptr(pks_d), n, ok.ctypes.data)
+        if rc_o != 0:
+            assert rc == ZKT_ERR_INFINITY and L.zkt_last_error_index() == 5, label
+        else:
+            assert rc == ZKT_OK and [bool(v) for v in ok] == [True] * 5 + [bool((lhs0[5] == rhs_d[0]).all())], label
 
 
 @pytest.mark.parametrize("k", [1, 2, 3, 4])

@@ -152,3 +152,42 @@ def test_rust_sources_are_balanced():
                 assert stack and "([{".index(stack[-1]) == ")]}".index(ch), f"{fn}: unbalanced {ch}"
                 stack.pop()
         assert not stack, f"{fn}: unclosed {stack[-3:]}"
+
+
+def test_reference_module_paths_and_runtime_order_field_types():
+    """The reference's call sites import by module path and pass the field as a VALUE (`PrimeField { order }`, prime_field.rs:15-33; elements `{ f: Arc<PrimeField>, e }`,
+    prime_field_elem.rs:57-61).  reference_paths.rs must offer both: the paths as re-exports of the shim's types, and non-generic field types with the reference's
+    constructor signatures that look the order up at run time."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "src", "reference_paths.rs")).read()
+    lib = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+    assert "pub use reference_paths::{building_block, zk};" in lib
+    def has_path(path, item):
+        """`pub mod a { pub mod b { ... pub use ...item` nested in that order"""
+        pos = 0
+        for seg in path.split("::"):
+            pos = src.find("pub mod %s" % seg, pos)
+            assert pos >= 0, f"{path}: module {seg} missing"
+        tail = src[pos:pos + 400]
+        assert re.search(r"pub (use [^;]*\b%s\b|struct %s\b)" % (item, item), tail), f"{path}::{item} not exported"
+    for path, item in [("building_block::curves::bls12_381::g1_point", "G1Point"), ("building_block::curves::bls12_381::g2_point", "G2Point"),
+                       ("building_block::curves::bls12_381::pairing", "Pairing"), ("building_block::curves::bls12_381::gt_point", "GTPoint"),
+                       ("building_block::curves::bls12_381::fq12", "Fq12"), ("building_block::curves::bls12_381::signature", "Signer"),
+                       ("building_block::curves::secp256k1::affine_points", "AffinePoints"), ("building_block::field::prime_field", "PrimeField"),
+                       ("building_block::field::prime_field_elem", "PrimeFieldElem"), ("building_block::field::sparse_vec", "SparseVec"),
+                       ("zk::w_trusted_setup::groth16::zktoolkit_based::prover", "Prover"), ("zk::w_trusted_setup::groth16::zktoolkit_based::verifier", "Verifier"),
+                       ("zk::w_trusted_setup::groth16::zktoolkit_based::crs", "CRS"), ("zk::w_trusted_setup::pinocchio::verifier", "Verifier"),
+                       ("zk::wo_trusted_setup::bulletproofs", "Bulletproofs")]:
+        has_path(path, item)
+    # the reference's own shapes, verbatim
+    assert "pub struct PrimeField { order: BigUint }" in src                                         # prime_field.rs:16-18
+    assert "pub fn new(order: &impl ToBigUint) -> Self" in src                                       # prime_field.rs:21
+    assert "pub struct PrimeFieldElem { pub f: Arc<PrimeField>, pub e: BigUint }" in src             # prime_field_elem.rs:57-61
+    assert "pub fn new(f: &Arc<PrimeField>, e: &impl ToBigUint) -> Self" in src                      # prime_field_elem.rs:263
+    assert "pub fn rand_elem(&self, exclude_zero: bool) -> PrimeFieldElem" in src                    # prime_field.rs:73
+    for needle in ("pub fn plus(&self, rhs: &impl ToBigUint) -> Self", "pub fn safe_inv(&self) -> Result<Self, String>", "pub fn pow_seq(&self, n: usize) -> Vec<Self>"):
+        assert needle in src, needle
+    # every re-exported item exists in the module it is re-exported from
+    for mod, item in re.findall(r"pub use crate::(\w+)::\{?([\w, ]+)\}?;", src):
+        body = open(os.path.join(ROOT, "bindings", "rust", "src", mod + ".rs")).read()
+        for it in [x.strip() for x in item.split(",")]:
+            assert re.search(r"pub (struct|enum|type|trait) %s\b" % it, body), f"{mod}::{it} does not exist"

@@ -45,7 +45,14 @@ def scan(co):
     bp, direct, calls = {}, {}, collections.defaultdict(set)
     for f, ins in funcs.items():
         bp[f] = any(op == "s_mov_b32" and a.replace(" ", "") == "s34,s32" for _, op, a in ins)
-        direct[f] = (not bp[f]) and any(writes_s34(op, a) for _, op, a in ins)
+        # a callee that treats s34 as callee-saved (what the ABI says, and what the compiler emits when the inter-procedural register allocation is off:
+        # -mllvm -enable-ipra=0) parks it in a VGPR lane before its first write and brings it back before it returns: `v_writelane_b32 vN, s34, L` ... `v_readlane_b32 s34, vN, L`
+        saved = None
+        for _, op, a in ins:
+            if op == "v_writelane_b32" and re.match(r"v\d+,\s*s34,", a): saved = a.split(",")[0].strip() + "," + a.split(",")[2].strip(); break
+            if writes_s34(op, a): break
+        restored = saved is not None and any(op == "v_readlane_b32" and a.replace(" ", "") == "s34," + saved for _, op, a in ins)
+        direct[f] = (not bp[f]) and not restored and any(writes_s34(op, a) for _, op, a in ins)
         for i, (addr, op, a) in enumerate(ins):
             if op != "s_getpc_b64" or i + 2 >= len(ins): continue
             m = re.match(r"s\[(\d+):(\d+)\]", a)

@@ -257,6 +257,7 @@ int zkt_init(int device) {
   return ZKT_OK;
 }
 extern "C" void zkt_internal_clear_caches();       // zkt_protocols.hip
+static void tate_events_release();
 void zkt_shutdown(void) {
   if (g.ready) (void)hipSetDevice(g.device);
   zkt_comm_finalize();                                // the communicator and its buffers live on this device
@@ -266,6 +267,7 @@ void zkt_shutdown(void) {
   (void)hipSetDevice(g.device);
   group_release_device_state();                       // generator comb tables
   pairing_release_device_state();                     // guard side stream + events
+  tate_events_release();
   if (g.arena) (void)hipFree(g.arena);
   if (g.d_err) (void)hipFree(g.d_err);
   if (g.d_small) (void)hipFree(g.d_small);
@@ -494,21 +496,34 @@ int zkt_g2_mul_batch_dev(const zkt_g2_affine* p, const uint64_t* k, int limbs, z
 // eight streams of its own would spend 8 x 6 GiB on them.  So the kernel never runs on the caller's stream: it runs on the library's ONE staging stream,
 // ordered behind the caller's stream by an event (the inputs were produced there), and the call returns after the result is complete, so work the caller
 // queues afterwards on ANY stream sees it.  tests/test_gpu_parity.py::test_tate_dev_from_many_caller_streams drives 8 streams through this.
+// Three persistent events of the staging stream (created on first use under g.mu, released with the library's other device state): nothing is created or
+// destroyed per call, and an early return leaks nothing.
+static hipEvent_t g_tate_ev[3] = {nullptr, nullptr, nullptr};
+static int tate_events() {
+  if (g_tate_ev[0]) return ZKT_OK;
+  hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+  if (hipEventCreateWithFlags(&e[0], hipEventDisableTiming) != hipSuccess || hipEventCreate(&e[1]) != hipSuccess || hipEventCreate(&e[2]) != hipSuccess) {
+    for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x);
+    (void)hipGetLastError(); return ZKT_ERR_DEVICE;
+  }
+  for (int i = 0; i < 3; ++i) g_tate_ev[i] = e[i];
+  return ZKT_OK;
+}
+static void tate_events_release() { for (hipEvent_t& x : g_tate_ev) { if (x) (void)hipEventDestroy(x); x = nullptr; } }
+// BLOCKING, unlike the other *_dev entry points (include/zkt.h): the result is complete on return, and calls are serialised on the staging stream.
 int zkt_tate_batch_dev(const zkt_g1_affine* g1, const zkt_g2_affine* g2, uint64_t* out, size_t n, void* stream) {
   if (ensure_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
   std::lock_guard<std::mutex> lk(g.mu);
   hipStream_t s = g.stream;
-  hipEvent_t ein; HIPCHK(hipEventCreateWithFlags(&ein, hipEventDisableTiming));
-  HIPCHK(hipEventRecord(ein, (hipStream_t)stream));
-  HIPCHK(hipStreamWaitEvent(s, ein, 0));
-  int rc = reset_err(s); if (rc) { hipEventDestroy(ein); return rc; }
-  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  HIPCHK(hipEventRecord(e0, s));
+  int rc = tate_events(); if (rc) return rc;
+  HIPCHK(hipEventRecord(g_tate_ev[0], (hipStream_t)stream));
+  HIPCHK(hipStreamWaitEvent(s, g_tate_ev[0], 0));
+  rc = reset_err(s); if (rc) return rc;
+  HIPCHK(hipEventRecord(g_tate_ev[1], s));
   HIPCHK(launch_tate((const uint32_t*)g1, (const uint32_t*)g2, (uint32_t*)out, n, g.d_err, s));
-  HIPCHK(hipEventRecord(e1, s));
+  HIPCHK(hipEventRecord(g_tate_ev[2], s));
   rc = fetch_err(s, ZKT_ERR_INFINITY);                  // synchronises the staging stream: the pairings are done when this returns
-  HIPCHK(hipEventElapsedTime(&t_kernel_ms, e0, e1)); t_kernel_name = "k_tate";
-  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(ein);
+  HIPCHK(hipEventElapsedTime(&t_kernel_ms, g_tate_ev[1], g_tate_ev[2])); t_kernel_name = "k_tate";
   return rc;
 }
 
@@ -641,6 +656,7 @@ static int msm_collect_locked(zkt_bases_impl* h, int slot, void* out, uint32_t* 
   if (out) memcpy(out, S.h_out, grp_pt_bytes(h->grp));
   float ms = 0.f;
   if (S.timed && hipEventElapsedTime(&ms, S.e_acc0, S.e_acc1) == hipSuccess) { t_kernel_ms = ms; t_kernel_name = "k_accumulate"; }
+  else { t_kernel_ms = 0.f; t_kernel_name = "msm_graph"; }      // a graph-replayed MSM carries no per-kernel events: say so instead of leaving the previous operation's figures
   S.busy = false;
   return ZKT_OK;
 }

@@ -637,7 +637,7 @@ __global__ void __launch_bounds__(64) k_dproduct(PairArgs a, const uint32_t* __r
   const unsigned long long neq = __ballot(diff != 0) & lmask;
   if (live && pair == 0 && c.r.g == 0) {
     if (bad_inf) { atomicMin(err, (unsigned long long)e); ok[e] = 0; }
-    else ok[e] = (neq == 0 && bad_g1 == 0) ? 1u : 0u;
+    else ok[e] = bad_g1 ? 3u : (neq == 0 ? 1u : 0u);      // 3 = OK_EXACT (zkt_pairing.hip): a G1 argument outside the order-r subgroup — decided the reference's way behind
   }
 }
 

@@ -36,6 +36,7 @@ hipError_t launch_group_mul(int grp, const uint32_t* pts, const uint32_t* scalar
 // out[k * n + i] = point i of array k lies on E and in G1 (or is the point at infinity); K <= 4 arrays, `stride` in u32 words
 struct G1Fits { const uint32_t* pts[4]; uint32_t stride[4]; };
 hipError_t launch_g1_fits(const G1Fits& f, int K, uint32_t* out, size_t n, hipStream_t s);
+
 hipError_t launch_group_pred(int grp, int pred, const uint32_t* pts, const uint32_t* order, int order_words, uint32_t* out, size_t n, hipStream_t s);
 hipError_t launch_group_sum_inplace(int grp, uint32_t* pts, size_t n, hipStream_t s);
 // several independent batched scalar multiplications in one launch (strides in u32 words, 0 = broadcast one point / one scalar)
@@ -76,6 +77,9 @@ hipError_t launch_ate_key_prep(const uint32_t* alpha, const uint32_t* beta, cons
 size_t stmt_wide_table_words(int n_pts);
 hipError_t launch_stmt_wide_tables(const uint32_t* points, int n_pts, uint32_t* tables, hipStream_t s);
 hipError_t launch_stmt_sums_wide(const uint32_t* tables, const uint32_t* stmt, int n_stmt, uint32_t* out, size_t n, hipStream_t s);
+// elements with a G1 argument outside the order-r subgroup (or a point off its curve): 0 = both sides evaluated the reference's way (default), 1 = rejected
+void verify_set_fail_closed(int on);
+int verify_fail_closed();
 size_t dproduct_limit();      // elements x pairs up to which the verification entry points use the lane-distributed kernels
 // stmt_tables (optional): fixed-base tables of the n_stmt statement points (launch_fixed_tables), which replace the statement's 255-step scalar multiplications
 hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt_tables, const uint32_t* stmt, int n_stmt,
@@ -123,7 +127,17 @@ struct MsmPlan {
   int direct;          // 1 = table-free one-shot form: `table` is the n bases themselves, every window has its own 2^(c-1) buckets
   size_t half;         // buckets per window, 2^(c-1)
   uint32_t chunk;      // most entries one accumulate task (lane) adds: buckets with more are cut into equal pieces (8..128, pick_chunk)
+  int aff_rounds;      // G2, large resident MSMs: pair-tree rounds in affine coordinates ahead of the XYZZ accumulate (zkt_msm_affine.hip); 0 = none
+  size_t aff_off;      // byte offset of their buffers inside the workspace
 };
+// buffers of the affine rounds (zkt_msm_affine.hip): layer r >= 1 = points + infinity bytes at (offsets[b] >> r) + b; cntR / offR describe the last layer
+struct MsmAffineWs { uint32_t *cntR, *offR, *pref; uint32_t* pts[5]; uint8_t* inf[5]; };
+static constexpr int MSM_AFFINE_MAX_ROUNDS = 4;
+size_t msm_affine_ws_bytes(size_t entries, size_t nbuckets, int rounds, int coord_words);
+MsmAffineWs msm_affine_carve(void* base, size_t entries, size_t nbuckets, int rounds, int coord_words);
+hipError_t launch_msm_affine_final_layer(const uint32_t* offsets, size_t nbuckets, int rounds, const MsmAffineWs& w, hipStream_t s);
+hipError_t launch_msm_affine_rounds_g2(const uint32_t* table, const uint32_t* entries, const uint32_t* offsets, size_t nbuckets, size_t entries_bound, int rounds,
+                                       const MsmAffineWs& w, hipStream_t s);
 MsmPlan msm_plan(size_t n, int grp);
 // table-free form for one-shot calls (zkt_*_msm with host pointers): no window-multiple table to build — nwin bucket sets, the per-window
 // sums reduced side by side (grid.y = window) and joined by nwin-1 runs of c doublings
@@ -147,3 +161,6 @@ hipError_t launch_msm_jac_sum_to_affine(int grp, const uint32_t* jac_partials, s
 // G2 bucket accumulation with two lanes per task (zkt_msm_g2pair.hip, a translation unit with its own namespace): global scope
 hipError_t zkt_launch_accumulate_g2_pair(const uint32_t* table, const uint32_t* entries, const uint32_t* offsets, const void* order, const uint32_t* task_off,
                                          size_t nbuckets, uint32_t* sums, uint32_t* partial, size_t max_tasks, hipStream_t s);
+// DIRECT form behind the affine rounds: bucket b = the points pts[off[b] .. off[b] + cnt[b]) of the last layer (inf[slot] != 0: skip), no entry list, no signs
+hipError_t zkt_launch_accumulate_g2_pair_direct(const uint32_t* pts, const uint8_t* inf, const uint32_t* off, const uint32_t* cnt, const void* order, const uint32_t* task_off,
+                                                size_t nbuckets, uint32_t* sums, uint32_t* partial, size_t max_tasks, hipStream_t s);

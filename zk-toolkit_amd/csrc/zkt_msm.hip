@@ -79,7 +79,14 @@ MsmPlan msm_plan(size_t n, int grp) {
   if (c > 20) c = 20;
   p.c = c; p.nwin = (256 + 1 + c - 1) / c; p.nbuckets = size_t(1) << (c - 1);
   size_t ent = (size_t)p.nwin * n;
-  p.chunk = pick_chunk(ent, grp);
+  // G2: pair-tree rounds in affine coordinates ahead of the XYZZ accumulate (zkt_msm_affine.hip).  OFF by default: measured inside the product the rounds LOSE to the
+  // lane-pair XYZZ kernel (2^20-term pipelined G2 MSM 8.06 ms without, 8.75 / 9.05 / 9.59 ms with 1 / 2 / 3 rounds; profiles/r04_batched_affine_go_no_go.md) — kept as a
+  // tested alternative behind ZKT_G2_AFFINE_ROUNDS (1..4) and ZKT_G2_AFFINE_MIN_ENTRIES for A/B measurements on other shapes.
+  static const int aff_rounds_cfg = [] { const char* e = getenv("ZKT_G2_AFFINE_ROUNDS"); int r = e ? atoi(e) : 0; return r < 0 ? 0 : r > MSM_AFFINE_MAX_ROUNDS ? MSM_AFFINE_MAX_ROUNDS : r; }();
+  static const size_t aff_min_cfg = [] { const char* e = getenv("ZKT_G2_AFFINE_MIN_ENTRIES"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t(1) << 22); }();
+  p.aff_rounds = (grp == G_G2 && ent >= aff_min_cfg) ? aff_rounds_cfg : 0;
+  p.aff_off = 0;
+  p.chunk = pick_chunk(ent >> p.aff_rounds, grp);
   size_t b = 0;
   b += (p.nbuckets + 1) * 4 * 3;          // counts, offsets, cursor
   b += 2 * ent * 4 + 256;                  // entries, slots
@@ -90,6 +97,7 @@ MsmPlan msm_plan(size_t n, int grp) {
   b += 64 * 64 * XYW * 4 + 1024;                                  // block sums of hot buckets (k_merge_hot), hot list
   b += part_ws_bytes(n, p.nbuckets, p.nwin);
   b += 4096;
+  if (p.aff_rounds) { b = (b + 255) & ~(size_t)255; p.aff_off = b; b += msm_affine_ws_bytes(ent, p.nbuckets, p.aff_rounds, coord_words(grp)) + 512; }
   p.ws_bytes = b;
   p.direct = 0; p.half = p.nbuckets;
   return p;
@@ -117,6 +125,7 @@ MsmPlan msm_plan_direct(size_t n, int grp) {
   if (c < 9) c = 9;                 // nwin <= 29: k_join_windows folds at most 32 windows in one wave
   if (c > 16) c = 16;
   p.c = c; p.nwin = (256 + 1 + c - 1) / c; p.half = size_t(1) << (c - 1); p.nbuckets = (size_t)p.nwin * p.half; p.direct = 1;
+  p.aff_rounds = 0; p.aff_off = 0;
   size_t ent = (size_t)p.nwin * n;
   p.chunk = pick_chunk(ent, grp);
   size_t b = 0;
@@ -677,17 +686,26 @@ MsmWs carve(const MsmPlan& P, void* workspace) {
 
 // The pipeline clears its counters with a kernel of its own rather than hipMemsetAsync: inside a captured graph (zkt_api.cpp, msm_submit_locked) a memset becomes a
 // runtime-owned node, and the pipeline's launches should be the same objects whether they are issued or replayed.
-static __global__ void __launch_bounds__(256) k_zero_words(uint4* __restrict__ p, size_t quads, uint32_t* __restrict__ tail, int tail_words) {
+static __global__ void __launch_bounds__(256) k_zero_words(uint32_t* __restrict__ p, int head_words, size_t quads, int tail_words) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < quads) p[i] = uint4{0u, 0u, 0u, 0u};
-  if (i < (size_t)tail_words) tail[i] = 0u;
+  if (i < (size_t)head_words) p[i] = 0u;                                              // words before the first 16-byte boundary
+  uint4* q = reinterpret_cast<uint4*>(p + head_words);
+  if (i < quads) q[i] = uint4{0u, 0u, 0u, 0u};
+  if (i < (size_t)tail_words) p[(size_t)head_words + quads * 4 + i] = 0u;
 }
-static hipError_t zero_async(void* ptr, size_t bytes, hipStream_t s) {      // ptr 16-byte aligned (workspace carve), bytes a multiple of 4
+// ptr 4-byte aligned (the carve puts `offsets` at 4 mod 16), bytes a multiple of 4.  Never a hipMemsetAsync: a captured graph must hold kernel nodes only
+// (zkt_api.cpp, msm_submit_locked: a runtime-owned memset node faults on the first replay after any later hipFree), and a zero-term MSM is captured like any other.
+static hipError_t zero_async(void* ptr, size_t bytes, hipStream_t s) {
   if (bytes == 0) return hipSuccess;
-  if (((uintptr_t)ptr & 15u) || (bytes & 3u)) return hipMemsetAsync(ptr, 0, bytes, s);
-  const size_t quads = bytes / 16; const int tail = (int)((bytes % 16) / 4);
-  const size_t items = quads > (size_t)tail ? quads : (size_t)tail;
-  hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (uint4*)ptr, quads, (uint32_t*)ptr + quads * 4, tail);
+  if (((uintptr_t)ptr & 3u) || (bytes & 3u)) return hipErrorInvalidValue;
+  size_t words = bytes / 4;
+  int head = (int)(((16u - ((uintptr_t)ptr & 15u)) & 15u) / 4);
+  if ((size_t)head > words) head = (int)words;
+  words -= (size_t)head;
+  const size_t quads = words / 4; const int tail = (int)(words % 4);
+  size_t items = quads > (size_t)tail ? quads : (size_t)tail;
+  if (items < (size_t)head) items = (size_t)head;
+  hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (uint32_t*)ptr, head, quads, tail);
   return hipGetLastError();
 }
 // stage 1 (atomic/memory bound): signed digits, counting sort by bucket, bucket order by population
@@ -720,15 +738,29 @@ hipError_t PART(launch_msm_sort)(const MsmPlan& P, const uint8_t* inf, const uin
   } else {
     if ((e = zero_async(w.offsets, (B + 1) * 4, s)) != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_task_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, P.chunk, w.ntask, w.size_hist);
+  const uint32_t* task_counts = w.counts;
+  if (P.aff_rounds) {                      // the accumulate kernel sees what the affine rounds leave: ceil(cnt / 2^R) points per bucket
+    const MsmAffineWs aw = msm_affine_carve((uint8_t*)workspace + P.aff_off, (size_t)P.nwin * n, B, P.aff_rounds, coord_words(P.grp));
+    if ((e = launch_msm_affine_final_layer(w.offsets, B, P.aff_rounds, aw, s)) != hipSuccess) return e;
+    task_counts = aw.cntR;
+  }
+  hipLaunchKernelGGL(k_task_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, task_counts, B, P.chunk, w.ntask, w.size_hist);
   launch_scan(w.ntask, w.task_off, B, w.scan_tmp, s);
-  hipLaunchKernelGGL(k_task_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const uint32_t*)w.counts, B, P.chunk, (const uint32_t*)w.size_hist, w.size_cur, w.order, w.hot);
+  hipLaunchKernelGGL(k_task_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, task_counts, B, P.chunk, (const uint32_t*)w.size_hist, w.size_cur, w.order, w.hot);
   return hipGetLastError();
 }
 // stage 2 (VALU bound, the dominant kernel): one bucket per lane
 hipError_t PART(launch_msm_accumulate)(const MsmPlan& P, const uint32_t* table, void* workspace, hipStream_t s) {
   MsmWs w = carve(P, workspace);
 #if defined(ZKT_MSM_PART_OTHER) && !defined(ZKT_G2_ONE_LANE)
+  if (P.grp == G_G2 && P.aff_rounds) {      // affine pair-tree rounds, then the XYZZ accumulate over their last layer (zkt_msm_affine.hip)
+    const size_t ent = (size_t)P.nwin * P.n;
+    const MsmAffineWs aw = msm_affine_carve((uint8_t*)workspace + P.aff_off, ent, P.nbuckets, P.aff_rounds, coord_words(P.grp));
+    hipError_t e = launch_msm_affine_rounds_g2(table, (const uint32_t*)w.entries, (const uint32_t*)w.offsets, P.nbuckets, ent, P.aff_rounds, aw, s);
+    if (e != hipSuccess) return e;
+    return ::zkt_launch_accumulate_g2_pair_direct(aw.pts[P.aff_rounds], aw.inf[P.aff_rounds], aw.offR, aw.cntR, (const void*)w.order, (const uint32_t*)w.task_off, P.nbuckets,
+                                                  w.sums, w.partial, w.max_tasks, s);
+  }
   if (P.grp == G_G2)        // two lanes per task: zkt_msm_g2pair.hip
     return ::zkt_launch_accumulate_g2_pair(table, (const uint32_t*)w.entries, (const uint32_t*)w.offsets, (const void*)w.order, (const uint32_t*)w.task_off, P.nbuckets,
                                            w.sums, w.partial, w.max_tasks, s);

@@ -80,6 +80,36 @@ k_accumulate_g2_pair(const uint32_t* __restrict__ table, const uint32_t* __restr
   st_half(out, acc.X); st_half(out + CW, acc.Y); st_half(out + 2 * CW, acc.ZZ); st_half(out + 3 * CW, acc.ZZZ);
 }
 
+// The same accumulation over the LAST LAYER of the affine rounds (zkt_msm_affine.hip): bucket b holds cnt[b] affine points side by side at off[b] — no entry list, no
+// signs, an infinity byte per slot (P + (-P) met in a round).  Same task list semantics: piece tk.y of nt equal pieces.
+__global__ void __launch_bounds__(64) ZKT_G2PAIR_ATTR
+k_accumulate_g2_pair_direct(const uint32_t* __restrict__ pts, const uint8_t* __restrict__ inf, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ cnts,
+                            const uint2* __restrict__ order, const uint32_t* __restrict__ task_off, size_t nbuckets,
+                            uint32_t* __restrict__ sums, uint32_t* __restrict__ partial) {
+  typedef Fq2Ops F;
+  constexpr int CW = 2 * FqC::N, XYW = 4 * CW;
+  const size_t t = ((size_t)blockIdx.x * 64 + threadIdx.x) >> 1;
+  if (t >= task_off[nbuckets]) return;
+  const uint2 tk = order[t];
+  const size_t b = tk.x;
+  const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
+  const uint32_t off = offs[b], cnt = cnts[b];
+  uint32_t beg = off, end = off + cnt;
+  if (nt != 1) {
+    const uint32_t q = cnt / nt, r = cnt - q * nt;
+    beg = off + tk.y * q + (tk.y < r ? tk.y : r); end = beg + q + (tk.y < r ? 1u : 0u);
+  }
+  Xyzz<F> acc = xyzz_inf<F>();
+  for (uint32_t e = beg; e < end; ++e) {
+    if (inf[e]) continue;                                            // pair-uniform: both lanes of a task read the same byte
+    const uint32_t* p = pts + (size_t)e * (2 * CW);
+    const Fq2 x = ld_half(p), y = ld_half(p + CW);
+    acc = xyzz_add_aff<F>(acc, x, y);
+  }
+  uint32_t* out = nt == 1 ? sums + b * XYW : partial + (size_t)(t0 + tk.y) * XYW;
+  st_half(out, acc.X); st_half(out + CW, acc.Y); st_half(out + 2 * CW, acc.ZZ); st_half(out + 3 * CW, acc.ZZZ);
+}
+
 }  // namespace zkt
 #undef zkt
 
@@ -87,6 +117,13 @@ hipError_t zkt_launch_accumulate_g2_pair(const uint32_t* table, const uint32_t* 
                                          size_t nbuckets, uint32_t* sums, uint32_t* partial, size_t max_tasks, hipStream_t s) {
   if (max_tasks == 0) return hipSuccess;
   hipLaunchKernelGGL(zkt_g2pair::k_accumulate_g2_pair, dim3((unsigned)((2 * max_tasks + 63) / 64)), dim3(64), 0, s, table, entries, offsets, (const uint2*)order, task_off,
+                     nbuckets, sums, partial);
+  return hipGetLastError();
+}
+hipError_t zkt_launch_accumulate_g2_pair_direct(const uint32_t* pts, const uint8_t* inf, const uint32_t* off, const uint32_t* cnt, const void* order, const uint32_t* task_off,
+                                                size_t nbuckets, uint32_t* sums, uint32_t* partial, size_t max_tasks, hipStream_t s) {
+  if (max_tasks == 0) return hipSuccess;
+  hipLaunchKernelGGL(zkt_g2pair::k_accumulate_g2_pair_direct, dim3((unsigned)((2 * max_tasks + 63) / 64)), dim3(64), 0, s, pts, inf, off, cnt, (const uint2*)order, task_off,
                      nbuckets, sums, partial);
   return hipGetLastError();
 }

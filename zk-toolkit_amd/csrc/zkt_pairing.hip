@@ -2,6 +2,7 @@
 // Groth16 verification (f-2) and pairing-product equalities (f-4).  The algorithm and why it is bit-identical to the reference are in pairing.h.
 #include <cstdlib>
 #include <mutex>
+#include <atomic>
 #include "abi.h"
 #include "zkt_internal.h"
 
@@ -112,6 +113,10 @@ hipError_t guard_join(hipStream_t s, hipStream_t side) {
 }
 // ok[i] <- OK_REDO where the guards say the element does not fit the 127-step loop
 static constexpr uint32_t OK_REDO = 2;
+// ok[i] <- OK_EXACT: a G1 argument outside the order-r subgroup, or a point off its curve.  There e(-P,Q) = e(P,Q)^-1 is not available and two addition chains
+// for the same multiple are different functions, so "lhs == rhs as a product == 1" is not the reference's decision by construction: k_product_exact_marked
+// evaluates both sides the reference's way (verifier.rs:36-53, signature.rs:34-39).  Round 3 failed such elements closed; zkt_verify_set_fail_closed(1) brings that back.
+static constexpr uint32_t OK_EXACT = 3;
 __global__ void __launch_bounds__(256) k_product_resolve(const uint32_t* __restrict__ flags, uint32_t* __restrict__ ok, size_t n) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n && !flags[i]) ok[i] = OK_REDO;
@@ -164,9 +169,10 @@ __global__ void __launch_bounds__(64) k_groth16_verify(const uint32_t* __restric
     if (!pairing_args_fit_short_loop<3>(xp, yp, xq, yq, shared_good ? (shared_good[0] & 3u) << 1 : 0u)) { ok[i] = OK_REDO; return; }      // gamma, delta: pairs 1, 2
     e = final_exponentiation_t<true>(miller_g1_g2_multi_short<3>(xp, yp, xq, yq, in_g1));      // the Tate product itself: comparable with alpha_beta
   } else {
+    for (int k = 0; k < 3; ++k) if (!g1_on_curve(xp[k], yp[k]) || !g2_on_curve(xq[k], yq[k])) { ok[i] = OK_EXACT; return; }      // off its curve: only the reference's own chain gives the reference's value
     e = final_exponentiation(miller_g1_g2_multi<3>(xp, yp, xq, yq, in_g1));
   }
-  if (!in_g1) { ok[i] = 0; return; }       // a G1 argument outside the order-r subgroup: e(-P,Q) = e(P,Q)^-1 is not available — fail closed
+  if (!in_g1) { ok[i] = OK_EXACT; return; }       // a G1 argument outside the order-r subgroup: e(-P,Q) = e(P,Q)^-1 is not available — both sides evaluated the reference's way behind
   uint32_t got[144]; st_fq12(got, e);
   uint32_t diff = 0;
   for (int k = 0; k < 144; ++k) diff |= got[k] ^ alpha_beta[k];
@@ -283,6 +289,76 @@ __global__ void __launch_bounds__(64) k_pairing_product_check_ate(PairArgs a, ui
   ok[i] = diff == 0;
 }
 
+// ---- elements marked OK_EXACT: the reference's own evaluation ------------------------------------------------------------------------
+// Verifier::verify (verifier.rs:36-53): lhs = tate(A, B); rhs = alpha_beta * tate(sum, gamma) * tate(C, delta); lhs == rhs.  Signer::verify (signature.rs:34-39):
+// tate(g1, sig) == tate(pk, H(m)).  Every pairing through the reference's chain (miller_g1_g2_exact: binary chain, vertical lines, its panics) and the exact final
+// exponentiation, the pairs with neg = 0 multiplied into the left side, those with neg = 1 (taken WITHOUT the negation) and the target into the right side, then
+// Fq12 equality on canonical words.  A panic of the reference (a multiple of P at infinity, a vanishing denominator) is the batch's error index.
+// 17 KB of scratch per lane: launched only when a read-back says an element is marked (finish_exact).
+__global__ void __launch_bounds__(64) k_product_exact_marked(PairArgs a, int K, const uint8_t* __restrict__ kcount, const uint32_t* __restrict__ target,
+                                                             uint32_t* __restrict__ ok, size_t n, unsigned long long* err) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n || ok[i] != OK_EXACT) return;
+  Fq12 side[2] = {fq12_one(), target ? ld_fq12(target) : fq12_one()}, t;
+  const int kc = kcount ? (int)kcount[i] : K;
+  for (int k = 0; k < kc; ++k) {
+    const Aff<FqOps> p = PtIO<FqOps>::ld(a.g1[k] + i * a.s1[k]);
+    const Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(a.g2[k] + i * a.s2[k]);
+    bool bad;
+    const Fq12 f = miller_g1_g2_exact(p.x, p.y, q.x, q.y, bad);
+    if (bad) { atomicMin(err, (unsigned long long)i); ok[i] = 0; return; }
+    Fq12 v;
+    if (fq12_is_zero(f)) { v = fq12_one(); v.c0.c0 = fq2_zero(); }      // 0^e = 0 (fq12.rs:42-57)
+    else v = final_exponentiation(f);
+    const int sd = a.neg[k] ? 1 : 0;
+    t = fq12_mul(side[sd], v); side[sd] = t;
+  }
+  uint32_t l[144], r[144]; st_fq12(l, side[0]); st_fq12(r, side[1]);
+  uint32_t diff = 0;
+  for (int k = 0; k < 144; ++k) diff |= l[k] ^ r[k];
+  ok[i] = diff == 0;
+}
+__global__ void __launch_bounds__(256) k_count_exact(const uint32_t* __restrict__ ok, size_t n, uint32_t* __restrict__ count, int to_zero) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || ok[i] != OK_EXACT) return;
+  if (to_zero) const_cast<uint32_t*>(ok)[i] = 0; else atomicAdd(count, 1u);
+}
+// S_i = sum_j stmt[i][j] * uvw_stmt[j] (verifier.rs:41-45) for the marked elements only, one lane each
+__global__ void __launch_bounds__(64) k_stmt_sums_marked(const uint32_t* __restrict__ uvw_stmt, const uint32_t* __restrict__ stmt, int n_stmt, const uint32_t* __restrict__ ok,
+                                                         uint32_t* __restrict__ S, size_t n) {
+  size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n || ok[i] != OK_EXACT) return;
+  Jac<FqOps> acc = jac_inf<FqOps>();
+  for (int j = 0; j < n_stmt; ++j) acc = jac_add(acc, scalar_mul_aff<FqOps>(PtIO<FqOps>::ld(uvw_stmt + (size_t)j * ABI_G1_WORDS), stmt + ((size_t)i * n_stmt + j) * 8, 8));
+  PtIO<FqOps>::st(S + i * ABI_G1_WORDS, jac_to_aff(acc));
+}
+static std::atomic<int> g_fail_closed{[] { const char* e = getenv("ZKT_VERIFY_FAIL_CLOSED"); return e && atoi(e) ? 1 : 0; }()};
+void verify_set_fail_closed(int on) { g_fail_closed.store(on ? 1 : 0); }
+int verify_fail_closed() { return g_fail_closed.load(); }
+// The last step of every deciding launch sequence: elements the kernels before left marked OK_EXACT.  One 4-byte read-back (the stream is synchronised here: the
+// entry points block on their result anyway); honest batches stop there.  fail-closed mode: the marks become rejections, no read-back.
+static hipError_t finish_exact(const PairArgs& a, int K, const uint8_t* kcount, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const dim3 g256((unsigned)((n + 255) / 256));
+  if (verify_fail_closed()) { hipLaunchKernelGGL(k_count_exact, g256, dim3(256), 0, s, (const uint32_t*)ok, n, (uint32_t*)nullptr, 1); return hipGetLastError(); }
+  uint32_t* d = nullptr; uint32_t host = 0; hipError_t e;
+  if ((e = hipMallocAsync((void**)&d, 4, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(d, 0, 4, s)) != hipSuccess) { (void)hipFreeAsync(d, s); return e; }
+  hipLaunchKernelGGL(k_count_exact, g256, dim3(256), 0, s, (const uint32_t*)ok, n, d, 0);
+  if ((e = hipMemcpyAsync(&host, d, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) { (void)hipFreeAsync(d, s); return e; }
+  if ((e = hipFreeAsync(d, s)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+  if (host) hipLaunchKernelGGL(k_product_exact_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a, K, kcount, target, ok, n, err);
+  return hipGetLastError();
+}
+static PairArgs groth16_pairs(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* S, const uint32_t* gamma, const uint32_t* delta) {
+  PairArgs a{};
+  a.g1[0] = A; a.s1[0] = ABI_G1_WORDS; a.g2[0] = B; a.s2[0] = ABI_G2_WORDS; a.neg[0] = 0;
+  a.g1[1] = S; a.s1[1] = ABI_G1_WORDS; a.g2[1] = gamma; a.s2[1] = 0; a.neg[1] = 1;
+  a.g1[2] = C; a.s1[2] = ABI_G1_WORDS; a.g2[2] = delta; a.s2[2] = 0; a.neg[2] = 1;
+  return a;
+}
+
 // e(A,B) == alpha_beta e(S,gamma) e(C,delta) per proof on the lane-distributed kernels; tmp: n_stmt * n G1 points, S: n G1 points (device)
 hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt_tables, const uint32_t* stmt, int n_stmt,
                                        const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* tmp, uint32_t* S, uint32_t* ok, size_t n,
@@ -313,7 +389,8 @@ hipError_t launch_groth16_verify_small(const uint32_t* A, const uint32_t* B, con
   hipLaunchKernelGGL(k_product_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint32_t*)flags, ok, n);
   if ((e = hipFreeAsync(flags, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr, (const uint32_t*)S);
-  return hipGetLastError();
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  return finish_exact(a, 3, nullptr, alpha_beta, ok, n, err, s);
 }
 hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uint32_t* C, const uint32_t* uvw_stmt, const uint32_t* stmt, int n_stmt,
                                  const uint32_t* gamma, const uint32_t* delta, const uint32_t* alpha_beta, uint32_t* ok, size_t n,
@@ -331,6 +408,7 @@ hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uin
     hipLaunchKernelGGL(k_groth16_verify_ate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, (const uint32_t*)S, ate_key, ok, n, err, (const uint32_t*)fits);
     if ((e = hipFreeAsync(fits, s)) != hipSuccess) { (void)hipFreeAsync(S, s); return e; }
     hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr, (const uint32_t*)S);
+    if ((e = hipGetLastError()) != hipSuccess || (e = finish_exact(groth16_pairs(A, B, C, S, gamma, delta), 3, nullptr, alpha_beta, ok, n, err, s)) != hipSuccess) { (void)hipFreeAsync(S, s); return e; }
     if ((e = hipFreeAsync(S, s)) != hipSuccess) return e;
     return hipGetLastError();
   }
@@ -350,6 +428,12 @@ hipError_t launch_groth16_verify(const uint32_t* A, const uint32_t* B, const uin
   }
   hipLaunchKernelGGL(k_groth16_verify<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 0, (const uint32_t*)good, (const uint32_t*)S);
   hipLaunchKernelGGL(k_groth16_verify<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, A, B, C, uvw_stmt, stmt, n_stmt, gamma, delta, alpha_beta, ok, n, err, 1, (const uint32_t*)nullptr, (const uint32_t*)S);
+  if (!S) {                                  // statements the batched multiplication does not take (n_stmt = 0 or > 12): the sums of the marked elements, one lane each
+    if ((e = hipMallocAsync((void**)&S, n * ABI_G1_WORDS * 4, s)) != hipSuccess) { (void)hipFreeAsync(good, s); return e; }
+    hipLaunchKernelGGL(k_stmt_sums_marked, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, uvw_stmt, stmt, n_stmt, (const uint32_t*)ok, S, n);
+  }
+  if ((e = hipGetLastError()) != hipSuccess || (e = finish_exact(groth16_pairs(A, B, C, S, gamma, delta), 3, nullptr, alpha_beta, ok, n, err, s)) != hipSuccess) {
+    (void)hipFreeAsync(good, s); if (tmp) (void)hipFreeAsync(tmp, s); (void)hipFreeAsync(S, s); return e; }
   if ((e = hipFreeAsync(good, s)) != hipSuccess) return e;
   if (tmp && (e = hipFreeAsync(tmp, s)) != hipSuccess) return e;
   if (S && (e = hipFreeAsync(S, s)) != hipSuccess) return e;
@@ -379,9 +463,10 @@ __global__ void __launch_bounds__(64) k_pairing_product_check(PairArgs a, uint32
     if (!pairing_args_fit_short_loop<K>(xp, yp, xq, yq)) { ok[i] = OK_REDO; return; }
     e = final_exponentiation(miller_g1_g2_multi_short<K>(xp, yp, xq, yq, in_g1));
   } else {
+    for (int k = 0; k < K; ++k) if (!g1_on_curve(xp[k], yp[k]) || !g2_on_curve(xq[k], yq[k])) { ok[i] = OK_EXACT; return; }
     e = final_exponentiation(miller_g1_g2_multi<K>(xp, yp, xq, yq, in_g1));
   }
-  if (!in_g1) { ok[i] = 0; return; }       // fail closed, as in k_groth16_verify
+  if (!in_g1) { ok[i] = OK_EXACT; return; }       // as in k_groth16_verify
   uint32_t got[144]; st_fq12(got, e);
   uint32_t diff = got[132] ^ 1u;                       // canonical one: w0.v0.u0 = 1 (the last Fq of the {w1,w0} layout), all else 0
   for (int k = 0; k < 144; ++k) if (k != 132) diff |= got[k];
@@ -449,7 +534,8 @@ hipError_t launch_pairing_product_check(const PairArgs& a, int K, uint32_t* ok, 
 #undef ZKT_PRODUCT_CHECK
   if (p_good) { hipError_t e = hipFreeAsync(p_good, s); if (e != hipSuccess) return e; }
   if (fits) { hipError_t e = hipFreeAsync(fits, s); if (e != hipSuccess) return e; }
-  return hipGetLastError();
+  { hipError_t e = hipGetLastError(); if (e != hipSuccess) return e; }
+  return finish_exact(a, K, nullptr, nullptr, ok, n, err, s);
 }
 
 }  // namespace zkt

@@ -371,10 +371,13 @@ __global__ void __launch_bounds__(256) k_bytes_mod_r(const uint8_t* __restrict__
 using namespace zkt;
 
 namespace {
-struct Dev {   // tiny RAII device buffer
-  void* p = nullptr;
-  explicit Dev(size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) p = nullptr; }
-  ~Dev() { if (p) hipFree(p); }
+struct Dev {   // tiny RAII device buffer.  pooled: stream-ordered on the legacy stream (hipMallocAsync / hipFreeAsync) — for the per-call buffers of the verification entry
+               // points, which run entirely on that stream: a dozen hipMalloc (33-72 us each) and the device-wide wait inside every hipFree were ~0.6 ms of a 4.9 ms verification
+  void* p = nullptr; bool pooled = false;
+  explicit Dev(size_t bytes, bool pool = false) : pooled(pool) {
+    if ((pooled ? hipMallocAsync(&p, bytes ? bytes : 4, nullptr) : hipMalloc(&p, bytes ? bytes : 4)) != hipSuccess) { p = nullptr; (void)hipGetLastError(); }
+  }
+  ~Dev() { if (p) { if (pooled) (void)hipFreeAsync(p, nullptr); else (void)hipFree(p); } }
   uint32_t* w() const { return (uint32_t*)p; }
   Dev(const Dev&) = delete; Dev& operator=(const Dev&) = delete;
 };
@@ -547,8 +550,9 @@ int zkt_groth16_verify_batch(const zkt_groth16_crs* c, const zkt_g1_affine* A, c
   if (!c || !A || !B || !C || !ok || (n_stmt && !stmt_wires) || n_stmt > c->l + 1) return ZKT_ERR_SHAPE;
   if (n_proofs == 0) return ZKT_OK;
   hipStream_t s = nullptr;
-  Dev dA(n_proofs * G1B), dB(n_proofs * G2B), dC(n_proofs * G1B), dU((n_stmt ? n_stmt : 1) * G1B), dW((n_proofs * n_stmt ? n_proofs * n_stmt : 1) * FRB),
-      dg(G2B), dd(G2B), dab(576), dok(n_proofs * 4), derr(8);
+  const bool P = true;       // pooled: everything below runs on the legacy stream
+  Dev dA(n_proofs * G1B, P), dB(n_proofs * G2B, P), dC(n_proofs * G1B, P), dU((n_stmt ? n_stmt : 1) * G1B, P), dW((n_proofs * n_stmt ? n_proofs * n_stmt : 1) * FRB, P),
+      dg(G2B, P), dd(G2B, P), dab(576, P), dok(n_proofs * 4, P), derr(8, P);
   int rc;
   if ((rc = up(dA, A, n_proofs * G1B, s)) || (rc = up(dB, B, n_proofs * G2B, s)) || (rc = up(dC, C, n_proofs * G1B, s)) ||
       (rc = up(dU, c->g1_uvw_stmt, n_stmt * G1B, s)) || (rc = up(dW, stmt_wires, n_proofs * n_stmt * FRB, s)) ||
@@ -556,7 +560,7 @@ int zkt_groth16_verify_batch(const zkt_groth16_crs* c, const zkt_g1_affine* A, c
   unsigned long long noerr = NO_ERR; if ((rc = up(derr, &noerr, 8, s))) return rc;
   if (!dok.p) return ZKT_ERR_DEVICE;
   if (n_stmt >= 1 && n_stmt <= 12 && n_proofs * 3 <= dproduct_limit()) {      // few proofs: one proof per three lane groups (zkt_dpairing.hip), ~15 ms instead of ~105 ms
-    Dev dtmp(n_stmt * n_proofs * G1B), dS(n_proofs * G1B);
+    Dev dtmp(n_stmt * n_proofs * G1B, P), dS(n_proofs * G1B, P);
     if (!dtmp.p || !dS.p) return ZKT_ERR_DEVICE;
     const std::shared_ptr<void> tabs = stmt_tables_for(c->g1_uvw_stmt, n_stmt, dU.w(), s);     // held until the synchronisation below
     const std::shared_ptr<void> akey = ate_key_for(c, n_stmt, dU.w(), dg.w(), dd.w(), s, false);      // null: a key the 63-step loop may not serve, or a key seen for the first time (ate_key_for) -> the 127-step loop against alpha_beta
@@ -574,6 +578,23 @@ int zkt_groth16_verify_batch(const zkt_groth16_crs* c, const zkt_g1_affine* A, c
   if ((rc = down(ok, dok.p, n_proofs * 4, s)) || (rc = down(&e, derr.p, 8, s))) return rc;
   PCHK(hipStreamSynchronize(s));
   if (e != NO_ERR) { zkt_internal_set_error_index((size_t)e); return ZKT_ERR_INFINITY; }
+  return ZKT_OK;
+}
+// What a verifier that KNOWS its key calls once: the statement points' fixed-base tables and the key's entry for the 63-step loop (line tables of gamma and delta,
+// the ate counterpart of alpha_beta, 8-bit statement tables; ~20 ms) are built now instead of at the second verification against the key (verifier.rs:30-54 builds
+// nothing per key; crs.rs:137-139 computes alpha_beta once).  Returns ZKT_OK whether or not the key qualifies for the 63-step loop (a key carrying a point outside its
+// group, or an alpha_beta that is not tate(alpha, beta), keeps the value-comparing kernels — decisions are the same either way).
+int zkt_groth16_vk_prepare(const zkt_groth16_crs* c, size_t n_stmt) {
+  if (zkt_internal_ready() != ZKT_OK) return ZKT_ERR_DEVICE;
+  if (!c || n_stmt > c->l + 1) return ZKT_ERR_SHAPE;
+  if (n_stmt < 1 || n_stmt > 12) return ZKT_OK;      // such statements are summed in the lanes: nothing to prepare
+  hipStream_t s = nullptr;
+  Dev dU(n_stmt * G1B, true), dg(G2B, true), dd(G2B, true);
+  int rc;
+  if ((rc = up(dU, c->g1_uvw_stmt, n_stmt * G1B, s)) || (rc = up(dg, c->g2_gamma, G2B, s)) || (rc = up(dd, c->g2_delta, G2B, s))) return rc;
+  const std::shared_ptr<void> tabs = stmt_tables_for(c->g1_uvw_stmt, n_stmt, dU.w(), s);
+  const std::shared_ptr<void> akey = ate_key_for(c, n_stmt, dU.w(), dg.w(), dd.w(), s, true);
+  PCHK(hipStreamSynchronize(s));
   return ZKT_OK;
 }
 // single proof: 1 = accept, 0 = reject, negative = -status (a pairing argument at infinity panics in the reference)
@@ -1092,6 +1113,7 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   return memcmp(hth, hlr, FRB) == 0 ? 1 : 0;                                          // :147-149
 }
 
+void zkt_verify_set_fail_closed(int on) { zkt::verify_set_fail_closed(on); }
 // ---- f-4: pairing-product equalities and BLS signatures ----------------------------------------------------------------
 // prod_k tate(+-P[i][k], Q[i][k]) == 1 for n elements of k <= 4 pairs each; negate[k] != 0 negates slot k's G1 point.
 int zkt_pairing_product_check_batch(const zkt_g1_affine* g1, const zkt_g2_affine* g2, const uint8_t* negate, size_t k, size_t n, uint32_t* ok) {
@@ -1099,7 +1121,7 @@ int zkt_pairing_product_check_batch(const zkt_g1_affine* g1, const zkt_g2_affine
   if (!g1 || !g2 || !ok || k == 0 || k > 4) return ZKT_ERR_SHAPE;
   if (n == 0) return ZKT_OK;
   hipStream_t s = nullptr;
-  Dev d1(n * k * G1B), d2(n * k * G2B), dok(n * 4), derr(8);
+  Dev d1(n * k * G1B, true), d2(n * k * G2B, true), dok(n * 4, true), derr(8, true);      // pooled: all on the legacy stream
   int rc;
   if ((rc = up(d1, g1, n * k * G1B, s)) || (rc = up(d2, g2, n * k * G2B, s))) return rc;
   unsigned long long noerr = NO_ERR, e = NO_ERR; if ((rc = up(derr, &noerr, 8, s))) return rc;

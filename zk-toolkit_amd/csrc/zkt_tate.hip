@@ -31,6 +31,8 @@ __global__ void __launch_bounds__(64) ZKT_TATE_ATTR k_tate(const uint32_t* __res
     atomicMin(err, (unsigned long long)i);
     return;
   }
+  // (Round 4 measured the curve equations and the G2 membership test of tate_short moved AHEAD of this kernel, onto lane pairs at two waves per SIMD: k_tate 48.0 ms
+  //  against 47.8 with them inside — the 63-doubling chain over Fq2 is not where this kernel's time goes.  Taken out again.)
   Fq12 r;
   const int route = tate_short(p.x, p.y, q.x, q.y, r);
   if (route == TATE_ROUTE_SHORT) st_fq12(out + i * 144, r);
