@@ -506,13 +506,24 @@ def main():
                 tot2 = sum(int.from_bytes(a.tobytes(), "little") * int.from_bytes(b.tobytes(), "little") for a, b in zip(hk2, hs2)) % R_MOD
                 ok2 = bool((o2 == g2_arr([to_abi_g2(py_g2_mul(((x0, x1), (y0, y1)), tot2))])).all())
                 L.zkt_g2_bases_free(h2); del t_b, t_s, t_k
-                g2sq = load_profile(PROFILE_ROUND + "_g2_msm_sq_counters.json") or {}
+                g2sq = load_profile(PROFILE_ROUND + "_g2_msm_sq_counters.json") or load_profile("r02_g2_msm_sq_counters.json") or {}
+                g2mem = load_profile(PROFILE_ROUND + "_g2_msm_memory_counters.json") or {}
+                g2k = next((v for k, v in (g2sq.get("kernels") or {}).items() if "k_accumulate_g2_pair" in k and "direct" not in k), None)
+                g2m = next((v for k, v in (g2mem.get("kernels") or {}).items() if "k_accumulate_g2_pair" in k and "direct" not in k), None)
+                g2valu = None
+                if g2k and sq and args.g2_log2n == 20 and g2k.get("valu_lane_instr_per_launch"):
+                    pk = sq["valu_peak"]["int_mad_lane_ops_per_s_T"]
+                    g2valu = {"kernel": "k_accumulate_g2_pair", "lane_instr_per_launch": g2k["valu_lane_instr_per_launch"], "lane_instr_per_bucket_add": g2k["valu_lane_instr_per_launch"] / (13 * gn2),
+                              "vgpr": g2k.get("vgpr"), "wait_any_frac": g2k.get("wait_any_frac_of_wave_cycles"),
+                              "achieved_lower_bound": g2k["valu_lane_instr_per_launch"] / (dt2) / 1e12, "peak": pk, "unit": "T lane-instr/s", "frac_lower_bound": g2k["valu_lane_instr_per_launch"] / dt2 / 1e12 / pk,
+                              "note": "counted lane-instructions of ONE accumulate launch over the whole pipelined step time (the kernel's own time is shorter: a lower bound of its issue rate)",
+                              "traffic_bytes_per_launch": ((g2m.get("FETCH_SIZE_KB_avg_per_launch", 0) + g2m.get("WRITE_SIZE_KB_avg_per_launch", 0)) * 1024) if g2m else None}
                 g2blk = {"metric": "G2 MSM scalar-muls/sec at 2^%d bases (resident, pipelined)" % args.g2_log2n, "value": gn2 / dt2, "ms_per_msm": dt2 * 1e3, "single_msm_latency_ms": round(lat2 * 1e3, 3),
                          "bases_setup_s": round(t_setup2, 3), "full_size_check": "ok" if ok2 else "MISMATCH",
                          "plan": "sort -> XYZZ accumulate on lane pairs (k_accumulate_g2_pair) -> four-lane reduce; affine pair-tree rounds: %s (ZKT_G2_AFFINE_ROUNDS, off by default: profiles/r04_batched_affine_go_no_go.md)" % os.environ.get("ZKT_G2_AFFINE_ROUNDS", "0"),
                          "roofline": {"bound": "hbm", "achieved": 224 * gn2 / dt2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 224 * gn2 / dt2 / 1e9 / HBM_PEAK_GBS,
                                       "algorithmic_bytes_per_msm": 224 * gn2, "note": "192 B base + 32 B scalar per term over the whole pipelined step (sort, accumulate and reduce kernels of consecutive MSMs overlap); integer-VALU bound",
-                                      "counters": g2sq.get("summary"), "counters_stale": stale(g2sq) if g2sq else None}}
+                                      "valu": g2valu, "counters_stale": stale(g2sq) if g2sq else None}}
                 result["g2_msm"] = g2blk
                 failed = failed or not ok2
             except Exception as e:

@@ -16,6 +16,11 @@ python3 tools/pmc_summary.py $P/${T}_tate_memory_counters.json "rocprofv3 --pmc 
 if ls $O/prof_${T}_hbm_verify_FETCH_SIZE/*/*counter_collection.csv > /dev/null 2>&1; then
 python3 tools/pmc_summary.py $P/${T}_verify_memory_counters.json "rocprofv3 --pmc FETCH_SIZE (one pass) / --pmc WRITE_SIZE (another) -- python3 tools/bench_g16_batch_verify.py 65536 (MI355X, round ${T#r}, final build; tools/gpu_job.sh $T pmc_verify_hbm)" "$(newest "$O/prof_${T}_hbm_verify_FETCH_SIZE/*/*counter_collection.csv")" "$(newest "$O/prof_${T}_hbm_verify_WRITE_SIZE/*/*counter_collection.csv")"
 fi
+if ls $O/prof_${T}_sq_g2/*/*counter_collection.csv > /dev/null 2>&1; then
+python3 tools/sq_summary.py $P/${T}_g2_msm_sq_counters.json $UB "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -- python3 tools/bench_g2_msm.py 20 4 (MI355X, round ${T#r}, final build; tools/gpu_job.sh $T pmc_g2): the G2 accumulate on lane pairs and the Fq2 reduce kernels at 2^20 terms" "$(newest "$O/prof_${T}_sq_g2/*/*counter_collection.csv")" > /dev/null
+python3 tools/pmc_summary.py $P/${T}_g2_msm_memory_counters.json "rocprofv3 --pmc FETCH_SIZE (one pass) / --pmc WRITE_SIZE (another) -- python3 tools/bench_g2_msm.py 20 4 (MI355X, round ${T#r}, final build; tools/gpu_job.sh $T pmc_g2)" "$(newest "$O/prof_${T}_hbm_g2_FETCH_SIZE/*/*counter_collection.csv")" "$(newest "$O/prof_${T}_hbm_g2_WRITE_SIZE/*/*counter_collection.csv")" > /dev/null
+fi
+[ -f $O/${T}_verify_latency.txt ] && cp $O/${T}_verify_latency.txt $P/${T}_verify_latency.txt
 cp $O/${T}_bench.json $P/${T}_bench.json
 cp $O/${T}_bench_msm_pairing.json $P/${T}_bench_msm_pairing.json
 cp "$(newest "$O/prof_${T}_stats/*/*kernel_stats.csv")" $P/${T}_bench_kernel_stats.csv

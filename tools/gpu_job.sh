@@ -13,6 +13,9 @@
 #   protocols_stats   the same under rocprofv3 --kernel-trace --stats
 #   bp                tools/bench_bp.py (range proof / inner-product argument)
 #   pmc_acc | pmc_hbm | pmc_tate | pmc_tate_hbm   counter passes (their own runs: no trace domains beside --pmc)
+#   pmc_g2            SQ counters, then FETCH_SIZE / WRITE_SIZE passes over tools/bench_g2_msm.py 20 4 (k_accumulate_g2_pair and the Fq2 reduce kernels)
+#   ubench            ./build/valu_roof (tools/ubench/valu_roof.hip, built by hipcc beforehand) -> <tag>_valu_ubench.txt
+#   verify_latency    tools/bench_verify_latency.py (unprepared / prepared key, calls 1..5; batch sizes)
 #   pmc_verify_hbm    FETCH_SIZE / WRITE_SIZE passes over tools/bench_g16_batch_verify.py (the 63-step deciding kernels)
 #   rehearsal         two ranks on one card through the callback transport (bench.py --gpus 2, gloo)
 #   py:<script> [..]  python3 <script> -> <tag>_<script>.log
@@ -32,7 +35,7 @@ for STEP in "$@"; do
       tail -14 $O/${TAG}_gputests.log ;;
     bench) timeout -k 10 900 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || fail bench $O/${TAG}_bench.err
       python3 -c "import json,sys; d=json.loads(open('$O/${TAG}_bench.json').read().strip().splitlines()[-1]); print({k:d[k] for k in ('value','ms_per_step')}, d.get('roofline'), d['config'].get('single_msm_latency_ms'), d.get('pairing',{}).get('value'), d.get('groth16',{}).get('value'), d.get('bulletproofs'))" ;;
-    bench_stats) timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_stats -- python3 bench.py --groth16-log2n 0 > $O/${TAG}_bench_msm_pairing.json 2> $O/prof_${TAG}_stats.err || fail bench_stats $O/prof_${TAG}_stats.err ;;
+    bench_stats) timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_stats -- python3 bench.py --groth16-log2n 0 --g2-log2n 0 > $O/${TAG}_bench_msm_pairing.json 2> $O/prof_${TAG}_stats.err || fail bench_stats $O/prof_${TAG}_stats.err ;;
     msm_latency) timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_${TAG}_lat -- python3 tools/bench_msm_latency.py > $O/${TAG}_msm_latency.log 2>&1 || fail msm_latency $O/${TAG}_msm_latency.log
       grep "latency" $O/${TAG}_msm_latency.log
       python3 tools/trace_summary.py $(ls $O/prof_${TAG}_lat/*/*kernel_trace.csv | head -1) > $O/${TAG}_msm_latency_kernel_trace.txt 2>&1 || true
@@ -55,10 +58,18 @@ for STEP in "$@"; do
     protocols_stats) timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_protocols -- python3 tools/bench_protocols.py > $O/${TAG}_protocols_b.json 2> $O/prof_${TAG}_protocols.err || fail protocols_stats $O/prof_${TAG}_protocols.err ;;
     bp) timeout -k 10 600 python3 tools/bench_bp.py > $O/${TAG}_bp.log 2>&1 || fail bp $O/${TAG}_bp.log
       tail -12 $O/${TAG}_bp.log ;;
-    pmc_acc) timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $O/prof_${TAG}_sq_acc --output-format csv -- python3 bench.py --no-cpu --no-bulletproofs --steps 8 --warmup 2 --pairings 0 --groth16-log2n 0 > $O/prof_${TAG}_sq_acc.log 2>&1 || fail pmc_acc $O/prof_${TAG}_sq_acc.log ;;
+    pmc_acc) timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $O/prof_${TAG}_sq_acc --output-format csv -- python3 bench.py --no-cpu --no-bulletproofs --steps 8 --warmup 2 --pairings 0 --groth16-log2n 0 --g2-log2n 0 > $O/prof_${TAG}_sq_acc.log 2>&1 || fail pmc_acc $O/prof_${TAG}_sq_acc.log ;;
     pmc_hbm) for CNT in FETCH_SIZE WRITE_SIZE; do      # one counter per pass: together they exceed what the hardware collects at once (rocprofv3 aborts)
-        timeout -k 10 300 rocprofv3 --pmc $CNT -d $O/prof_${TAG}_hbm_$CNT --output-format csv -- python3 bench.py --no-cpu --no-bulletproofs --steps 8 --warmup 2 --pairings 0 --groth16-log2n 0 > $O/prof_${TAG}_hbm_$CNT.log 2>&1 || fail "pmc_hbm $CNT" $O/prof_${TAG}_hbm_$CNT.log
+        timeout -k 10 300 rocprofv3 --pmc $CNT -d $O/prof_${TAG}_hbm_$CNT --output-format csv -- python3 bench.py --no-cpu --no-bulletproofs --steps 8 --warmup 2 --pairings 0 --groth16-log2n 0 --g2-log2n 0 > $O/prof_${TAG}_hbm_$CNT.log 2>&1 || fail "pmc_hbm $CNT" $O/prof_${TAG}_hbm_$CNT.log
       done ;;
+    pmc_g2) timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/prof_${TAG}_sq_g2 --output-format csv -- python3 tools/bench_g2_msm.py 20 4 > $O/prof_${TAG}_sq_g2.log 2>&1 || fail pmc_g2 $O/prof_${TAG}_sq_g2.log
+      for CNT in FETCH_SIZE WRITE_SIZE; do
+        timeout -k 10 300 rocprofv3 --pmc $CNT -d $O/prof_${TAG}_hbm_g2_$CNT --output-format csv -- python3 tools/bench_g2_msm.py 20 4 > $O/prof_${TAG}_hbm_g2_$CNT.log 2>&1 || fail "pmc_g2 $CNT" $O/prof_${TAG}_hbm_g2_$CNT.log
+      done ;;
+    ubench) timeout -k 10 300 ./build/valu_roof > $O/${TAG}_valu_ubench.txt 2>&1 || fail ubench $O/${TAG}_valu_ubench.txt
+      grep "v_mad_u64_u32\|field mix" $O/${TAG}_valu_ubench.txt | head -8 ;;
+    verify_latency) timeout -k 10 300 python3 tools/bench_verify_latency.py 2>&1 | grep -v "^[WEI]2026\|amdgpu.ids" > $O/${TAG}_verify_latency.txt || fail verify_latency $O/${TAG}_verify_latency.txt
+      head -3 $O/${TAG}_verify_latency.txt ;;
     pmc_tate) timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/prof_${TAG}_sq_tate --output-format csv -- python3 tools/bench_pairing.py 65536 > $O/prof_${TAG}_sq_tate.log 2>&1 || fail pmc_tate $O/prof_${TAG}_sq_tate.log ;;
     pmc_tate_hbm) for CNT in FETCH_SIZE WRITE_SIZE; do
         timeout -k 10 300 rocprofv3 --pmc $CNT -d $O/prof_${TAG}_hbm_tate_$CNT --output-format csv -- python3 tools/bench_pairing.py 65536 > $O/prof_${TAG}_hbm_tate_$CNT.log 2>&1 || fail "pmc_tate_hbm $CNT" $O/prof_${TAG}_hbm_tate_$CNT.log

@@ -442,7 +442,7 @@ ZKT_HD void fq6_mul_sparse04(const Fq6& x, const Fq2& s0, const Fq2& s4, Fq2& r0
   r0 = fq2_add_mul_xi(p0, q4);                                                 // x0 s0 + xi x1 s4
   r1 = fq2_add_mul_xi(q0, p2);                                                 // x1 s0 + xi x2 s4
 }
-ZKT_FN Fq12 fq12_mul_ate_line(const Fq12& f, const Fq2& c0, const Fq2& c1, const Fq2& c4) {
+ZKT_FQ12 Fq12 fq12_mul_ate_line(const Fq12& f, const Fq2& c0, const Fq2& c1, const Fq2& c4) {
   const Fq6 &x = f.c0, &y = f.c1;
   Fq2 a0, a1, a2, s0, s1, s2;
   fq6_mul_sparse04(x, c0, c4, a0, a1, a2);

@@ -162,6 +162,13 @@ ZKT_HD Fq6 fq6_mul_inl(const Fq6& a, const Fq6& b) {
 ZKT_FN Fq6 fq6_mul(const Fq6& a, const Fq6& b) { return fq6_mul_inl(a, b); }
 // inside the Fq12 square/product the Fq6 products are inlined (ZKT_FQ6_INLINE): operands and partial results stay in the
 // 512-entry register file instead of round-tripping through scratch between calls
+// the Fq12-level routines are real functions by default (operands and results travel through per-lane scratch: ~2 KB per call, the pairing kernels' memory traffic);
+// -DZKT_FQ12_INLINE inlines them into their callers (A/B experiment of round 4: does the accumulator of a Miller loop stay in registers?)
+#ifdef ZKT_FQ12_INLINE
+#define ZKT_FQ12 ZKT_HD
+#else
+#define ZKT_FQ12 ZKT_FN
+#endif
 #ifdef ZKT_FQ6_CALLS
 #define FQ6_MUL12 fq6_mul
 #else
@@ -184,7 +191,7 @@ ZKT_HD Fq12 fq12_sub(const Fq12& a, const Fq12& b) { return Fq12{fq6_sub(a.c0, b
 ZKT_HD Fq12 fq12_neg(const Fq12& a) { return Fq12{fq6_neg(a.c0), fq6_neg(a.c1)}; }
 ZKT_HD Fq12 fq12_conj(const Fq12& a) { return Fq12{a.c0, fq6_neg(a.c1)}; }
 // fq12.rs:135-147 is 4 Fq6 products; Karatsuba (3) gives the same element
-ZKT_FN Fq12 fq12_mul(const Fq12& a, const Fq12& b) {
+ZKT_FQ12 Fq12 fq12_mul(const Fq12& a, const Fq12& b) {
   Fq6 v0 = FQ6_MUL12(a.c0, b.c0), v1 = FQ6_MUL12(a.c1, b.c1);
   Fq6 s = FQ6_MUL12(fq6_add(a.c0, a.c1), fq6_add(b.c0, b.c1));
   Fq12 r;
@@ -193,7 +200,7 @@ ZKT_FN Fq12 fq12_mul(const Fq12& a, const Fq12& b) {
   return r;
 }
 // complex squaring: (a0 + a1 w)^2 = (a0+a1)(a0+v a1) - v0 - v v0 + 2 v0 w,  v0 = a0 a1
-ZKT_FN Fq12 fq12_sqr(const Fq12& a) {
+ZKT_FQ12 Fq12 fq12_sqr(const Fq12& a) {
   Fq6 v0 = FQ6_MUL12(a.c0, a.c1);
   Fq6 t = FQ6_MUL12(fq6_add(a.c0, a.c1), fq6_add(a.c0, fq6_mul_v(a.c1)));
   // (left as two-term passes: restructuring this return into three-term passes trips an AMDGPU backend error at -O1 —
@@ -213,7 +220,7 @@ ZKT_HD void fq4_sqr(const Fq2& a, const Fq2& b, Fq2& c0, Fq2& c1) {
   c0 = fq2_add(fq2_mul_xi(t1), t0);
   c1 = fq2_sub(fq2_sub(fq2_sqr(fq2_add(a, b)), t0), t1);
 }
-ZKT_FN Fq12 fq12_cyclotomic_sqr(const Fq12& f) {
+ZKT_FQ12 Fq12 fq12_cyclotomic_sqr(const Fq12& f) {
   Fq2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
   Fq2 t0, t1, t2, t3;
   auto three_minus_two = [](const Fq2& t, const Fq2& z) { Fq2 d = fq2_sub(t, z); return fq2_add(fq2_dbl(d), t); };   // 3t - 2z
@@ -258,7 +265,7 @@ template <int K> ZKT_FN Fq12 fq12_frob(const Fq12& a) { return fq12_frob_inl<K>(
 
 // f * (a + b v^2 + c v w) with a in Fq, b,c in Fq2: the value of a Miller line at
 // an untwisted G2 point has exactly these slots (g12_point.rs:47-68).
-ZKT_FN Fq12 fq12_mul_line(const Fq12& f, const Fq& a, const Fq2& b, const Fq2& c) {
+ZKT_FQ12 Fq12 fq12_mul_line(const Fq12& f, const Fq& a, const Fq2& b, const Fq2& c) {
   // (x + y w)(a + b v^2 + c v w), w^2 = v, v^3 = xi:
   //   c0 = x a + x b v^2 + y c v^2         c1 = y a + x c v + y b v^2
   // The six products x_i b and y_i c serve c0; the cross terms of c1 pair up slot by slot — x2 c + y1 b, x1 c + y0 b and
