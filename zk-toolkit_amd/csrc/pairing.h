@@ -249,10 +249,12 @@ ZKT_FN bool pairing_args_fit_short_loop(const Fq* xp, const Fq* yp, const Fq2* x
 // (a in the cyclotomic subgroup: Granger-Scott squarings)
 ZKT_FN Fq12 fq12_pow_xabs(const Fq12& a) {
   Fq12 r = a, t;
+  int run = 0;                                                  // squarings owed: done as ONE in-register run before the next product (fq12_cyclotomic_sqr_n)
   for (int i = 62; i >= 0; --i) {
-    t = fq12_cyclotomic_sqr(r); r = t;
-    if ((BLS_X_ABS >> i) & 1) { t = fq12_mul(r, a); r = t; }
+    ++run;
+    if ((BLS_X_ABS >> i) & 1) { fq12_cyclotomic_sqr_n(r, run); run = 0; t = fq12_mul(r, a); r = t; }
   }
+  if (run) fq12_cyclotomic_sqr_n(r, run);
   return r;
 }
 // a^x for x = -|x|, a in the cyclotomic subgroup (inverse = conjugate)
@@ -263,18 +265,19 @@ ZKT_HD Fq12 fq12_pow_x(const Fq12& a) { return fq12_conj(fq12_pow_xabs(a)); }
 ZKT_FN Fq12 fq12_pow_e1(const Fq12& a) {
   Fq12 a3, r, t, m;
   t = fq12_cyclotomic_sqr(a); a3 = fq12_mul(t, a);
-  bool started = false;
+  bool started = false; int run = 0;                              // squarings owed, done as one in-register run (fq12_cyclotomic_sqr_n)
   for (int i = 0; i < E1_WNAF_DIGITS; ++i) {
     uint32_t nz = 0, ng = 0, th = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { nz = (j == (i >> 5)) ? e1_wnaf_nz_word(j) : nz; ng = (j == (i >> 5)) ? e1_wnaf_neg_word(j) : ng; th = (j == (i >> 5)) ? e1_wnaf_three_word(j) : th; }
-    if (started) { t = fq12_cyclotomic_sqr(r); r = t; }
+    if (started) ++run;
     if ((nz >> (i & 31)) & 1) {                                   // wave-uniform (compile-time tables)
       m = ((th >> (i & 31)) & 1) ? a3 : a;
       if ((ng >> (i & 31)) & 1) m = fq12_conj(m);
-      if (started) { t = fq12_mul(r, m); r = t; } else { r = m; started = true; }
+      if (started) { if (run) { fq12_cyclotomic_sqr_n(r, run); run = 0; } t = fq12_mul(r, m); r = t; } else { r = m; started = true; }
     }
   }
+  if (run) fq12_cyclotomic_sqr_n(r, run);
   return r;
 }
 
