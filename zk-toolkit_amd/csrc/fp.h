@@ -57,6 +57,11 @@ ZKT_HD void mac_k(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
 ZKT_HD uint32_t addc(uint32_t a, uint32_t b, uint32_t& c) { unsigned co; uint32_t r = __builtin_addc(a, b, c, &co); c = co; return r; }
 ZKT_HD uint32_t subb(uint32_t a, uint32_t b, uint32_t& c) { unsigned co; uint32_t r = __builtin_subc(a, b, c, &co); c = co; return r; }
 
+// Gives the enclosing function a 64-byte aligned stack object, i.e. a realigned frame with its own base pointer (s34 saved on entry, restored on exit).  For the few
+// real functions that hold whole Fq12 values in REGISTERS (round 4: the in-register squaring runs and fused Miller steps): without a frame of their own the register allocator
+// hands them s34 as scratch, and their callers keep their base pointer there (DESIGN §5 "A compiler limit"; tools/check_base_pointer.py flags exactly this).
+#define ZKT_FORCE_FRAME() do { alignas(64) volatile uint32_t zkt_frame_anchor_[16]; zkt_frame_anchor_[0] = 0u; } while (0)
+
 template <class C> ZKT_HD Fp<C> fp_zero() { Fp<C> r;
 #pragma unroll
   for (int i = 0; i < C::N; ++i) r.v[i] = 0; return r; }

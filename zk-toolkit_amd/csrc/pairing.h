@@ -88,8 +88,7 @@ ZKT_FN Fq12 miller_g1_g2(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& y
     for (int j = 0; j < 8; ++j) { nz = (j == (i >> 5)) ? miller_naf_nz_word(j) : nz; ng = (j == (i >> 5)) ? miller_naf_neg_word(j) : ng; }
     const bool bit = (nz >> (i & 31)) & 1, neg = (ng >> (i & 31)) & 1;          // wave-uniform (compile-time tables)
     miller_dbl_step(V, Xq, Yq, l);
-    ft = fq12_sqr(f);
-    f = fq12_mul_line(ft, l.a, l.b, l.c);
+    fq12_sqr_mul_line(f, l.a, l.b, l.c);
     if (bit) {
       miller_add_step(V, xp, neg ? yn : yp, Xq, Yq, l);
       ft = fq12_mul_line(f, l.a, l.b, l.c);
@@ -158,8 +157,7 @@ ZKT_FN Fq12 miller_g1_g2_short(const Fq& xp, const Fq& yp, const Fq2& xq, const 
     for (int j = 0; j < 4; ++j) w = (j == (i >> 5)) ? miller_x2_bits_word(j) : w;
     const bool bit = (w >> (i & 31)) & 1;                                       // wave-uniform (compile-time table)
     miller_dbl_step(V, Xq, Yq, l);
-    ft = fq12_sqr(f);
-    f = fq12_mul_line(ft, l.a, l.b, l.c);
+    fq12_sqr_mul_line(f, l.a, l.b, l.c);
     if (bit) {
       miller_add_step(V, xp, yp, Xq, Yq, l);
       ft = fq12_mul_line(f, l.a, l.b, l.c);
@@ -186,10 +184,10 @@ ZKT_FN Fq12 miller_g1_g2_multi(const Fq* xp, const Fq* yp, const Fq2* xq, const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { nz = (j == (i >> 5)) ? miller_naf_nz_word(j) : nz; ng = (j == (i >> 5)) ? miller_naf_neg_word(j) : ng; }
     const bool bit = (nz >> (i & 31)) & 1, neg = (ng >> (i & 31)) & 1;
-    ft = fq12_sqr(f); f = ft;
     for (int k = 0; k < K; ++k) {
       miller_dbl_step(V[k], Xq[k], Yq[k], l);
-      ft = fq12_mul_line(f, l.a, l.b, l.c); f = ft;
+      if (k == 0) fq12_sqr_mul_line(f, l.a, l.b, l.c);          // the shared squaring, fused with the first pair's line (f stays out of scratch between them)
+      else { ft = fq12_mul_line(f, l.a, l.b, l.c); f = ft; }
     }
     if (bit) {
       for (int k = 0; k < K; ++k) {
@@ -218,10 +216,10 @@ ZKT_FN Fq12 miller_g1_g2_multi_short(const Fq* xp, const Fq* yp, const Fq2* xq, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) w = (j == (i >> 5)) ? miller_x2_bits_word(j) : w;
     const bool bit = (w >> (i & 31)) & 1;
-    ft = fq12_sqr(f); f = ft;
     for (int k = 0; k < K; ++k) {
       miller_dbl_step(V[k], Xq[k], Yq[k], l);
-      ft = fq12_mul_line(f, l.a, l.b, l.c); f = ft;
+      if (k == 0) fq12_sqr_mul_line(f, l.a, l.b, l.c);          // the shared squaring, fused with the first pair's line (f stays out of scratch between them)
+      else { ft = fq12_mul_line(f, l.a, l.b, l.c); f = ft; }
     }
     if (bit) {
       for (int k = 0; k < K; ++k) {
@@ -248,11 +246,12 @@ ZKT_FN bool pairing_args_fit_short_loop(const Fq* xp, const Fq* yp, const Fq2* x
 // a^|x| , |x| = 0xd201000000010000 (bits 63,62,60,57,48,16)
 // (a in the cyclotomic subgroup: Granger-Scott squarings)
 ZKT_FN Fq12 fq12_pow_xabs(const Fq12& a) {
-  Fq12 r = a, t;
+  ZKT_FORCE_FRAME();
+  Fq12 r = a;
   int run = 0;                                                  // squarings owed: done as ONE in-register run before the next product (fq12_cyclotomic_sqr_n)
   for (int i = 62; i >= 0; --i) {
     ++run;
-    if ((BLS_X_ABS >> i) & 1) { fq12_cyclotomic_sqr_n(r, run); run = 0; t = fq12_mul(r, a); r = t; }
+    if ((BLS_X_ABS >> i) & 1) { fq12_cyclotomic_sqr_n_mul(r, run, &a); run = 0; }
   }
   if (run) fq12_cyclotomic_sqr_n(r, run);
   return r;
@@ -274,7 +273,7 @@ ZKT_FN Fq12 fq12_pow_e1(const Fq12& a) {
     if ((nz >> (i & 31)) & 1) {                                   // wave-uniform (compile-time tables)
       m = ((th >> (i & 31)) & 1) ? a3 : a;
       if ((ng >> (i & 31)) & 1) m = fq12_conj(m);
-      if (started) { if (run) { fq12_cyclotomic_sqr_n(r, run); run = 0; } t = fq12_mul(r, m); r = t; } else { r = m; started = true; }
+      if (started) { fq12_cyclotomic_sqr_n_mul(r, run, &m); run = 0; } else { r = m; started = true; }
     }
   }
   if (run) fq12_cyclotomic_sqr_n(r, run);
@@ -445,7 +444,7 @@ ZKT_HD void fq6_mul_sparse04(const Fq6& x, const Fq2& s0, const Fq2& s4, Fq2& r0
   r0 = fq2_add_mul_xi(p0, q4);                                                 // x0 s0 + xi x1 s4
   r1 = fq2_add_mul_xi(q0, p2);                                                 // x1 s0 + xi x2 s4
 }
-ZKT_FQ12 Fq12 fq12_mul_ate_line(const Fq12& f, const Fq2& c0, const Fq2& c1, const Fq2& c4) {
+ZKT_HD Fq12 fq12_mul_ate_line_body(const Fq12& f, const Fq2& c0, const Fq2& c1, const Fq2& c4) {
   const Fq6 &x = f.c0, &y = f.c1;
   Fq2 a0, a1, a2, s0, s1, s2;
   fq6_mul_sparse04(x, c0, c4, a0, a1, a2);
@@ -455,6 +454,13 @@ ZKT_FQ12 Fq12 fq12_mul_ate_line(const Fq12& f, const Fq2& c0, const Fq2& c1, con
   r.c0.c0 = fq2_add_mul_xi(a0, b2); r.c0.c1 = fq2_add(a1, b0); r.c0.c2 = fq2_add(a2, b1);
   r.c1.c0 = fq2_subsub(s0, a0, b0); r.c1.c1 = fq2_subsub(s1, a1, b1); r.c1.c2 = fq2_subsub(s2, a2, b2);
   return r;
+}
+ZKT_FQ12 Fq12 fq12_mul_ate_line(const Fq12& f, const Fq2& c0, const Fq2& c1, const Fq2& c4) { return fq12_mul_ate_line_body(f, c0, c1, c4); }
+// f <- f^2 * line in place: the 63-step loop's shared squaring fused with the first pair's line (see fq12_sqr_mul_line)
+ZKT_FN void fq12_sqr_mul_ate_line(Fq12& f, const Fq2& c0, const Fq2& c1, const Fq2& c4) {
+  ZKT_FORCE_FRAME();
+  const Fq12 t = fq12_sqr_body(f);
+  f = fq12_mul_ate_line_body(t, c0, c1, c4);
 }
 ZKT_HD AteLine ld_ate_line(const uint32_t* p) {
   AteLine l; Fq* e[6] = {&l.a0.c0, &l.a0.c1, &l.a1.c0, &l.a1.c1, &l.c4.c0, &l.c4.c1};
@@ -492,15 +498,22 @@ ZKT_FN Fq12 miller_ate_multi(const Fq* xp, const Fq* yp, const Fq2* xq, const Fq
   Fq12 f = fq12_one(), ft;
   int li = 0;
   for (int i = 62; i >= 0; --i) {
-    if (i != 62) { ft = fq12_sqr(f); f = ft; }
+    // the step's squaring is owed until the first line of the step takes it along (fq12_sqr_mul_ate_line).  Fused for the two shapes that carry the protocol throughput —
+    // Groth16 batch verification <1, 2> and signature verification <2, 0> — only: every fused instantiation adds ~1.5 min to the build of this object
+    constexpr bool FUSE = true;      // (while the fused step had to be INLINED to keep its callers' base pointers safe, only two shapes were fused: ~1.5 min of compile time each)
+    bool sq = i != 62;
+    if (!FUSE && sq) { ft = fq12_sqr(f); f = ft; sq = false; }
     for (int k = 0; k < KV; ++k) {
       ate_dbl_step(T[k], l);
-      ft = fq12_mul_ate_line(f, fq2_mul_fq(l.a0, xp[k]), fq2_mul_fq(l.a1, yp[k]), l.c4); f = ft;
+      if (sq) { fq12_sqr_mul_ate_line(f, fq2_mul_fq(l.a0, xp[k]), fq2_mul_fq(l.a1, yp[k]), l.c4); sq = false; }
+      else { ft = fq12_mul_ate_line(f, fq2_mul_fq(l.a0, xp[k]), fq2_mul_fq(l.a1, yp[k]), l.c4); f = ft; }
     }
     for (int j = 0; j < KF; ++j) {
       l = ld_ate_line(tab[j] + (size_t)li * ATE_LINE_WORDS);
-      ft = fq12_mul_ate_line(f, fq2_mul_fq(l.a0, xp[KV + j]), fq2_mul_fq(l.a1, yp[KV + j]), l.c4); f = ft;
+      if (sq) { fq12_sqr_mul_ate_line(f, fq2_mul_fq(l.a0, xp[KV + j]), fq2_mul_fq(l.a1, yp[KV + j]), l.c4); sq = false; }
+      else { ft = fq12_mul_ate_line(f, fq2_mul_fq(l.a0, xp[KV + j]), fq2_mul_fq(l.a1, yp[KV + j]), l.c4); f = ft; }
     }
+    if (sq) { ft = fq12_sqr(f); f = ft; }                                        // no pair at all (KV + KF = 0 is not instantiated; kept for completeness)
     ++li;
     if (ate_bit(i)) {                                                          // wave-uniform
       for (int k = 0; k < KV; ++k) {

@@ -191,7 +191,7 @@ ZKT_HD Fq12 fq12_sub(const Fq12& a, const Fq12& b) { return Fq12{fq6_sub(a.c0, b
 ZKT_HD Fq12 fq12_neg(const Fq12& a) { return Fq12{fq6_neg(a.c0), fq6_neg(a.c1)}; }
 ZKT_HD Fq12 fq12_conj(const Fq12& a) { return Fq12{a.c0, fq6_neg(a.c1)}; }
 // fq12.rs:135-147 is 4 Fq6 products; Karatsuba (3) gives the same element
-ZKT_FQ12 Fq12 fq12_mul(const Fq12& a, const Fq12& b) {
+ZKT_HD Fq12 fq12_mul_body(const Fq12& a, const Fq12& b) {
   Fq6 v0 = FQ6_MUL12(a.c0, b.c0), v1 = FQ6_MUL12(a.c1, b.c1);
   Fq6 s = FQ6_MUL12(fq6_add(a.c0, a.c1), fq6_add(b.c0, b.c1));
   Fq12 r;
@@ -199,14 +199,16 @@ ZKT_FQ12 Fq12 fq12_mul(const Fq12& a, const Fq12& b) {
   r.c1.c0 = fq2_subsub(s.c0, v0.c0, v1.c0); r.c1.c1 = fq2_subsub(s.c1, v0.c1, v1.c1); r.c1.c2 = fq2_subsub(s.c2, v0.c2, v1.c2);
   return r;
 }
+ZKT_FQ12 Fq12 fq12_mul(const Fq12& a, const Fq12& b) { return fq12_mul_body(a, b); }
 // complex squaring: (a0 + a1 w)^2 = (a0+a1)(a0+v a1) - v0 - v v0 + 2 v0 w,  v0 = a0 a1
-ZKT_FQ12 Fq12 fq12_sqr(const Fq12& a) {
+ZKT_HD Fq12 fq12_sqr_body(const Fq12& a) {
   Fq6 v0 = FQ6_MUL12(a.c0, a.c1);
   Fq6 t = FQ6_MUL12(fq6_add(a.c0, a.c1), fq6_add(a.c0, fq6_mul_v(a.c1)));
   // (left as two-term passes: restructuring this return into three-term passes trips an AMDGPU backend error at -O1 —
   //  "Illegal instruction detected: Operand has incorrect register class ... $src_private_base" — in the verification kernels)
   return Fq12{fq6_sub(fq6_sub(t, v0), fq6_mul_v(v0)), fq6_add(v0, v0)};
 }
+ZKT_FQ12 Fq12 fq12_sqr(const Fq12& a) { return fq12_sqr_body(a); }
 ZKT_FN Fq12 fq12_inv(const Fq12& a) {                                    // fq12.rs:31-40
   Fq6 t = fq6_inv(fq6_sub(fq6_mul(a.c0, a.c0), fq6_mul_v(fq6_mul(a.c1, a.c1))));
   return Fq12{fq6_mul(a.c0, t), fq6_neg(fq6_mul(a.c1, t))};
@@ -239,7 +241,9 @@ ZKT_FQ12 Fq12 fq12_cyclotomic_sqr(const Fq12& f) {
 // n consecutive cyclotomic squarings IN PLACE (round 4).  The hard part of the final exponentiation is runs of squarings between a few products (|x| = 0xd201000000010000:
 // runs of 1, 2, 3, 9, 32 and 16; the signed digits of e1: runs of ~4).  One call per squaring read the value from per-lane scratch and wrote it back (1.3 KB per call, 315 calls
 // per pairing = 28 % of the pairing kernel's memory traffic); here the six Fq2 coefficients stay in registers for the whole run.  Same arithmetic, same element.
-ZKT_FN void fq12_cyclotomic_sqr_n(Fq12& f, int n) {
+// m (optional): the run's value is multiplied by *m before it goes back to memory — a square-and-multiply step "n squarings, one product" without the round trip between them.
+ZKT_FN void fq12_cyclotomic_sqr_n_mul(Fq12& f, int n, const Fq12* m) {
+  ZKT_FORCE_FRAME();
   Fq2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
   auto three_minus_two = [](const Fq2& t, const Fq2& z) { Fq2 d = fq2_sub(t, z); return fq2_add(fq2_dbl(d), t); };   // 3t - 2z
   auto three_plus_two = [](const Fq2& t, const Fq2& z) { Fq2 d = fq2_add(t, z); return fq2_add(fq2_dbl(d), t); };     // 3t + 2z
@@ -254,8 +258,10 @@ ZKT_FN void fq12_cyclotomic_sqr_n(Fq12& f, int n) {
     t0 = fq2_mul_xi(t3);
     z2 = three_plus_two(t0, z2); z3 = three_minus_two(t2, z3);
   }
-  f.c0 = Fq6{z0, z4, z3}; f.c1 = Fq6{z2, z1, z5};
+  Fq12 r; r.c0 = Fq6{z0, z4, z3}; r.c1 = Fq6{z2, z1, z5};
+  if (m) f = fq12_mul_body(r, *m); else f = r;
 }
+ZKT_HD void fq12_cyclotomic_sqr_n(Fq12& f, int n) { fq12_cyclotomic_sqr_n_mul(f, n, nullptr); }
 
 // Frobenius pi^K, K in {1,2}: conj^K on every Fq2 coefficient of w^i times gamma_i^(K)
 template <int K> ZKT_HD Fq2 frob_const(int idx) {
@@ -286,7 +292,7 @@ template <int K> ZKT_FN Fq12 fq12_frob(const Fq12& a) { return fq12_frob_inl<K>(
 
 // f * (a + b v^2 + c v w) with a in Fq, b,c in Fq2: the value of a Miller line at
 // an untwisted G2 point has exactly these slots (g12_point.rs:47-68).
-ZKT_FQ12 Fq12 fq12_mul_line(const Fq12& f, const Fq& a, const Fq2& b, const Fq2& c) {
+ZKT_HD Fq12 fq12_mul_line_body(const Fq12& f, const Fq& a, const Fq2& b, const Fq2& c) {
   // (x + y w)(a + b v^2 + c v w), w^2 = v, v^3 = xi:
   //   c0 = x a + x b v^2 + y c v^2         c1 = y a + x c v + y b v^2
   // The six products x_i b and y_i c serve c0; the cross terms of c1 pair up slot by slot — x2 c + y1 b, x1 c + y0 b and
@@ -306,6 +312,14 @@ ZKT_FQ12 Fq12 fq12_mul_line(const Fq12& f, const Fq& a, const Fq2& b, const Fq2&
   r.c1.c1 = fq2_add(fq2_mul_fq(y.c1, a), fq2_subsub(k1, xb0, fq2_mul_xi(yc2)));        // y1 a + x0 c + xi y2 b
   r.c1.c2 = fq2_add(fq2_mul_fq(y.c2, a), fq2_subsub(k2, xb1, yc0));                    // y2 a + x1 c + y0 b
   return r;
+}
+ZKT_FQ12 Fq12 fq12_mul_line(const Fq12& f, const Fq& a, const Fq2& b, const Fq2& c) { return fq12_mul_line_body(f, a, b, c); }
+// One Miller doubling step on the accumulator, IN PLACE: f <- f^2 * line.  As two calls the square travelled through per-lane scratch between them (672 B out, 672 B back,
+// 127 times per pairing); as one function it is the compiler's to keep (round 4, after fq12_cyclotomic_sqr_n showed what those round trips cost).
+ZKT_FN void fq12_sqr_mul_line(Fq12& f, const Fq& a, const Fq2& b, const Fq2& c) {
+  ZKT_FORCE_FRAME();
+  const Fq12 t = fq12_sqr_body(f);
+  f = fq12_mul_line_body(t, a, b, c);
 }
 
 // square-and-multiply by a run-time exponent (u32 limbs, little endian), MSB first.
