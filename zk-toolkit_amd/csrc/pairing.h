@@ -91,8 +91,7 @@ ZKT_FN Fq12 miller_g1_g2(const Fq& xp, const Fq& yp, const Fq2& xq, const Fq2& y
     fq12_sqr_mul_line(f, l.a, l.b, l.c);
     if (bit) {
       miller_add_step(V, xp, neg ? yn : yp, Xq, Yq, l);
-      ft = fq12_mul_line(f, l.a, l.b, l.c);
-      f = ft;
+      fq12_mul_line_ip(f, l.a, l.b, l.c);
     }
   }
   in_g1 = miller_pt_is_neg(V, xp, yp);
@@ -160,8 +159,7 @@ ZKT_FN Fq12 miller_g1_g2_short(const Fq& xp, const Fq& yp, const Fq2& xq, const 
     fq12_sqr_mul_line(f, l.a, l.b, l.c);
     if (bit) {
       miller_add_step(V, xp, yp, Xq, Yq, l);
-      ft = fq12_mul_line(f, l.a, l.b, l.c);
-      f = ft;
+      fq12_mul_line_ip(f, l.a, l.b, l.c);
     }
   }
   ok = miller_pt_is_x2(V, xp, yp);
@@ -187,12 +185,12 @@ ZKT_FN Fq12 miller_g1_g2_multi(const Fq* xp, const Fq* yp, const Fq2* xq, const 
     for (int k = 0; k < K; ++k) {
       miller_dbl_step(V[k], Xq[k], Yq[k], l);
       if (k == 0) fq12_sqr_mul_line(f, l.a, l.b, l.c);          // the shared squaring, fused with the first pair's line (f stays out of scratch between them)
-      else { ft = fq12_mul_line(f, l.a, l.b, l.c); f = ft; }
+      else fq12_mul_line_ip(f, l.a, l.b, l.c);
     }
     if (bit) {
       for (int k = 0; k < K; ++k) {
         miller_add_step(V[k], xp[k], neg ? yn[k] : yp[k], Xq[k], Yq[k], l);
-        ft = fq12_mul_line(f, l.a, l.b, l.c); f = ft;
+        fq12_mul_line_ip(f, l.a, l.b, l.c);
       }
     }
   }
@@ -219,12 +217,12 @@ ZKT_FN Fq12 miller_g1_g2_multi_short(const Fq* xp, const Fq* yp, const Fq2* xq, 
     for (int k = 0; k < K; ++k) {
       miller_dbl_step(V[k], Xq[k], Yq[k], l);
       if (k == 0) fq12_sqr_mul_line(f, l.a, l.b, l.c);          // the shared squaring, fused with the first pair's line (f stays out of scratch between them)
-      else { ft = fq12_mul_line(f, l.a, l.b, l.c); f = ft; }
+      else fq12_mul_line_ip(f, l.a, l.b, l.c);
     }
     if (bit) {
       for (int k = 0; k < K; ++k) {
         miller_add_step(V[k], xp[k], yp[k], Xq[k], Yq[k], l);
-        ft = fq12_mul_line(f, l.a, l.b, l.c); f = ft;
+        fq12_mul_line_ip(f, l.a, l.b, l.c);
       }
     }
   }
@@ -456,6 +454,11 @@ ZKT_HD Fq12 fq12_mul_ate_line_body(const Fq12& f, const Fq2& c0, const Fq2& c1, 
   return r;
 }
 ZKT_FQ12 Fq12 fq12_mul_ate_line(const Fq12& f, const Fq2& c0, const Fq2& c1, const Fq2& c4) { return fq12_mul_ate_line_body(f, c0, c1, c4); }
+ZKT_FN void fq12_mul_ate_line_ip(Fq12& f, const Fq2& c0, const Fq2& c1, const Fq2& c4) {      // f <- f * line in place (see fq12_mul_line_ip)
+  ZKT_FORCE_FRAME();
+  const Fq12 t = fq12_mul_ate_line_body(f, c0, c1, c4);
+  f = t;
+}
 // f <- f^2 * line in place: the 63-step loop's shared squaring fused with the first pair's line (see fq12_sqr_mul_line)
 ZKT_FN void fq12_sqr_mul_ate_line(Fq12& f, const Fq2& c0, const Fq2& c1, const Fq2& c4) {
   ZKT_FORCE_FRAME();
@@ -506,23 +509,23 @@ ZKT_FN Fq12 miller_ate_multi(const Fq* xp, const Fq* yp, const Fq2* xq, const Fq
     for (int k = 0; k < KV; ++k) {
       ate_dbl_step(T[k], l);
       if (sq) { fq12_sqr_mul_ate_line(f, fq2_mul_fq(l.a0, xp[k]), fq2_mul_fq(l.a1, yp[k]), l.c4); sq = false; }
-      else { ft = fq12_mul_ate_line(f, fq2_mul_fq(l.a0, xp[k]), fq2_mul_fq(l.a1, yp[k]), l.c4); f = ft; }
+      else fq12_mul_ate_line_ip(f, fq2_mul_fq(l.a0, xp[k]), fq2_mul_fq(l.a1, yp[k]), l.c4);
     }
     for (int j = 0; j < KF; ++j) {
       l = ld_ate_line(tab[j] + (size_t)li * ATE_LINE_WORDS);
       if (sq) { fq12_sqr_mul_ate_line(f, fq2_mul_fq(l.a0, xp[KV + j]), fq2_mul_fq(l.a1, yp[KV + j]), l.c4); sq = false; }
-      else { ft = fq12_mul_ate_line(f, fq2_mul_fq(l.a0, xp[KV + j]), fq2_mul_fq(l.a1, yp[KV + j]), l.c4); f = ft; }
+      else fq12_mul_ate_line_ip(f, fq2_mul_fq(l.a0, xp[KV + j]), fq2_mul_fq(l.a1, yp[KV + j]), l.c4);
     }
     if (sq) { ft = fq12_sqr(f); f = ft; }                                        // no pair at all (KV + KF = 0 is not instantiated; kept for completeness)
     ++li;
     if (ate_bit(i)) {                                                          // wave-uniform
       for (int k = 0; k < KV; ++k) {
         ate_add_step(T[k], xq[k], yq[k], l);
-        ft = fq12_mul_ate_line(f, fq2_mul_fq(l.a0, xp[k]), fq2_mul_fq(l.a1, yp[k]), l.c4); f = ft;
+        fq12_mul_ate_line_ip(f, fq2_mul_fq(l.a0, xp[k]), fq2_mul_fq(l.a1, yp[k]), l.c4);
       }
       for (int j = 0; j < KF; ++j) {
         l = ld_ate_line(tab[j] + (size_t)li * ATE_LINE_WORDS);
-        ft = fq12_mul_ate_line(f, fq2_mul_fq(l.a0, xp[KV + j]), fq2_mul_fq(l.a1, yp[KV + j]), l.c4); f = ft;
+        fq12_mul_ate_line_ip(f, fq2_mul_fq(l.a0, xp[KV + j]), fq2_mul_fq(l.a1, yp[KV + j]), l.c4);
       }
       ++li;
     }

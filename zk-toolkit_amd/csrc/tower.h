@@ -314,6 +314,13 @@ ZKT_HD Fq12 fq12_mul_line_body(const Fq12& f, const Fq& a, const Fq2& b, const F
   return r;
 }
 ZKT_FQ12 Fq12 fq12_mul_line(const Fq12& f, const Fq& a, const Fq2& b, const Fq2& c) { return fq12_mul_line_body(f, a, b, c); }
+// f <- f * line IN PLACE (the lines of a step after the first, and the addition steps): "ft = f * line; f = ft" wrote the product, read it back and wrote it again
+// (2.3 KB per line more than this form)
+ZKT_FN void fq12_mul_line_ip(Fq12& f, const Fq& a, const Fq2& b, const Fq2& c) {
+  ZKT_FORCE_FRAME();
+  const Fq12 t = fq12_mul_line_body(f, a, b, c);
+  f = t;
+}
 // One Miller doubling step on the accumulator, IN PLACE: f <- f^2 * line.  As two calls the square travelled through per-lane scratch between them (672 B out, 672 B back,
 // 127 times per pairing); as one function it is the compiler's to keep (round 4, after fq12_cyclotomic_sqr_n showed what those round trips cost).
 ZKT_FN void fq12_sqr_mul_line(Fq12& f, const Fq& a, const Fq2& b, const Fq2& c) {
