@@ -260,8 +260,9 @@ ZKT_HD Fq12 fq12_pow_x(const Fq12& a) { return fq12_conj(fq12_pow_xabs(a)); }
 // a^e1, e1 = (x-1)^2/3, a in the cyclotomic subgroup: width-3 signed digits {0, +-1, +-3} (a^-1 = conj(a)), 126 Granger-Scott squarings
 // and 30 products (+ a^3) instead of the 47 products of the binary chain
 ZKT_FN Fq12 fq12_pow_e1(const Fq12& a) {
-  Fq12 a3, r, t, m;
+  Fq12 a3, r, t, ac, a3c;
   t = fq12_cyclotomic_sqr(a); a3 = fq12_mul(t, a);
+  ac = fq12_conj(a); a3c = fq12_conj(a3);                         // the four multipliers once, so that a digit hands over a POINTER (a copy + a conjugation per digit were ~3 KB of traffic each)
   bool started = false; int run = 0;                              // squarings owed, done as one in-register run (fq12_cyclotomic_sqr_n)
   for (int i = 0; i < E1_WNAF_DIGITS; ++i) {
     uint32_t nz = 0, ng = 0, th = 0;
@@ -269,9 +270,9 @@ ZKT_FN Fq12 fq12_pow_e1(const Fq12& a) {
     for (int j = 0; j < 4; ++j) { nz = (j == (i >> 5)) ? e1_wnaf_nz_word(j) : nz; ng = (j == (i >> 5)) ? e1_wnaf_neg_word(j) : ng; th = (j == (i >> 5)) ? e1_wnaf_three_word(j) : th; }
     if (started) ++run;
     if ((nz >> (i & 31)) & 1) {                                   // wave-uniform (compile-time tables)
-      m = ((th >> (i & 31)) & 1) ? a3 : a;
-      if ((ng >> (i & 31)) & 1) m = fq12_conj(m);
-      if (started) { fq12_cyclotomic_sqr_n_mul(r, run, &m); run = 0; } else { r = m; started = true; }
+      const bool three = (th >> (i & 31)) & 1, neg = (ng >> (i & 31)) & 1;
+      const Fq12* m = three ? (neg ? &a3c : &a3) : (neg ? &ac : &a);
+      if (started) { fq12_cyclotomic_sqr_n_mul(r, run, m); run = 0; } else { r = *m; started = true; }
     }
   }
   if (run) fq12_cyclotomic_sqr_n(r, run);
@@ -294,11 +295,11 @@ template <bool SHORT> ZKT_FN Fq12 final_exponentiation_t(const Fq12& f) {
   a = fq12_mul(t, g);                      // ^(q^2+1): easy part, now in a
   g = a;
   a = fq12_pow_e1(g);                      // ^e1
-  t = fq12_pow_xabs(a); t = fq12_conj(t);  // a^x (x < 0: conjugate = inverse in the cyclotomic subgroup)
+  t = fq12_pow_xabs(a); fq12_conj_ip(t);  // a^x (x < 0: conjugate = inverse in the cyclotomic subgroup)
   b = fq12_frob_inl<1>(a);
   a = fq12_mul(t, b);                      // a := ^(x+q)
-  t = fq12_pow_xabs(a); t = fq12_conj(t);
-  b = fq12_pow_xabs(t); b = fq12_conj(b);  // b = a^(x^2)
+  t = fq12_pow_xabs(a); fq12_conj_ip(t);
+  b = fq12_pow_xabs(t); fq12_conj_ip(b);  // b = a^(x^2)
   t = fq12_frob<2>(a);
   b = fq12_mul(b, t) ;                     // (aliasing a source here costs one temporary; kept for clarity)
   t = fq12_conj(a);
@@ -325,17 +326,17 @@ ZKT_FN Fq12 final_exponentiation_3h(const Fq12& f) {
   t = fq12_frob<2>(g);
   a = fq12_mul(t, g);                      // ^(q^2+1): easy part
   g = a;
-  t = fq12_pow_xabs(g); t = fq12_conj(t);  // g^x
+  t = fq12_pow_xabs(g); fq12_conj_ip(t);  // g^x
   b = fq12_conj(g);
   a = fq12_mul(t, b);                      // g^(x-1)
-  t = fq12_pow_xabs(a); t = fq12_conj(t);
+  t = fq12_pow_xabs(a); fq12_conj_ip(t);
   b = fq12_conj(a);
   a = fq12_mul(t, b);                      // g^((x-1)^2)
-  t = fq12_pow_xabs(a); t = fq12_conj(t);
+  t = fq12_pow_xabs(a); fq12_conj_ip(t);
   b = fq12_frob_inl<1>(a);                 // inlined: this function keeps a base pointer (see final_exponentiation_t)
   a = fq12_mul(t, b);                      // ^(x+q)
-  t = fq12_pow_xabs(a); t = fq12_conj(t);
-  b = fq12_pow_xabs(t); b = fq12_conj(b);  // a^(x^2)
+  t = fq12_pow_xabs(a); fq12_conj_ip(t);
+  b = fq12_pow_xabs(t); fq12_conj_ip(b);  // a^(x^2)
   t = fq12_frob<2>(a);
   b = fq12_mul(b, t);
   t = fq12_conj(a);

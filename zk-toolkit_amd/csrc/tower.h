@@ -190,6 +190,7 @@ ZKT_HD Fq12 fq12_add(const Fq12& a, const Fq12& b) { return Fq12{fq6_add(a.c0, b
 ZKT_HD Fq12 fq12_sub(const Fq12& a, const Fq12& b) { return Fq12{fq6_sub(a.c0, b.c0), fq6_sub(a.c1, b.c1)}; }
 ZKT_HD Fq12 fq12_neg(const Fq12& a) { return Fq12{fq6_neg(a.c0), fq6_neg(a.c1)}; }
 ZKT_HD Fq12 fq12_conj(const Fq12& a) { return Fq12{a.c0, fq6_neg(a.c1)}; }
+ZKT_HD void fq12_conj_ip(Fq12& a) { a.c1 = fq6_neg(a.c1); }      // in place: only the w-half moves
 // fq12.rs:135-147 is 4 Fq6 products; Karatsuba (3) gives the same element
 ZKT_HD Fq12 fq12_mul_body(const Fq12& a, const Fq12& b) {
   Fq6 v0 = FQ6_MUL12(a.c0, b.c0), v1 = FQ6_MUL12(a.c1, b.c1);
