@@ -327,54 +327,11 @@ static __global__ void __launch_bounds__(256) k_scan_final(const uint32_t* __res
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < m) out[base + k] = run; run += v[k]; }
 }
-// Small sets: ONE block scans the whole array (m <= SCAN1_MAX counters, 128 per thread at most) — one launch instead of three.  A small MSM is a graph of kernel nodes
-// that reach the queue one by one at 10-20 us each, so for the latency-bound protocols (range proof, small Groth16 / Pinocchio keys) a node is worth more
-// than the ~10 us of lost parallelism.  CHUNK > 0: the input is bucket COUNTS and the scanned quantity is the task count of each bucket (k_task_count fused in:
-// ntask[] and the size histogram are written on the way).
-static constexpr int SCAN1_TPB = 1024; static constexpr size_t SCAN1_MAX = (size_t)SCAN1_TPB * 128;
-__device__ inline uint32_t ntasks_of(uint32_t c, uint32_t chunk);
-__device__ inline uint32_t task_size_of(uint32_t c, uint32_t nt);
-template <bool TASKS>
-static __global__ void __launch_bounds__(SCAN1_TPB) k_scan_one_block(const uint32_t* __restrict__ in, size_t m, uint32_t* __restrict__ out, uint32_t chunk,
-                                                                     uint32_t* __restrict__ ntask, uint32_t* __restrict__ hist, int bins, int max_chunk) {
-  ZKT_SIDE_PRIO;
-  // tiles of 4 x 1024 counters, four ADJACENT counters per thread (coalesced; a first version gave every thread one long contiguous range — 64 lines per wave-load — and
-  // took ~125 us per scan: the 2^17-term MSM went from 1.25 to 1.51 ms); per tile a wave-shuffle scan, the sixteen wave totals through LDS, a running carry
-  __shared__ uint32_t wsum[16], h[160], carry_s;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  if (TASKS) { for (int i = t; i < bins; i += SCAN1_TPB) h[i] = 0; }
-  if (t == 0) carry_s = 0;
-  __syncthreads();
-  for (size_t base = 0; base < m; base += 4 * SCAN1_TPB) {
-    const size_t i0 = base + 4 * (size_t)t;
-    uint32_t v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      v[k] = i0 + k < m ? in[i0 + k] : 0u;
-      if (TASKS && i0 + k < m) { const uint32_t nt = ntasks_of(v[k], chunk); atomicAdd(&h[max_chunk - task_size_of(v[k], nt)], nt); v[k] = nt; ntask[i0 + k] = nt; }
-    }
-    const uint32_t s4 = v[0] + v[1] + v[2] + v[3];
-    uint32_t inc = s4;                                             // inclusive scan over the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d); if (lane >= d) inc += x; }
-    if (lane == 63) wsum[wv] = inc;
-    __syncthreads();
-    uint32_t wpre = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { const uint32_t x = wsum[k]; if (k < wv) wpre += x; total += x; }
-    uint32_t run = carry_s + wpre + inc - s4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { if (i0 + k < m) out[i0 + k] = run; run += v[k]; }
-    __syncthreads();                                               // everybody has read carry_s and wsum
-    if (t == 0) carry_s += total;
-    __syncthreads();
-  }
-  if (t == 0) out[m] = carry_s;
-  if (TASKS) { for (int i = t; i < bins; i += SCAN1_TPB) hist[i] = h[i]; }
-}
+// (Round 4 measured ONE block scanning a small set's counters — and the task count fused into that scan — to save kernel nodes of a small MSM's graph: the one-block scan of
+//  65,536 counters takes 40 us against 18 us for the three kernels below plus their launch gaps, and the 2^17-term MSM, the range proof and the small Groth16 keys did not move
+//  (1.28 ms, 3.3-3.6 ms, 2.5 ms).  Taken out again: a node of a replayed graph does not cost what DESIGN §9 (round 3) assumed.)
 // out[0..m) = exclusive scan of in, out[m] = total.  scratch: >= ceil(m/2048) words
 static void launch_scan(const uint32_t* in, uint32_t* out, size_t m, uint32_t* scratch, hipStream_t s) {
-  if (m <= SCAN1_MAX) { hipLaunchKernelGGL(k_scan_one_block<false>, dim3(1), dim3(SCAN1_TPB), 0, s, in, m, out, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, 0, 0); return; }
   int nblk = (int)((m + SCAN_TILE - 1) / SCAN_TILE);
   hipLaunchKernelGGL(k_scan_sums, dim3(nblk), dim3(256), 0, s, in, m, scratch);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, scratch, nblk, out + m);
@@ -790,13 +747,8 @@ hipError_t PART(launch_msm_sort)(const MsmPlan& P, const uint8_t* inf, const uin
     if ((e = launch_msm_affine_final_layer(w.offsets, B, P.aff_rounds, aw, s)) != hipSuccess) return e;
     task_counts = aw.cntR;
   }
-  if (B <= SCAN1_MAX) {                    // small sets: task counts, their histogram and their scan in ONE launch
-    static_assert(SIZE_BINS <= 160, "k_scan_one_block keeps the size histogram in 160 LDS words");
-    hipLaunchKernelGGL(k_scan_one_block<true>, dim3(1), dim3(SCAN1_TPB), 0, s, task_counts, B, w.task_off, P.chunk, w.ntask, w.size_hist, SIZE_BINS, (int)CHUNK);
-  } else {
-    hipLaunchKernelGGL(k_task_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, task_counts, B, P.chunk, w.ntask, w.size_hist);
-    launch_scan(w.ntask, w.task_off, B, w.scan_tmp, s);
-  }
+  hipLaunchKernelGGL(k_task_count, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, task_counts, B, P.chunk, w.ntask, w.size_hist);
+  launch_scan(w.ntask, w.task_off, B, w.scan_tmp, s);
   hipLaunchKernelGGL(k_task_scatter, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, task_counts, B, P.chunk, (const uint32_t*)w.size_hist, w.size_cur, w.order, w.hot);
   return hipGetLastError();
 }
