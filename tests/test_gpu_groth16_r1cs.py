@@ -105,12 +105,12 @@ def _g2_gen_c0c1():
     return ((x0, x1), (y0, y1))
 
 
-@pytest.mark.parametrize("n", [1000, 1 << 16])
+@pytest.mark.parametrize("n", [1000, 4097, 1 << 16])
 def test_r1cs_proof_points_equal_python_integer_multiples(L, n):
     """Beyond the oracle's reach (its dense prover is O(m n)) the proof POINTS are still checkable: with the trapdoor injected the discrete logarithms of
     A, B, C are O(n) python-integer arithmetic (qap_util.groth16_proof_scalars, checked against the coefficient-form prover on the CPU by
     tests/test_r1cs_domain_math.py), and the points are those multiples of the generators in python integers — no HIP code and no oracle code on the
-    checking side (prover.rs:96-147, crs.rs:49-146)."""
+    checking side (prover.rs:96-147, crs.rs:49-146).  n = 4097: the unsharded quotient needs 4096 values, i.e. TWO input blocks of 4096 (the second holds one value)."""
     mats, wires, l, m = chain_circuit_sparse(n, seed=23)
     rng = SplitMix64(4321 + n)
     trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
@@ -125,11 +125,13 @@ def test_r1cs_proof_points_equal_python_integer_multiples(L, n):
     assert (gp[2] == g1_arr([py_g1_mul(G1_GEN, Cs)])).all(), "C"
 
 
-def test_r1cs_sharded_proof_equals_unsharded(L):
-    """BASELINE config 4 on one card: three shards of the resident base sets, each produces its three Jacobian partials; summing
-    them (the all_gather + combine step of the multi-GPU run) gives the unsharded proof bit for bit."""
+@pytest.mark.parametrize("n,shards", [(200, 3), (3000, 5), (2500, 8), (12, 11)])
+def test_r1cs_sharded_proof_equals_unsharded(L, n, shards):
+    """BASELINE config 4 on one card: the shards of the resident base sets each produce their three Jacobian partials; summing
+    them (the all_gather + combine step of the multi-GPU run) gives the unsharded proof bit for bit.  Every rank evaluates only its own
+    range of the quotient's values (blocked convolution, csrc/zkt_groth16_r1cs.hip k_recip_blocks): (200, 3) is one input block per rank,
+    (3000, 5) three blocks of 1024 with a ragged last one, (2500, 8) likewise with eight ranks, (12, 11) ranges of one term (one quotient value per rank)."""
     import torch
-    n, shards = 200, 3
     mats, wires, l, m = chain_circuit_sparse(n, seed=5)
     rng = SplitMix64(999)
     trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]

@@ -173,10 +173,20 @@ __global__ void __launch_bounds__(256) k_hbasis(const uint32_t* __restrict__ con
   st_fp<C>(hb_canon + i * FW, fp_mul(fp_mul(ldm(consts + K_HB * FW), ldm(xinv + (n + i) * FW)), c));
   stm(P + i * FW, fp_mul(ldm(fact + (n + i) * FW), ldm(invfact + i * FW)));
 }
-// convolution kernel g[d] = 1/d = (d-1)!/d!, d = 1..2n-1; g[0] = 0 and zero padding up to N
-__global__ void __launch_bounds__(256) k_recip(const uint32_t* __restrict__ fact, const uint32_t* __restrict__ invfact, size_t n, size_t N, uint32_t* __restrict__ g) {
-  size_t d = (size_t)blockIdx.x * 256 + threadIdx.x; if (d >= N) return;
-  stm(g + d * FW, (d >= 1 && d <= 2 * n - 1) ? fp_mul(ldm(fact + (d - 1) * FW), ldm(invfact + d * FW)) : fp_zero<C>());
+// The quotient's convolution, cut into blocks (overlap-save).  A rank needs S_p(s) = sum_{j=1..n} f_j / (n+s-j) for the `cnt` values
+// s = s0 .. s0+cnt-1 whose bases [Lambda_s t/delta] it holds.  The inputs j = 1..n are cut into Q blocks of Bi (a power of two >= cnt); block q meets the
+// kernel slice g[base_q + e], base_q = n + s0 - 1 - q Bi, e = -(Bi-1) .. cnt-1, in a cyclic convolution of size M = 2 Bi (negative e at M + e), and the Q
+// products are summed in the spectrum, so a rank runs Q forward transforms of size M per polynomial and ONE inverse — no exchange between ranks, and with
+// one rank (cnt = n-1, Q = 1, M >= 2n) exactly the single convolution of size >= 2n.  g[d] = 1/d = (d-1)!/d! for 1 <= d <= 2n-1, 0 elsewhere (d <= 0 only
+// ever meets the zero padding of the last block).  Layout [q][M].
+__global__ void __launch_bounds__(256) k_recip_blocks(const uint32_t* __restrict__ fact, const uint32_t* __restrict__ invfact, size_t n, size_t s0, size_t cnt,
+                                                      size_t Bi, size_t Q, uint32_t* __restrict__ g) {
+  const size_t M = 2 * Bi, i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= Q * M) return;
+  const size_t q = i / M, e = i % M;
+  const long long base = (long long)(n + s0 - 1) - (long long)(q * Bi);
+  long long d = 0;
+  if (e < cnt) d = base + (long long)e; else if (e > M - Bi) d = base - (long long)(M - e);
+  stm(g + i * FW, (d >= 1 && d <= (long long)(2 * n - 1)) ? fp_mul(ldm(fact + (d - 1) * FW), ldm(invfact + d * FW)) : fp_zero<C>());
 }
 // y_i = (beta u_i(x) + alpha v_i(x) + w_i(x)) / (gamma | delta), canonical  (crs.rs:66-84)
 __global__ void __launch_bounds__(256) k_uvw(const uint32_t* __restrict__ consts, const uint32_t* __restrict__ ue, const uint32_t* __restrict__ ve, const uint32_t* __restrict__ we,
@@ -193,13 +203,16 @@ __global__ void __launch_bounds__(256) k_uvw(const uint32_t* __restrict__ consts
 // consecutive radix-2 stages (butterfly distances 2^lo .. 2^(lo+cnt-1)) on a tile of 2^cnt strided rows x 2^cbits
 // adjacent columns (<= 1024 elements, 32 KB), every element read and written once per launch, rows of >= 128 B contiguous.
 // logN = 21 is three launches per transform (10 + 8 + 3 stages) instead of 21.
+// A launch covers any number of transforms of the same size: consecutive ones simply continue blockIdx.x (the twiddle of a butterfly depends on its position
+// inside its group only), blockIdx.y steps over arrays `ystride` elements apart.  `mulvec` is indexed like the consecutive transforms of one array.
 // (one-wave workgroups for the transform were measured at the end of round 3, in case its four-wave workgroups were what starved beside an accumulate grid: 9.1 ms against 7.6
 // for a shard of a proof, 40 against 50 proofs/s on one GPU — not that)
 static constexpr int NTT_TILE_LOG = 10, NTT_TPB = 256;
 template <bool DIF>
 __global__ void __launch_bounds__(NTT_TPB) k_ntt_group(uint32_t* __restrict__ a, int logN, int lo, int cnt, int cbits, const uint32_t* __restrict__ tw,
-                                                       const uint32_t* __restrict__ mulvec) {
+                                                       const uint32_t* __restrict__ mulvec, size_t ystride) {
   __shared__ uint32_t lds[(1 << NTT_TILE_LOG) * FW];
+  a += (size_t)blockIdx.y * ystride * FW;                         // grid.y: independent arrays (the three polynomials), sharing `mulvec`
   const int tile = 1 << (cnt + cbits), cmask = (1 << cbits) - 1;
   const size_t tiles_per_hi = (size_t)1 << (lo - cbits);
   const size_t hi = blockIdx.x / tiles_per_hi, c0 = (blockIdx.x % tiles_per_hi) << cbits;
@@ -241,18 +254,28 @@ __global__ void __launch_bounds__(256) k_scale_all(uint32_t* __restrict__ a, con
 }
 
 // ---- prover Fr stage -----------------------------------------------------------------------------------------
-// f[0] = 0, f[j] = p(j) / t'(j) for j = 1..n, zero up to N
-__global__ void __launch_bounds__(256) k_prep_f(const uint32_t* __restrict__ pz, const uint32_t* __restrict__ cinv, size_t n, size_t N, uint32_t* __restrict__ f) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= N) return;
-  stm(f + i * FW, (i >= 1 && i <= n) ? fp_mul(ldm(pz + (i - 1) * FW), ldm(cinv + (i - 1) * FW)) : fp_zero<C>());
+// X[p][q][e] = f_p(q Bi + 1 + e) = p(j) / t'(j) at j = q Bi + 1 + e for e < Bi and j <= n, zero elsewhere (the second half of every block of M = 2 Bi, the tail of the last block)
+__global__ void __launch_bounds__(256) k_prep_blocks(const uint32_t* __restrict__ z0, const uint32_t* __restrict__ z1, const uint32_t* __restrict__ z2,
+                                                     const uint32_t* __restrict__ cinv, size_t n, size_t Bi, size_t Q, uint32_t* __restrict__ X) {
+  const size_t M = 2 * Bi, i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= Q * M) return;
+  const size_t q = i / M, e = i % M, j0 = q * Bi + e;            // j - 1
+  const uint32_t* z = blockIdx.y == 0 ? z0 : blockIdx.y == 1 ? z1 : z2;
+  stm(X + ((size_t)blockIdx.y * Q * M + i) * FW, (e < Bi && j0 < n) ? fp_mul(ldm(z + j0 * FW), ldm(cinv + j0 * FW)) : fp_zero<C>());
 }
-// h(n+s) = (P Sa * P Sb - P Sc) / t(n+s) with t(n+s) = P  =>  P Sa Sb - Sc,  s = 1..n-1, canonical for the MSM
-__global__ void __launch_bounds__(256) k_hvals(const uint32_t* __restrict__ Sa, const uint32_t* __restrict__ Sb, const uint32_t* __restrict__ Sc,
-                                               const uint32_t* __restrict__ P, size_t n, uint32_t* __restrict__ h_canon) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i + 1 >= n) return;
-  size_t k = n + 1 + i;
-  Fr h = fp_sub(fp_mul(fp_mul(ldm(P + i * FW), ldm(Sa + k * FW)), ldm(Sb + k * FW)), ldm(Sc + k * FW));
-  st_fp<C>(h_canon + i * FW, h);
+// the Q block spectra (already multiplied by their kernel spectra) summed into block 0 of every polynomial
+__global__ void __launch_bounds__(256) k_sum_blocks(uint32_t* __restrict__ X, size_t M, size_t Q) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; if (e >= M) return;
+  uint32_t* x = X + ((size_t)blockIdx.y * Q * M + e) * FW;
+  Fr acc = ldm(x);
+  for (size_t q = 1; q < Q; ++q) acc = fp_add(acc, ldm(x + q * M * FW));
+  stm(x, acc);
+}
+// h(n+s) = (P Sa * P Sb - P Sc) / t(n+s) with t(n+s) = P  =>  P Sa Sb - Sc,  s = s0 + i, i < cnt, canonical for the MSM.  S_p(s0 + i) = X[p][0][i]; P and h are indexed by s - 1.
+__global__ void __launch_bounds__(256) k_hvals(const uint32_t* __restrict__ X, size_t pstride, const uint32_t* __restrict__ P, size_t s0, size_t cnt, uint32_t* __restrict__ h_canon) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i >= cnt) return;
+  const size_t k = s0 - 1 + i;
+  Fr h = fp_sub(fp_mul(fp_mul(ldm(P + k * FW), ldm(X + i * FW)), ldm(X + (pstride + i) * FW)), ldm(X + (2 * pstride + i) * FW));
+  st_fp<C>(h_canon + k * FW, h);
 }
 // scalar vectors of the three MSMs (canonical).  rs = {r, s} canonical.
 //   sA = [Az | 1 | r]   sB = [Bz | 1 | s]   sC = [s Az + r Bz | wires[l+1..m] | s | r | r s || h]   (C1 || C2; h is written in place by k_hvals)
@@ -328,18 +351,19 @@ int ntt_groups(int logN, NttGroup* g) {
   }
   return k;
 }
-// forward: natural -> bit-reversed; if `mulvec`, the spectrum is multiplied by it on the way out
-int ntt_forward(uint32_t* a, int logN, const uint32_t* tw, const uint32_t* mulvec, hipStream_t s) {
+// forward: natural -> bit-reversed; if `mulvec`, the spectrum is multiplied by it on the way out.  `batch` consecutive transforms per array, `ny` arrays `ystride` elements apart.
+int ntt_forward(uint32_t* a, int logN, const uint32_t* tw, const uint32_t* mulvec, hipStream_t s, size_t batch = 1, unsigned ny = 1, size_t ystride = 0) {
   NttGroup g[8]; const int k = ntt_groups(logN, g);
   for (int i = k - 1; i >= 0; --i)
-    hipLaunchKernelGGL(k_ntt_group<true>, dim3((unsigned)(((size_t)1 << logN) >> (g[i].cnt + g[i].cbits))), dim3(NTT_TPB), 0, s, a, logN, g[i].lo, g[i].cnt, g[i].cbits, tw,
-                       i == 0 ? mulvec : (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_ntt_group<true>, dim3((unsigned)((batch << logN) >> (g[i].cnt + g[i].cbits)), ny), dim3(NTT_TPB), 0, s, a, logN, g[i].lo, g[i].cnt, g[i].cbits, tw,
+                       i == 0 ? mulvec : (const uint32_t*)nullptr, ystride);
   RCHK(hipGetLastError()); return ZKT_OK;
 }
-int ntt_inverse(uint32_t* a, int logN, const uint32_t* twinv, hipStream_t s) {
+int ntt_inverse(uint32_t* a, int logN, const uint32_t* twinv, hipStream_t s, size_t batch = 1, unsigned ny = 1, size_t ystride = 0) {
   NttGroup g[8]; const int k = ntt_groups(logN, g);
   for (int i = 0; i < k; ++i)
-    hipLaunchKernelGGL(k_ntt_group<false>, dim3((unsigned)(((size_t)1 << logN) >> (g[i].cnt + g[i].cbits))), dim3(NTT_TPB), 0, s, a, logN, g[i].lo, g[i].cnt, g[i].cbits, twinv, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_ntt_group<false>, dim3((unsigned)((batch << logN) >> (g[i].cnt + g[i].cbits)), ny), dim3(NTT_TPB), 0, s, a, logN, g[i].lo, g[i].cnt, g[i].cbits, twinv,
+                       (const uint32_t*)nullptr, ystride);
   RCHK(hipGetLastError()); return ZKT_OK;
 }
 void spmv(const Csr& M, const uint32_t* vec, uint32_t* out, hipStream_t s) {
@@ -382,7 +406,9 @@ int upload_csr(const zkt_sparse_rows* M, size_t n, size_t cols, Csr& rowwise, Cs
 }  // namespace
 
 struct zkt_groth16_pk {
-  size_t n = 0, l = 0, m = 0, N = 0; int logN = 0;
+  size_t n = 0, l = 0, m = 0;
+  // the quotient's blocked convolution (k_recip_blocks): this rank's cnt = hiC2 - loC2 values h(n+s), s = qs0 .. qs0+cnt-1, from Q input blocks of Bi, transforms of size M = 2 Bi
+  size_t qcnt = 0, qs0 = 1, Bi = 1, M = 2, Q = 1; int logM = 1;
   Csr A, B, Cm;                                  // constraint rows (device), values in Montgomery form
   DBuf cinv, P, ghat, tw, twinv;                  // Fr tables
   zkt_g1_bases *setA = nullptr, *setC1 = nullptr, *setC2 = nullptr; zkt_g2_bases* setB = nullptr;   // the resident base sets (see the file header)
@@ -393,7 +419,7 @@ struct zkt_groth16_pk {
   // per-proof work buffers.  The MSM scalar vectors (and r, s) are double-buffered: proof k+1's Fr stage may run while the MSMs of proof k
   // are still reading theirs (zkt_groth16_prove_r1cs_submit / _collect); everything else is consumed in stream order before it is rewritten.
   static constexpr int PSLOTS = 2;
-  DBuf wires_c, wires_m, z_m[3], f[3], sA[PSLOTS], sB[PSLOTS], sC[PSLOTS], rs[PSLOTS];
+  DBuf wires_c, wires_m, z_m[3], X, sA[PSLOTS], sB[PSLOTS], sC[PSLOTS], rs[PSLOTS];       // X[p][q][M]: the block spectra of a, b, c
   bool pending[PSLOTS] = {false, false};
   hipStream_t s = nullptr, sq = nullptr;        // the key's stream (head of the Fr stage, collection) and the quotient stage's own (three transform pairs; high priority)
   hipEvent_t e_head = nullptr, e_q = nullptr;   // (A w), (B w), (C w) and the scalar vectors are ready / the quotient stage has consumed them
@@ -414,8 +440,9 @@ extern void zkt_internal_set_error_index(size_t i);
 extern "C" {
 
 // Multi-GPU form (BASELINE config 4): rank `shard` of `nshards` keeps a contiguous index range of each of the three base
-// sets resident; the Fr stage of a proof is replicated (it is ~10 % of the work), the three MSMs run on the shard, and the only
-// exchange is an all_gather of the three Jacobian partials followed by zkt_g{1,2}_jac_sum_dev.
+// sets resident and runs the three MSMs on them.  The Fr stage needs no exchange either: the mat-vecs are replicated (75 us), and of the quotient every rank
+// evaluates only the h(n+s) whose bases it holds — W forward transforms of size 2n/W per polynomial and ONE inverse instead of a forward and an inverse of
+// size 2n (k_recip_blocks).  The only exchange is an all_gather of the three Jacobian partials followed by zkt_g{1,2}_jac_sum_dev.
 int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_sparse_rows* A, const zkt_sparse_rows* B, const zkt_sparse_rows* Cmat,
                                    const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma, const uint64_t* delta, const uint64_t* x,
                                    size_t shard, size_t nshards, zkt_groth16_crs* vk, zkt_groth16_pk** out) {
@@ -428,8 +455,14 @@ int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_spars
   std::unique_ptr<zkt_groth16_pk> pk(new zkt_groth16_pk);
   pk->n = n; pk->l = l; pk->m = m;
   const size_t rows = m + 1;
-  int logN = 1; while (((size_t)1 << logN) < 2 * n) ++logN;
-  const size_t N = (size_t)1 << logN; pk->N = N; pk->logN = logN;
+  const size_t nw = m - l, nh = n >= 2 ? n - 1 : 0, nA = n + 2, nC1 = n + nw + 3, nC2 = nh, nC = nC1 + nC2;
+  pk->nA = nA; pk->nC1 = nC1; pk->nC2 = nC2; pk->shard = shard; pk->nshards = nshards;
+  auto range = [&](size_t tot, size_t& lo, size_t& hi) { size_t base = tot / nshards, extra = tot % nshards; lo = shard * base + (shard < extra ? shard : extra); hi = lo + base + (shard < extra ? 1 : 0); };
+  range(nA, pk->loA, pk->hiA); range(nC1, pk->loC1, pk->hiC1); range(nC2, pk->loC2, pk->hiC2);
+  pk->qcnt =pk->hiC2 - pk->loC2; pk->qs0 = pk->loC2 + 1;
+  int logM = 1; while (((size_t)1 << (logM - 1)) < pk->qcnt || (logM <= 10 && ((size_t)1 << (logM - 1)) < n)) ++logM;      // Bi >= cnt; not below min(n, 1024) (many ranks on a small circuit)
+  const size_t M = (size_t)1 << logM, Bi = M / 2, Q = pk->qcnt ? (n + Bi - 1) / Bi : 1, QM = Q * M;
+  pk->logM = logM; pk->M = M; pk->Bi = Bi; pk->Q = Q;
   { int lo = 0, hi = 0; RCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     RCHK(hipStreamCreateWithFlags(&pk->s, hipStreamNonBlocking)); RCHK(hipStreamCreateWithPriority(&pk->sq, hipStreamNonBlocking, hi));
     RCHK(hipEventCreateWithFlags(&pk->e_head, hipEventDisableTiming)); RCHK(hipEventCreateWithFlags(&pk->e_q, hipEventDisableTiming)); }
@@ -438,15 +471,15 @@ int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_spars
   ZCHK(upload_csr(A, n, rows, pk->A, At, s)); ZCHK(upload_csr(B, n, rows, pk->B, Bt, s)); ZCHK(upload_csr(Cmat, n, rows, pk->Cm, Ct, s));
 
   // ---- Fr tables ----
-  DBuf dtrap, consts, fact, invfact, xm, pre, xinv, Lm, Lc, hbc, g, derr;
+  DBuf dtrap, consts, fact, invfact, xm, pre, xinv, Lm, Lc, hbc, derr;
   ZCHK(dtrap.alloc(160)); ZCHK(consts.alloc(K_COUNT * FRB)); ZCHK(fact.alloc((2 * n + 1) * FRB)); ZCHK(invfact.alloc((2 * n + 1) * FRB));
   ZCHK(xm.alloc((2 * n) * FRB)); ZCHK(pre.alloc((2 * n) * FRB)); ZCHK(xinv.alloc((2 * n) * FRB)); ZCHK(Lm.alloc(n * FRB)); ZCHK(Lc.alloc(n * FRB));
-  ZCHK(hbc.alloc(n * FRB)); ZCHK(g.alloc(N * FRB)); ZCHK(derr.alloc(8));
-  ZCHK(pk->cinv.alloc(n * FRB)); ZCHK(pk->P.alloc(n * FRB)); ZCHK(pk->ghat.alloc(N * FRB)); ZCHK(pk->tw.alloc(N / 2 * FRB)); ZCHK(pk->twinv.alloc(N / 2 * FRB));
+  ZCHK(hbc.alloc(n * FRB)); ZCHK(derr.alloc(8));
+  ZCHK(pk->cinv.alloc(n * FRB)); ZCHK(pk->P.alloc(n * FRB)); ZCHK(pk->ghat.alloc(QM * FRB)); ZCHK(pk->tw.alloc(M / 2 * FRB)); ZCHK(pk->twinv.alloc(M / 2 * FRB));
   unsigned long long noerr = NO_ERR;
   RCHK(hipMemcpyAsync(derr.p, &noerr, 8, hipMemcpyHostToDevice, s));
   RCHK(hipMemcpyAsync(dtrap.p, trap, 160, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_setup_consts, dim3(1), dim3(64), 0, s, (const uint32_t*)dtrap.w(), consts.w(), logN);
+  hipLaunchKernelGGL(k_setup_consts, dim3(1), dim3(64), 0, s, (const uint32_t*)dtrap.w(), consts.w(), logM);
   hipLaunchKernelGGL(k_iota, dim3(nb(2 * n + 1)), dim3(256), 0, s, fact.w(), 2 * n + 1);
   ZCHK(scan_mul(fact.w(), fact.w(), 2 * n + 1, s));
   hipLaunchKernelGGL(k_inv, dim3(nb(2 * n + 1)), dim3(256), 0, s, (const uint32_t*)fact.w(), invfact.w(), 2 * n + 1, (unsigned long long*)derr.p);
@@ -460,15 +493,15 @@ int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_spars
   hipLaunchKernelGGL(k_setup_consts2, dim3(1), dim3(64), 0, s, (const uint32_t*)pre.w(), n, consts.w());
   hipLaunchKernelGGL(k_lagrange, dim3(nb(n)), dim3(256), 0, s, (const uint32_t*)consts.w(), (const uint32_t*)invfact.w(), (const uint32_t*)xinv.w(), n, pk->cinv.w(), Lm.w(), Lc.w());
   if (n >= 2) hipLaunchKernelGGL(k_hbasis, dim3(nb(n - 1)), dim3(256), 0, s, (const uint32_t*)consts.w(), (const uint32_t*)fact.w(), (const uint32_t*)invfact.w(), (const uint32_t*)xinv.w(), n, hbc.w(), pk->P.w());
-  hipLaunchKernelGGL(k_recip, dim3(nb(N)), dim3(256), 0, s, (const uint32_t*)fact.w(), (const uint32_t*)invfact.w(), n, N, g.w());
-  // twiddles: w^k and w^-k, k < N/2, as prefix products
-  hipLaunchKernelGGL(k_fill_pow, dim3(nb(N / 2)), dim3(256), 0, s, (const uint32_t*)(consts.w() + K_OMEGA * FW), pk->tw.w(), N / 2);
-  ZCHK(scan_mul(pk->tw.w(), pk->tw.w(), N / 2, s));
-  hipLaunchKernelGGL(k_fill_pow, dim3(nb(N / 2)), dim3(256), 0, s, (const uint32_t*)(consts.w() + K_OMEGA_INV * FW), pk->twinv.w(), N / 2);
-  ZCHK(scan_mul(pk->twinv.w(), pk->twinv.w(), N / 2, s));
-  RCHK(hipMemcpyAsync(pk->ghat.p, g.p, N * FRB, hipMemcpyDeviceToDevice, s));
-  ZCHK(ntt_forward(pk->ghat.w(), logN, pk->tw.w(), nullptr, s));
-  hipLaunchKernelGGL(k_scale_all, dim3(nb(N)), dim3(256), 0, s, pk->ghat.w(), (const uint32_t*)(consts.w() + K_NINV * FW), N);
+  // twiddles: w^k and w^-k, k < M/2, as prefix products
+  hipLaunchKernelGGL(k_fill_pow, dim3(nb(M / 2)), dim3(256), 0, s, (const uint32_t*)(consts.w() + K_OMEGA * FW), pk->tw.w(), M / 2);
+  ZCHK(scan_mul(pk->tw.w(), pk->tw.w(), M / 2, s));
+  hipLaunchKernelGGL(k_fill_pow, dim3(nb(M / 2)), dim3(256), 0, s, (const uint32_t*)(consts.w() + K_OMEGA_INV * FW), pk->twinv.w(), M / 2);
+  ZCHK(scan_mul(pk->twinv.w(), pk->twinv.w(), M / 2, s));
+  // the Q kernel slices of this rank and their spectra (with the 1/M of the inverse transform)
+  hipLaunchKernelGGL(k_recip_blocks, dim3(nb(QM)), dim3(256), 0, s, (const uint32_t*)fact.w(), (const uint32_t*)invfact.w(), n, pk->qs0, pk->qcnt, Bi, Q, pk->ghat.w());
+  ZCHK(ntt_forward(pk->ghat.w(), logM, pk->tw.w(), nullptr, s, Q));
+  hipLaunchKernelGGL(k_scale_all, dim3(nb(QM)), dim3(256), 0, s, pk->ghat.w(), (const uint32_t*)(consts.w() + K_NINV * FW), QM);
 
   // ---- per-wire evaluations u_i(x) = sum_j A[j][i] L_j(x)  and the scalars of crs.rs:66-84 ----
   DBuf ue, ve, we, y; ZCHK(ue.alloc(rows * FRB)); ZCHK(ve.alloc(rows * FRB)); ZCHK(we.alloc(rows * FRB)); ZCHK(y.alloc(rows * FRB));
@@ -478,10 +511,6 @@ int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_spars
   RCHK(hipGetLastError());
 
   // ---- group side: fixed-base multiplications of the generators (crs.rs:85-135), written straight into the three base sets ----
-  const size_t nw = m - l, nh = n >= 2 ? n - 1 : 0, nA = n + 2, nC1 = n + nw + 3, nC2 = nh, nC = nC1 + nC2;
-  pk->nA = nA; pk->nC1 = nC1; pk->nC2 = nC2; pk->shard = shard; pk->nshards = nshards;
-  auto range = [&](size_t tot, size_t& lo, size_t& hi) { size_t base = tot / nshards, extra = tot % nshards; lo = shard * base + (shard < extra ? shard : extra); hi = lo + base + (shard < extra ? 1 : 0); };
-  range(nA, pk->loA, pk->hiA); range(nC1, pk->loC1, pk->hiC1); range(nC2, pk->loC2, pk->hiC2);
   DBuf gen1, gen2, pU, pA, pB, pC, small1, small2, gt;
   ZCHK(gen1.alloc(G1B)); ZCHK(gen2.alloc(G2B)); ZCHK(pU.alloc(rows * G1B)); ZCHK(pA.alloc(nA * G1B)); ZCHK(pB.alloc(nA * G2B)); ZCHK(pC.alloc(nC * G1B));
   ZCHK(small1.alloc(3 * G1B)); ZCHK(small2.alloc(3 * G2B)); ZCHK(gt.alloc(576));
@@ -540,7 +569,8 @@ int zkt_groth16_setup_r1cs_sharded(size_t n, size_t l, size_t m, const zkt_spars
   ZCHK(pk->wires_c.alloc(rows * FRB)); ZCHK(pk->wires_m.alloc(rows * FRB));
   for (int k = 0; k < zkt_groth16_pk::PSLOTS; ++k) { ZCHK(pk->rs[k].alloc(2 * FRB)); ZCHK(pk->sA[k].alloc(nA * FRB)); ZCHK(pk->sB[k].alloc(nA * FRB)); ZCHK(pk->sC[k].alloc(nC * FRB)); }
   ZCHK(pk->cparts.alloc(2 * ZKT_G1_PARTIAL_WORDS * 4));
-  for (int k = 0; k < 3; ++k) { ZCHK(pk->z_m[k].alloc(n * FRB)); ZCHK(pk->f[k].alloc(N * FRB)); }
+  for (int k = 0; k < 3; ++k) ZCHK(pk->z_m[k].alloc(n * FRB));
+  ZCHK(pk->X.alloc(3 * QM * FRB));
   *out = pk.release();
   return ZKT_OK;
 }
@@ -559,11 +589,11 @@ static int prove_submit(zkt_groth16_pk* pk, int ps, const uint64_t* wires, bool 
   if (!pk) return ZKT_ERR_SHAPE;
   std::lock_guard<std::recursive_mutex> lk(pk->mu);
   if (!wires || !r || !s_ || ps < 0 || ps >= zkt_groth16_pk::PSLOTS || pk->pending[ps]) return ZKT_ERR_SHAPE;
-  const size_t n = pk->n, l = pk->l, m = pk->m, rows = m + 1, N = pk->N, nw = m - l;
+  const size_t n = pk->n, l = pk->l, m = pk->m, rows = m + 1, nw = m - l;
   hipStream_t s = pk->s;
   DBuf &sA = pk->sA[ps], &sB = pk->sB[ps], &sC = pk->sC[ps], &drs = pk->rs[ps];
   uint64_t rs[8]; memcpy(rs, r, 32); memcpy(rs + 4, s_, 32);
-  RCHK(hipStreamWaitEvent(s, pk->e_q, 0));        // z_m and f are shared by the proof slots: the previous proof's quotient stage has to be through with them
+  RCHK(hipStreamWaitEvent(s, pk->e_q, 0));        // z_m and X are shared by the proof slots: the previous proof's quotient stage has to be through with them
   RCHK(hipMemcpyAsync(drs.p, rs, 64, hipMemcpyHostToDevice, s));
   RCHK(hipMemcpyAsync(pk->wires_c.p, wires, rows * FRB, wires_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_to_mont, dim3(nb(rows)), dim3(256), 0, s, (const uint32_t*)pk->wires_c.w(), pk->wires_m.w(), rows);
@@ -577,16 +607,17 @@ static int prove_submit(zkt_groth16_pk* pk, int ps, const uint64_t* wires, bool 
   // A, B and the first part of C only need (A w), (B w) and the wires: their input event is recorded on `s`, which the chain is not on.
   const size_t nC1 = pk->nC1;
   hipStream_t q = s;
-  if (n >= 2) {
+  if (pk->qcnt) {                       // (an empty range of the quotient's bases — n = 1, or more ranks than bases — has nothing to evaluate)
     q = pk->sq;
+    const size_t M = pk->M, Q = pk->Q, QM = Q * M;
     RCHK(hipEventRecord(pk->e_head, s)); RCHK(hipStreamWaitEvent(q, pk->e_head, 0));
-    for (int k = 0; k < 3; ++k) {
-      hipLaunchKernelGGL(k_prep_f, dim3(nb(N)), dim3(256), 0, q, (const uint32_t*)pk->z_m[k].w(), (const uint32_t*)pk->cinv.w(), n, N, pk->f[k].w());
-      ZCHK(ntt_forward(pk->f[k].w(), pk->logN, pk->tw.w(), pk->ghat.w(), q));          // spectrum * spectrum of 1/d (and 1/N)
-      ZCHK(ntt_inverse(pk->f[k].w(), pk->logN, pk->twinv.w(), q));
-    }
-    hipLaunchKernelGGL(k_hvals, dim3(nb(n - 1)), dim3(256), 0, q, (const uint32_t*)pk->f[0].w(), (const uint32_t*)pk->f[1].w(), (const uint32_t*)pk->f[2].w(), (const uint32_t*)pk->P.w(), n,
-                       sC.w() + nC1 * FW);
+    // a, b, c side by side (grid.y): 2 + 2 k launches for transforms of k passes instead of 3 (1 + 2 k)
+    hipLaunchKernelGGL(k_prep_blocks, dim3(nb(QM), 3), dim3(256), 0, q, (const uint32_t*)pk->z_m[0].w(), (const uint32_t*)pk->z_m[1].w(), (const uint32_t*)pk->z_m[2].w(),
+                       (const uint32_t*)pk->cinv.w(), n, pk->Bi, Q, pk->X.w());
+    ZCHK(ntt_forward(pk->X.w(), pk->logM, pk->tw.w(), pk->ghat.w(), q, Q, 3, QM));     // block spectrum * spectrum of its slice of 1/d (and 1/M)
+    if (Q > 1) hipLaunchKernelGGL(k_sum_blocks, dim3(nb(M), 3), dim3(256), 0, q, pk->X.w(), M, Q);
+    ZCHK(ntt_inverse(pk->X.w(), pk->logM, pk->twinv.w(), q, 1, 3, QM));
+    hipLaunchKernelGGL(k_hvals, dim3(nb(pk->qcnt)), dim3(256), 0, q, (const uint32_t*)pk->X.w(), QM, (const uint32_t*)pk->P.w(), pk->qs0, pk->qcnt, sC.w() + nC1 * FW);
     RCHK(hipGetLastError());
     RCHK(hipEventRecord(pk->e_q, q));
   }
