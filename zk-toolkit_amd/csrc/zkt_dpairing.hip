@@ -852,19 +852,31 @@ __global__ void __launch_bounds__(64) k_dproduct_ate(PairArgs a, const uint32_t*
 }
 // The ate counterpart of a verifying key's alpha_beta for k_ate_key_prep's buffer: a(beta, alpha) raised like the deciding kernels raise their products, by one lane group
 // (4 ms; on ONE lane of the tower code it was 25 of the 45 ms a key cost when first seen).  out: 144 words in the ABI's Fq12 layout; flag |= bit when beta's chain ended on -psi(beta).
-__global__ void __launch_bounds__(64) k_dab_ate(const uint32_t* __restrict__ alpha, const uint32_t* __restrict__ beta, uint32_t* __restrict__ out, uint32_t* __restrict__ flag, uint32_t bit) {
+// Block 1 of the same launch (round 4): tate(alpha, beta) itself, which the host compares with the key's stored alpha_beta (verifier.rs:48 compares against that GTPoint, so
+// only a key whose alpha_beta IS the pairing of its alpha and beta may be served by the 63-step loop).  Two launches one after the other were 4.0 + 4.8 ms of a key's entry;
+// side by side they are 4.8.  gt (144 words, zeroed by the host) stays zero — never a pairing value — when alpha is outside G1 or an argument is infinity.
+__global__ void __launch_bounds__(64) k_key_ab(const uint32_t* __restrict__ alpha, const uint32_t* __restrict__ beta, uint32_t* __restrict__ out, uint32_t* __restrict__ flag, uint32_t bit,
+                                               uint32_t* __restrict__ gt) {
   __shared__ uint32_t lds[LDS_WORDS];
   const Ctx c = make_ctx(lds);
   Aff<FqOps> p = PtIO<FqOps>::ld(alpha);
   Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(beta);
   const bool inf = p.inf || q.inf;
   if (inf) { p.x = fp_one<FqC>(); p.y = fp_one<FqC>(); q.x = fq2_one(); q.y = fq2_one(); }      // run on dummy data: the barriers stay uniform
-  bool q_ok;
-  const Fq f = d_miller_ate(c, p, q, q_ok);
-  const Fq r = d_final_exp_3h(c, f);
-  if (inf || !q_ok || threadIdx.x >= GL) return;                                                    // every group computed the same pairing; the first one reports
-  st_fp<FqC>(out + abi_word(c.r.m, c.r.part), r);
-  if (threadIdx.x == 0) atomicOr(flag, bit);
+  if (blockIdx.x == 0) {
+    bool q_ok;
+    const Fq f = d_miller_ate(c, p, q, q_ok);
+    const Fq r = d_final_exp_3h(c, f);
+    if (inf || !q_ok || threadIdx.x >= GL) return;                                                  // every group computed the same pairing; the first one reports
+    st_fp<FqC>(out + abi_word(c.r.m, c.r.part), r);
+    if (threadIdx.x == 0) atomicOr(flag, bit);
+  } else {
+    bool in_g1;
+    const Fq f = d_miller<true>(c, p, q, in_g1);
+    const Fq r = d_final_exp<true>(c, f);
+    if (inf || !in_g1 || threadIdx.x >= GL) return;
+    st_fp<FqC>(gt + abi_word(c.r.m, c.r.part), r);
+  }
 }
 }  // namespace dp
 
@@ -889,8 +901,8 @@ hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uin
 #undef ZKT_DPRODUCT
   return hipGetLastError();
 }
-hipError_t launch_dab_ate(const uint32_t* alpha, const uint32_t* beta, uint32_t* out, uint32_t* flag, uint32_t bit, hipStream_t s) {
-  hipLaunchKernelGGL(dp::k_dab_ate, dim3(1), dim3(64), 0, s, alpha, beta, out, flag, bit);
+hipError_t launch_key_ab(const uint32_t* alpha, const uint32_t* beta, uint32_t* out, uint32_t* flag, uint32_t bit, uint32_t* gt, hipStream_t s) {
+  hipLaunchKernelGGL(dp::k_key_ab, dim3(2), dim3(64), 0, s, alpha, beta, out, flag, bit, gt);
   return hipGetLastError();
 }
 hipError_t launch_dproduct_ate(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s, const uint8_t* kcount) {

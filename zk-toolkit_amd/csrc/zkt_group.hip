@@ -278,7 +278,7 @@ hipError_t launch_fixed_muls_batch(int grp, const uint32_t* tables, const uint32
 // ---- statement sums of a large verification batch from 8-bit window tables (Groth16 verifier.rs:41-45) ---------------------------------------------------
 // S_i = sum_j stmt[i][j] * U_j for 65,536 proofs is 196,608 scalar multiplications by the SAME n_stmt points: a 255-step chain each (1.2 M multiply-adds) when done
 // as variable-base multiplications.  The key's cache entry instead carries, per statement point, the 32 x 256 Jacobian multiples d * 256^w * U_j (1.4 MB per point,
-// built once per key: k_stmt_wide_tables, one lane per (point, window)); a proof's lane then adds one table entry per scalar byte — 32 n_stmt additions and ONE
+// built once per key: k_stmt_wide_tables); a proof's lane then adds one table entry per scalar byte — 32 n_stmt additions and ONE
 // inversion for the affine S_i.  Entry 0 of a window is the point at infinity, which the complete addition absorbs.
 static constexpr int WIDE_WINDOWS = 32, WIDE_ENTRIES = 256, WIDE_JW = 3 * FqC::N;      // words per Jacobian entry in the kernels' own limb form
 __device__ inline void st_jac_words(uint32_t* p, const Jac<FqOps>& a) {
@@ -291,15 +291,19 @@ __device__ inline Jac<FqOps> ld_jac_words(const uint32_t* p) {
   for (int i = 0; i < FqC::N; ++i) { a.X.v[i] = p[i]; a.Y.v[i] = p[FqC::N + i]; a.Z.v[i] = p[2 * FqC::N + i]; }
   return a;
 }
-__global__ void __launch_bounds__(64) k_stmt_wide_tables(const uint32_t* __restrict__ points, int n_pts, uint32_t* __restrict__ tables) {
+// One lane per (point, window, high nibble): 256^w U_j and 16 * 256^w U_j are entries 2w and 2w+1 of the point's 16^k table (k_fixed_table, built for the key's small
+// batches anyway), so the lane forms hi * (16 * base) in <= 4 doublings and additions and walks its sixteen entries by mixed additions — a chain of <= 23 group operations
+// where one lane per (point, window) ran 8w doublings and 255 additions (8.3 ms of the 21 a key's entry cost; profiles/r04_protocols_kernel_stats.csv).
+__global__ void __launch_bounds__(64) k_stmt_wide_tables(const uint32_t* __restrict__ tab16, int n_pts, uint32_t* __restrict__ tables) {
   const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= n_pts * WIDE_WINDOWS) return;
-  const int j = t / WIDE_WINDOWS, w = t % WIDE_WINDOWS;
-  Jac<FqOps> base = jac_from_aff(PtIO<FqOps>::ld(points + (size_t)j * ABI_G1_WORDS));
-  for (int d = 0; d < 8 * w; ++d) base = jac_dbl(base);
-  uint32_t* out = tables + ((size_t)j * WIDE_WINDOWS + w) * WIDE_ENTRIES * WIDE_JW;
+  if (t >= n_pts * WIDE_WINDOWS * 16) return;
+  const int hi = t & 15, w = (t >> 4) % WIDE_WINDOWS, j = (t >> 4) / WIDE_WINDOWS;
+  const uint32_t* tj = tab16 + (size_t)j * 64 * ABI_G1_WORDS;
+  const Aff<FqOps> base = PtIO<FqOps>::ld(tj + (size_t)(2 * w) * ABI_G1_WORDS), b16 = PtIO<FqOps>::ld(tj + (size_t)(2 * w + 1) * ABI_G1_WORDS);
   Jac<FqOps> acc = jac_inf<FqOps>();
-  for (int d = 0; d < WIDE_ENTRIES; ++d) { st_jac_words(out + (size_t)d * WIDE_JW, acc); acc = jac_add<FqOps>(acc, base); }
+  for (int b = 3; b >= 0; --b) { acc = jac_dbl(acc); if ((hi >> b) & 1) acc = jac_add_aff(acc, b16); }
+  uint32_t* out = tables + (((size_t)j * WIDE_WINDOWS + w) * WIDE_ENTRIES + 16 * hi) * WIDE_JW;
+  for (int lo = 0; lo < 16; ++lo) { st_jac_words(out + (size_t)lo * WIDE_JW, acc); acc = jac_add_aff(acc, base); }
 }
 __global__ void __launch_bounds__(64) k_stmt_sums_wide(const uint32_t* __restrict__ tables, const uint32_t* __restrict__ stmt, int n_stmt, uint32_t* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -315,9 +319,9 @@ __global__ void __launch_bounds__(64) k_stmt_sums_wide(const uint32_t* __restric
   PtIO<FqOps>::st(out + i * ABI_G1_WORDS, jac_to_aff(acc));
 }
 size_t stmt_wide_table_words(int n_pts) { return (size_t)n_pts * WIDE_WINDOWS * WIDE_ENTRIES * WIDE_JW; }
-hipError_t launch_stmt_wide_tables(const uint32_t* points, int n_pts, uint32_t* tables, hipStream_t s) {
-  if (n_pts < 1 || n_pts > 12) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_stmt_wide_tables, dim3((unsigned)((n_pts * WIDE_WINDOWS + 63) / 64)), dim3(64), 0, s, points, n_pts, tables);
+hipError_t launch_stmt_wide_tables(const uint32_t* tab16, int n_pts, uint32_t* tables, hipStream_t s) {      // tab16: the points' 64-entry tables of launch_fixed_tables, [point][64] affine
+  if (n_pts < 1 || n_pts > 12 || !tab16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_stmt_wide_tables, dim3((unsigned)(n_pts * WIDE_WINDOWS * 16 / 64)), dim3(64), 0, s, tab16, n_pts, tables);
   return hipGetLastError();
 }
 hipError_t launch_stmt_sums_wide(const uint32_t* tables, const uint32_t* stmt, int n_stmt, uint32_t* out, size_t n, hipStream_t s) {

@@ -75,7 +75,7 @@ hipError_t launch_ate_key_prep(const uint32_t* alpha, const uint32_t* beta, cons
                                uint32_t* key, hipStream_t s);
 // 8-bit window tables of a key's statement points and the statement sums of a large batch from them (zkt_group.hip)
 size_t stmt_wide_table_words(int n_pts);
-hipError_t launch_stmt_wide_tables(const uint32_t* points, int n_pts, uint32_t* tables, hipStream_t s);
+hipError_t launch_stmt_wide_tables(const uint32_t* tab16, int n_pts, uint32_t* tables, hipStream_t s);
 hipError_t launch_stmt_sums_wide(const uint32_t* tables, const uint32_t* stmt, int n_stmt, uint32_t* out, size_t n, hipStream_t s);
 // elements with a G1 argument outside the order-r subgroup (or a point off its curve): 0 = both sides evaluated the reference's way (default), 1 = rejected
 void verify_set_fail_closed(int on);
@@ -99,7 +99,7 @@ hipError_t launch_dtate(const uint32_t* g1, const uint32_t* g2, uint32_t* out, s
 hipError_t launch_dproduct(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, bool short_loop, hipStream_t s, const uint8_t* kcount = nullptr);
 // the same decision on the 63-step loop (target: the ate counterpart of a key's alpha_beta, or NULL for == 1); ok = 2 where a Q is outside G2 (left to the kernels behind)
 hipError_t launch_dproduct_ate(const PairArgs& a, int K, const uint32_t* target, uint32_t* ok, size_t n, unsigned long long* err, hipStream_t s, const uint8_t* kcount = nullptr);
-hipError_t launch_dab_ate(const uint32_t* alpha, const uint32_t* beta, uint32_t* out, uint32_t* flag, uint32_t bit, hipStream_t s);      // a(beta, alpha)^(3h) by one lane group; *flag |= bit when beta is in G2
+hipError_t launch_key_ab(const uint32_t* alpha, const uint32_t* beta, uint32_t* out, uint32_t* flag, uint32_t bit, uint32_t* gt, hipStream_t s);      // one launch, two lane groups' worth of blocks: a(beta, alpha)^(3h) into out (*flag |= bit when beta is in G2) and tate(alpha, beta) into gt
 hipError_t launch_ate_guards(const PairArgs& a, int K, uint32_t* flags, size_t n, hipStream_t s, uint32_t p_skip = 0);      // flags[i] = 1: every P of element i on E and in G1, every Q on E'
 // Small batches of products with DIFFERENT pair counts in one launch (K = the largest): the 127-step kernels with their guards beside them, as
 // launch_pairing_product_check does for n*K <= the small-batch limit, but WITHOUT the 255-step / exact re-evaluation: ok[i] = 2 means "element i does not fit

@@ -188,11 +188,11 @@ __global__ void __launch_bounds__(64) k_stmt_sums(const uint32_t* __restrict__ t
   PtIO<FqOps>::st(out + i * ABI_G1_WORDS, jac_to_aff(acc));
 }
 // ---- the deciding entry points on the 63-step loop (pairing.h, "optimal ate") ---------------------------------------------------------
-// What a verifying key contributes, prepared ONCE per key (the host caches it by the key's bytes, zkt_protocols.hip ate_key_for):
+// What a verifying key contributes, prepared ONCE per key (the host caches it by the key's bytes, zkt_protocols.hip ate_key_begin):
 //   words [0, T)      the 68 line triples of gamma          T = ATE_LINES * ATE_LINE_WORDS
 //   words [T, 2T)     ... of delta
 //   words [2T, +144)  final_exponentiation(f_{|x|,beta}(alpha)) — the ate counterpart of the key's alpha_beta (compared in the ABI's Fq12 layout)
-//   word  2T + 144    bit 0 gamma in G2, bit 1 delta in G2, bit 2 alpha in G1 and beta on E', bit 3 every statement point in G1, bit 4 beta in G2 (k_dab_ate, which writes the pairing)
+//   word  2T + 144    bit 0 gamma in G2, bit 1 delta in G2, bit 2 alpha in G1 and beta on E', bit 3 every statement point in G1, bit 4 beta in G2 (k_key_ab, which writes the pairing)
 // The host uses the 63-step kernel for a key only when all five bits are set AND the key's alpha_beta equals tate(alpha, beta) (one small-batch pairing).
 __global__ void __launch_bounds__(64) k_ate_key_prep(const uint32_t* __restrict__ alpha, const uint32_t* __restrict__ beta, const uint32_t* __restrict__ gamma,
                                                      const uint32_t* __restrict__ delta, const uint32_t* __restrict__ uvw_stmt, int n_stmt, uint32_t* __restrict__ key) {
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(64) k_ate_key_prep(const uint32_t* __restrict_
       if (!q.inf && g2_on_curve(q.x, q.y) && ate_line_table(q.x, q.y, key + j * T)) atomicOr(key + 2 * T + 144, 1u << j);
     }
   } else if (blockIdx.x == 1) {
-    if (j == 0) {       // alpha on E and in G1, beta on E'; beta in G2 and the pairing itself come from k_dab_ate (bit 4), one lane group instead of this one lane
+    if (j == 0) {       // alpha on E and in G1, beta on E'; beta in G2 and the pairing itself come from k_key_ab (bit 4), one lane group instead of this one lane
       Aff<FqOps> p = PtIO<FqOps>::ld(alpha); Aff<Fq2Ops> q = PtIO<Fq2Ops>::ld(beta);
       if (!p.inf && !q.inf && g1_on_curve(p.x, p.y) && g1_in_subgroup(p.x, p.y) && g2_on_curve(q.x, q.y)) atomicOr(key + 2 * T + 144, 4u);
     }
@@ -217,12 +217,11 @@ __global__ void __launch_bounds__(64) k_ate_key_prep(const uint32_t* __restrict_
     if (__ballot(!ok) == 0 && j == 0 && n_stmt <= 64) atomicOr(key + 2 * T + 144, 8u);
   }
 }
+// (the verdict word is zeroed by the caller; the pairing a(beta, alpha), bit 4 and tate(alpha, beta) come from launch_key_ab, zkt_dpairing.hip)
 hipError_t launch_ate_key_prep(const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma, const uint32_t* delta, const uint32_t* uvw_stmt, int n_stmt,
                                uint32_t* key, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(key + 2 * (size_t)ATE_LINES * ATE_LINE_WORDS + 144, 0, sizeof(uint32_t), s);
-  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_ate_key_prep, dim3(3), dim3(64), 0, s, alpha, beta, gamma, delta, uvw_stmt, n_stmt, key);
-  return launch_dab_ate(alpha, beta, key + 2 * (size_t)ATE_LINES * ATE_LINE_WORDS, key + 2 * (size_t)ATE_LINES * ATE_LINE_WORDS + 144, 16u, s);
+  return hipGetLastError();
 }
 // e(A,B) == alpha_beta e(S,gamma) e(C,delta)  <=>  a(B,A) a(gamma,-S) a(delta,-C) == a(beta,alpha): B runs its chain in the lane (its G2 test comes with it),
 // gamma and delta bring their tables, S is a sum of multiples of statement points tested with the key.  A and C are tested here (127 doublings each).
