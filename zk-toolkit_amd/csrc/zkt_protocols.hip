@@ -427,18 +427,21 @@ std::shared_ptr<void> stmt_tables_for(const zkt_g1_affine* pts, size_t n_stmt, c
 // (verifier.rs:48), so a key whose alpha_beta is anything else keeps the value-comparing kernels.  `usable` caches that verdict too.
 //
 // The entry is built at FIRST sight of a key, beside the call that brought it (round 4; before, at second sight and inside that call: 10 / 24 / 5 / 5 ms for the first four
-// verifications against a key).  Three pieces: (i) the line tables of gamma and delta, the group tests and the 8-bit statement tables — frames of < 1 KB, so they run on a side
-// stream of their own while the call's own kernels run (ate_key_begin); (ii) the two pairings of (alpha, beta), ONE launch of two blocks with the pairing kernels' frame,
-// enqueued on the call's stream BEHIND the call's result (ate_key_check_async: the caller waits for its result, not for them); (iii) the verdict, read from pinned host memory
-// by the next call on that key (ate_key_lookup), which has to queue behind (ii) anyway.  A small batch on a key never seen before is served by the 127-step kernels, which need
-// nothing of the key; a large batch, and zkt_groth16_vk_prepare, wait for the entry.
+// verifications against a key, now 10.5 / 5 / 5 / 5).  The pieces and where they run (timeline: profiles/r04_verify_first_sight_timeline.txt):
+//   the two pairings of (alpha, beta), ONE launch of two blocks (k_key_ab, 4.8 ms)        -> the library's ONE guard stream (zkt_pairing.hip), from the start of the call: they need
+//                                                                                            nothing but alpha and beta, and the guard stream is where pairing-sized frames may live
+//   line tables of gamma and delta, group tests (k_ate_key_prep, 3 ms)                     -> a side stream for frames below 1 KB, from the start of the call
+//   8-bit statement tables (k_stmt_wide_tables, 0.3 ms) from the points' 16^k tables        -> the same side stream, once the call's stream has built those (3 ms)
+//   the verdict (flags, tate(alpha, beta)) into pinned host memory                          -> the guard stream, behind both; read by the next call on that key (ate_key_lookup)
+// so a key's entry is complete ~5 ms into the call that first showed it, under that call's own 127-step kernels (which need nothing of the key); the call's guards queue behind
+// the pairings on the guard stream (+0.5 ms on that one call).  A large batch, and zkt_groth16_vk_prepare, wait for the entry (5.5 ms instead of 21).
 struct AteHost { uint32_t flags; uint32_t pad[3]; uint64_t gt[72]; };
 struct AteKey {
   std::vector<uint8_t> key, want_gt; std::shared_ptr<void> dev; bool usable = false; uint64_t stamp = 0;
   int state = 0;                       // 0 settled (or empty), 1 begun: side stream at work, pairings not enqueued, 2 pairings enqueued: verdict lands in *host when ev_done has passed
-  hipEvent_t ev_in = nullptr, ev_side = nullptr, ev_done = nullptr; AteHost* host = nullptr;
+  hipEvent_t ev_in = nullptr, ev_side = nullptr, ev_done = nullptr; AteHost* host = nullptr; hipStream_t guard = nullptr;
 };
-std::mutex g_ate_mu; AteKey g_ate[4]; uint64_t g_ate_clock = 0; hipStream_t g_ate_side = nullptr;
+std::mutex g_ate_mu; AteKey g_ate[4]; uint64_t g_ate_clock = 0; hipStream_t g_ate_side = nullptr;      // the side stream: kernels with frames below 1 KB only (scratch per queue, zkt_pairing.hip GuardStreams)
 enum { ATE_READY = 0, ATE_UNUSABLE, ATE_ABSENT, ATE_BUSY };
 static constexpr size_t ATE_TAIL_ALPHA = 0, ATE_TAIL_BETA = 28, ATE_TAIL_GT = 80, ATE_TAIL_WORDS = 224;      // behind the key words and the statement tables: alpha, beta, tate(alpha, beta)
 std::vector<uint8_t> ate_key_bytes(const zkt_groth16_crs* c, size_t n_stmt) {
@@ -474,10 +477,10 @@ int ate_key_lookup(const zkt_groth16_crs* c, size_t n_stmt, std::shared_ptr<void
   }
   return ATE_ABSENT;
 }
-// Piece (i) for a key that ate_key_lookup reported ABSENT.  `s` (the call's stream) holds dU, dg, dd and the 16^k tables `tab16` of the statement points by the time of this
-// call.  Returns the entry's index, or -1 (nothing started: the caller carries on without).  A begun entry MUST be followed by ate_key_check_async or ate_key_abandon.
-int ate_key_begin(const zkt_groth16_crs* c, size_t n_stmt, const uint32_t* dU, const uint32_t* dg, const uint32_t* dd, const uint32_t* tab16, hipStream_t s) {
-  if (!ate_key_applies(c, n_stmt) || !tab16) return -1;
+// First half, for a key that ate_key_lookup reported ABSENT: everything that needs no table.  `s` (the call's stream) holds dU, dg, dd by the time of this call.  Returns the
+// entry's index, or -1 (nothing started: the caller carries on without).  A begun entry MUST be followed by ate_key_tables or ate_key_abandon.
+int ate_key_begin(const zkt_groth16_crs* c, size_t n_stmt, const uint32_t* dU, const uint32_t* dg, const uint32_t* dd, hipStream_t s) {
+  if (!ate_key_applies(c, n_stmt)) return -1;
   std::vector<uint8_t> kb = ate_key_bytes(c, n_stmt);
   std::lock_guard<std::mutex> lk(g_ate_mu);
   AteKey* victim = nullptr;
@@ -495,59 +498,57 @@ int ate_key_begin(const zkt_groth16_crs* c, size_t n_stmt, const uint32_t* dU, c
   if (hipMalloc(&mem, (key_words + ATE_TAIL_WORDS) * 4) != hipSuccess) { (void)hipGetLastError(); return -1; }      // [line tables, alpha_beta, verdicts | statement tables | alpha, beta, tate(alpha, beta)]
   std::shared_ptr<void> dev(mem, [](void* q) { if (q) hipFree(q); });
   uint32_t* key = (uint32_t*)mem; uint32_t* tail = key + key_words;
+  e.host->flags = 0; memset(e.host->gt, 0, 576);
   if (hipMemsetAsync(key + ATE_KEY_WORDS - 1, 0, 4, s) != hipSuccess || hipMemsetAsync(tail + ATE_TAIL_GT, 0, 576, s) != hipSuccess ||
       hipMemcpyAsync(tail + ATE_TAIL_ALPHA, c->g1_alpha, G1B, hipMemcpyHostToDevice, s) != hipSuccess || hipMemcpyAsync(tail + ATE_TAIL_BETA, c->g2_beta, G2B, hipMemcpyHostToDevice, s) != hipSuccess ||
       hipEventRecord(e.ev_in, s) != hipSuccess || hipStreamWaitEvent(g_ate_side, e.ev_in, 0) != hipSuccess ||
       launch_ate_key_prep(tail + ATE_TAIL_ALPHA, tail + ATE_TAIL_BETA, dg, dd, dU, (int)n_stmt, key, g_ate_side) != hipSuccess ||
-      launch_stmt_wide_tables(tab16, (int)n_stmt, key + ATE_KEY_WORDS, g_ate_side) != hipSuccess || hipEventRecord(e.ev_side, g_ate_side) != hipSuccess) {
-    (void)hipGetLastError(); (void)hipStreamSynchronize(g_ate_side); (void)hipStreamSynchronize(s); return -1;
+      guard_fork(s, &e.guard) != hipSuccess ||
+      launch_key_ab(tail + ATE_TAIL_ALPHA, tail + ATE_TAIL_BETA, key + 2 * (size_t)68 * 84, key + ATE_KEY_WORDS - 1, 16u, tail + ATE_TAIL_GT, e.guard) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipStreamSynchronize(g_ate_side); if (e.guard) (void)hipStreamSynchronize(e.guard); (void)hipStreamSynchronize(s); return -1;
   }
   e.key = std::move(kb); e.want_gt.assign((const uint8_t*)c->gt_alpha_beta, (const uint8_t*)c->gt_alpha_beta + 576); e.dev = dev; e.usable = false; e.stamp = ++g_ate_clock; e.state = 1;
   return (int)(victim - g_ate);
 }
-// Piece (ii): the pairings of (alpha, beta) and the verdict's way home, on `s` behind whatever the caller has enqueued; `s` also waits for the side stream, so the caller's
-// per-call buffers (stream-ordered frees on `s`) outlive the side stream's reads.
-void ate_key_check_async(int idx, hipStream_t s) {
+// Second half, once `s` holds the statement points' 16^k tables: the 8-bit tables on the side stream, the verdict's way home on the guard stream behind both, and `s` waits for
+// the side stream (whose kernels read the caller's per-call buffers, freed in stream order on `s`).
+void ate_key_tables(int idx, const uint32_t* tab16, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_ate_mu);
   AteKey& e = g_ate[idx];
   uint32_t* key = (uint32_t*)e.dev.get(); const size_t n_stmt = (e.key.size() - (G1B + 3 * G2B + 576)) / G1B;
   uint32_t* tail = key + ATE_KEY_WORDS + stmt_wide_table_words((int)n_stmt);
-  e.host->flags = 0; memset(e.host->gt, 0, 576);
-  const bool ok = hipStreamWaitEvent(s, e.ev_side, 0) == hipSuccess &&
-                  launch_key_ab(tail + ATE_TAIL_ALPHA, tail + ATE_TAIL_BETA, key + 2 * (size_t)68 * 84, key + ATE_KEY_WORDS - 1, 16u, tail + ATE_TAIL_GT, s) == hipSuccess &&
-                  hipMemcpyAsync(&e.host->flags, key + ATE_KEY_WORDS - 1, 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                  hipMemcpyAsync(e.host->gt, tail + ATE_TAIL_GT, 576, hipMemcpyDeviceToHost, s) == hipSuccess && hipEventRecord(e.ev_done, s) == hipSuccess;
+  const bool ok = tab16 && hipEventRecord(e.ev_in, s) == hipSuccess && hipStreamWaitEvent(g_ate_side, e.ev_in, 0) == hipSuccess &&
+                  launch_stmt_wide_tables(tab16, (int)n_stmt, key + ATE_KEY_WORDS, g_ate_side) == hipSuccess && hipEventRecord(e.ev_side, g_ate_side) == hipSuccess &&
+                  hipStreamWaitEvent(e.guard, e.ev_side, 0) == hipSuccess && hipStreamWaitEvent(s, e.ev_side, 0) == hipSuccess &&
+                  hipMemcpyAsync(&e.host->flags, key + ATE_KEY_WORDS - 1, 4, hipMemcpyDeviceToHost, e.guard) == hipSuccess &&
+                  hipMemcpyAsync(e.host->gt, tail + ATE_TAIL_GT, 576, hipMemcpyDeviceToHost, e.guard) == hipSuccess && hipEventRecord(e.ev_done, e.guard) == hipSuccess;
   if (ok) { e.state = 2; return; }
-  (void)hipGetLastError(); (void)hipStreamSynchronize(g_ate_side); (void)hipStreamSynchronize(s);
+  (void)hipGetLastError(); (void)hipStreamSynchronize(g_ate_side); (void)hipStreamSynchronize(e.guard); (void)hipStreamSynchronize(s);
   e.usable = false; e.state = 0;                                      // remembered as a key the 63-step loop does not serve
 }
 void ate_key_abandon(int idx, hipStream_t s) {                        // the call failed between begin and check: drain, forget
   std::lock_guard<std::mutex> lk(g_ate_mu);
   AteKey& e = g_ate[idx];
-  (void)hipStreamSynchronize(g_ate_side); (void)hipStreamSynchronize(s);
+  (void)hipStreamSynchronize(g_ate_side); (void)hipStreamSynchronize(e.guard); (void)hipStreamSynchronize(s);
   e.dev.reset(); e.key.clear(); e.stamp = 0; e.usable = false; e.state = 0;
 }
-struct AteBuild {                                                     // begin ... check, or abandon when the scope is left early
+struct AteBuild {                                                     // begin ... tables, or abandon when the scope is left early
   int idx = -1; hipStream_t s = nullptr;
-  void check() { if (idx >= 0) { ate_key_check_async(idx, s); idx = -1; } }
+  void tables(const uint32_t* tab16) { if (idx >= 0) { ate_key_tables(idx, tab16, s); idx = -1; } }
   ~AteBuild() { if (idx >= 0) ate_key_abandon(idx, s); }
 };
 // the entry, built now if need be and waited for (large batches, zkt_groth16_vk_prepare); null: the value-comparing kernels
-std::shared_ptr<void> ate_key_now(const zkt_groth16_crs* c, size_t n_stmt, const uint32_t* dU, const uint32_t* dg, const uint32_t* dd, const uint32_t* tab16, hipStream_t s) {
+std::shared_ptr<void> ate_key_now(const zkt_groth16_crs* c, size_t n_stmt, const uint32_t* dU, const uint32_t* dg, const uint32_t* dd, hipStream_t s) {
   std::shared_ptr<void> k;
   int st = ate_key_lookup(c, n_stmt, &k);
   if (st == ATE_ABSENT) {
-    AteBuild b; b.s = s; b.idx = ate_key_begin(c, n_stmt, dU, dg, dd, tab16, s);
+    AteBuild b; b.s = s; b.idx = ate_key_begin(c, n_stmt, dU, dg, dd, s);
     if (b.idx < 0) return nullptr;
-    b.check();
-    st = ate_key_lookup(c, n_stmt, &k);
+    const std::shared_ptr<void> tabs = stmt_tables_for(c->g1_uvw_stmt, n_stmt, dU, s);
+    b.tables((const uint32_t*)tabs.get());
+    st = ate_key_lookup(c, n_stmt, &k);                                // waits for the verdict; `tabs` is held until then
   }
   return st == ATE_READY ? k : nullptr;
-}
-hipEvent_t call_event() {                                             // one per caller thread, for "my result is there" on a stream that carries more than my work
-  thread_local hipEvent_t ev = nullptr;
-  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; (void)hipGetLastError(); }
-  return ev;
 }
 }  // namespace
 extern "C" {
@@ -653,22 +654,20 @@ int zkt_groth16_verify_batch(const zkt_groth16_crs* c, const zkt_g1_affine* A, c
   if (n_stmt >= 1 && n_stmt <= 12 && n_proofs * 3 <= dproduct_limit()) {      // few proofs: one proof per three lane groups (zkt_dpairing.hip), ~15 ms instead of ~105 ms
     Dev dtmp(n_stmt * n_proofs * G1B, P), dS(n_proofs * G1B, P);
     if (!dtmp.p || !dS.p) return ZKT_ERR_DEVICE;
-    const std::shared_ptr<void> tabs = stmt_tables_for(c->g1_uvw_stmt, n_stmt, dU.w(), s);     // held until the synchronisation below
     std::shared_ptr<void> akey;                                                                   // null: a key the 63-step loop may not serve, or one whose entry is not there yet -> the 127-step loop against alpha_beta
     AteBuild build; build.s = s;
-    if (ate_key_lookup(c, n_stmt, &akey) == ATE_ABSENT) build.idx = ate_key_begin(c, n_stmt, dU.w(), dg.w(), dd.w(), (const uint32_t*)tabs.get(), s);      // first sight: the entry is built beside this call
+    if (ate_key_lookup(c, n_stmt, &akey) == ATE_ABSENT) build.idx = ate_key_begin(c, n_stmt, dU.w(), dg.w(), dd.w(), s);      // first sight: the entry is built beside this call
+    const std::shared_ptr<void> tabs = stmt_tables_for(c->g1_uvw_stmt, n_stmt, dU.w(), s);     // held until the synchronisation below
+    build.tables((const uint32_t*)tabs.get());
     const uint32_t* ate_target = akey ? (const uint32_t*)akey.get() + 2 * (size_t)68 * 84 : nullptr;
     PCHK(launch_groth16_verify_small(dA.w(), dB.w(), dC.w(), dU.w(), (const uint32_t*)tabs.get(), dW.w(), (int)n_stmt, dg.w(), dd.w(), dab.w(), dtmp.w(), dS.w(), dok.w(), n_proofs, (unsigned long long*)derr.p, s, ate_target));
     unsigned long long e2 = NO_ERR;
     if ((rc = down(ok, dok.p, n_proofs * 4, s)) || (rc = down(&e2, derr.p, 8, s))) return rc;
-    hipEvent_t mine = build.idx >= 0 ? call_event() : nullptr;
-    if (mine) { PCHK(hipEventRecord(mine, s)); build.check(); PCHK(hipEventSynchronize(mine)); }      // the key's pairings follow this call's result on the stream; only the result is waited for
-    else { build.check(); PCHK(hipStreamSynchronize(s)); }
+    PCHK(hipStreamSynchronize(s));
     if (e2 != NO_ERR) { zkt_internal_set_error_index((size_t)e2); return ZKT_ERR_INFINITY; }
     return ZKT_OK;
   }
-  const std::shared_ptr<void> tabs = stmt_tables_for(c->g1_uvw_stmt, n_stmt, dU.w(), s);
-  const std::shared_ptr<void> akey = ate_key_now(c, n_stmt, dU.w(), dg.w(), dd.w(), (const uint32_t*)tabs.get(), s);      // held until the synchronisation below; null: the value-comparing kernels
+  const std::shared_ptr<void> akey = ate_key_now(c, n_stmt, dU.w(), dg.w(), dd.w(), s);      // held until the synchronisation below; null: the value-comparing kernels
   PCHK(launch_groth16_verify(dA.w(), dB.w(), dC.w(), dU.w(), dW.w(), (int)n_stmt, dg.w(), dd.w(), dab.w(), dok.w(), n_proofs, (unsigned long long*)derr.p, s, (const uint32_t*)akey.get()));
   unsigned long long e = NO_ERR;
   if ((rc = down(ok, dok.p, n_proofs * 4, s)) || (rc = down(&e, derr.p, 8, s))) return rc;
@@ -688,8 +687,8 @@ int zkt_groth16_vk_prepare(const zkt_groth16_crs* c, size_t n_stmt) {
   Dev dU(n_stmt * G1B, true), dg(G2B, true), dd(G2B, true);
   int rc;
   if ((rc = up(dU, c->g1_uvw_stmt, n_stmt * G1B, s)) || (rc = up(dg, c->g2_gamma, G2B, s)) || (rc = up(dd, c->g2_delta, G2B, s))) return rc;
+  const std::shared_ptr<void> akey = ate_key_now(c, n_stmt, dU.w(), dg.w(), dd.w(), s);      // builds the statement points' 16^k tables on its way
   const std::shared_ptr<void> tabs = stmt_tables_for(c->g1_uvw_stmt, n_stmt, dU.w(), s);
-  const std::shared_ptr<void> akey = ate_key_now(c, n_stmt, dU.w(), dg.w(), dd.w(), (const uint32_t*)tabs.get(), s);
   PCHK(hipStreamSynchronize(s));
   return ZKT_OK;
 }
@@ -782,7 +781,8 @@ extern "C" void zkt_internal_clear_caches() {             // zkt_shutdown: devic
       if (e.ev_in) { (void)hipEventDestroy(e.ev_in); (void)hipEventDestroy(e.ev_side); (void)hipEventDestroy(e.ev_done); (void)hipHostFree(e.host); e.ev_in = e.ev_side = e.ev_done = nullptr; e.host = nullptr; }
       e.dev.reset(); e.key.clear(); e.stamp = 0; e.usable = false; e.state = 0;
     }
-    if (g_ate_side) { (void)hipStreamSynchronize(g_ate_side); (void)hipStreamDestroy(g_ate_side); g_ate_side = nullptr; } }
+    if (g_ate_side) { (void)hipStreamSynchronize(g_ate_side); (void)hipStreamDestroy(g_ate_side); g_ate_side = nullptr; }
+  }
 }
 extern "C" {
 int zkt_bp_ipa_ctx_create(size_t n, const zkt_secp_affine* gg, const zkt_secp_affine* hh, const zkt_secp_affine* u, zkt_bp_ipa_ctx** out) {
