@@ -230,10 +230,10 @@ int zkt_groth16_prove(const zkt_groth16_crs* crs, const uint64_t* ui, const uint
  * one final exponentiation (the decision is a bool, so this is parity-safe).  stmt_wires: n_proofs x n_stmt.  ok[i] = 1/0. */
 int zkt_groth16_verify_batch(const zkt_groth16_crs* crs, const zkt_g1_affine* A, const zkt_g2_affine* B, const zkt_g1_affine* C,
                              const uint64_t* stmt_wires, size_t n_stmt, size_t n_proofs, uint32_t* ok);
-/* Optional, once per verifying key: build the per-key tables of the verification fast path now (statement points' fixed-base tables, line tables of gamma and delta,
- * the ate counterpart of alpha_beta: ~20 ms).  Without it the library serves the FIRST small-batch verification against a key with kernels that need nothing of the
- * key and builds the tables at the second (a one-off verification costs 6 ms, not 26; the second call then takes ~23 ms, later ones ~5 ms); a caller that knows its key
- * avoids that bump.  Keys are cached by their bytes (last four).  Decisions do not depend on whether this was called. */
+/* Optional, once per verifying key: build the per-key tables of the verification fast path now and wait for them (statement points' fixed-base tables, line tables of
+ * gamma and delta, the ate counterpart of alpha_beta: ~5 ms).  Without it the library builds them at the FIRST small-batch verification against a key, beside that call
+ * (which is served by kernels that need nothing of the key: ~10.5 ms instead of ~5); every later call on the key takes ~5 ms.  Keys are cached by their bytes (last
+ * four).  Decisions do not depend on whether this was called. */
 int zkt_groth16_vk_prepare(const zkt_groth16_crs* crs, size_t n_stmt);
 /* returns 1 accept, 0 reject, negative = -status (a pairing argument at infinity panics in the reference) */
 int zkt_groth16_verify(const zkt_groth16_crs* crs, const zkt_g1_affine* A, const zkt_g2_affine* B, const zkt_g1_affine* C,

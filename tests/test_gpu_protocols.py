@@ -367,9 +367,59 @@ def test_g1_one_shot_msm_sizes_by_linearity(L, n):
     assert (got == g1_arr([py_g1_mul(G1_GEN, tot)])).all()
 
 
+def test_groth16_verify_from_four_threads(L):
+    """Verifier::verify (verifier.rs:30-54) from four caller threads at once, three keys between them, none of them seen before: the key cache is shared state (an entry is
+    begun by the first caller that shows a key — guard stream, side stream, pinned verdict — while another thread may look the same key up, find it busy and take the 127-step
+    kernels).  Every decision must be the single-threaded one: accept for the key's own proof, reject for a wrong statement and for another key's proof."""
+    import threading
+    A_, B_, C_, wit, l = example_cubic()
+    n, m = len(A_), len(wit) - 1
+    ui, vi, wi, h, _ = qap_from_r1cs(A_, B_, C_, wit)
+    U, V, W = dense(ui, n), dense(vi, n), dense(wi, n)
+    wires, H = ints_to_arr(wit, 4), ints_to_arr(h, 4)
+    stmt = ints_to_arr(wit[:l + 1], 4)
+    bad = stmt.copy(); bad[l, 0] ^= np.uint64(1)
+    keys = []
+    for k in range(3):
+        rng = SplitMix64(7700 + k); trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+        crs, buf = alloc_crs(n, l, m)
+        zk.check(L.zkt_groth16_setup(ctypes.byref(crs), ptr(U), ptr(V), ptr(W), *[ptr(t) for t in trap]))
+        pf = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+        zk.check(L.zkt_groth16_prove(ctypes.byref(crs), ptr(U), ptr(V), ptr(wires), ptr(H), len(h), ptr(fr(rng.below(R - 1) + 1)), ptr(fr(rng.below(R - 1) + 1)), *[ptr(x) for x in pf]))
+        keys.append((crs, buf, pf))
+    errors = []
+    start = threading.Barrier(4)
+    def worker(t):
+        try:
+            start.wait()
+            for it in range(6):
+                k = (t + it) % 3
+                crs, pf, other = keys[k][0], keys[k][2], keys[(k + 1) % 3][2]
+                st, bd = stmt.copy(), bad.copy()
+                got = (L.zkt_groth16_verify(ctypes.byref(crs), *[ptr(x) for x in pf], ptr(st), l + 1),
+                       L.zkt_groth16_verify(ctypes.byref(crs), *[ptr(x) for x in pf], ptr(bd), l + 1),
+                       L.zkt_groth16_verify(ctypes.byref(crs), *[ptr(x) for x in other], ptr(st), l + 1))
+                if got != (1, 0, 0): errors.append((t, it, k, got))
+        except Exception as e:                                              # a thread's exception must fail the test, not vanish
+            errors.append((t, repr(e)))
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errors, errors
+    # a batch of 4,096 proofs on one of those keys right afterwards (the per-lane kernel reads the same entry)
+    k = 4096
+    pf = keys[1][2]
+    As, Bs, Cs = np.repeat(pf[0], k, axis=0), np.repeat(pf[1], k, axis=0), np.repeat(pf[2], k, axis=0)
+    sts = np.repeat(stmt.reshape(1, -1), k, axis=0).copy(); sts[17] = bad.reshape(-1)
+    ok = np.zeros(k, np.uint32)
+    zk.check(L.zkt_groth16_verify_batch(ctypes.byref(keys[1][0]), ptr(As), ptr(Bs), ptr(Cs), ptr(sts), l + 1, k, ok.ctypes.data))
+    want = np.ones(k, np.uint32); want[17] = 0
+    assert (ok == want).all()
+
+
 def test_groth16_verify_with_several_keys(L):
     """The verifier keeps what a key contributes to the 63-step loop (line tables of gamma and delta, the ate counterpart of alpha_beta, statement tables) for the last four
-    keys, builds an entry at the SECOND sight of a key (first sight is served by the 127-step kernels) and evicts the least recently used one.  Five keys in rotation, each
+    keys, builds an entry at the FIRST sight of a key, beside the call that brought it (that call is served by the 127-step kernels), and evicts the least recently used one.  Five keys in rotation, each
     verified three times in a row and revisited after its entry has been evicted: every decision equals the oracle's, for the valid proof and for a wrong statement."""
     A_, B_, C_, wit, l = example_cubic()
     n, m = len(A_), len(wit) - 1
