@@ -241,7 +241,7 @@ def main():
 
     # ---- BASELINE config 4: Groth16 prove + verify at 2^20 constraints on the synthetic chain R1CS, sparse-R1CS path (row f-3).
     # N = 1: the whole proof on one GPU, two proofs in flight.  N > 1: (a) ONE proof sharded — every rank keeps an index range of the three resident
-    # base sets, the Fr stage is replicated, one all-gather of 672 B per proof inside zkt_groth16_prove_r1cs_sharded; (b) replicas — every rank
+    # base sets and evaluates only its own range of the quotient (no exchange in the Fr stage), one all-gather of 672 B per proof inside zkt_groth16_prove_r1cs_sharded; (b) replicas — every rank
     # its own key and its own proofs, no exchange at all.
     g16 = None
     if args.groth16_log2n > 0:
@@ -298,8 +298,9 @@ def main():
                 L.zkt_groth16_pk_free(pk)
                 g16["sharded"] = {"value": 1.0 / dt, "ms_per_proof": dt * 1e3, "setup_s": round(g_setup, 2),
                                   "sharding": "index ranges of the three resident MSM base sets per rank; one all-gather of 672-B Jacobian partials per proof (C ABI, RCCL)",
-                                  "amdahl_note": "the Fr stage (3 mat-vecs + 6 NTTs of 2^21, ~10 % of a one-GPU proof) is replicated on every rank and the MSM shards of 2^20/N terms sit on "
-                                                 "the latency floor of the sort + reduce stages: speed-up <= 1/(0.1 + 0.9/N) and in practice lower (DESIGN.md §6)"}
+                                  "amdahl_note": "every rank evaluates only its own range of the quotient (N forward transforms of 2n/N and one inverse per polynomial, no exchange: about half of a "
+                                                 "replicated Fr stage); the MSM shards of 2^20/N terms sit on the latency floor of the sort + reduce stages and run more windows per term than one "
+                                                 "2^20-term MSM, which is what bounds the speed-up (DESIGN.md §6)"}
                 sharded_proof = [x.copy() for x in gp]
             stage = "setup"
             rc, pk, vk1, vbuf1, g_setup = setup(0, 1)

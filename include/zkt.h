@@ -447,7 +447,7 @@ int zkt_g1_msm_sharded_collect(zkt_g1_bases* bases, int slot, zkt_g1_affine* out
 int zkt_g2_msm_sharded_collect(zkt_g2_bases* bases, int slot, zkt_g2_affine* out);
 int zkt_secp_msm_sharded_collect(zkt_secp_bases* bases, int slot, zkt_secp_affine* out);
 /* Prover::prove (prover.rs:96-147) for ONE proof sharded over the ranks (BASELINE config 4): pk from zkt_groth16_setup_r1cs_sharded(…,
- * zkt_comm_rank(), zkt_comm_world(), …).  The Fr stage (mat-vecs, NTTs) is replicated; collective. */
+ * zkt_comm_rank(), zkt_comm_world(), …).  The mat-vecs are replicated; of the quotient every rank evaluates its own range only (no exchange); collective. */
 int zkt_groth16_prove_r1cs_sharded(zkt_groth16_pk* pk, const uint64_t* dev_wires, const uint64_t* r, const uint64_t* s,
                                    zkt_g1_affine* A, zkt_g2_affine* B, zkt_g1_affine* C);
 

@@ -49,7 +49,7 @@ if args.rank < 0:
     print(f"prove: {dt*1e3:.1f} ms/proof = {1/dt:.2f} proofs/s (wires resident in HBM); verify -> {ok} in {tv*1e3:.1f} ms")
     L.zkt_groth16_pk_free(pk)
 if args.shard_of > 1:
-    # what ONE rank of a W-GPU proof does before the 672-byte exchange: its index ranges of the three base sets, the Fr stage replicated
+    # what ONE rank of a W-GPU proof does before the 672-byte exchange: its index ranges of the three base sets, its own range of the quotient
     W = args.shard_of
     parts = torch.zeros(1024, dtype=torch.int32, device="cuda")
     for rank in (sorted({0, W // 2, W - 1}) if args.rank < 0 else [args.rank]):
