@@ -722,13 +722,18 @@ struct zkt_bp_ipa_ctx {
   hipStream_t main = nullptr;              // the range proof's own stream: on the legacy NULL stream every one of its ~150 small launches pays the implicit barriers (~45 us each)
   // fixed-base tables (launch_fixed_table) of the range proof's g, h and of u: 3 x 64 points; g and h arrive per call and are cached by value
   Dev dfix{3 * 64 * SPB};
+  // the range proof's work buffers (32 n-vectors, scalars, partial sums, points: range_proof_core carves them), kept with the context: seven hipMalloc and, worse, seven
+  // hipFree per proof — each free waits for the whole device — were 0.26 ms of a 3.5 ms proof (hip trace, round 4)
+  static constexpr int RP_NV = 32, RP_NS = 96;
+  static size_t rp_arena_bytes(size_t n) { return (size_t)RP_NV * n * FRB + (size_t)RP_NS * FRB + 64 + 64 * FRB + 8 * 80 + 48 * 80 + 7 * ((n + 255) / 256) * FRB + 1024; }
+  Dev rp_arena;
   zkt_secp_affine fix_g{}, fix_h{}; bool fix_g_ok = false, fix_h_ok = false, fix_u_ok = false;
   static size_t log2z(size_t n) { size_t l = 0; for (size_t t = n; t > 1; t >>= 1) ++l; return l; }
   explicit zkt_bp_ipa_ctx(size_t n)
       : N(n), NB(2 * n + 1), levels(log2z(n)), lv1(levels ? levels : 1), dbase(NB * SPB), da(N * FRB), db(N * FRB), da2(N * FRB), db2(N * FRB), dwG(N * FRB), dwH(N * FRB),
         dsc((size_t)IPA_SLOTS * NB * FRB), dPp(SPB), dx(lv1 * FRB), dch(4 * FRB), dsq(lv1 * 2 * FRB), dc(2 * FRB), dlr(lv1 * 2 * SPB), dm(lv1 * 2 * SPB), dt(SPB), dcomb(NB * FRB),
-        dAL(2 * N * FRB), dBL(2 * N * FRB), dchall(lv1 * 4 * FRB), dpart(lv1 * 2 * 16 * FRB) {}      // dpart: IPA_DOT_SPLIT (16) partial sums per (level, side)
-  bool ok() const { return dfix.p && dbase.p && da.p && db.p && da2.p && db2.p && dwG.p && dwH.p && dsc.p && dPp.p && dx.p && dch.p && dsq.p && dc.p && dlr.p && dm.p && dt.p && dcomb.p && dAL.p && dBL.p && dchall.p && dpart.p; }
+        dAL(2 * N * FRB), dBL(2 * N * FRB), dchall(lv1 * 4 * FRB), dpart(lv1 * 2 * 16 * FRB), rp_arena(rp_arena_bytes(n)) {}      // dpart: IPA_DOT_SPLIT (16) partial sums per (level, side)
+  bool ok() const { return dfix.p && dbase.p && da.p && db.p && da2.p && db2.p && dwG.p && dwH.p && dsc.p && dPp.p && dx.p && dch.p && dsq.p && dc.p && dlr.p && dm.p && dt.p && dcomb.p && dAL.p && dBL.p && dchall.p && dpart.p && rp_arena.p; }
   ~zkt_bp_ipa_ctx() {
     for (hipStream_t x : side) if (x) { hipStreamSynchronize(x); hipStreamDestroy(x); }
     if (main) { hipStreamSynchronize(main); hipStreamDestroy(main); }
@@ -983,9 +988,12 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   const int PW = 18;
   unsigned long long* noerr = nullptr;
   // scalar-field vectors on the device (canonical residues), simple arena of n-vectors and scalars
-  const int NV = 32, NS = 96;
-  Dev vec((size_t)NV * n * FRB), sc((size_t)NS * FRB), derr(8);
-  if (!vec.p || !sc.p || !derr.p) return -ZKT_ERR_DEVICE;
+  const int NV = zkt_bp_ipa_ctx::RP_NV, NS = zkt_bp_ipa_ctx::RP_NS;
+  struct View { uint8_t* p; uint32_t* w() const { return (uint32_t*)p; } };                 // carved from the context's arena (the context's lock is held: one proof at a time)
+  uint8_t* arena = (uint8_t*)c->rp_arena.p;
+  auto carve = [&](size_t bytes) { View v{arena}; arena += (bytes + 63) & ~(size_t)63; return v; };
+  static_assert(sizeof(zkt_secp_affine) <= 80, "arena sizing");
+  const View vec = carve((size_t)NV * n * FRB), sc = carve((size_t)NS * FRB), derr = carve(8);
   noerr = (unsigned long long*)derr.p;
   int vi = 0, si = 0;
   auto newv = [&]() { return vec.w() + (size_t)(vi++) * n * 8; };
@@ -998,8 +1006,7 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   auto vscl = [&](const uint32_t* a, const uint32_t* k) { flush_scalars(); uint32_t* o = newv(); hipLaunchKernelGGL(k_scale<SnC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, k, n, o); return o; };
   auto vpow = [&](const uint32_t* b) { flush_scalars(); uint32_t* o = newv(); hipLaunchKernelGGL(k_powseq<SnC>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, b, n, o); return o; };
   auto vsum = [&](const uint32_t* a) { uint32_t* o = news(); hipLaunchKernelGGL(k_sum<SnC>, dim3(1), dim3(256), 0, s, a, n, o); return o; };
-  Dev dparts(64 * FRB);
-  if (!dparts.p) return -ZKT_ERR_DEVICE;
+  const View dparts = carve(64 * FRB);
   auto vdot = [&](const uint32_t* a, const uint32_t* b) {
     uint32_t* o = news();
     if (n < 4096) { hipLaunchKernelGGL(k_dot<SnC>, dim3(1), dim3(256), 0, s, a, b, n, o); return o; }
@@ -1027,8 +1034,7 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   // with scalars v o y^-n, and the argument starts from the coefficients y^-i on hh.  res = A S T1 T2 P | single-point scratch.
   int rc;
   const size_t NB = c->NB;
-  Dev pts(8 * SPB), res(48 * SPB);
-  if (!pts.p || !res.p) return -ZKT_ERR_DEVICE;
+  const View pts = carve(8 * SPB), res = carve(48 * SPB);
   uint32_t *Gp = pts.w(), *Hp = Gp + PW, *Vp = Hp + PW, *Up = c->dbase.w() + 2 * n * PW;
   hipMemcpyAsync(Gp, g, SPB, hipMemcpyHostToDevice, s); hipMemcpyAsync(Hp, h, SPB, hipMemcpyHostToDevice, s); hipMemcpyAsync(Vp, V, SPB, hipMemcpyHostToDevice, s);
   uint32_t* R = res.w();
@@ -1064,8 +1070,7 @@ static int range_proof_core(zkt_bp_ipa_ctx* c, const zkt_secp_affine* V, const u
   uint32_t *d_gamma = sput(gamma), *one = sput(one64), *two = sput(two64);
   uint32_t *z2, *yinv_n, *t1, *t2, *t_hat, *tau_x, *mu, *l, *r, *lr, *k_g, *k_h, *two_n = nullptr, *v_val = nullptr;
   static const bool fused = [] { const char* e = getenv("ZKT_RP_FUSED"); return !e || atoi(e) != 0; }();
-  Dev dparts7(7 * ((n + 255) / 256) * FRB);
-  if (!dparts7.p) return -ZKT_ERR_DEVICE;
+  const View dparts7 = carve(7 * ((n + 255) / 256) * FRB);
   if (fused) {                                                                        // the whole vector stage in one launch (k_rp_fused)
     z2 = smul(z, z);
     uint32_t *yinv = sinv(y), *x2 = smul(x, x), *z3 = smul(z2, z);
