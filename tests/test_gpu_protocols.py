@@ -367,6 +367,43 @@ def test_g1_one_shot_msm_sizes_by_linearity(L, n):
     assert (got == g1_arr([py_g1_mul(G1_GEN, tot)])).all()
 
 
+def test_groth16_vk_prepare(L):
+    """zkt_groth16_vk_prepare builds a key's entry for the 63-step loop ahead of the first verification (verifier.rs:30-54 builds nothing per key; crs.rs:137-139 computes
+    alpha_beta once).  Decisions do not depend on it: a prepared key accepts its proof and rejects a wrong statement from the first call on; a key whose stored alpha_beta is NOT
+    tate(alpha, beta) is prepared without error, never qualifies for the 63-step loop, and is decided against the stored element exactly as the oracle decides; shapes are checked."""
+    A_, B_, C_, wit, l = example_cubic()
+    n, m = len(A_), len(wit) - 1
+    ui, vi, wi, h, _ = qap_from_r1cs(A_, B_, C_, wit)
+    U, V, W = dense(ui, n), dense(vi, n), dense(wi, n)
+    wires, H = ints_to_arr(wit, 4), ints_to_arr(h, 4)
+    stmt = ints_to_arr(wit[:l + 1], 4)
+    bad = stmt.copy(); bad[l, 0] ^= np.uint64(1)
+    rng = SplitMix64(8800); trap = [fr(rng.below(R - 1) + 1) for _ in range(5)]
+    crs, buf = alloc_crs(n, l, m)
+    zk.check(L.zkt_groth16_setup(ctypes.byref(crs), ptr(U), ptr(V), ptr(W), *[ptr(t) for t in trap]))
+    pf = (np.zeros((1, G1W), np.uint64), np.zeros((1, G2W), np.uint64), np.zeros((1, G1W), np.uint64))
+    zk.check(L.zkt_groth16_prove(ctypes.byref(crs), ptr(U), ptr(V), ptr(wires), ptr(H), len(h), ptr(fr(rng.below(R - 1) + 1)), ptr(fr(rng.below(R - 1) + 1)), *[ptr(x) for x in pf]))
+    L.zkt_groth16_vk_prepare.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    assert L.zkt_groth16_vk_prepare(ctypes.byref(crs), l + 2) == ZKT_ERR_SHAPE               # more statement wires than the key has
+    assert L.zkt_groth16_vk_prepare(None, l + 1) == ZKT_ERR_SHAPE
+    assert L.zkt_groth16_vk_prepare(ctypes.byref(crs), 0) == 0                               # nothing to prepare
+    assert L.zkt_groth16_vk_prepare(ctypes.byref(crs), l + 1) == 0
+    assert L.zkt_groth16_vk_prepare(ctypes.byref(crs), l + 1) == 0                           # again: the entry exists
+    for st, want in ((stmt, 1), (bad, 0), (stmt, 1)):
+        assert L.zkt_groth16_verify(ctypes.byref(crs), *[ptr(x) for x in pf], ptr(st), l + 1) == want
+        assert O.zkto_groth16_verify(ctypes.byref(crs), *[ptr(x) for x in pf], ptr(st), l + 1) == want
+    # the same key with another GT element in place of alpha_beta (here: its square): preparing succeeds, the verifier compares against THAT element like the reference does
+    crs2, buf2 = alloc_crs(n, l, m)
+    zk.check(L.zkt_groth16_setup(ctypes.byref(crs2), ptr(U), ptr(V), ptr(W), *[ptr(t) for t in trap]))
+    gt = buf2["gt_alpha_beta"]
+    sq = np.zeros_like(gt); zk.check(L.zkt_fq12_mul_batch(ptr(gt.copy()), ptr(gt.copy()), ptr(sq), 1)); gt[:] = sq
+    assert L.zkt_groth16_vk_prepare(ctypes.byref(crs2), l + 1) == 0
+    for st in (stmt, bad):
+        want = O.zkto_groth16_verify(ctypes.byref(crs2), *[ptr(x) for x in pf], ptr(st), l + 1)
+        assert want == 0                                                                      # the proof was made for alpha_beta, not for its square
+        for _ in range(2): assert L.zkt_groth16_verify(ctypes.byref(crs2), *[ptr(x) for x in pf], ptr(st), l + 1) == want
+
+
 def test_groth16_verify_from_four_threads(L):
     """Verifier::verify (verifier.rs:30-54) from four caller threads at once, three keys between them, none of them seen before: the key cache is shared state (an entry is
     begun by the first caller that shows a key — guard stream, side stream, pinned verdict — while another thread may look the same key up, find it busy and take the 127-step
