@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_merge_hot(const uint32
   if (grp == 0) coop_store<F>(g, r, hot_part + ((size_t)h * HOT_FAN + blockIdx.x) * XYW);
 }
 
-// split buckets: sums[b] = sum of the bucket's partials.  A block takes tiles of RED_NG buckets: a bucket cut into a few pieces is summed by its own
+// split buckets: sums[b] = sum of the bucket's partials.  A block takes tiles of RED_NG buckets (strided, below): a bucket cut into a few pieces is summed by its own
 // group, piece after piece (small MSMs cut every bucket); a bucket with many pieces takes the whole block (groups in parallel + the tree), and a
 // listed hot bucket is the sum of the HOT_FAN block sums k_merge_hot left.
 template <class F>
@@ -231,8 +231,12 @@ __global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_merge_partials(const u
   uint32_t* g = lds + grp * K::GW;
   const uint32_t hc = hot[0];
   const uint32_t my_hot = threadIdx.x < hc && hc <= HOT_CAP ? hot[1 + threadIdx.x] : 0xffffffffu;
-  for (size_t b0 = (size_t)blockIdx.x * RED_NG; b0 < nbuckets; b0 += (size_t)gridDim.x * RED_NG) {
-    const size_t mine = b0 + grp;
+  // A tile is RED_NG buckets `ntiles` apart, NOT RED_NG neighbours: buckets with many pieces come in runs of neighbours (the few digits a narrow top window can hold, small
+  // witness values) and a tile works through its many-piece buckets one after the other — sixteen neighbours in one tile were 0.84 ms of a 1.6 ms MSM (2^14 terms at c = 14,
+  // profiles/r04_msm_window_sweep.txt), spread over sixteen tiles they are one bucket's time.
+  const size_t ntiles = (nbuckets + RED_NG - 1) / RED_NG;
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t mine = tile + (size_t)grp * ntiles;
     const uint32_t my_t0 = mine < nbuckets ? task_off[mine] : 0u, my_nt = mine < nbuckets ? task_off[mine + 1] - my_t0 : 1u;
     const unsigned long long few = __ballot(my_nt > 1 && my_nt <= MERGE_GROUP_MAX);
     if (few) {                                                          // wave-uniform
@@ -254,7 +258,7 @@ __global__ void __launch_bounds__(RED_TPB) ZKT_RED_ATTR k_merge_partials(const u
     unsigned long long todo = __ballot(my_nt > MERGE_GROUP_MAX && r == 0);
     while (todo) {                                                      // wave-uniform: one bucket with many pieces at a time, the whole block on it
       const int l = __ffsll((long long)todo) - 1; todo &= todo - 1;
-      const size_t b = b0 + (l >> 2);
+      const size_t b = tile + (size_t)(l >> 2) * ntiles;
       const uint32_t t0 = task_off[b], nt = task_off[b + 1] - t0;
       const unsigned long long listed = __ballot(my_hot == (uint32_t)b);
       // a listed hot bucket: the HOT_FAN block sums of k_merge_hot; any other: its partials

@@ -75,12 +75,15 @@ MsmPlan msm_plan(size_t n, int grp) {
   const size_t XYW = 4 * (size_t)coord_words(grp);
   int lg = 0; while ((size_t(1) << (lg + 1)) <= (n ? n : 1)) ++lg;   // floor(log2 n)
   // Window width.  2^20 terms: c = 20, 2^19 buckets ~ n/2, ~2*nwin ~ 26 points per bucket.  Below 2^19 terms the MSM is latency-bound and the width is MEASURED, not derived
-  // (profiles/r04_msm_window_sweep.txt: single and pipelined time of resident G1 and G2 MSMs for c = lg-2 .. lg+2 at sizes 2^8 .. 2^18, forced widths at 2^4 .. 2^11 and 2^19): the time is far from monotonic in c —
-  // widths whose TOP window holds a few bits of a 255-bit scalar (c = 12, 14, 18: three bits) put n entries into 8-16 buckets that are long chains for the merge kernels yet
-  // below the hot-bucket fan-out, and cost 1.5-2.5x — so the plan picks from the widths that measured well: 16 (windows end at bit 256: no carry window at all), 15, 13, 11, 10.
-  // c = 17 for 2^17 terms (round 3's c = lg) -> 16: 1.24 -> 1.16 ms single, G2 at 2^18 terms 6.2 -> 4.2 ms, a rank's share of a sharded Groth16 proof 6.3 -> 5.1 ms.
+  // (profiles/r04_msm_window_sweep.txt: single and pipelined time of resident G1 and G2 MSMs over widths and sizes 2^4 .. 2^19).  Round 3's c = floor(log2 n) met widths whose
+  // TOP window holds a few bits of a 255-bit scalar (256 + c is not a multiple of c: the last window is a remainder; three bits at c = 12, 14, 18): every scalar then lands in one
+  // of 8-16 NEIGHBOURING buckets of that window, which (i) one tile of k_merge_partials summed one after the other (0.84 ms of a 1.6 ms MSM at 2^14 terms — fixed there: tiles
+  // are strided now) and (ii) serialise the counting sort's atomics on 8-16 counters (k_digits 1.2-1.5 ms at 2^18 terms, c = 18).  The plan picks widths that measured well on
+  // both counts: 16 from 2^14 terms on (windows end exactly at bit 256: no remainder window), 13 / 11 / 10 below.  c = 17 -> 16 at 2^17 terms: 1.24 -> 1.14 ms single,
+  // 2^18 terms 2.90 -> 1.62 ms, G2 at 2^18 terms 6.2 -> 4.2 ms, a rank's share of a sharded Groth16 proof 6.3 -> 5.1 ms; 2^19 terms: c = 20 as well (2.17 / 1.45 ms single /
+  // pipelined against 3.27 / 1.69 at c = 19).
   static const int forced_c = [] { const char* e = getenv("ZKT_MSM_C"); return e ? atoi(e) : 0; }();
-  int c = lg >= 19 ? 20 : lg >= 14 ? 16 : lg == 13 ? 15 : lg >= 11 ? 13 : lg == 10 ? 11 : 10;      // (2^19 terms: c = 20 as well — 2.17 / 1.45 ms single / pipelined against 3.27 / 1.69 at c = 19)
+  int c = lg >= 19 ? 20 : lg >= 14 ? 16 : lg >= 11 ? 13 : lg == 10 ? 11 : 10;      // (2^19 terms: c = 20 as well — 2.17 / 1.45 ms single / pipelined against 3.27 / 1.69 at c = 19)
   if (forced_c) c = forced_c;
   if (c < 4) c = 4;
   if (c > 20) c = 20;
