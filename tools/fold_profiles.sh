@@ -31,6 +31,7 @@ cp $O/${T}_protocols.json $P/${T}_protocols.json
 cp "$(newest "$O/prof_${T}_protocols/*/*kernel_stats.csv")" $P/${T}_protocols_kernel_stats.csv
 [ -f $O/${T}_g16_shard.txt ] && cp $O/${T}_g16_shard.txt $P/${T}_groth16_shard_of_8.txt
 [ -f $O/${T}_bp.log ] && grep -v "amdgpu.ids" $O/${T}_bp.log > $P/${T}_bulletproofs_latency.txt
+for X in groth16_small_circuits verify_first_sight_timeline msm_small_valued_scalars; do [ -f $O/${T}_$X.txt ] && cp $O/${T}_$X.txt $P/${T}_$X.txt; done
 echo "folded into $P/${T}_*  (kernel sources $(python3 tools/src_hash.py))"
 python3 - "$P/${T}_tate_memory_counters.json" <<'PY'
 import json, sys

@@ -18,6 +18,10 @@
 #   verify_latency    tools/bench_verify_latency.py (unprepared / prepared key, calls 1..5; batch sizes)
 #   pmc_verify_hbm    FETCH_SIZE / WRITE_SIZE passes over tools/bench_g16_batch_verify.py (the 63-step deciding kernels)
 #   rehearsal         two ranks on one card through the callback transport (bench.py --gpus 2, gloo)
+#   small_circuits    Groth16 proofs at 2^12 / 2^16 / 2^18 constraints and the Pinocchio latencies -> <tag>_groth16_small_circuits.txt
+#   window_sweep      tools/diag/msm_window_sweep.py: forced window widths 12..18 at 2^10..2^18 terms (G1), 14..18 (G2) beside the plan's own table -> <tag>_msm_window_sweep_now.txt
+#   verify_timeline   kernel timeline of the first verifications against unseen keys (rocprofv3 --kernel-trace of tools/bench_verify_latency.py) -> <tag>_verify_first_sight_timeline.txt
+#   msm_skew          tools/diag/msm_skew.py 14 17 18 20: resident G1 MSM on scalars of 1 / 4 / 8 / 255 bits -> <tag>_msm_small_valued_scalars.txt
 #   py:<script> [..]  python3 <script> -> <tag>_<script>.log
 #   cmd:<shell>       any shell command (quoted)
 set -o pipefail
@@ -78,6 +82,20 @@ for STEP in "$@"; do
         timeout -k 10 300 rocprofv3 --pmc $CNT -d $O/prof_${TAG}_hbm_verify_$CNT --output-format csv -- python3 tools/bench_g16_batch_verify.py 65536 > $O/prof_${TAG}_hbm_verify_$CNT.log 2>&1 || fail "pmc_verify_hbm $CNT" $O/prof_${TAG}_hbm_verify_$CNT.log
       done ;;
     rehearsal) ZKT_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --groth16-log2n 16 --groth16-proofs 3 --pairings 4096 --no-cpu > $O/${TAG}_bench_rehearsal_2ranks_1gpu.json 2> $O/${TAG}_rehearsal.err || fail rehearsal $O/${TAG}_rehearsal.err ;;
+    small_circuits) : > $O/${TAG}_groth16_small_circuits.txt
+      for LN in 12 16 18; do timeout -k 10 300 python3 tools/bench_groth16.py --log-n $LN --proofs 10 2>&1 | grep "^prove" | sed "s/^/2^$LN /" >> $O/${TAG}_groth16_small_circuits.txt || fail "small_circuits $LN" $O/${TAG}_groth16_small_circuits.txt; done
+      timeout -k 10 300 python3 tools/bench_pinocchio.py 2>&1 | grep -v "^[WEI]2026\|amdgpu.ids" | tail -4 >> $O/${TAG}_groth16_small_circuits.txt || fail small_circuits $O/${TAG}_groth16_small_circuits.txt
+      cat $O/${TAG}_groth16_small_circuits.txt ;;
+    window_sweep) : > $O/${TAG}_msm_window_sweep_now.txt
+      timeout -k 10 300 python3 tools/diag/msm_window_sweep.py g1 4 8 10 12 14 16 17 18 19 2>&1 | grep "^c " >> $O/${TAG}_msm_window_sweep_now.txt || fail window_sweep $O/${TAG}_msm_window_sweep_now.txt
+      for C in 12 14 16 17 18; do ZKT_MSM_C=$C timeout -k 10 300 python3 tools/diag/msm_window_sweep.py g1 10 12 14 16 17 18 2>&1 | grep "^c " >> $O/${TAG}_msm_window_sweep_now.txt || fail "window_sweep $C" $O/${TAG}_msm_window_sweep_now.txt; done
+      for C in 14 16 18; do ZKT_MSM_C=$C timeout -k 10 300 python3 tools/diag/msm_window_sweep.py g2 14 17 18 2>&1 | grep "^c " >> $O/${TAG}_msm_window_sweep_now.txt || fail "window_sweep g2 $C" $O/${TAG}_msm_window_sweep_now.txt; done
+      tail -5 $O/${TAG}_msm_window_sweep_now.txt ;;
+    verify_timeline) timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/prof_${TAG}_vl -- python3 tools/bench_verify_latency.py > $O/prof_${TAG}_vl.log 2>&1 || fail verify_timeline $O/prof_${TAG}_vl.log
+      python3 tools/diag/verify_trace.py $(ls -t $O/prof_${TAG}_vl/*/*kernel_trace.csv | head -1) 60 > $O/${TAG}_verify_first_sight_timeline.txt 2>&1 || true
+      head -14 $O/${TAG}_verify_first_sight_timeline.txt ;;
+    msm_skew) timeout -k 10 400 python3 tools/diag/msm_skew.py 14 17 18 20 2>&1 | grep "^g1" > $O/${TAG}_msm_small_valued_scalars.txt || fail msm_skew $O/${TAG}_msm_small_valued_scalars.txt
+      cat $O/${TAG}_msm_small_valued_scalars.txt ;;
     py:*) S="${STEP#py:}"; N=$(basename ${S%% *} .py)
       timeout -k 10 900 python3 $S > $O/${TAG}_${N}.log 2>&1 || fail "$STEP" $O/${TAG}_${N}.log
       grep -v "^[WEI]2026" $O/${TAG}_${N}.log | tail -25 ;;
