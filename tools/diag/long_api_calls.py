@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""The twelve longest HIP API calls of the last 600 ms of a rocprofv3 --hip-trace run (what a slow call was waiting in).  usage: long_api_calls.py <dir with *_hip_api_trace.csv>"""
 import csv,glob,sys
 d=sys.argv[1]
 at=list(csv.DictReader(open(glob.glob(d+"/*hip_api_trace.csv")[0])))
