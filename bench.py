@@ -312,6 +312,31 @@ def main():
                         "mode": "one key, two proofs in flight" if world == 1 else "replicas: one key and two proofs in flight per GPU, no exchange"})
             if world > 1:
                 g16["sharded"]["equals_unsharded_proof"] = bool(all((a == b).all() for a, b in zip(sharded_proof, gp)))
+            elif gn >= 64:
+                # BASELINE config 4 on ONE card: what rank 3 of 8 does for one proof sharded over 8 GPUs (its index ranges of the three base sets, its own range of the quotient,
+                # the three Jacobian partials; the exchange is 672 B more) — one proof at a time, against one unpipelined proof on this GPU.  Not a scaling measurement:
+                # the per-rank time a node of 8 would run at (the eight ranks' partials combine to the unsharded proof: tests/test_gpu_fullsize.py).
+                stage = "share of 8"
+                rc, spk, svk, svbuf, s_setup = setup(3, 8)
+                if rc != 0: raise RuntimeError("sharded setup (rank 3 of 8) failed: rc %d" % rc)
+                d_parts = torch.zeros(1024, dtype=torch.int32, device=dev)
+                for _ in range(2): zk.check(L.zkt_groth16_prove_r1cs_partials(spk, d_w.data_ptr(), pr.ctypes.data, ps.ctypes.data, d_parts.data_ptr()))
+                torch.cuda.synchronize(); tsh = []
+                for _ in range(7):
+                    t0 = time.perf_counter(); zk.check(L.zkt_groth16_prove_r1cs_partials(spk, d_w.data_ptr(), pr.ctypes.data, ps.ctypes.data, d_parts.data_ptr())); tsh.append(time.perf_counter() - t0)
+                L.zkt_groth16_pk_free(spk)
+                rc, pk, vkx, vbufx, _ = setup(0, 1)
+                if rc != 0: raise RuntimeError("setup failed: rc %d" % rc)
+                for _ in range(2): zk.check(L.zkt_groth16_prove_r1cs_dev(pk, d_w.data_ptr(), pr.ctypes.data, ps.ctypes.data, *outs))
+                tone = []
+                for _ in range(5):
+                    t0 = time.perf_counter(); zk.check(L.zkt_groth16_prove_r1cs_dev(pk, d_w.data_ptr(), pr.ctypes.data, ps.ctypes.data, *outs)); tone.append(time.perf_counter() - t0)
+                L.zkt_groth16_pk_free(pk)
+                g16["share_of_8"] = {"rank": 3, "ms_per_rank_median": sorted(tsh)[3] * 1e3, "ms_per_rank_best": min(tsh) * 1e3, "one_proof_unpipelined_ms": sorted(tone)[2] * 1e3,
+                                     "ratio": sorted(tone)[2] / sorted(tsh)[3], "setup_s": round(s_setup, 2),
+                                     "note": "one rank's share of ONE proof sharded over 8 GPUs, measured on this one card (its MSM shards + its own range of the quotient, no exchange in the Fr "
+                                             "stage; the all-gather of 672 B is not included); ratio = one unpipelined proof on one GPU / this share — the latency ratio a node of 8 would reach, "
+                                             "not a measured scaling curve"}
             if rank == 0:
                 stmt = wires[:gl + 1].copy()
                 # an UNPREPARED key: the library builds the key's entry for the 63-step loop at first sight, beside the first call (served by kernels that need nothing of
