@@ -125,12 +125,12 @@ def test_r1cs_proof_points_equal_python_integer_multiples(L, n):
     assert (gp[2] == g1_arr([py_g1_mul(G1_GEN, Cs)])).all(), "C"
 
 
-@pytest.mark.parametrize("n,shards", [(200, 3), (3000, 5), (2500, 8), (12, 11)])
+@pytest.mark.parametrize("n,shards", [(200, 3), (3000, 5), (2500, 8), (12, 11), (3, 3)])
 def test_r1cs_sharded_proof_equals_unsharded(L, n, shards):
     """BASELINE config 4 on one card: the shards of the resident base sets each produce their three Jacobian partials; summing
     them (the all_gather + combine step of the multi-GPU run) gives the unsharded proof bit for bit.  Every rank evaluates only its own
     range of the quotient's values (blocked convolution, csrc/zkt_groth16_r1cs.hip k_recip_blocks): (200, 3) is one input block per rank,
-    (3000, 5) three blocks of 1024 with a ragged last one, (2500, 8) likewise with eight ranks, (12, 11) ranges of one term (one quotient value per rank)."""
+    (3000, 5) three blocks of 1024 with a ragged last one, (2500, 8) likewise with eight ranks, (12, 11) ranges of one term (one quotient value per rank), (3, 3) a rank with NO quotient value (two values, three ranks)."""
     import torch
     mats, wires, l, m = chain_circuit_sparse(n, seed=5)
     rng = SplitMix64(999)
