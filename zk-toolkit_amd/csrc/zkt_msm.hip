@@ -302,58 +302,40 @@ __device__ inline uint32_t block_excl_scan_256(uint32_t v, uint32_t* lds /*256*/
   __syncthreads();
   return excl;
 }
-// One-wave forms of the three scan kernels (TPB = 64, 32 items per lane, the same 2048-item tiles) for sets below 2^19 terms: a 256-thread workgroup needs four free wave
-// slots on ONE compute unit at the same moment, which it rarely finds while a G2 accumulate fills the chip with one-wave workgroups (k_scan_sums 544 us instead of 5 in a
-// rank's share of a sharded proof, profiles/r04_groth16_shard_of_8.txt); a one-wave workgroup takes any slot.
-template <int TPB> __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* lds, uint32_t& total) {
-  if constexpr (TPB == 64) {
-    const int lane = threadIdx.x;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d); if (lane >= d) inc += x; }
-    total = __shfl(inc, 63);
-    return inc - v;
-  } else return block_excl_scan_256(v, lds, total);
-}
-template <int TPB>
-static __global__ void __launch_bounds__(TPB) k_scan_sums(const uint32_t* __restrict__ in, size_t m, uint32_t* __restrict__ blocksum) {
+static __global__ void __launch_bounds__(256) k_scan_sums(const uint32_t* __restrict__ in, size_t m, uint32_t* __restrict__ blocksum) {
   ZKT_SIDE_PRIO;
-  constexpr int ITEMS = SCAN_TILE / TPB;
   __shared__ uint32_t lds[256];
-  size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * ITEMS;
+  size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
   uint32_t s = 0;
 #pragma unroll
-  for (int k = 0; k < ITEMS; ++k) if (base + k < m) s += in[base + k];
-  uint32_t tot; (void)block_excl_scan<TPB>(s, lds, tot);
+  for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < m) s += in[base + k];
+  uint32_t tot; (void)block_excl_scan_256(s, lds, tot);
   if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
 }
-template <int TPB>
-static __global__ void __launch_bounds__(TPB) k_scan_top(uint32_t* __restrict__ blocksum, int nblk, uint32_t* __restrict__ grand_total) {
+static __global__ void __launch_bounds__(256) k_scan_top(uint32_t* __restrict__ blocksum, int nblk, uint32_t* __restrict__ grand_total) {
   ZKT_SIDE_PRIO;
   __shared__ uint32_t lds[256];
   uint32_t run = 0;
-  for (int base = 0; base < nblk; base += TPB) {          // nblk <= 2^19/2048 = 256 in practice
+  for (int base = 0; base < nblk; base += 256) {          // nblk <= 2^19/2048 = 256 in practice
     int i = base + threadIdx.x;
     uint32_t v = i < nblk ? blocksum[i] : 0, tot;
-    uint32_t ex = block_excl_scan<TPB>(v, lds, tot);
+    uint32_t ex = block_excl_scan_256(v, lds, tot);
     if (i < nblk) blocksum[i] = run + ex;
     run += tot;
   }
   if (threadIdx.x == 0) *grand_total = run;
 }
-template <int TPB>
-static __global__ void __launch_bounds__(TPB) k_scan_final(const uint32_t* __restrict__ in, size_t m, const uint32_t* __restrict__ blocksum,
+static __global__ void __launch_bounds__(256) k_scan_final(const uint32_t* __restrict__ in, size_t m, const uint32_t* __restrict__ blocksum,
                                                     uint32_t* __restrict__ out) {
   ZKT_SIDE_PRIO;
-  constexpr int ITEMS = SCAN_TILE / TPB;
   __shared__ uint32_t lds[256];
-  size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * ITEMS;
-  uint32_t v[ITEMS], s = 0;
+  size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS], s = 0;
 #pragma unroll
-  for (int k = 0; k < ITEMS; ++k) { v[k] = base + k < m ? in[base + k] : 0; s += v[k]; }
-  uint32_t tot; uint32_t run = block_excl_scan<TPB>(s, lds, tot) + blocksum[blockIdx.x];
+  for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = base + k < m ? in[base + k] : 0; s += v[k]; }
+  uint32_t tot; uint32_t run = block_excl_scan_256(s, lds, tot) + blocksum[blockIdx.x];
 #pragma unroll
-  for (int k = 0; k < ITEMS; ++k) { if (base + k < m) out[base + k] = run; run += v[k]; }
+  for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < m) out[base + k] = run; run += v[k]; }
 }
 // (Round 4 measured ONE block scanning a small set's counters — and the task count fused into that scan — to save kernel nodes of a small MSM's graph: the one-block scan of
 //  65,536 counters takes 40 us against 18 us for the three kernels below plus their launch gaps, and the 2^17-term MSM, the range proof and the small Groth16 keys did not move
@@ -361,16 +343,9 @@ static __global__ void __launch_bounds__(TPB) k_scan_final(const uint32_t* __res
 // out[0..m) = exclusive scan of in, out[m] = total.  scratch: >= ceil(m/2048) words
 static void launch_scan(const uint32_t* in, uint32_t* out, size_t m, uint32_t* scratch, hipStream_t s) {
   int nblk = (int)((m + SCAN_TILE - 1) / SCAN_TILE);
-  static const int wave_cfg = [] { const char* e = getenv("ZKT_MSM_WAVE_SCAN"); return e ? atoi(e) : 1; }();
-  if (wave_cfg && m <= (size_t(1) << 18)) {          // the counters of a set below 2^19 terms (<= 2^15 .. 2^18 of them): one-wave workgroups
-    hipLaunchKernelGGL(k_scan_sums<64>, dim3(nblk), dim3(64), 0, s, in, m, scratch);
-    hipLaunchKernelGGL(k_scan_top<64>, dim3(1), dim3(64), 0, s, scratch, nblk, out + m);
-    hipLaunchKernelGGL(k_scan_final<64>, dim3(nblk), dim3(64), 0, s, in, m, (const uint32_t*)scratch, out);
-    return;
-  }
-  hipLaunchKernelGGL(k_scan_sums<256>, dim3(nblk), dim3(256), 0, s, in, m, scratch);
-  hipLaunchKernelGGL(k_scan_top<256>, dim3(1), dim3(256), 0, s, scratch, nblk, out + m);
-  hipLaunchKernelGGL(k_scan_final<256>, dim3(nblk), dim3(256), 0, s, in, m, (const uint32_t*)scratch, out);
+  hipLaunchKernelGGL(k_scan_sums, dim3(nblk), dim3(256), 0, s, in, m, scratch);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, scratch, nblk, out + m);
+  hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(256), 0, s, in, m, (const uint32_t*)scratch, out);
 }
 
 // ---------------------------------------------------------------------------------
